@@ -1,0 +1,163 @@
+/*
+ * muxgl.h -- C-ABI of libmuxgl, the MI355X (gfx950) genotype-likelihood engine behind popscle's
+ *            demuxlet / freemuxlet hot path.
+ *
+ * popscle has no plugin/FFI surface: the hot loops are inline in cmdCramDemuxlet / cmdCramFreemux2.  The drop-in
+ * boundary is therefore the data hand-over between `scl.load_from_plp(...)` returning
+ * (cmd_cram_demuxlet.cpp:122, cmd_cram_freemux2.cpp:87) and the `hprintf` row writers
+ * (cmd_cram_demuxlet.cpp:993-1013, cmd_cram_freemux2.cpp:608-665).  Each entry point below names the reference
+ * lines it replaces.  INTEGRATION.md shows the glue a popscle maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C, no exceptions across the ABI; every call returns 0 on success, nonzero on failure, and
+ *     muxgl_last_error(h) (or muxgl_last_error(NULL) after a failed muxgl_create) describes the failure.  This
+ *     replaces the reference's error() -> throw pexception -> abort (Error.cpp:29-43).
+ *   - the library needs a HIP device; there is NO CPU fallback.  muxgl_create fails if no gfx950 device is usable.
+ *   - all pointer arguments are HOST pointers borrowed for the duration of the call unless the name ends in _dev.
+ *   - every call is synchronous: results are complete when it returns.  One handle = one device; the reference is
+ *     single-threaded and so is each handle (use one handle per thread/process/GPU).
+ *
+ * Packed pileup (what sc_dropseq_lib_t holds after load_from_plp, sc_drop_seq.h:130-184, flattened):
+ *   cell_ptr   int64[C+1]   entries of cell c = [cell_ptr[c], cell_ptr[c+1])   <- cell_umis[c] (std::map order =
+ *                           ascending SNP id, sc_drop_seq.h:165)
+ *   entry_snp  int32[nnz]   SNP id of the entry                                <- cell_umis[c] keys
+ *   entry_rptr int64[nnz+1] reads of entry e = [entry_rptr[e], entry_rptr[e+1]) <- sc_snp_droplet_t iteration order
+ *   reads      uint8[R]     bit7 allele (0 ref, 1 alt), bits0-6 capped BQ; MUXGL_READ_OTHER = allele "2"
+ *                           <- (allele<<24 | bq<<16 | count) words of sc_drop_seq.h:23-27
+ */
+#ifndef MUXGL_H
+#define MUXGL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUXGL_VERSION 1
+#define MUXGL_READ_OTHER 0xFF
+#define MUXGL_MAX_ALPHA 16
+
+enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
+
+typedef struct muxgl_handle muxgl_handle;
+
+typedef struct {
+  int32_t device_id; /* HIP device ordinal this handle runs on */
+  int32_t flags;     /* reserved, 0 */
+} muxgl_config;
+
+/* demuxlet parameters: --alpha grid and --doublet-prior (cmd_cram_demuxlet.cpp:32,62-63,85-89) */
+typedef struct {
+  int32_t n_alpha;
+  int32_t _pad;
+  double alpha[MUXGL_MAX_ALPHA];
+  double doublet_prior;
+} muxgl_demux_params;
+
+/* per-cell demuxlet result: every quantity cmd_cram_demuxlet.cpp:788-991 derives and :993-1013 prints.
+ * Sample indices are positions in the GP tensor's V axis; -1 = none.  valid=0: the cell has no entries and the
+ * reference prints no row (:653). */
+typedef struct {
+  int32_t valid;
+  int32_t nsnps;
+  int32_t type, next_type;
+  int32_t sBest, sNext;
+  int32_t dBest1, dBest2, dBestA;
+  int32_t dNext1, dNext2, dNextA;
+  int32_t jBest, kBest, aBest;
+  int32_t jNext, kNext, aNext;
+  double sngBestLLK, sngNextLLK, dblBestLLK, dblNextLLK;
+  double sumLLK, sngLLK;
+  double bestLLK, nextLLK;
+  double bestPP, sngPP, sngOnlyPP;
+} muxgl_demux_cell;
+
+/* freemuxlet parameters: --doublet-prior, --geno-error (cmd_cram_freemux2.cpp:19-20) */
+typedef struct {
+  double doublet_prior;
+  double geno_error;
+} muxgl_fmx_params;
+
+/* per-cell freemuxlet state/result (cmd_cram_freemux2.cpp:345-367, printed at :660-665) */
+typedef struct {
+  int32_t type;  /* 0 SNG, 1 DBL, 2 AMB, -1 never classified */
+  int32_t clust; /* clusts[i]: jBest for SNG after an iteration, else -1 */
+  int32_t jBest, kBest, jNext, kNext;
+  int32_t sBest, sNext, dBest1, dBest2, dNext1, dNext2;
+  double bestLLK, nextLLK;
+  double sngBestLLK, sngNextLLK, dblBestLLK, dblNextLLK;
+  double bestPP, sngPP, sngOnlyPP, sumLLK;
+} muxgl_fmx_cell;
+
+/* kernel timings of the most recent *_run / *_iterate call, milliseconds, measured with hipEvents recorded on the
+ * stream the kernels were launched on */
+enum {
+  MUXGL_T_DEMUX_ENTRY = 0, /* per-entry doublet-genotype likelihoods (a4,a5) */
+  MUXGL_T_DEMUX_SWEEP = 1, /* sample-pair x alpha sweep (a6) */
+  MUXGL_T_DEMUX_CALL = 2,  /* evidence sums, best/next scans, call (a7-a9) */
+  MUXGL_T_DEMUX_D2H = 3,   /* per-cell records to host */
+  MUXGL_T_FMX_ENTRY = 4,   /* entry 9-GL pileup + cell scores (b1,b2) */
+  MUXGL_T_FMX_GP = 5,      /* cluster genotype posterior tensor */
+  MUXGL_T_FMX_ESTEP = 6,   /* E-step pair sweep (b6) */
+  MUXGL_T_FMX_CALL = 7,    /* scans + re-assignment (b7,b8 classification) */
+  MUXGL_T_FMX_MSTEP = 8,   /* ordered clamped merge (b5,b8) */
+  MUXGL_T_COUNT = 16
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+int muxgl_create(const muxgl_config* cfg, muxgl_handle** out);
+void muxgl_destroy(muxgl_handle* h);
+const char* muxgl_last_error(const muxgl_handle* h);
+int muxgl_version(void);
+
+/* ---- pileup hand-over: replaces the in-memory result of sc_dropseq_lib_t::load_from_plp
+ *      (sc_drop_seq.cpp:103-384; containers sc_drop_seq.h:130-184).  Copies to device memory. --------------------- */
+int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                     const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads);
+
+/* ---- demuxlet ------------------------------------------------------------------------------------------------ */
+/* genotype-probability tensor gp[S][V][3] (sc_snp_t::gps, sc_drop_seq.h:29-37, built at sc_drop_seq.cpp:287-315) and
+ * has_gp[S] (0 <=> gps == NULL, sc_drop_seq.cpp:258-282) */
+int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8_t* has_gp);
+
+/* replaces the per-cell loop cmd_cram_demuxlet.cpp:636-991.  out: NULL or [C].  full_ll: NULL or [C][V][V][n_alpha]
+ * receiving llksAB for the entries the reference ever reads: (j,0,0) and (j,k!=j,n>=1); other slots are 0. */
+int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_cell* out, double* full_ll);
+
+/* pinned host view of the last run's [C] records (valid until the next run or destroy) */
+const muxgl_demux_cell* muxgl_demux_results(const muxgl_handle* h);
+
+/* per-entry pGs[nnz][n_alpha*9] of the last run (cmd_cram_demuxlet.cpp:655-725), for parity tests */
+int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg);
+
+/* ---- freemuxlet ---------------------------------------------------------------------------------------------- */
+/* b1+b2: calculate_snp_droplet_pileup for every entry (sc_drop_seq.cpp:452-509) and the per-cell singlet scores
+ * (cmd_cram_freemux2.cpp:117-160).  af[S] from the .var.gz AF column.  Outputs [C], any may be NULL. */
+int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
+                      int32_t* cell_nreads);
+
+/* entry pileups for host-side greedy init (cmd_cram_freemux2.cpp:217-261) and parity: gls[nnz][9],
+ * counts[nnz][3] = nreads,nref,nalt.  Either may be NULL. */
+int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
+
+/* initial clusters (after --init-cluster or greedy init): builds the cluster pileups in ascending cell id
+ * (cmd_cram_freemux2.cpp:277-288) and resets types/jBest/kBest (:263-265,349-350).  clust[C], -1 = unassigned. */
+int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust);
+
+/* one EM iteration, cmd_cram_freemux2.cpp:375-597: E-step, scans, re-assignment, ordered M-step.
+ * out: NULL or [C].  full_ll: NULL or [C][K(K+1)/2]. */
+int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
+                      int32_t* nchanged, double* full_ll);
+
+/* cluster pileups for the .clust1.vcf.gz writer (cmd_cram_freemux2.cpp:608-658): gls[K][S][9], counts[K][S][3] */
+int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
+
+/* ---- measurement --------------------------------------------------------------------------------------------- */
+/* ms[MUXGL_T_COUNT]: hipEvent durations of the kernels of the most recent run/iterate call (0 where not run) */
+int muxgl_get_timing(const muxgl_handle* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+/*
+ * muxgl_oracle.h -- CPU restatement of popscle's demuxlet / freemuxlet genotype-likelihood path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under popscle_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * PARITY STATUS: "parity unpinned" for everything except the Phred tables.
+ *   - The reference (statgen/popscle) ships no tests, fixtures or golden vectors for this path.
+ *   - Its hot loops live inline in cmdCramDemuxlet / cmdCramFreemux2, whose translation units include
+ *     htslib headers (via cramore.h -> hts_utils.h and sc_drop_seq.h -> bcf_filtered_reader.h).  htslib is
+ *     absent from this image, so those TUs are unbuildable here without stand-in headers, which we do not write.
+ *   - The only on-path TU that compiles from its own source is PhredHelper.cpp; oracle/Makefile builds it into
+ *     oracle/_ref/libphred_ref.so and tests/test_oracle.py pins oracle_phred_tables() to it bit-for-bit.
+ *   - Everything else below is a literal, operation-order-preserving restatement, each function citing the
+ *     reference file:line it follows (paths relative to the reference root).
+ *
+ * Packed pileup (same layout the C-ABI in include/muxgl.h takes):
+ *   cell_ptr   int64[C+1]   entries of cell c are [cell_ptr[c], cell_ptr[c+1]), ascending SNP id
+ *   entry_snp  int32[nnz]   SNP id of each (cell,SNP) entry
+ *   entry_rptr int64[nnz+1] reads of entry e are [entry_rptr[e], entry_rptr[e+1]), in the reference's iteration
+ *                           order (std::map<std::string UMI> order, sc_drop_seq.h:26)
+ *   reads      uint8[R]     bit7 = allele (0 ref / 1 alt), bits0-6 = capped base quality; 0xFF = allele "2" (other)
+ */
+#ifndef MUXGL_ORACLE_H
+#define MUXGL_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_READ_OTHER 0xFF
+
+/* droplet types; the reference prints the strings, freemux2 stores 0/1/2 (cmd_cram_freemux2.cpp:528,540,568) */
+enum { ORACLE_SNG = 0, ORACLE_DBL = 1, ORACLE_AMB = 2 };
+
+/* per-cell result of demuxlet, one field per quantity of cmd_cram_demuxlet.cpp:788-1013 */
+typedef struct {
+  int32_t valid;                 /* 0: cell has no entries -> the reference emits no row (:653) */
+  int32_t nsnps;                 /* scl.cell_umis[i].size() (:996) */
+  int32_t type, next_type;       /* bestType / nextType */
+  int32_t sBest, sNext;          /* :827-837 */
+  int32_t dBest1, dBest2, dBestA;/* :883-906 */
+  int32_t dNext1, dNext2, dNextA;
+  int32_t jBest, kBest, aBest;   /* :921-988 */
+  int32_t jNext, kNext, aNext;
+  double sngBestLLK, sngNextLLK, dblBestLLK, dblNextLLK;
+  double sumLLK, sngLLK;
+  double bestLLK, nextLLK;
+  double bestPP, sngPP, sngOnlyPP;
+} oracle_demux_cell;
+
+/* per-(cell,SNP) or per-(cluster,SNP) pileup, sc_drop_seq.h:65-75 minus logdenom (never read outside the struct) */
+typedef struct {
+  int32_t nreads, nref, nalt, _pad;
+  double gls[9];
+} oracle_plp;
+
+/* per-cell result of one freemuxlet EM iteration / of the final table (cmd_cram_freemux2.cpp:458-584,660-665) */
+typedef struct {
+  int32_t type;                  /* 0 SNG, 1 DBL, 2 AMB, -1 never classified */
+  int32_t clust;                 /* clusts[i] after the iteration: jBest for SNG, else -1 */
+  int32_t jBest, kBest, jNext, kNext;
+  int32_t sBest, sNext, dBest1, dBest2, dNext1, dNext2;
+  double bestLLK, nextLLK;
+  double sngBestLLK, sngNextLLK, dblBestLLK, dblNextLLK;
+  double bestPP, sngPP, sngOnlyPP, sumLLK;
+} oracle_fmx_cell;
+
+/* PhredHelper.cpp:24-41 */
+void oracle_phred_tables(double* err256, double* mat256);
+
+/* sc_drop_seq.cpp:5-8 */
+double oracle_logadd(double la, double lb);
+
+/* demuxlet, cmd_cram_demuxlet.cpp:636-991.  gp = [S][V][3] doubles, has_gp = [S] (0 => gps==NULL, :733).
+ * full_ll: NULL or [C][V][V][nAlpha] receiving llksAB of every cell.  nthreads<=1: serial, else OpenMP over cells
+ * (cells are independent; results do not depend on nthreads).  Returns 0. */
+int oracle_demux(int64_t C, int64_t S, int32_t V,
+                 const int64_t* cell_ptr, const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads,
+                 const double* gp, const uint8_t* has_gp,
+                 int32_t nAlpha, const double* alphas, double doublet_prior,
+                 oracle_demux_cell* out, double* full_ll, int32_t nthreads);
+
+/* per-entry normalised doublet-genotype likelihoods pGs[nAlpha*9] of demuxlet, cmd_cram_demuxlet.cpp:655-725 */
+void oracle_demux_entry_pg(const uint8_t* reads, int64_t nreads, int32_t nAlpha, const double* alphas, double* pGs);
+
+/* freemuxlet b1: calculate_snp_droplet_pileup(alpha=0.5), sc_drop_seq.cpp:452-509, for every entry */
+void oracle_fmx_entry_pileup(int64_t nnz, const int64_t* entry_rptr, const uint8_t* reads, oracle_plp* out);
+
+/* snp_droplet_pileup::merge, sc_drop_seq.h:77-101 */
+void oracle_plp_merge(oracle_plp* dst, const oracle_plp* src);
+
+/* freemuxlet b2: per-cell llk0/llk2, nSNPs, nReads, cmd_cram_freemux2.cpp:117-160 */
+void oracle_fmx_cell_scores(int64_t C, const int64_t* cell_ptr, const int32_t* entry_snp, const oracle_plp* eplp,
+                            const double* af, double* llk0, double* llk2, int32_t* nsnps, int32_t* nreads);
+
+/* freemuxlet b3: order = cells sorted by score descending, ties by id descending
+ * (cmd_cram_freemux2.cpp:184-189, comparator sc_drop_seq.h:187-198) */
+void oracle_fmx_sort(int64_t C, const double* scores, int32_t* order);
+
+/* freemuxlet b4: greedy initial clustering, cmd_cram_freemux2.cpp:217-261 + sc_drop_seq.cpp:544-578.
+ * clust[C] receives the cluster id (or -1 if skipped by frac_init / score threshold). */
+void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                            const oracle_plp* eplp, const double* af, const double* scores, const int32_t* order,
+                            double frac_init_clust, double singlet_score_thres, int32_t* clust);
+
+/* cluster pileup from assignments, ascending cell id, cmd_cram_freemux2.cpp:277-288.
+ * cplp = [K][S], default-constructed (gls all 1, counts 0) where nothing merged. */
+void oracle_fmx_build_cluster_pileup(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                                     const oracle_plp* eplp, const int32_t* clust, oracle_plp* cplp);
+
+/* one EM iteration, cmd_cram_freemux2.cpp:375-597: E-step + scans for all cells from cplp, then re-assignment and the
+ * sequential M-step that rebuilds cplp in place.  cells[C] carries types/jBest/kBest from the previous iteration
+ * (initialise with oracle_fmx_init_cells).  Returns nchanged; writes nsingle/namb. */
+int32_t oracle_fmx_iterate(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                           const oracle_plp* eplp, const double* af, double doublet_prior, double geno_error,
+                           oracle_plp* cplp, oracle_fmx_cell* cells, int32_t* nsingle, int32_t* namb,
+                           double* full_ll /* NULL or [C][K(K+1)/2] */, int32_t nthreads);
+
+/* state before the first iteration: types[i] = 0 if clust[i]>=0 else -1 (:194,213,244), jBest=kBest=-1 (:349-350) */
+void oracle_fmx_init_cells(int64_t C, const int32_t* clust, oracle_fmx_cell* cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+// common.hpp -- handle layout, error plumbing and small device helpers shared by the libmuxgl translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../include/muxgl.h"
+
+#define MUXGL_WAVE 64
+
+// device-side per-(cell,SNP) or per-(cluster,SNP) pileup counts; gls are kept in separate SoA/AoS arrays
+struct muxgl_counts {
+  int32_t nreads, nref, nalt;
+};
+
+struct muxgl_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // packed pileup (device)
+  int64_t C = 0, S = 0, nnz = 0, R = 0;
+  int64_t* d_cell_ptr = nullptr;
+  int32_t* d_entry_snp = nullptr;
+  int64_t* d_entry_rptr = nullptr;
+  uint8_t* d_reads = nullptr;
+  int32_t* d_entry_cell = nullptr;  // cell id of each entry (for SNP-major views)
+  int64_t max_cell_entries = 0;
+
+  // Phred LUT: [0..127] = phred2Err, [128..255] = phred2Mat (bq is 7 bits in the packed read byte)
+  double* d_lut = nullptr;
+
+  // demuxlet
+  int32_t V = 0;
+  double* d_gp = nullptr;
+  uint8_t* d_has_gp = nullptr;
+  double* d_ll = nullptr;  // [C][V][V][A]
+  size_t ll_cap = 0;
+  bool ll_zeroed = false;
+  int32_t ll_V = 0, ll_A = 0;
+  muxgl_demux_cell* d_dcells = nullptr;
+  muxgl_demux_cell* h_dcells = nullptr;  // pinned
+  int64_t dcells_cap = 0;
+  uint32_t* d_pairs = nullptr;  // packed (j | k<<8 | nmask<<16) work list of the sweep
+  int32_t n_pairs = 0;
+  int32_t pairs_cap = 0;
+  muxgl_demux_params last_dp{};
+  bool have_dp = false;
+
+  // freemuxlet
+  double* d_af = nullptr;
+  double* d_egls = nullptr;       // [nnz][9] entry pileup likelihoods (b1)
+  int32_t* d_ecnt = nullptr;      // [nnz][3] nreads,nref,nalt
+  int32_t K = 0;
+  double* d_cgls = nullptr;       // [K][S][9] cluster pileup likelihoods
+  int32_t* d_ccnt = nullptr;      // [K][S][3]
+  double* d_cgp = nullptr;        // [S][K][3] cluster genotype posteriors for the E-step
+  int32_t* d_clust = nullptr;     // [C] current singlet cluster or -1
+  muxgl_fmx_cell* d_fcells = nullptr;
+  muxgl_fmx_cell* h_fcells = nullptr;  // pinned
+  double* d_fll = nullptr;        // [C][K(K+1)/2]
+  int32_t* d_fstat = nullptr;     // nsingle, namb, nchanged
+  // SNP-major (CSC) view of the entries, cells ascending inside each SNP: M-step walks it
+  int64_t* d_snp_ptr = nullptr;   // [S+1]
+  int64_t* d_snp_entry = nullptr; // [nnz] entry index
+  bool fmx_prepared = false;
+
+  hipEvent_t ev[2 * MUXGL_T_COUNT] = {};
+  bool ev_used[MUXGL_T_COUNT] = {};
+  float ms[MUXGL_T_COUNT] = {};
+};
+
+extern thread_local std::string g_muxgl_create_error;
+
+#define MUXGL_FAIL(h, ...)                                  \
+  do {                                                      \
+    char _buf[512];                                         \
+    snprintf(_buf, sizeof(_buf), __VA_ARGS__);              \
+    (h)->err = _buf;                                        \
+    return 1;                                               \
+  } while (0)
+
+#define HIPCHK(h, call)                                                                         \
+  do {                                                                                          \
+    hipError_t _e = (call);                                                                     \
+    if (_e != hipSuccess) MUXGL_FAIL(h, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),  \
+                                     __FILE__, __LINE__);                                       \
+  } while (0)
+
+template <typename T>
+static inline int dev_alloc(muxgl_handle* h, T** p, size_t n) {
+  if (*p) {
+    (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (n == 0) n = 1;
+  HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+  return 0;
+}
+
+template <typename T>
+static inline void dev_free(T** p) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+}
+
+static inline void tic(muxgl_handle* h, int id) {
+  (void)hipEventRecord(h->ev[2 * id], h->stream);
+  h->ev_used[id] = true;
+}
+static inline void toc(muxgl_handle* h, int id) { (void)hipEventRecord(h->ev[2 * id + 1], h->stream); }
+static inline void clear_timing(muxgl_handle* h) {
+  for (int i = 0; i < MUXGL_T_COUNT; ++i) {
+    h->ev_used[i] = false;
+    h->ms[i] = 0.f;
+  }
+}
+static inline void collect_timing(muxgl_handle* h) {
+  for (int i = 0; i < MUXGL_T_COUNT; ++i) {
+    if (h->ev_used[i]) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) h->ms[i] += t;
+    }
+  }
+}
+
+// ---- device helpers ---------------------------------------------------------------------------------------------
+
+// product accumulator: value = m * 2^e, renormalised to m in [0.5,1) every few factors so that a cell's
+// sum of log(sumP) becomes one log() at the end:  sum log x_i = log(prod mantissas) + ln2 * sum exponents
+struct prodacc {
+  double m;
+  int32_t e;
+};
+__device__ __forceinline__ void prodacc_renorm(double& m, int32_t& e) {
+  int ex;
+  m = frexp(m, &ex);
+  e += ex;
+}
+__device__ __forceinline__ double prodacc_log(double m, int32_t e) { return log(m) + (double)e * 0.6931471805599453094; }
+
+// sc_drop_seq.cpp:5-8
+__device__ __forceinline__ double dev_logadd(double la, double lb) {
+  if (la > lb) return la + log(1.0 + exp(lb - la));
+  return lb + log(1.0 + exp(la - lb));
+}
+
+// kernel launchers implemented in the kernel TUs
+int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg);
+int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
+int fmx_build_clusters_launch(muxgl_handle* h);
+int fmx_iterate_launch(muxgl_handle* h, const muxgl_fmx_params* p);

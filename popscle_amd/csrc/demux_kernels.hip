@@ -1,0 +1,496 @@
+// demux_kernels.hip -- demuxlet hot path on gfx950: per-entry doublet-genotype likelihoods (a4,a5), the
+// sample-pair x alpha sweep (a6) and the per-cell evidence/scan/call step (a7-a9).
+//
+// Reference being replaced: cmd_cram_demuxlet.cpp:636-991 (statgen/popscle).  FP64 throughout.
+//
+// Data-parallel decomposition (new design, the reference is one thread):
+//   * one workgroup per (cell, pair-tile); lanes own (j,k) sample pairs and keep one product accumulator per alpha
+//     in registers for the whole cell, so a cell's  sum_e log(sumP_e)  becomes  log(prod_e sumP_e)  with the
+//     mantissa/exponent split of prodacc (one log per hypothesis instead of one per entry).
+//   * the cell's entries stream through the workgroup in chunks: phase 1, lane <-> entry, turns the entry's reads
+//     into pG[nAlpha][3][3] (LDS); the SNP's GP row gp[snp][V][3] is staged coalesced into LDS; phase 2, every lane
+//     reads its g_j, g_k (LDS) and the chunk's pG (LDS broadcast) and multiplies its accumulators.
+//   * only hypotheses the reference ever reads are computed: (j,0,0) singlets and (j,k!=j,n>=1) doublets; for
+//     alpha==0.5 the likelihood is symmetric in (j,k), so k<j is computed once and mirrored.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxChunk = 64;
+
+__device__ __forceinline__ double lut_err(const double* lut, uint32_t bq) { return lut[bq]; }
+__device__ __forceinline__ double lut_mat(const double* lut, uint32_t bq) { return lut[128 + bq]; }
+
+// cmd_cram_demuxlet.cpp:655-725 for one entry.  pG[n*9+l*3+m]; reads in the reference's iteration order.
+// Division by the running max is a multiplication by its reciprocal (<=1 ulp per element, tolerance 1e-5 on LLs).
+template <int NA>
+__device__ __forceinline__ void entry_pg(const uint8_t* __restrict__ reads, int64_t r0, int64_t r1, int nAlpha,
+                                         const double* __restrict__ alpha, const double* lut, double (&pG)[NA * 9]) {
+#pragma unroll
+  for (int i = 0; i < NA * 9; ++i) pG[i] = 1.0;
+  for (int64_t r = r0; r < r1; ++r) {
+    uint32_t b = reads[r];
+    if (b == MUXGL_READ_OTHER) continue;  // :664
+    uint32_t al = b >> 7, bq = b & 0x7f;
+    double e3 = lut_err(lut, bq) / 3.0, mt = lut_mat(lut, bq);
+    double pR = (al == 0) ? mt : e3;  // :666
+    double pA = (al == 1) ? mt : e3;  // :667
+    double mx = 0.0;
+#pragma unroll
+    for (int n = 0; n < NA; ++n) {
+      if (n < nAlpha) {
+        double a = alpha[n];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            double p = 0.5 * l + (m - l) * 0.5 * a;  // :673
+            double v = pG[n * 9 + l * 3 + m] * (pR * (1.0 - p) + pA * p);
+            pG[n * 9 + l * 3 + m] = v;
+            mx = fmax(mx, v);
+          }
+        }
+      }
+    }
+    double inv = 1.0 / mx;
+#pragma unroll
+    for (int i = 0; i < NA * 9; ++i) pG[i] *= inv;
+  }
+  double mx = 0.0;
+#pragma unroll
+  for (int n = 0; n < NA; ++n) {
+    if (n < nAlpha) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        pG[n * 9 + i] += 1e-10;  // :711
+        mx = fmax(mx, pG[n * 9 + i]);
+      }
+    }
+  }
+  double inv = 1.0 / mx;
+#pragma unroll
+  for (int i = 0; i < NA * 9; ++i) pG[i] *= inv;
+}
+
+struct alpha_args {
+  double a[MUXGL_MAX_ALPHA];
+};
+
+// standalone per-entry kernel: only used by muxgl_demux_get_entry_pg (parity of a4/a5); the product path fuses
+// the same entry_pg<> into the sweep below.
+template <int NA>
+__global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr,
+                                                              const uint8_t* __restrict__ reads,
+                                                              const double* __restrict__ lut_g, int nAlpha,
+                                                              alpha_args al, double* __restrict__ pg) {
+  __shared__ double lut[256];
+  lut[threadIdx.x] = lut_g[threadIdx.x];
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    double pG[NA * 9];
+    entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], nAlpha, al.a, lut, pG);
+#pragma unroll
+    for (int n = 0; n < NA; ++n)
+      if (n < nAlpha) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pg[(size_t)e * nAlpha * 9 + n * 9 + i] = pG[n * 9 + i];
+      }
+  }
+}
+
+// fused entry + pair sweep.  grid = (C, n_tiles); block = T threads; thread t of tile y owns pairs[y*T + t].
+// dynamic LDS: lut[256] | rows[EC][V*3] | pgs[EC][nAlpha*9] | snp_ok[EC] (int32: snp id or -1)
+template <int NA>
+__global__ void __launch_bounds__(256)
+    demux_sweep_kernel(const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ entry_snp,
+                       const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
+                       const double* __restrict__ gp, const uint8_t* __restrict__ has_gp,
+                       const double* __restrict__ lut_g, const uint32_t* __restrict__ pairs, int n_pairs, int V,
+                       int nAlpha, uint32_t symmask, alpha_args al, int EC, double* __restrict__ ll) {
+  extern __shared__ double smem[];
+  double* lut = smem;
+  double* rows = lut + 256;
+  double* pgs = rows + (size_t)EC * V * 3;
+  int32_t* snp_ok = (int32_t*)(pgs + (size_t)EC * nAlpha * 9);
+
+  const int T = blockDim.x;
+  const int t = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if (e0 == e1) return;
+
+  for (int i = t; i < 256; i += T) lut[i] = lut_g[i];
+
+  const int pi = blockIdx.y * T + t;
+  uint32_t pk = (pi < n_pairs) ? pairs[pi] : 0u;
+  const int j = pk & 0xff, k = (pk >> 8) & 0xff;
+  const uint32_t nmask = pk >> 16;
+
+  double acc[NA];
+  int32_t ex[NA];
+#pragma unroll
+  for (int n = 0; n < NA; ++n) {
+    acc[n] = 1.0;
+    ex[n] = 0;
+  }
+  const int V3 = V * 3;
+  const int PG = nAlpha * 9;
+  __syncthreads();
+
+  for (int64_t eb = e0; eb < e1; eb += EC) {
+    const int nc = (int)((e1 - eb) < EC ? (e1 - eb) : EC);
+    // phase 1: lane <-> entry
+    if (t < nc) {
+      const int64_t e = eb + t;
+      double pG[NA * 9];
+      entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], nAlpha, al.a, lut, pG);
+#pragma unroll
+      for (int n = 0; n < NA; ++n)
+        if (n < nAlpha) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) pgs[t * PG + n * 9 + i] = pG[n * 9 + i];
+        }
+      const int32_t s = entry_snp[e];
+      snp_ok[t] = has_gp[s] ? s : -1;
+    }
+    __syncthreads();
+    // stage the GP rows of the chunk, coalesced along the row
+    for (int idx = t; idx < nc * V3; idx += T) {
+      const int r = idx / V3, i = idx - r * V3;
+      const int32_t s = snp_ok[r];
+      if (s >= 0) rows[r * V3 + i] = gp[(size_t)s * V3 + i];
+    }
+    __syncthreads();
+    // phase 2: lane <-> pair
+    if (nmask) {
+      for (int r = 0; r < nc; ++r) {
+        if (snp_ok[r] >= 0) {  // :733
+          const double* g = rows + r * V3;
+          const double gj0 = g[j * 3], gj1 = g[j * 3 + 1], gj2 = g[j * 3 + 2];
+          const double gk0 = g[k * 3], gk1 = g[k * 3 + 1], gk2 = g[k * 3 + 2];
+          const double p00 = gj0 * gk0, p01 = gj0 * gk1, p02 = gj0 * gk2;  // :740
+          const double p10 = gj1 * gk0, p11 = gj1 * gk1, p12 = gj1 * gk2;
+          const double p20 = gj2 * gk0, p21 = gj2 * gk1, p22 = gj2 * gk2;
+          const double* q = pgs + r * PG;
+#pragma unroll
+          for (int n = 0; n < NA; ++n) {
+            if (n < nAlpha && ((nmask >> n) & 1u)) {
+              const double* qn = q + n * 9;
+              double s = p00 * qn[0];
+              s = fma(p01, qn[1], s);
+              s = fma(p02, qn[2], s);
+              s = fma(p10, qn[3], s);
+              s = fma(p11, qn[4], s);
+              s = fma(p12, qn[5], s);
+              s = fma(p20, qn[6], s);
+              s = fma(p21, qn[7], s);
+              s = fma(p22, qn[8], s);
+              acc[n] *= s;  // :746 as a product
+            }
+          }
+        }
+        if ((r & 15) == 15) {
+#pragma unroll
+          for (int n = 0; n < NA; ++n) prodacc_renorm(acc[n], ex[n]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (nmask) {
+    double* out = ll + (size_t)c * V * V * nAlpha;
+#pragma unroll
+    for (int n = 0; n < NA; ++n) {
+      if (n < nAlpha && ((nmask >> n) & 1u)) {
+        const double v = prodacc_log(acc[n], ex[n]);
+        out[((size_t)j * V + k) * nAlpha + n] = v;
+        if ((symmask >> n) & 1u) out[((size_t)k * V + j) * nAlpha + n] = v;
+      }
+    }
+  }
+}
+
+// a7-a9: cmd_cram_demuxlet.cpp:788-991, one lane per cell, the reference's scan order.
+__global__ void __launch_bounds__(64) demux_call_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv,
+                                                         int nAlpha, alpha_args al, double doublet_prior,
+                                                         const double* __restrict__ ll,
+                                                         muxgl_demux_cell* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  muxgl_demux_cell o;
+  memset(&o, 0, sizeof(o));
+  o.nsnps = (int32_t)(cell_ptr[i + 1] - cell_ptr[i]);
+  if (o.nsnps == 0) {
+    out[i] = o;
+    return;
+  }
+  o.valid = 1;
+  const double* llksAB = ll + (size_t)i * nv * nv * nAlpha;
+  const double* gridAlpha = al.a;
+  int32_t j, k, n;
+  int32_t sBest = -1, sNext = -1, dBest1 = -1, dBest2 = -1, dNext1 = -1, dNext2 = -1, dblBestAlpha = -1,
+          dblNextAlpha = -1;
+  double sngBestLLK = -1e300, sngNextLLK = -1e300;
+  double dblBestLLK = -1e300, dblNextLLK = -1e300;
+  double sumLLK = -1e-300, sngLLK = -1e-300;  // :791 (sic)
+  double bestPP = -1e300;
+  const double log_single_prior = log((1.0 - doublet_prior) / nv);
+  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
+  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
+
+  for (j = 0; j < nv; ++j) {  // :804-821 evidence, :827-837 singlet scan, :883-906 doublet scan
+    const double s = llksAB[(size_t)j * nv * nAlpha];
+    sumLLK = dev_logadd(sumLLK, s + log_single_prior);
+    sngLLK = dev_logadd(sngLLK, s + log_single_prior);
+    if (sngBestLLK < s) {
+      sngNextLLK = sngBestLLK;
+      sNext = sBest;
+      sBest = j;
+      sngBestLLK = s;
+    } else if (sngNextLLK < s) {
+      sNext = j;
+      sngNextLLK = s;
+    }
+    for (k = 0; k < nv; ++k) {
+      if (j == k) continue;
+      for (n = 1; n < nAlpha; ++n) {
+        const double v = llksAB[((size_t)j * nv + k) * nAlpha + n];
+        if (gridAlpha[n] == 0.5) {
+          if (k < j) sumLLK = dev_logadd(sumLLK, v + log_doublet_prior2);
+        } else
+          sumLLK = dev_logadd(sumLLK, v + log_doublet_prior1);
+        if (dblBestLLK < v) {
+          dNext1 = dBest1;
+          dNext2 = dBest2;
+          dblNextAlpha = dblBestAlpha;
+          dblNextLLK = dblBestLLK;
+          dBest1 = j;
+          dBest2 = k;
+          dblBestAlpha = n;
+          dblBestLLK = v;
+        } else if (dblNextLLK < v) {
+          dNext1 = j;
+          dNext2 = k;
+          dblNextAlpha = n;
+          dblNextLLK = v;
+        }
+      }
+    }
+  }
+
+  int32_t bestType, nextType, jBest, kBest, jNext, kNext, alphaBest, alphaNext;
+  double bestLLK, nextLLK;
+  if (dblBestLLK > sngBestLLK + 2) {  // :925
+    bestType = MUXGL_DBL;
+    bestPP = exp(dblBestLLK + ((gridAlpha[dblBestAlpha] == 0.5) ? log_doublet_prior2 : log_doublet_prior1) - sumLLK);
+    jBest = dBest1;
+    kBest = dBest2;
+    bestLLK = dblBestLLK;
+    alphaBest = dblBestAlpha;
+    if (dblNextLLK > sngBestLLK + 2) {
+      nextType = MUXGL_DBL;
+      jNext = dNext1;
+      kNext = dNext2;
+      nextLLK = dblNextLLK;
+      alphaNext = dblNextAlpha;
+    } else {
+      nextType = MUXGL_SNG;
+      jNext = kNext = sBest;
+      nextLLK = sngBestLLK;
+      alphaNext = 0;
+    }
+  } else {
+    bestType = (sngBestLLK > sngNextLLK + 2) ? MUXGL_SNG : MUXGL_AMB;  // :947 / :968 (same body)
+    bestPP = sngBestLLK + log_single_prior - sumLLK;                   // log value, as the reference (:949,970)
+    jBest = kBest = sBest;
+    bestLLK = sngBestLLK;
+    alphaBest = 0;
+    if (dblBestLLK > sngNextLLK + 2) {
+      nextType = MUXGL_DBL;
+      jNext = dBest1;
+      kNext = dBest2;
+      nextLLK = dblBestLLK;
+      alphaNext = dblBestAlpha;
+    } else {
+      nextType = MUXGL_SNG;
+      jNext = kNext = sNext;
+      nextLLK = sngNextLLK;
+      alphaNext = 0;
+    }
+  }
+  o.type = bestType;
+  o.next_type = nextType;
+  o.sBest = sBest;
+  o.sNext = sNext;
+  o.dBest1 = dBest1;
+  o.dBest2 = dBest2;
+  o.dBestA = dblBestAlpha;
+  o.dNext1 = dNext1;
+  o.dNext2 = dNext2;
+  o.dNextA = dblNextAlpha;
+  o.jBest = jBest;
+  o.kBest = kBest;
+  o.aBest = alphaBest;
+  o.jNext = jNext;
+  o.kNext = kNext;
+  o.aNext = alphaNext;
+  o.sngBestLLK = sngBestLLK;
+  o.sngNextLLK = sngNextLLK;
+  o.dblBestLLK = dblBestLLK;
+  o.dblNextLLK = dblNextLLK;
+  o.sumLLK = sumLLK;
+  o.sngLLK = sngLLK;
+  o.bestLLK = bestLLK;
+  o.nextLLK = nextLLK;
+  o.bestPP = bestPP;
+  o.sngPP = exp(sngLLK - sumLLK);                              // :990
+  o.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);   // :991
+  out[i] = o;
+}
+
+template <int NA>
+int launch_sweep(muxgl_handle* h, const muxgl_demux_params* p, uint32_t symmask, const alpha_args& al) {
+  const int V = h->V, A = p->n_alpha;
+  int T = ((h->n_pairs + 63) / 64) * 64;
+  if (T > 256) T = 256;
+  if (T < 64) T = 64;
+  const int tiles = (h->n_pairs + T - 1) / T;
+  int EC = (36 * 1024) / (V * 24);
+  if (EC > kMaxChunk) EC = kMaxChunk;
+  if (EC > T) EC = T;
+  if (EC < 1) EC = 1;
+  size_t lds = sizeof(double) * (256 + (size_t)EC * V * 3 + (size_t)EC * A * 9) + sizeof(int32_t) * EC;
+  if (lds > 160 * 1024) MUXGL_FAIL(h, "demux sweep needs %zu B of LDS for V=%d (max 163840)", lds, V);
+  HIPCHK(h, hipFuncSetAttribute((const void*)demux_sweep_kernel<NA>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  dim3 grid((unsigned)h->C, (unsigned)tiles);
+  hipLaunchKernelGGL(demux_sweep_kernel<NA>, grid, dim3(T), lds, h->stream, h->d_cell_ptr, h->d_entry_snp,
+                     h->d_entry_rptr, h->d_reads, h->d_gp, h->d_has_gp, h->d_lut, h->d_pairs, h->n_pairs, V, A,
+                     symmask, al, EC, h->d_ll);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+template <int NA>
+int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg) {
+  int64_t blocks = (h->nnz + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(demux_entry_pg_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->nnz,
+                     h->d_entry_rptr, h->d_reads, h->d_lut, p->n_alpha, al, d_pg);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+#define DISPATCH_NA(A, CALL)                    \
+  do {                                          \
+    if ((A) <= 2) return CALL(2);               \
+    if ((A) <= 3) return CALL(3);               \
+    if ((A) <= 4) return CALL(4);               \
+    if ((A) <= 6) return CALL(6);               \
+    if ((A) <= 8) return CALL(8);               \
+    if ((A) <= 12) return CALL(12);             \
+    return CALL(16);                            \
+  } while (0)
+
+// builds the (j,k,nmask) work list: (j,0) pairs first so that the singlet slot n=0 lives in the first wave(s)
+static int build_pairs(muxgl_handle* h, const muxgl_demux_params* p, uint32_t* symmask_out) {
+  const int V = h->V, A = p->n_alpha;
+  uint32_t symmask = 0;
+  for (int n = 1; n < A; ++n)
+    if (p->alpha[n] == 0.5) symmask |= 1u << n;
+  std::string key;
+  uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)V * V + 4);
+  int np = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int j = 0; j < V; ++j) {
+      for (int k = 0; k < V; ++k) {
+        if ((pass == 0) != (k == 0)) continue;
+        uint32_t nmask = 0;
+        if (k == 0) nmask |= 1u;  // singlet slot llksAB[j][0][0] (:806,828)
+        if (j != k) {
+          for (int n = 1; n < A; ++n) {
+            if ((symmask >> n) & 1u) {
+              if (k < j) nmask |= 1u << n;  // mirrored on store
+            } else
+              nmask |= 1u << n;
+          }
+        }
+        if (nmask) tmp[np++] = (uint32_t)j | ((uint32_t)k << 8) | (nmask << 16);
+      }
+    }
+  }
+  if (np > h->pairs_cap) {
+    if (dev_alloc(h, &h->d_pairs, (size_t)np)) {
+      free(tmp);
+      return 1;
+    }
+    h->pairs_cap = np;
+  }
+  hipError_t e = hipMemcpyAsync(h->d_pairs, tmp, sizeof(uint32_t) * np, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  free(tmp);
+  if (e != hipSuccess) MUXGL_FAIL(h, "pair list upload failed: %s", hipGetErrorString(e));
+  h->n_pairs = np;
+  *symmask_out = symmask;
+  return 0;
+}
+
+static bool same_params(const muxgl_demux_params& a, const muxgl_demux_params& b) {
+  if (a.n_alpha != b.n_alpha) return false;
+  for (int i = 0; i < a.n_alpha; ++i)
+    if (a.alpha[i] != b.alpha[i]) return false;
+  return true;
+}
+
+int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  const int A = p->n_alpha;
+  alpha_args al;
+  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : 0.0;
+  uint32_t symmask = 0;
+  for (int n = 1; n < A; ++n)
+    if (p->alpha[n] == 0.5) symmask |= 1u << n;
+  if (!h->have_dp || !same_params(h->last_dp, *p)) {
+    if (build_pairs(h, p, &symmask)) return 1;
+    h->last_dp = *p;
+    h->have_dp = true;
+    h->ll_zeroed = false;
+  }
+  // LL tensor [C][V][V][A]; slots the sweep never writes must read 0
+  const size_t need = (size_t)h->C * h->V * h->V * A;
+  if (need > h->ll_cap) {
+    if (dev_alloc(h, &h->d_ll, need)) return 1;
+    h->ll_cap = need;
+    h->ll_zeroed = false;
+  }
+  if (!h->ll_zeroed) {
+    HIPCHK(h, hipMemsetAsync(h->d_ll, 0, sizeof(double) * (need ? need : 1), h->stream));
+    h->ll_zeroed = true;
+  }
+  tic(h, MUXGL_T_DEMUX_SWEEP);
+#define CALL_SWEEP(N) launch_sweep<N>(h, p, symmask, al)
+  int rc = [&]() -> int { DISPATCH_NA(A, CALL_SWEEP); }();
+#undef CALL_SWEEP
+  if (rc) return rc;
+  toc(h, MUXGL_T_DEMUX_SWEEP);
+
+  tic(h, MUXGL_T_DEMUX_CALL);
+  const unsigned blocks = (unsigned)((h->C + 63) / 64);
+  hipLaunchKernelGGL(demux_call_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
+                     A, al, p->doublet_prior, h->d_ll, h->d_dcells);
+  HIPCHK(h, hipGetLastError());
+  toc(h, MUXGL_T_DEMUX_CALL);
+  return 0;
+}
+
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg) {
+  const int A = p->n_alpha;
+  alpha_args al;
+  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : 0.0;
+#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg)
+  DISPATCH_NA(A, CALL_PG);
+#undef CALL_PG
+}

@@ -1,0 +1,235 @@
+// muxgl_api.hip -- the C-ABI of include/muxgl.h: handle lifetime, hand-over of the packed pileup and GP tensor to
+// device memory, and the synchronous run/iterate entry points.  No CPU fallback: every compute call needs a HIP device.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+thread_local std::string g_muxgl_create_error;
+
+extern "C" {
+
+int muxgl_version(void) { return MUXGL_VERSION; }
+
+const char* muxgl_last_error(const muxgl_handle* h) { return h ? h->err.c_str() : g_muxgl_create_error.c_str(); }
+
+int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
+  if (!out) {
+    g_muxgl_create_error = "muxgl_create: out is NULL";
+    return 1;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_muxgl_create_error = std::string("muxgl_create: no HIP device available (") +
+                           (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                           "); libmuxgl has no CPU fallback";
+    return 1;
+  }
+  const int dev = cfg ? cfg->device_id : 0;
+  if (dev < 0 || dev >= ndev) {
+    g_muxgl_create_error = "muxgl_create: device_id out of range";
+    return 1;
+  }
+  muxgl_handle* h = new muxgl_handle();
+  h->device = dev;
+  auto fail = [&](const char* what, hipError_t err) {
+    g_muxgl_create_error = std::string("muxgl_create: ") + what + ": " + hipGetErrorString(err);
+    delete h;
+    return 1;
+  };
+  if ((e = hipSetDevice(dev)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
+    if ((e = hipEventCreate(&h->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+
+  // Phred tables, PhredHelper.cpp:24-41: phred2Err[i] = (i > 1) ? pow(0.1, i*0.1) : 0.75; phred2Mat = 1 - Err.
+  // The packed read byte carries 7 bits of quality, so 128 entries of each suffice.
+  double lut[256];
+  for (int i = 0; i < 128; ++i) {
+    lut[i] = (i > 1) ? pow(0.1, i * 0.1) : 0.75;
+    lut[128 + i] = 1. - lut[i];
+  }
+  if ((e = hipMalloc((void**)&h->d_lut, sizeof(lut))) != hipSuccess) return fail("hipMalloc(lut)", e);
+  if ((e = hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(lut)", e);
+  if ((e = hipMalloc((void**)&h->d_fstat, 4 * sizeof(int32_t))) != hipSuccess) return fail("hipMalloc(stat)", e);
+  *out = h;
+  return 0;
+}
+
+void muxgl_destroy(muxgl_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  dev_free(&h->d_cell_ptr);
+  dev_free(&h->d_entry_snp);
+  dev_free(&h->d_entry_rptr);
+  dev_free(&h->d_reads);
+  dev_free(&h->d_entry_cell);
+  dev_free(&h->d_lut);
+  dev_free(&h->d_gp);
+  dev_free(&h->d_has_gp);
+  dev_free(&h->d_ll);
+  dev_free(&h->d_dcells);
+  dev_free(&h->d_pairs);
+  dev_free(&h->d_af);
+  dev_free(&h->d_egls);
+  dev_free(&h->d_ecnt);
+  dev_free(&h->d_cgls);
+  dev_free(&h->d_ccnt);
+  dev_free(&h->d_cgp);
+  dev_free(&h->d_clust);
+  dev_free(&h->d_fcells);
+  dev_free(&h->d_fll);
+  dev_free(&h->d_fstat);
+  dev_free(&h->d_snp_ptr);
+  dev_free(&h->d_snp_entry);
+  if (h->h_dcells) (void)hipHostFree(h->h_dcells);
+  if (h->h_fcells) (void)hipHostFree(h->h_fcells);
+  for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                     const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (C < 0 || S < 0 || nnz < 0 || R < 0) MUXGL_FAIL(h, "muxgl_set_pileup: negative size");
+  if (!cell_ptr || !entry_rptr || (nnz > 0 && !entry_snp) || (R > 0 && !reads))
+    MUXGL_FAIL(h, "muxgl_set_pileup: NULL array");
+  if (S > INT32_MAX) MUXGL_FAIL(h, "muxgl_set_pileup: S exceeds int32");
+  // structural validation (the reference's containers make these states unrepresentable)
+  if (cell_ptr[0] != 0 || cell_ptr[C] != nnz) MUXGL_FAIL(h, "muxgl_set_pileup: cell_ptr must span [0,nnz]");
+  if (entry_rptr[0] != 0 || entry_rptr[nnz] != R) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr must span [0,R]");
+  int64_t maxlen = 0;
+  for (int64_t c = 0; c < C; ++c) {
+    const int64_t len = cell_ptr[c + 1] - cell_ptr[c];
+    if (len < 0) MUXGL_FAIL(h, "muxgl_set_pileup: cell_ptr not monotone at cell %lld", (long long)c);
+    if (len > maxlen) maxlen = len;
+    for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; ++e) {
+      if (entry_snp[e] < 0 || entry_snp[e] >= S)
+        MUXGL_FAIL(h, "muxgl_set_pileup: entry %lld has SNP id %d outside [0,%lld)", (long long)e, entry_snp[e],
+                   (long long)S);
+      if (e > cell_ptr[c] && entry_snp[e] <= entry_snp[e - 1])
+        MUXGL_FAIL(h, "muxgl_set_pileup: SNP ids of cell %lld are not strictly ascending", (long long)c);
+    }
+  }
+  for (int64_t e = 0; e < nnz; ++e)
+    if (entry_rptr[e + 1] < entry_rptr[e]) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr not monotone at %lld", (long long)e);
+
+  h->C = C;
+  h->S = S;
+  h->nnz = nnz;
+  h->R = R;
+  h->max_cell_entries = maxlen;
+  if (dev_alloc(h, &h->d_cell_ptr, (size_t)C + 1)) return 1;
+  if (dev_alloc(h, &h->d_entry_snp, (size_t)nnz)) return 1;
+  if (dev_alloc(h, &h->d_entry_rptr, (size_t)nnz + 1)) return 1;
+  if (dev_alloc(h, &h->d_reads, (size_t)R)) return 1;
+  HIPCHK(h, hipMemcpyAsync(h->d_cell_ptr, cell_ptr, sizeof(int64_t) * (C + 1), hipMemcpyHostToDevice, h->stream));
+  if (nnz) HIPCHK(h, hipMemcpyAsync(h->d_entry_snp, entry_snp, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_entry_rptr, entry_rptr, sizeof(int64_t) * (nnz + 1), hipMemcpyHostToDevice, h->stream));
+  if (R) HIPCHK(h, hipMemcpyAsync(h->d_reads, reads, (size_t)R, hipMemcpyHostToDevice, h->stream));
+
+  // per-cell result buffers
+  if (C > h->dcells_cap) {
+    if (dev_alloc(h, &h->d_dcells, (size_t)C)) return 1;
+    if (dev_alloc(h, &h->d_fcells, (size_t)C)) return 1;
+    if (dev_alloc(h, &h->d_clust, (size_t)C)) return 1;
+    if (h->h_dcells) (void)hipHostFree(h->h_dcells);
+    if (h->h_fcells) (void)hipHostFree(h->h_fcells);
+    h->h_dcells = nullptr;
+    h->h_fcells = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_dcells, sizeof(muxgl_demux_cell) * (size_t)(C ? C : 1)));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_fcells, sizeof(muxgl_fmx_cell) * (size_t)(C ? C : 1)));
+    h->dcells_cap = C;
+  }
+  h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
+  h->fmx_prepared = false;
+  h->K = 0;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8_t* has_gp) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (V < 1 || V > 255) MUXGL_FAIL(h, "muxgl_demux_set_gp: V=%d outside [1,255]", V);
+  if (!gp || !has_gp) MUXGL_FAIL(h, "muxgl_demux_set_gp: NULL array");
+  if (h->S <= 0 && h->nnz > 0) MUXGL_FAIL(h, "muxgl_demux_set_gp: call muxgl_set_pileup first");
+  const size_t n = (size_t)h->S * V * 3;
+  if (dev_alloc(h, &h->d_gp, n)) return 1;
+  if (dev_alloc(h, &h->d_has_gp, (size_t)h->S)) return 1;
+  if (n) HIPCHK(h, hipMemcpyAsync(h->d_gp, gp, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  if (h->S) HIPCHK(h, hipMemcpyAsync(h->d_has_gp, has_gp, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
+  h->V = V;
+  h->have_dp = false;
+  h->ll_zeroed = false;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int check_demux_params(muxgl_handle* h, const muxgl_demux_params* p) {
+  if (!p) MUXGL_FAIL(h, "demux params NULL");
+  if (p->n_alpha < 1 || p->n_alpha > MUXGL_MAX_ALPHA)
+    MUXGL_FAIL(h, "n_alpha=%d outside [1,%d]", p->n_alpha, MUXGL_MAX_ALPHA);
+  if (!h->d_cell_ptr) MUXGL_FAIL(h, "no pileup set (muxgl_set_pileup)");
+  if (!h->d_gp) MUXGL_FAIL(h, "no GP tensor set (muxgl_demux_set_gp)");
+  return 0;
+}
+
+int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_cell* out, double* full_ll) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (check_demux_params(h, p)) return 1;
+  clear_timing(h);
+  if (h->C > 0) {
+    if (demux_launch(h, p)) return 1;
+    tic(h, MUXGL_T_DEMUX_D2H);
+    HIPCHK(h, hipMemcpyAsync(h->h_dcells, h->d_dcells, sizeof(muxgl_demux_cell) * (size_t)h->C, hipMemcpyDeviceToHost,
+                             h->stream));
+    toc(h, MUXGL_T_DEMUX_D2H);
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  if (out && h->C) memcpy(out, h->h_dcells, sizeof(muxgl_demux_cell) * (size_t)h->C);
+  if (full_ll && h->C)
+    HIPCHK(h, hipMemcpy(full_ll, h->d_ll, sizeof(double) * (size_t)h->C * h->V * h->V * p->n_alpha,
+                        hipMemcpyDeviceToHost));
+  return 0;
+}
+
+const muxgl_demux_cell* muxgl_demux_results(const muxgl_handle* h) { return h ? h->h_dcells : nullptr; }
+
+int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->have_dp) MUXGL_FAIL(h, "muxgl_demux_get_entry_pg: no previous muxgl_demux_run");
+  if (!pg) MUXGL_FAIL(h, "muxgl_demux_get_entry_pg: NULL output");
+  const size_t n = (size_t)h->nnz * h->last_dp.n_alpha * 9;
+  double* d_pg = nullptr;
+  if (dev_alloc(h, &d_pg, n)) return 1;
+  int rc = demux_entry_pg_launch(h, &h->last_dp, d_pg);
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && n) e = hipMemcpy(pg, d_pg, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      h->err = std::string("muxgl_demux_get_entry_pg: ") + hipGetErrorString(e);
+      rc = 1;
+    }
+  }
+  dev_free(&d_pg);
+  return rc;
+}
+
+int muxgl_get_timing(const muxgl_handle* h, float* ms) {
+  if (!h || !ms) return 1;
+  memcpy(ms, h->ms, sizeof(float) * MUXGL_T_COUNT);
+  return 0;
+}
+
+}  // extern "C"

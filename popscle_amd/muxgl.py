@@ -1,0 +1,248 @@
+"""ctypes binding of libmuxgl.so (include/muxgl.h).
+
+This is plumbing: it loads the in-tree shared library, mirrors the C structs as numpy dtypes and checks return
+codes.  There is no Python or CPU implementation of the hot path behind it -- if the library is missing, or no HIP
+device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmuxgl.so")
+
+MAX_ALPHA = 16
+READ_OTHER = 0xFF
+SNG, DBL, AMB = 0, 1, 2
+TYPE_NAMES = {SNG: "SNG", DBL: "DBL", AMB: "AMB"}
+
+# timing slots of muxgl_get_timing
+T_DEMUX_ENTRY, T_DEMUX_SWEEP, T_DEMUX_CALL, T_DEMUX_D2H = 0, 1, 2, 3
+T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
+T_COUNT = 16
+
+DEMUX_CELL = np.dtype(
+    [(n, np.int32) for n in ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA",
+                             "dNext1", "dNext2", "dNextA", "jBest", "kBest", "aBest", "jNext", "kNext", "aNext")]
+    + [(n, np.float64) for n in ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK", "sumLLK", "sngLLK",
+                                 "bestLLK", "nextLLK", "bestPP", "sngPP", "sngOnlyPP")],
+    align=True,
+)
+FMX_CELL = np.dtype(
+    [(n, np.int32) for n in ("type", "clust", "jBest", "kBest", "jNext", "kNext", "sBest", "sNext", "dBest1",
+                             "dBest2", "dNext1", "dNext2")]
+    + [(n, np.float64) for n in ("bestLLK", "nextLLK", "sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK",
+                                 "bestPP", "sngPP", "sngOnlyPP", "sumLLK")],
+    align=True,
+)
+assert DEMUX_CELL.itemsize == 18 * 4 + 11 * 8
+assert FMX_CELL.itemsize == 12 * 4 + 10 * 8
+
+
+class _Config(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("flags", C.c_int32)]
+
+
+class _DemuxParams(C.Structure):
+    _fields_ = [("n_alpha", C.c_int32), ("_pad", C.c_int32), ("alpha", C.c_double * MAX_ALPHA),
+                ("doublet_prior", C.c_double)]
+
+
+class _FmxParams(C.Structure):
+    _fields_ = [("doublet_prior", C.c_double), ("geno_error", C.c_double)]
+
+
+# every symbol include/muxgl.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = {
+    "muxgl_version": (C.c_int, []),
+    "muxgl_create": (C.c_int, [C.POINTER(_Config), C.POINTER(_VP)]),
+    "muxgl_destroy": (None, [_VP]),
+    "muxgl_last_error": (C.c_char_p, [_VP]),
+    "muxgl_set_pileup": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP]),
+    "muxgl_demux_set_gp": (C.c_int, [_VP, C.c_int32, _VP, _VP]),
+    "muxgl_demux_run": (C.c_int, [_VP, C.POINTER(_DemuxParams), _VP, _VP]),
+    "muxgl_demux_results": (_VP, [_VP]),
+    "muxgl_demux_get_entry_pg": (C.c_int, [_VP, _VP]),
+    "muxgl_fmx_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "muxgl_fmx_get_entry_gls": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
+    "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
+    "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_get_timing": (C.c_int, [_VP, _VP]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libmuxgl.so and attach prototypes.  Raises if the in-tree build is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build it with `python -m popscle_amd.build` (hipcc, gfx950); "
+                           "there is no fallback implementation")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class MuxglError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_VP)
+
+
+def _arr(a, dtype, name):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.dtype != np.dtype(dtype):
+        raise TypeError(name)
+    return a
+
+
+class Engine:
+    """One muxgl handle = one GPU.  Methods mirror the C-ABI one to one."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        self.h = _VP()
+        cfg = _Config(device_id, 0)
+        if self.lib.muxgl_create(C.byref(cfg), C.byref(self.h)) != 0:
+            raise MuxglError(self.lib.muxgl_last_error(None).decode())
+        self.C = self.S = self.nnz = self.R = 0
+        self.V = 0
+        self.K = 0
+        self.n_alpha = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.muxgl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MuxglError(self.lib.muxgl_last_error(self.h).decode())
+
+    # ---- pileup
+    def set_pileup(self, S, cell_ptr, entry_snp, entry_rptr, reads):
+        cell_ptr = _arr(cell_ptr, np.int64, "cell_ptr")
+        entry_snp = _arr(entry_snp, np.int32, "entry_snp")
+        entry_rptr = _arr(entry_rptr, np.int64, "entry_rptr")
+        reads = _arr(reads, np.uint8, "reads")
+        C_ = cell_ptr.size - 1
+        nnz = entry_snp.size
+        R = reads.size
+        if entry_rptr.size != nnz + 1:
+            raise ValueError("entry_rptr must have nnz+1 elements")
+        self._check(self.lib.muxgl_set_pileup(self.h, C_, int(S), nnz, R, _ptr(cell_ptr), _ptr(entry_snp),
+                                               _ptr(entry_rptr), _ptr(reads)))
+        self.C, self.S, self.nnz, self.R = C_, int(S), nnz, R
+
+    # ---- demuxlet
+    def demux_set_gp(self, gp, has_gp):
+        gp = _arr(gp, np.float64, "gp")
+        has_gp = _arr(has_gp, np.uint8, "has_gp")
+        if gp.ndim != 3 or gp.shape[0] != self.S or gp.shape[2] != 3 or has_gp.shape != (self.S,):
+            raise ValueError("gp must be [S][V][3] and has_gp [S]")
+        self._check(self.lib.muxgl_demux_set_gp(self.h, gp.shape[1], _ptr(gp), _ptr(has_gp)))
+        self.V = gp.shape[1]
+
+    def demux_run(self, alphas=(0.0, 0.5), doublet_prior=0.5, want_cells=True, want_full_ll=False):
+        p = _DemuxParams()
+        p.n_alpha = len(alphas)
+        if len(alphas) > MAX_ALPHA:
+            raise ValueError("too many alphas")
+        for i, a in enumerate(alphas):
+            p.alpha[i] = float(a)
+        p.doublet_prior = float(doublet_prior)
+        out = np.zeros(self.C, dtype=DEMUX_CELL) if want_cells else None
+        full = np.zeros((self.C, self.V, self.V, len(alphas)), dtype=np.float64) if want_full_ll else None
+        self._check(self.lib.muxgl_demux_run(self.h, C.byref(p), _ptr(out), _ptr(full)))
+        self.n_alpha = len(alphas)
+        if want_full_ll:
+            return out, full
+        return out
+
+    def demux_results_view(self):
+        """zero-copy view of the pinned [C] record buffer of the last run"""
+        p = self.lib.muxgl_demux_results(self.h)
+        buf = (C.c_char * (self.C * DEMUX_CELL.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=DEMUX_CELL, count=self.C)
+
+    def demux_entry_pg(self):
+        pg = np.zeros((self.nnz, self.n_alpha, 3, 3), dtype=np.float64)
+        self._check(self.lib.muxgl_demux_get_entry_pg(self.h, _ptr(pg)))
+        return pg
+
+    # ---- freemuxlet
+    def fmx_prepare(self, af):
+        af = _arr(af, np.float64, "af")
+        if af.shape != (self.S,):
+            raise ValueError("af must be [S]")
+        llk0 = np.zeros(self.C)
+        llk2 = np.zeros(self.C)
+        nsnps = np.zeros(self.C, dtype=np.int32)
+        nreads = np.zeros(self.C, dtype=np.int32)
+        self._check(self.lib.muxgl_fmx_prepare(self.h, _ptr(af), _ptr(llk0), _ptr(llk2), _ptr(nsnps), _ptr(nreads)))
+        return llk0, llk2, nsnps, nreads
+
+    def fmx_entry_gls(self):
+        gls = np.zeros((self.nnz, 9))
+        cnt = np.zeros((self.nnz, 3), dtype=np.int32)
+        self._check(self.lib.muxgl_fmx_get_entry_gls(self.h, _ptr(gls), _ptr(cnt)))
+        return gls, cnt
+
+    def fmx_set_clusters(self, K, clust):
+        clust = _arr(clust, np.int32, "clust")
+        if clust.shape != (self.C,):
+            raise ValueError("clust must be [C]")
+        self._check(self.lib.muxgl_fmx_set_clusters(self.h, int(K), _ptr(clust)))
+        self.K = int(K)
+
+    def fmx_iterate(self, doublet_prior=0.5, geno_error=0.1, want_cells=True, want_full_ll=False):
+        p = _FmxParams(float(doublet_prior), float(geno_error))
+        out = np.zeros(self.C, dtype=FMX_CELL) if want_cells else None
+        full = np.zeros((self.C, self.K * (self.K + 1) // 2)) if want_full_ll else None
+        ns, na, nc = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.muxgl_fmx_iterate(self.h, C.byref(p), _ptr(out), C.byref(ns), C.byref(na), C.byref(nc),
+                                                _ptr(full)))
+        stats = (ns.value, na.value, nc.value)
+        if want_full_ll:
+            return out, stats, full
+        return out, stats
+
+    def fmx_cluster_pileup(self):
+        gls = np.zeros((self.K, self.S, 9))
+        cnt = np.zeros((self.K, self.S, 3), dtype=np.int32)
+        self._check(self.lib.muxgl_fmx_get_cluster_pileup(self.h, _ptr(gls), _ptr(cnt)))
+        return gls, cnt
+
+    # ---- measurement
+    def timing(self):
+        ms = np.zeros(T_COUNT, dtype=np.float32)
+        self._check(self.lib.muxgl_get_timing(self.h, _ptr(ms)))
+        return ms

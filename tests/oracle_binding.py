@@ -1,0 +1,167 @@
+"""ctypes binding of the CPU oracle (oracle/libmuxgl_oracle.so).  TEST INFRASTRUCTURE: importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg only -- never from popscle_amd/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libmuxgl_oracle.so")
+REF_PHRED_SO = os.path.join(ORACLE_DIR, "_ref", "libphred_ref.so")
+
+DEMUX_CELL = np.dtype(
+    [(n, np.int32) for n in ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA",
+                             "dNext1", "dNext2", "dNextA", "jBest", "kBest", "aBest", "jNext", "kNext", "aNext")]
+    + [(n, np.float64) for n in ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK", "sumLLK", "sngLLK",
+                                 "bestLLK", "nextLLK", "bestPP", "sngPP", "sngOnlyPP")],
+    align=True,
+)
+FMX_CELL = np.dtype(
+    [(n, np.int32) for n in ("type", "clust", "jBest", "kBest", "jNext", "kNext", "sBest", "sNext", "dBest1",
+                             "dBest2", "dNext1", "dNext2")]
+    + [(n, np.float64) for n in ("bestLLK", "nextLLK", "sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK",
+                                 "bestPP", "sngPP", "sngOnlyPP", "sumLLK")],
+    align=True,
+)
+PLP = np.dtype([("nreads", np.int32), ("nref", np.int32), ("nalt", np.int32), ("_pad", np.int32),
+                ("gls", np.float64, (9,))], align=True)
+assert PLP.itemsize == 16 + 72
+
+_VP = C.c_void_p
+_lib = None
+
+
+def build():
+    """(re)build the oracle with gcc; also builds oracle/_ref when /root/reference is present"""
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        _lib = C.CDLL(ORACLE_SO)
+        _lib.oracle_logadd.restype = C.c_double
+        _lib.oracle_logadd.argtypes = [C.c_double, C.c_double]
+        _lib.oracle_fmx_iterate.restype = C.c_int32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_VP)
+
+
+def phred_tables():
+    err = np.zeros(256)
+    mat = np.zeros(256)
+    lib().oracle_phred_tables(_p(err), _p(mat))
+    return err, mat
+
+
+def ref_phred_tables():
+    """phred2Err / phred2Mat of the reference's own PhredHelper.cpp (global object `phredConv`,
+    members in declaration order PhredHelper.h:27-33: Err, Prob, Mat, Mat3, LogMat, LogMat3, HalfLogMat3)"""
+    ref = C.CDLL(REF_PHRED_SO)
+    arr = (C.c_double * (256 * 7)).in_dll(ref, "phredConv")
+    a = np.frombuffer(arr, dtype=np.float64).copy()
+    return a[0:256], a[512:768]
+
+
+def logadd(a, b):
+    return lib().oracle_logadd(float(a), float(b))
+
+
+def demux_entry_pg(reads, alphas):
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    out = np.zeros(al.size * 9)
+    lib().oracle_demux_entry_pg(_p(reads), C.c_int64(reads.size), C.c_int32(al.size), _p(al), _p(out))
+    return out.reshape(al.size, 3, 3)
+
+
+def demux(plp, alphas=(0.0, 0.5), doublet_prior=0.5, full_ll=False, nthreads=1):
+    """oracle demuxlet over a popscle_amd.synth.Pileup-like object (needs gp/has_gp)"""
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    V = plp.gp.shape[1]
+    out = np.zeros(plp.C, dtype=DEMUX_CELL)
+    full = np.zeros((plp.C, V, V, al.size)) if full_ll else None
+    gp = np.ascontiguousarray(plp.gp, dtype=np.float64)
+    hg = np.ascontiguousarray(plp.has_gp, dtype=np.uint8)
+    rc = lib().oracle_demux(C.c_int64(plp.C), C.c_int64(plp.S), C.c_int32(V), _p(plp.cell_ptr), _p(plp.entry_snp),
+                            _p(plp.entry_rptr), _p(plp.reads), _p(gp), _p(hg), C.c_int32(al.size), _p(al),
+                            C.c_double(doublet_prior), _p(out), _p(full), C.c_int32(nthreads))
+    assert rc == 0
+    return (out, full) if full_ll else out
+
+
+def fmx_entry_pileup(plp):
+    out = np.zeros(plp.nnz, dtype=PLP)
+    lib().oracle_fmx_entry_pileup(C.c_int64(plp.nnz), _p(plp.entry_rptr), _p(plp.reads), _p(out))
+    return out
+
+
+def plp_merge(dst, src):
+    """dst, src: PLP scalars (arrays of shape (1,))"""
+    lib().oracle_plp_merge(_p(dst), _p(src))
+
+
+def fmx_cell_scores(plp, eplp):
+    llk0 = np.zeros(plp.C)
+    llk2 = np.zeros(plp.C)
+    ns = np.zeros(plp.C, dtype=np.int32)
+    nr = np.zeros(plp.C, dtype=np.int32)
+    af = np.ascontiguousarray(plp.af, dtype=np.float64)
+    lib().oracle_fmx_cell_scores(C.c_int64(plp.C), _p(plp.cell_ptr), _p(plp.entry_snp), _p(eplp), _p(af), _p(llk0),
+                                 _p(llk2), _p(ns), _p(nr))
+    return llk0, llk2, ns, nr
+
+
+def fmx_sort(scores):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    order = np.zeros(scores.size, dtype=np.int32)
+    lib().oracle_fmx_sort(C.c_int64(scores.size), _p(scores), _p(order))
+    return order
+
+
+def fmx_greedy_init(plp, eplp, K, scores, order, frac_init_clust=1.0, singlet_score_thres=-1e300):
+    clust = np.zeros(plp.C, dtype=np.int32)
+    af = np.ascontiguousarray(plp.af, dtype=np.float64)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    lib().oracle_fmx_greedy_init(C.c_int64(plp.C), C.c_int64(plp.S), C.c_int32(K), _p(plp.cell_ptr),
+                                 _p(plp.entry_snp), _p(eplp), _p(af), _p(scores), _p(order),
+                                 C.c_double(frac_init_clust), C.c_double(singlet_score_thres), _p(clust))
+    return clust
+
+
+def fmx_build_cluster_pileup(plp, eplp, K, clust):
+    cplp = np.zeros((K, plp.S), dtype=PLP)
+    clust = np.ascontiguousarray(clust, dtype=np.int32)
+    lib().oracle_fmx_build_cluster_pileup(C.c_int64(plp.C), C.c_int64(plp.S), C.c_int32(K), _p(plp.cell_ptr),
+                                          _p(plp.entry_snp), _p(eplp), _p(clust), _p(cplp))
+    return cplp
+
+
+def fmx_init_cells(clust):
+    clust = np.ascontiguousarray(clust, dtype=np.int32)
+    cells = np.zeros(clust.size, dtype=FMX_CELL)
+    lib().oracle_fmx_init_cells(C.c_int64(clust.size), _p(clust), _p(cells))
+    return cells
+
+
+def fmx_iterate(plp, eplp, K, cplp, cells, doublet_prior=0.5, geno_error=0.1, full_ll=False, nthreads=1):
+    """one EM iteration in place on cplp/cells; returns (nsingle, namb, nchanged[, full_ll])"""
+    af = np.ascontiguousarray(plp.af, dtype=np.float64)
+    ns, na = C.c_int32(), C.c_int32()
+    full = np.zeros((plp.C, K * (K + 1) // 2)) if full_ll else None
+    nch = lib().oracle_fmx_iterate(C.c_int64(plp.C), C.c_int64(plp.S), C.c_int32(K), _p(plp.cell_ptr),
+                                   _p(plp.entry_snp), _p(eplp), _p(af), C.c_double(doublet_prior),
+                                   C.c_double(geno_error), _p(cplp), _p(cells), C.byref(ns), C.byref(na), _p(full),
+                                   C.c_int32(nthreads))
+    if full_ll:
+        return ns.value, na.value, nch, full
+    return ns.value, na.value, nch

@@ -1,0 +1,97 @@
+"""CPU checks of the drop-in boundary: the in-tree C-ABI library loads and exports every symbol include/muxgl.h
+declares, the ctypes struct mirrors match the header's layout, and compute calls fail loudly without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from popscle_amd import muxgl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "muxgl.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(muxgl.LIB_PATH):
+        from popscle_amd.build import build_lib
+
+        build_lib()
+    return muxgl.load_library()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(muxgl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/muxgl.h but not exported by libmuxgl.so"
+    # and the binding knows every one of them
+    assert set(names) == set(muxgl.SYMBOLS)
+
+
+def test_version(lib):
+    assert lib.muxgl_version() == 1
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """compile a tiny C program against include/muxgl.h and compare sizeof/offsetof with the numpy/ctypes mirrors"""
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "muxgl.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu %zu\\n", sizeof(muxgl_demux_cell), sizeof(muxgl_fmx_cell), sizeof(muxgl_demux_params), sizeof(muxgl_fmx_params));\n'
+        'printf("%zu %zu %zu\\n", offsetof(muxgl_demux_cell, sngBestLLK), offsetof(muxgl_demux_cell, sngOnlyPP), offsetof(muxgl_fmx_cell, bestLLK));\n'
+        'printf("%zu %zu\\n", offsetof(muxgl_demux_params, alpha), offsetof(muxgl_demux_params, doublet_prior));\n'
+        "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    vals = list(map(int, out))
+    assert vals[0] == muxgl.DEMUX_CELL.itemsize
+    assert vals[1] == muxgl.FMX_CELL.itemsize
+    assert vals[2] == ctypes.sizeof(muxgl._DemuxParams)
+    assert vals[3] == ctypes.sizeof(muxgl._FmxParams)
+    assert vals[4] == muxgl.DEMUX_CELL.fields["sngBestLLK"][1]
+    assert vals[5] == muxgl.DEMUX_CELL.fields["sngOnlyPP"][1]
+    assert vals[6] == muxgl.FMX_CELL.fields["bestLLK"][1]
+    assert vals[7] == muxgl._DemuxParams.alpha.offset
+    assert vals[8] == muxgl._DemuxParams.doublet_prior.offset
+
+
+def test_oracle_and_library_records_share_a_layout():
+    import oracle_binding as ob
+
+    assert ob.DEMUX_CELL == muxgl.DEMUX_CELL
+    assert ob.FMX_CELL == muxgl.FMX_CELL
+
+
+def test_no_cpu_fallback(lib):
+    """without a HIP device the product path must fail loudly, not route anywhere else"""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    with pytest.raises(muxgl.MuxglError, match="no HIP device|no CPU fallback|hip"):
+        muxgl.Engine(0)
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(ROOT, "popscle_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"

@@ -1,0 +1,194 @@
+"""GPU parity tests of the demuxlet path: libmuxgl (HIP, through the C-ABI) vs the CPU oracle and the golden vectors.
+
+Bar: calls exact (unordered pairs at alpha 0.5, see tests/parity.py), log-likelihoods within 1e-5 absolute.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+from popscle_amd import muxgl, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+GRID6 = (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = muxgl.Engine(0)
+    yield e
+    e.close()
+
+
+def run_gpu(eng, p, alphas, doublet_prior=0.5, full=False):
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    eng.demux_set_gp(p.gp, p.has_gp)
+    return eng.demux_run(alphas, doublet_prior, want_full_ll=full)
+
+
+@pytest.mark.parametrize("name", ["demux_v4_a2", "demux_v4_a6", "demux_v16_a2"])
+def test_golden(eng, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    p = synth.Pileup(int(z["C"]), int(z["S"]), z["cell_ptr"], z["entry_snp"], z["entry_rptr"], z["reads"], z["af"],
+                     z["gp"], z["has_gp"])
+    alphas = tuple(z["alphas"])
+    got, full = run_gpu(eng, p, alphas, float(z["doublet_prior"]), full=True)
+    rep = parity.compare_demux(got, z["cells"], alphas)
+    worst = parity.compare_full_ll(full, z["full_ll"], p.gp.shape[1], alphas)
+    assert rep["max_abs_ll_diff"] < 1e-8 and worst < 1e-8  # expected ~1e-11; the bar is 1e-5
+
+
+@pytest.mark.parametrize("V,alphas,C,S,ment", [
+    (4, (0.0, 0.5), 200, 2000, 300),
+    (4, GRID6, 120, 2000, 300),
+    (16, (0.0, 0.5), 150, 5000, 600),
+    (16, GRID6, 60, 5000, 600),
+    (3, (0.0, 0.25, 0.5, 0.75), 80, 1000, 200),   # a non-0.5 alpha after 0.5, and 0.75
+    (2, (0.0, 0.5), 80, 1000, 200),
+    (1, (0.0, 0.5), 20, 500, 100),                # nv-1 == 0: infinite doublet prior, no doublet hypotheses
+    (5, (0.0,), 40, 800, 150),                    # nAlpha == 1 (reference quirk: division by nAlpha-1 == 0)
+    (7, (0.0, 0.3), 60, 1500, 200),               # no symmetric alpha at all
+    (33, (0.0, 0.5), 30, 4000, 400),              # more pairs than one 256-thread tile
+    (64, GRID6, 12, 6000, 500),                   # config-3 shape, few cells
+])
+def test_random_vs_oracle(eng, V, alphas, C, S, ment):
+    p = synth.make_pileup(C, S, V, seed=1000 + V * 7 + len(alphas), mean_entries=ment, min_entries=20,
+                          missing_gp_frac=0.03)
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
+    got, gfull = run_gpu(eng, p, alphas, full=True)
+    rep = parity.compare_demux(got, want, alphas)
+    worst = parity.compare_full_ll(gfull, wfull, V, alphas)
+    assert rep["max_abs_ll_diff"] < 1e-7 and worst < 1e-7
+    # slots the reference never reads stay 0 in the returned tensor
+    assert np.all(gfull[:, ~parity.needed_ll_mask(V, alphas)] == 0.0)
+
+
+def test_entry_pg_vs_oracle(eng):
+    p = synth.make_pileup(30, 800, 4, seed=77, mean_entries=100, min_entries=10, reads_lambda=2.5, other=0.05)
+    for alphas in [(0.0, 0.5), GRID6]:
+        run_gpu(eng, p, alphas)
+        pg = eng.demux_entry_pg()
+        for e in range(0, p.nnz, 17):
+            want = ob.demux_entry_pg(p.reads[p.entry_rptr[e]:p.entry_rptr[e + 1]], alphas)
+            assert np.allclose(pg[e], want, rtol=1e-13, atol=1e-24)
+
+
+def test_ragged_and_edge_inputs(eng):
+    """empty cells, entries without reads, entries with only 'other' alleles, SNPs without GP, one very deep entry,
+    one cell longer than several chunks"""
+    rng = np.random.default_rng(5)
+    S, V = 600, 5
+    base = synth.make_pileup(6, S, V, seed=31, mean_entries=120, min_entries=40)
+    lens = [0, 1, 3, 500, 0, 70, 0]
+    cell_ptr = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=cell_ptr[1:])
+    nnz = int(cell_ptr[-1])
+    entry_snp = np.concatenate([np.sort(rng.choice(S, n, replace=False)) for n in lens]).astype(np.int32)
+    nreads = rng.integers(0, 4, size=nnz)
+    nreads[5] = 300  # deep entry
+    nreads[7] = 0
+    entry_rptr = np.zeros(nnz + 1, dtype=np.int64)
+    np.cumsum(nreads, out=entry_rptr[1:])
+    R = int(entry_rptr[-1])
+    reads = ((rng.integers(0, 2, R) << 7) | rng.integers(13, 21, R)).astype(np.uint8)
+    reads[rng.random(R) < 0.1] = 0xFF
+    reads[entry_rptr[9]:entry_rptr[10]] = 0xFF  # an entry with only 'other' alleles
+    has_gp = base.has_gp.copy()
+    has_gp[entry_snp[4:40:5]] = 0
+    p = synth.Pileup(len(lens), S, cell_ptr, entry_snp, entry_rptr, reads, base.af, base.gp, has_gp)
+    for alphas in [(0.0, 0.5), GRID6]:
+        want, wfull = ob.demux(p, alphas=alphas, full_ll=True)
+        got, gfull = run_gpu(eng, p, alphas, full=True)
+        parity.compare_demux(got, want, alphas)
+        parity.compare_full_ll(gfull, wfull, V, alphas)
+        assert got["valid"].tolist() == [0, 1, 1, 1, 0, 1, 0]
+
+
+def test_zero_cells_and_reuse_of_handle(eng):
+    p = synth.make_pileup(10, 300, 3, seed=8, mean_entries=50, min_entries=10)
+    empty = synth.Pileup(0, p.S, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(1, np.int64),
+                         np.zeros(0, np.uint8), p.af, p.gp, p.has_gp)
+    out = run_gpu(eng, empty, (0.0, 0.5))
+    assert out.shape == (0,)
+    # same handle, new pileup, changing alpha grids back and forth: no stale state
+    a = run_gpu(eng, p, (0.0, 0.5))
+    b = run_gpu(eng, p, GRID6)
+    c = run_gpu(eng, p, (0.0, 0.5))
+    assert a.tobytes() == c.tobytes()
+    parity.compare_demux(b, ob.demux(p, alphas=GRID6), GRID6)
+
+
+def test_error_paths(eng):
+    p = synth.make_pileup(5, 100, 2, seed=1, mean_entries=20, min_entries=5)
+    bad = p.cell_ptr.copy()
+    bad[-1] += 1
+    with pytest.raises(muxgl.MuxglError):
+        eng.set_pileup(p.S, bad, p.entry_snp, p.entry_rptr, p.reads)
+    snp = p.entry_snp.copy()
+    snp[0] = p.S
+    with pytest.raises(muxgl.MuxglError):
+        eng.set_pileup(p.S, p.cell_ptr, snp, p.entry_rptr, p.reads)
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    eng.demux_set_gp(p.gp, p.has_gp)
+    with pytest.raises(muxgl.MuxglError):
+        eng.demux_run((), 0.5)  # n_alpha == 0
+
+
+# ---- BASELINE.json full size (configs[1]: 10k cells x 16 samples x 50k SNPs): size-independent properties ------
+
+@pytest.fixture(scope="module")
+def full_cfg(eng):
+    p = synth.make_config(1)
+    alphas = synth.CONFIGS[1]["alphas"]
+    cells, full = run_gpu(eng, p, alphas, full=True)
+    return p, alphas, cells, full
+
+
+def test_full_size_oracle_subsample(full_cfg):
+    p, alphas, cells, full = full_cfg
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(p.C, 64, replace=False))
+    sub = p.subset_cells(pick)
+    want, wfull = ob.demux(sub, alphas=alphas, full_ll=True, nthreads=4)
+    parity.compare_demux(cells[pick], want, alphas)
+    parity.compare_full_ll(full[pick], wfull, p.gp.shape[1], alphas)
+
+
+def test_full_size_mirror_symmetry(full_cfg):
+    p, alphas, cells, full = full_cfg
+    n = alphas.index(0.5)
+    assert np.array_equal(full[:, :, :, n], full[:, :, :, n].transpose(0, 2, 1))
+
+
+def test_full_size_cells_are_independent(eng, full_cfg):
+    """a cell's record does not depend on which other cells share the launch: bit-identical on a re-run of a subset"""
+    p, alphas, cells, full = full_cfg
+    pick = np.arange(0, p.C, 97)
+    sub = p.subset_cells(pick)
+    got = run_gpu(eng, sub, alphas)
+    assert got.tobytes() == cells[pick].tobytes()
+
+
+def test_full_size_sample_permutation_equivariance(eng, full_cfg):
+    """relabelling the samples relabels the calls; singlet LLs move with their sample (the singlet slot uses sample 0's
+    GP row as a factor, cmd_cram_demuxlet.cpp:806, so only pair hypotheses are compared across the relabelling)"""
+    p, alphas, cells, full = full_cfg
+    V = p.gp.shape[1]
+    perm = np.random.default_rng(3).permutation(V)
+    pick = np.arange(0, p.C, 211)
+    sub = p.subset_cells(pick)
+    sub.gp = np.ascontiguousarray(p.gp[:, perm, :])
+    got, gfull = run_gpu(eng, sub, alphas, full=True)
+    n = alphas.index(0.5)
+    ref = full[pick][:, perm][:, :, perm][:, :, :, n]
+    off = ~np.eye(V, dtype=bool)
+    assert np.max(np.abs(gfull[:, :, :, n][:, off] - ref[:, off])) < 1e-8
+    inv = np.argsort(perm)
+    dbl = cells[pick]["type"] == 1
+    a = np.sort(np.stack([inv[cells[pick]["dBest1"][dbl]], inv[cells[pick]["dBest2"][dbl]]]), axis=0)
+    b = np.sort(np.stack([got["dBest1"][dbl], got["dBest2"][dbl]]), axis=0)
+    assert np.array_equal(a, b)
