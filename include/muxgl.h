@@ -40,11 +40,14 @@ extern "C" {
 
 enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 
+/* muxgl_config.flags */
+#define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row kernel (lets tests cover the general tile sweep) */
+
 typedef struct muxgl_handle muxgl_handle;
 
 typedef struct {
   int32_t device_id; /* HIP device ordinal this handle runs on */
-  int32_t flags;     /* reserved, 0 */
+  int32_t flags;     /* MUXGL_FLAG_* bits, normally 0 */
 } muxgl_config;
 
 /* demuxlet parameters: --alpha grid and --doublet-prior (cmd_cram_demuxlet.cpp:32,62-63,85-89) */
@@ -93,8 +96,8 @@ typedef struct {
 /* kernel timings of the most recent *_run / *_iterate call, milliseconds, measured with hipEvents recorded on the
  * stream the kernels were launched on */
 enum {
-  MUXGL_T_DEMUX_ENTRY = 0, /* per-entry doublet-genotype likelihoods (a4,a5) */
-  MUXGL_T_DEMUX_SWEEP = 1, /* sample-pair x alpha sweep (a6) */
+  MUXGL_T_DEMUX_REDUCE = 0, /* row path only: chunk partial log-likelihoods summed per cell */
+  MUXGL_T_DEMUX_SWEEP = 1,  /* per-entry likelihoods (a4,a5) fused with the sample-pair x alpha sweep (a6) */
   MUXGL_T_DEMUX_CALL = 2,  /* evidence sums, best/next scans, call (a7-a9) */
   MUXGL_T_DEMUX_D2H = 3,   /* per-cell records to host */
   MUXGL_T_FMX_ENTRY = 4,   /* entry 9-GL pileup + cell scores (b1,b2) */

@@ -50,6 +50,9 @@ struct muxgl_handle {
   int32_t pairs_cap = 0;
   muxgl_demux_params last_dp{};
   bool have_dp = false;
+  bool pairs_valid = false;
+  struct muxgl_row_state* row = nullptr;  // chunk tables of the V<=16 row kernel (demux_row.hip)
+  int32_t flags = 0;
 
   // freemuxlet
   double* d_af = nullptr;
@@ -152,6 +155,9 @@ __device__ __forceinline__ double dev_logadd(double la, double lb) {
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg);
+int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr);
+int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
+void demux_row_free(muxgl_handle* h);
 int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
 int fmx_build_clusters_launch(muxgl_handle* h);
 int fmx_iterate_launch(muxgl_handle* h, const muxgl_fmx_params* p);

@@ -454,9 +454,9 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   for (int n = 1; n < A; ++n)
     if (p->alpha[n] == 0.5) symmask |= 1u << n;
   if (!h->have_dp || !same_params(h->last_dp, *p)) {
-    if (build_pairs(h, p, &symmask)) return 1;
     h->last_dp = *p;
     h->have_dp = true;
+    h->pairs_valid = false;
     h->ll_zeroed = false;
   }
   // LL tensor [C][V][V][A]; slots the sweep never writes must read 0
@@ -470,12 +470,21 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     HIPCHK(h, hipMemsetAsync(h->d_ll, 0, sizeof(double) * (need ? need : 1), h->stream));
     h->ll_zeroed = true;
   }
-  tic(h, MUXGL_T_DEMUX_SWEEP);
+
+  int rc = demux_row_launch(h, p);  // V <= 16: row kernel
+  if (rc > 0) return rc;
+  if (rc < 0) {                     // general tile sweep
+    if (!h->pairs_valid) {
+      if (build_pairs(h, p, &symmask)) return 1;
+      h->pairs_valid = true;
+    }
+    tic(h, MUXGL_T_DEMUX_SWEEP);
 #define CALL_SWEEP(N) launch_sweep<N>(h, p, symmask, al)
-  int rc = [&]() -> int { DISPATCH_NA(A, CALL_SWEEP); }();
+    rc = [&]() -> int { DISPATCH_NA(A, CALL_SWEEP); }();
 #undef CALL_SWEEP
-  if (rc) return rc;
-  toc(h, MUXGL_T_DEMUX_SWEEP);
+    if (rc) return rc;
+    toc(h, MUXGL_T_DEMUX_SWEEP);
+  }
 
   tic(h, MUXGL_T_DEMUX_CALL);
   const unsigned blocks = (unsigned)((h->C + 63) / 64);

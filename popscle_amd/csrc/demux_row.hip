@@ -1,0 +1,418 @@
+// demux_row.hip -- the demuxlet pair sweep for V <= 16 samples: the "row" kernel.
+//
+// Reference being replaced: cmd_cram_demuxlet.cpp:655-747 (per-read pG update, floor/normalise, pair sweep).
+//
+// Why a second kernel: at V = 16 with the reference's default grid {0, 0.5} an entry carries only 16 singlet + 120
+// unordered doublet hypotheses (~550 FP64 lane-instructions), so a workgroup-per-cell sweep that stages GP rows through
+// LDS is dominated by staging, barriers and LDS reads.  Here nothing but the per-entry pG (72..432 B) goes through LDS:
+//
+//   * a 64-lane wave is 4 "slots" x 16 lanes; a slot owns one chunk (<= CH entries of one cell), lane j of the slot
+//     owns sample j.  Lane j loads ITS OWN GP triple gp[snp][j][0..2] straight from global/L2 (the 16 lanes of a slot
+//     read the 384-byte row contiguously) -- no row staging.
+//   * with u[n][m] = sum_l g_j[l] * pG[n][l][m] (9 FMA per alpha, per lane), every pair term is
+//     sumP[j,k,n] = sum_m g_k[m] * u[n][m]  (3 FMA) and one multiply into the product accumulator; the partner's g_k
+//     arrives by rotating the slot's 16 lanes with DPP row_ror:1 (6 x v_mov_b32_dpp per shift, no LDS): after t shifts
+//     lane j holds the triple of sample k = kmap[t][j].  alpha = 0.5 is symmetric in (j,k): 8 shifts instead of 15.
+//   * per-hypothesis products are kept as mantissa * 2^exponent (prodacc) and turned into ONE log per chunk;
+//     demux_row_reduce_kernel then adds the chunk partials of each cell in chunk order (deterministic) into the
+//     [C][V][V][A] tensor the call kernel reads.
+//   * phase 1 of every 16-entry batch is lane <-> entry: all 64 lanes turn 64 entries' reads into pG (a4,a5).
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int ROW_CH = 128;  // entries per chunk
+
+struct row_chunk {
+  int64_t e0;
+  int32_t len;
+  int32_t cell;
+};
+
+struct row_alpha {
+  double a[MUXGL_MAX_ALPHA];     // internal order: [0] = the singlet slot's alpha, then non-symmetric, then 0.5
+  int32_t orig[MUXGL_MAX_ALPHA]; // internal index -> index in the caller's grid
+};
+
+__device__ __forceinline__ double dpp_ror1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x121, 0xF, 0xF, false);  // row_ror:1
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x121, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// which sample's triple lane j holds after t rotations (measured, so the kernels never assume a rotation direction)
+__global__ void row_kmap_kernel(int32_t* kmap /*[16][16] = [t][j]*/) {
+  const int lane = threadIdx.x;
+  int v = lane & 15;
+  kmap[lane & 15] = v;
+  for (int t = 1; t < 16; ++t) {
+    v = __builtin_amdgcn_mov_dpp(v, 0x121, 0xF, 0xF, false);
+    if (lane < 16) kmap[t * 16 + lane] = v;
+  }
+}
+
+// cmd_cram_demuxlet.cpp:655-725 for one entry (same arithmetic as entry_pg<> in demux_kernels.hip)
+template <int NA>
+__device__ __forceinline__ void row_entry_pg(const uint8_t* __restrict__ reads, int64_t r0, int64_t r1,
+                                             const double* __restrict__ alpha, const double* lut, double (&pG)[NA * 9]) {
+#pragma unroll
+  for (int i = 0; i < NA * 9; ++i) pG[i] = 1.0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const uint32_t b = reads[r];
+    if (b == MUXGL_READ_OTHER) continue;  // :664
+    const uint32_t al = b >> 7, bq = b & 0x7f;
+    const double e3 = lut[bq] / 3.0, mt = lut[128 + bq];
+    const double pR = (al == 0) ? mt : e3;  // :666
+    const double pA = (al == 1) ? mt : e3;  // :667
+    double mx = 0.0;
+#pragma unroll
+    for (int n = 0; n < NA; ++n) {
+      const double a = alpha[n];
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const double p = 0.5 * l + (m - l) * 0.5 * a;  // :673
+          const double v = pG[n * 9 + l * 3 + m] * (pR * (1.0 - p) + pA * p);
+          pG[n * 9 + l * 3 + m] = v;
+          mx = fmax(mx, v);
+        }
+      }
+    }
+    const double inv = 1.0 / mx;
+#pragma unroll
+    for (int i = 0; i < NA * 9; ++i) pG[i] *= inv;
+  }
+  double mx = 0.0;
+#pragma unroll
+  for (int i = 0; i < NA * 9; ++i) {
+    pG[i] += 1e-10;  // :711
+    mx = fmax(mx, pG[i]);
+  }
+  const double inv = 1.0 / mx;
+#pragma unroll
+  for (int i = 0; i < NA * 9; ++i) pG[i] *= inv;
+}
+
+// NNS = number of non-symmetric doublet alphas, NSY = 1 if the grid holds alpha == 0.5.
+// accumulators per lane: [0] singlet (j,0,n=0); then shift-major: t = 1..15 -> NNS slots (+1 symmetric slot if t <= 8)
+template <int NNS, int NSY>
+struct row_layout {
+  static constexpr int NA = 1 + NNS + NSY;
+  static constexpr int NSHIFT = (NNS > 0) ? 15 : (NSY ? 8 : 0);
+  static constexpr int NACC = 1 + 15 * NNS + 8 * NSY;
+  static constexpr int PGS = ((NA * 9 + 1) / 2) * 2;  // doubles per entry in LDS, even
+  static constexpr int SLOT_STRIDE = 16 * PGS + 4;    // +4 doubles: the 4 slots' broadcast reads fall on distinct banks
+  __host__ __device__ static constexpr int acc_index(int t, int n /*internal, >= 1*/) {
+    // slots of shifts 1..t-1, then this shift's
+    return 1 + (t - 1) * NNS + ((t - 1 < 8) ? (t - 1) : 8) * NSY + (n - 1);
+  }
+};
+
+template <int NNS, int NSY>
+__global__ void __launch_bounds__(64)
+    demux_row_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
+                     const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
+                     const double* __restrict__ gp, const uint8_t* __restrict__ has_gp,
+                     const double* __restrict__ lut_g, int V, row_alpha al, double* __restrict__ part) {
+  using L = row_layout<NNS, NSY>;
+  constexpr int NA = L::NA, NACC = L::NACC, PGS = L::PGS;
+  __shared__ double lut[256];
+  __shared__ __align__(16) double pgs[4 * L::SLOT_STRIDE];
+  __shared__ int32_t snps[64];
+
+  const int lane = threadIdx.x;
+  const int slot = lane >> 4, j = lane & 15;
+  for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
+
+  const int q = blockIdx.x * 4 + slot;
+  int64_t e0 = 0;
+  int len = 0;
+  if (q < n_chunks) {
+    e0 = chunks[q].e0;
+    len = chunks[q].len;
+  }
+  // chunks are ordered by non-increasing length, so slot 0 carries the wave's trip count
+  const int nb = (__builtin_amdgcn_readfirstlane(len) + 15) >> 4;
+
+  double acc[NACC];
+  int32_t ex[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    acc[a] = 1.0;
+    ex[a] = 0;
+  }
+  const int V3 = V * 3;
+  const bool live = j < V;
+  __syncthreads();
+
+  for (int b = 0; b < nb; ++b) {
+    // ---- phase 1: lane <-> entry (a4, a5) ----
+    {
+      const int idx = b * 16 + j;
+      double pG[NA * 9];
+      int32_t s = -1;
+      if (idx < len) {
+        const int64_t e = e0 + idx;
+        s = entry_snp[e];
+        if (has_gp[s]) {
+          row_entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], al.a, lut, pG);
+        } else {
+          s = -1;  // :733  marker without genotypes: contributes nothing
+        }
+      }
+      if (s < 0) {
+#pragma unroll
+        for (int i = 0; i < NA * 9; ++i) pG[i] = 1.0;  // with g = (1,0,0) every factor of a dead entry is exactly 1
+      }
+      double* dst = pgs + slot * L::SLOT_STRIDE + j * PGS;
+#pragma unroll
+      for (int i = 0; i < NA * 9; ++i) dst[i] = pG[i];
+      snps[lane] = s;
+    }
+    __syncthreads();
+
+    // ---- phase 2: lane <-> sample, 16 entries of the slot's chunk ----
+    int32_t s_next = snps[slot * 16];
+    double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0, nh0 = 1.0, nh1 = 0.0, nh2 = 0.0;
+    if (s_next >= 0) {
+      const double* row = gp + (size_t)s_next * V3;
+      nh0 = row[0], nh1 = row[1], nh2 = row[2];
+      if (live) ng0 = row[j * 3], ng1 = row[j * 3 + 1], ng2 = row[j * 3 + 2];
+    }
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+      const double g0 = ng0, g1 = ng1, g2 = ng2, h0 = nh0, h1 = nh1, h2 = nh2;
+      // prefetch the next entry's triples
+      ng0 = 1.0, ng1 = 0.0, ng2 = 0.0, nh0 = 1.0, nh1 = 0.0, nh2 = 0.0;
+      if (i + 1 < 16) {
+        s_next = snps[slot * 16 + i + 1];
+        if (s_next >= 0) {
+          const double* row = gp + (size_t)s_next * V3;
+          nh0 = row[0], nh1 = row[1], nh2 = row[2];
+          if (live) ng0 = row[j * 3], ng1 = row[j * 3 + 1], ng2 = row[j * 3 + 2];
+        }
+      }
+      const double* qn = pgs + slot * L::SLOT_STRIDE + i * PGS;
+      // singlet slot: llksAB[j][0][0] (:806,828) = sum_{l,m} g_j[l] g_0[m] pG[0][l][m]
+      {
+        const double u0 = fma(g2, qn[6], fma(g1, qn[3], g0 * qn[0]));
+        const double u1 = fma(g2, qn[7], fma(g1, qn[4], g0 * qn[1]));
+        const double u2 = fma(g2, qn[8], fma(g1, qn[5], g0 * qn[2]));
+        acc[0] *= fma(h2, u2, fma(h1, u1, h0 * u0));
+      }
+      if (L::NSHIFT > 0) {
+        double u[(NA > 1 ? NA - 1 : 1)][3];
+#pragma unroll
+        for (int n = 1; n < NA; ++n) {
+          const double* p = qn + n * 9;
+          u[n - 1][0] = fma(g2, p[6], fma(g1, p[3], g0 * p[0]));
+          u[n - 1][1] = fma(g2, p[7], fma(g1, p[4], g0 * p[1]));
+          u[n - 1][2] = fma(g2, p[8], fma(g1, p[5], g0 * p[2]));
+        }
+        double r0 = g0, r1 = g1, r2 = g2;
+#pragma unroll
+        for (int t = 1; t <= L::NSHIFT; ++t) {
+          r0 = dpp_ror1(r0);
+          r1 = dpp_ror1(r1);
+          r2 = dpp_ror1(r2);
+#pragma unroll
+          for (int n = 1; n < NA; ++n) {
+            const bool sym = NSY && (n == NA - 1);
+            if (!sym || t <= 8) {
+              const double sp = fma(r2, u[n - 1][2], fma(r1, u[n - 1][1], r0 * u[n - 1][0]));  // :738-744
+              acc[L::acc_index(t, n)] *= sp;                                                  // :746 as a product
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) prodacc_renorm(acc[a], ex[a]);
+    __syncthreads();
+  }
+
+  if (q < n_chunks) {
+    double* out = part + (size_t)q * NACC * 16;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) out[a * 16 + j] = prodacc_log(acc[a], ex[a]);
+  }
+}
+
+// adds the chunk partials of one cell, in chunk order, into ll[c][j][k][n] (+ mirror for alpha 0.5)
+template <int NNS, int NSY>
+__global__ void __launch_bounds__(256)
+    demux_row_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
+                            const double* __restrict__ part, const int32_t* __restrict__ kmap, int V, int A,
+                            row_alpha al, double* __restrict__ ll) {
+  using L = row_layout<NNS, NSY>;
+  constexpr int NA = L::NA, NACC = L::NACC;
+  const int64_t c = blockIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  if (c0 == c1) return;
+  double* out = ll + (size_t)c * V * V * A;
+  for (int idx = threadIdx.x; idx < NACC * 16; idx += blockDim.x) {
+    const int a = idx >> 4, j = idx & 15;
+    if (j >= V) continue;
+    int t = 0, n = 0;
+    if (a > 0) {
+      // invert acc_index
+      int rem = a - 1;
+      for (t = 1; t <= 15; ++t) {
+        const int cnt = NNS + ((t <= 8) ? NSY : 0);
+        if (rem < cnt) break;
+        rem -= cnt;
+      }
+      n = 1 + rem;
+    }
+    const int k = (a == 0) ? 0 : kmap[t * 16 + j];
+    if (k >= V) continue;
+    double s = 0.0;
+    for (int64_t ci = c0; ci < c1; ++ci) s += part[(size_t)cell_chunks[ci] * NACC * 16 + idx];
+    const int no = al.orig[n];
+    const bool sym = NSY && (n == NA - 1) && a > 0;
+    if (sym && t == 8 && j < k) continue;  // shift 8 visits every unordered pair twice: one writer
+    out[((size_t)j * V + k) * A + no] = s;
+    if (sym) out[((size_t)k * V + j) * A + no] = s;
+  }
+}
+
+struct row_plan {
+  std::vector<row_chunk> chunks;       // launch order: non-increasing length
+  std::vector<int64_t> cell_chunk_ptr; // [C+1]
+  std::vector<int32_t> cell_chunks;    // chunk ids (launch order positions) of each cell, in entry order
+};
+
+}  // namespace
+
+// device-side state of the row path (opaque to the other TUs)
+struct muxgl_row_state {
+  row_chunk* d_chunks = nullptr;
+  int64_t* d_cell_chunk_ptr = nullptr;
+  int32_t* d_cell_chunks = nullptr;
+  int32_t* d_kmap = nullptr;
+  double* d_part = nullptr;
+  size_t part_cap = 0;
+  int64_t n_chunks = 0;
+};
+
+void demux_row_free(muxgl_handle* h) {
+  muxgl_row_state* st = h->row;
+  if (!st) return;
+  dev_free(&st->d_chunks);
+  dev_free(&st->d_cell_chunk_ptr);
+  dev_free(&st->d_cell_chunks);
+  dev_free(&st->d_kmap);
+  dev_free(&st->d_part);
+  delete st;
+  h->row = nullptr;
+}
+
+// builds the chunk tables from the host copy of cell_ptr (called by muxgl_set_pileup)
+int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr) {
+  if (!h->row) h->row = new muxgl_row_state();
+  muxgl_row_state* st = h->row;
+  const int64_t C = h->C;
+  std::vector<row_chunk> chunks;
+  chunks.reserve((size_t)(h->nnz / ROW_CH + C + 1));
+  for (int64_t c = 0; c < C; ++c)
+    for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; e += ROW_CH) {
+      const int64_t len = std::min<int64_t>(ROW_CH, cell_ptr[c + 1] - e);
+      chunks.push_back(row_chunk{e, (int32_t)len, (int32_t)c});
+    }
+  // full chunks keep their order (entry locality), tails follow by decreasing length
+  std::stable_sort(chunks.begin(), chunks.end(), [](const row_chunk& a, const row_chunk& b) { return a.len > b.len; });
+  const int64_t n = (int64_t)chunks.size();
+  std::vector<int64_t> ccp((size_t)C + 1, 0);
+  for (const row_chunk& ch : chunks) ccp[(size_t)ch.cell + 1]++;
+  for (int64_t c = 0; c < C; ++c) ccp[(size_t)c + 1] += ccp[(size_t)c];
+  // chunk ids of each cell in ENTRY order (deterministic summation order of the partial logs)
+  std::vector<int32_t> ids((size_t)n);
+  {
+    std::vector<int32_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return chunks[(size_t)a].e0 < chunks[(size_t)b].e0; });
+    for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = order[(size_t)i];  // sorted by e0 == grouped by cell, in order
+  }
+  st->n_chunks = n;
+  if (dev_alloc(h, &st->d_chunks, (size_t)n)) return 1;
+  if (dev_alloc(h, &st->d_cell_chunk_ptr, (size_t)C + 1)) return 1;
+  if (dev_alloc(h, &st->d_cell_chunks, (size_t)n)) return 1;
+  if (n) HIPCHK(h, hipMemcpy(st->d_chunks, chunks.data(), sizeof(row_chunk) * n, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(st->d_cell_chunk_ptr, ccp.data(), sizeof(int64_t) * (C + 1), hipMemcpyHostToDevice));
+  if (n) HIPCHK(h, hipMemcpy(st->d_cell_chunks, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (!st->d_kmap) {
+    if (dev_alloc(h, &st->d_kmap, 256)) return 1;
+    hipLaunchKernelGGL(row_kmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_kmap);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+template <int NNS, int NSY>
+static int row_launch_t(muxgl_handle* h, const row_alpha& al, int A) {
+  using L = row_layout<NNS, NSY>;
+  muxgl_row_state* st = h->row;
+  const size_t need = (size_t)st->n_chunks * L::NACC * 16;
+  if (need > st->part_cap) {
+    if (dev_alloc(h, &st->d_part, need)) return 1;
+    st->part_cap = need;
+  }
+  const unsigned blocks = (unsigned)((st->n_chunks + 3) / 4);
+  if (blocks) {
+    hipLaunchKernelGGL((demux_row_kernel<NNS, NSY>), dim3(blocks), dim3(64), 0, h->stream, st->d_chunks,
+                       (int)st->n_chunks, h->d_entry_snp, h->d_entry_rptr, h->d_reads, h->d_gp, h->d_has_gp, h->d_lut,
+                       h->V, al, st->d_part);
+    HIPCHK(h, hipGetLastError());
+  }
+  toc(h, MUXGL_T_DEMUX_SWEEP);
+  tic(h, MUXGL_T_DEMUX_REDUCE);
+  if (h->C) {
+    hipLaunchKernelGGL((demux_row_reduce_kernel<NNS, NSY>), dim3((unsigned)h->C), dim3(256), 0, h->stream,
+                       st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_kmap, h->V, A, al, h->d_ll);
+    HIPCHK(h, hipGetLastError());
+  }
+  toc(h, MUXGL_T_DEMUX_REDUCE);
+  return 0;
+}
+
+// returns -1 when the row path does not apply (caller falls back to the tile sweep), 0 ok, 1 error
+int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  if (h->V > 16 || !h->row || h->C == 0 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
+  const int A = p->n_alpha;
+  row_alpha al;
+  int nns = 0, nsy = 0, pos = 0;
+  al.a[pos] = p->alpha[0];
+  al.orig[pos++] = 0;
+  for (int n = 1; n < A; ++n)
+    if (p->alpha[n] != 0.5) {
+      al.a[pos] = p->alpha[n];
+      al.orig[pos++] = n;
+      ++nns;
+    }
+  for (int n = 1; n < A; ++n)
+    if (p->alpha[n] == 0.5) {
+      if (nsy) return -1;  // 0.5 listed twice: generic path
+      al.a[pos] = p->alpha[n];
+      al.orig[pos++] = n;
+      ++nsy;
+    }
+  for (; pos < MUXGL_MAX_ALPHA; ++pos) {
+    al.a[pos] = 0.0;
+    al.orig[pos] = 0;
+  }
+  if (nns > 5) return -1;
+  tic(h, MUXGL_T_DEMUX_SWEEP);
+#define ROW_CASE(N, S) \
+  if (nns == N && nsy == S) return row_launch_t<N, S>(h, al, A);
+  ROW_CASE(0, 0) ROW_CASE(0, 1) ROW_CASE(1, 0) ROW_CASE(1, 1) ROW_CASE(2, 0) ROW_CASE(2, 1) ROW_CASE(3, 0)
+  ROW_CASE(3, 1) ROW_CASE(4, 0) ROW_CASE(4, 1) ROW_CASE(5, 0) ROW_CASE(5, 1)
+#undef ROW_CASE
+  return -1;
+}

@@ -35,6 +35,7 @@ int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
   }
   muxgl_handle* h = new muxgl_handle();
   h->device = dev;
+  h->flags = cfg ? cfg->flags : 0;
   auto fail = [&](const char* what, hipError_t err) {
     g_muxgl_create_error = std::string("muxgl_create: ") + what + ": " + hipGetErrorString(err);
     delete h;
@@ -86,6 +87,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_fstat);
   dev_free(&h->d_snp_ptr);
   dev_free(&h->d_snp_entry);
+  demux_row_free(h);
   if (h->h_dcells) (void)hipHostFree(h->h_dcells);
   if (h->h_fcells) (void)hipHostFree(h->h_fcells);
   for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
@@ -149,6 +151,7 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
     h->dcells_cap = C;
   }
   h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
+  if (demux_row_plan(h, cell_ptr)) return 1;
   h->fmx_prepared = false;
   h->K = 0;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -168,6 +171,7 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   if (h->S) HIPCHK(h, hipMemcpyAsync(h->d_has_gp, has_gp, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
   h->V = V;
   h->have_dp = false;
+  h->pairs_valid = false;
   h->ll_zeroed = false;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;

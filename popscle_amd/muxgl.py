@@ -20,7 +20,8 @@ SNG, DBL, AMB = 0, 1, 2
 TYPE_NAMES = {SNG: "SNG", DBL: "DBL", AMB: "AMB"}
 
 # timing slots of muxgl_get_timing
-T_DEMUX_ENTRY, T_DEMUX_SWEEP, T_DEMUX_CALL, T_DEMUX_D2H = 0, 1, 2, 3
+T_DEMUX_REDUCE, T_DEMUX_SWEEP, T_DEMUX_CALL, T_DEMUX_D2H = 0, 1, 2, 3
+FLAG_FORCE_TILE_SWEEP = 1
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
 T_COUNT = 16
 
@@ -115,10 +116,10 @@ def _arr(a, dtype, name):
 class Engine:
     """One muxgl handle = one GPU.  Methods mirror the C-ABI one to one."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, flags: int = 0):
         self.lib = load_library()
         self.h = _VP()
-        cfg = _Config(device_id, 0)
+        cfg = _Config(device_id, flags)
         if self.lib.muxgl_create(C.byref(cfg), C.byref(self.h)) != 0:
             raise MuxglError(self.lib.muxgl_last_error(None).decode())
         self.C = self.S = self.nnz = self.R = 0

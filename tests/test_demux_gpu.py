@@ -17,9 +17,11 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 GRID6 = (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)
 
 
-@pytest.fixture(scope="module")
-def eng():
-    e = muxgl.Engine(0)
+@pytest.fixture(scope="module", params=["row", "tile"])
+def eng(request):
+    """both sweep implementations: 'row' = default dispatch (row kernel for V <= 16, tile sweep above), 'tile' =
+    the general tile sweep forced for every shape"""
+    e = muxgl.Engine(0, muxgl.FLAG_FORCE_TILE_SWEEP if request.param == "tile" else 0)
     yield e
     e.close()
 
@@ -37,7 +39,7 @@ def test_golden(eng, name):
                      z["gp"], z["has_gp"])
     alphas = tuple(z["alphas"])
     got, full = run_gpu(eng, p, alphas, float(z["doublet_prior"]), full=True)
-    rep = parity.compare_demux(got, z["cells"], alphas)
+    rep = parity.compare_demux(got, z["cells"], alphas, want_full=z["full_ll"])
     worst = parity.compare_full_ll(full, z["full_ll"], p.gp.shape[1], alphas)
     assert rep["max_abs_ll_diff"] < 1e-8 and worst < 1e-8  # expected ~1e-11; the bar is 1e-5
 
@@ -60,7 +62,7 @@ def test_random_vs_oracle(eng, V, alphas, C, S, ment):
                           missing_gp_frac=0.03)
     want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
     got, gfull = run_gpu(eng, p, alphas, full=True)
-    rep = parity.compare_demux(got, want, alphas)
+    rep = parity.compare_demux(got, want, alphas, want_full=wfull)
     worst = parity.compare_full_ll(gfull, wfull, V, alphas)
     assert rep["max_abs_ll_diff"] < 1e-7 and worst < 1e-7
     # slots the reference never reads stay 0 in the returned tensor
@@ -103,7 +105,7 @@ def test_ragged_and_edge_inputs(eng):
     for alphas in [(0.0, 0.5), GRID6]:
         want, wfull = ob.demux(p, alphas=alphas, full_ll=True)
         got, gfull = run_gpu(eng, p, alphas, full=True)
-        parity.compare_demux(got, want, alphas)
+        parity.compare_demux(got, want, alphas, want_full=wfull)
         parity.compare_full_ll(gfull, wfull, V, alphas)
         assert got["valid"].tolist() == [0, 1, 1, 1, 0, 1, 0]
 
@@ -154,7 +156,7 @@ def test_full_size_oracle_subsample(full_cfg):
     pick = np.sort(rng.choice(p.C, 64, replace=False))
     sub = p.subset_cells(pick)
     want, wfull = ob.demux(sub, alphas=alphas, full_ll=True, nthreads=4)
-    parity.compare_demux(cells[pick], want, alphas)
+    parity.compare_demux(cells[pick], want, alphas, want_full=wfull)
     parity.compare_full_ll(full[pick], wfull, p.gp.shape[1], alphas)
 
 
