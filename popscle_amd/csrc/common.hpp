@@ -17,6 +17,24 @@ struct muxgl_counts {
   int32_t nreads, nref, nalt;
 };
 
+// one work unit of the row kernels (demux_row.hip, fmx_kernels.hip): <= 128 consecutive entries of one cell
+struct row_chunk {
+  int64_t e0;
+  int32_t len;
+  int32_t cell;
+};
+
+// chunk tables of the row kernels, built by demux_row_plan() at muxgl_set_pileup time
+struct muxgl_row_state {
+  row_chunk* d_chunks = nullptr;        // launch order: non-increasing length, then ascending first SNP
+  int64_t* d_cell_chunk_ptr = nullptr;  // [C+1]
+  int32_t* d_cell_chunks = nullptr;     // chunk positions of each cell in entry order
+  int32_t* d_kmap = nullptr;            // [16][16]: sample held by lane j after t DPP row rotations
+  double* d_part = nullptr;             // per-chunk partial log-likelihoods
+  size_t part_cap = 0;
+  int64_t n_chunks = 0;
+};
+
 struct muxgl_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -155,7 +173,7 @@ __device__ __forceinline__ double dev_logadd(double la, double lb) {
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg);
-int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr);
+int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);
 int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);

@@ -26,12 +26,6 @@ namespace {
 
 constexpr int ROW_CH = 128;  // entries per chunk
 
-struct row_chunk {
-  int64_t e0;
-  int32_t len;
-  int32_t cell;
-};
-
 struct row_alpha {
   double a[MUXGL_MAX_ALPHA];     // internal order: [0] = the singlet slot's alpha, then non-symmetric, then 0.5
   int32_t orig[MUXGL_MAX_ALPHA]; // internal index -> index in the caller's grid
@@ -289,17 +283,6 @@ struct row_plan {
 
 }  // namespace
 
-// device-side state of the row path (opaque to the other TUs)
-struct muxgl_row_state {
-  row_chunk* d_chunks = nullptr;
-  int64_t* d_cell_chunk_ptr = nullptr;
-  int32_t* d_cell_chunks = nullptr;
-  int32_t* d_kmap = nullptr;
-  double* d_part = nullptr;
-  size_t part_cap = 0;
-  int64_t n_chunks = 0;
-};
-
 void demux_row_free(muxgl_handle* h) {
   muxgl_row_state* st = h->row;
   if (!st) return;
@@ -313,7 +296,7 @@ void demux_row_free(muxgl_handle* h) {
 }
 
 // builds the chunk tables from the host copy of cell_ptr (called by muxgl_set_pileup)
-int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr) {
+int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp) {
   if (!h->row) h->row = new muxgl_row_state();
   muxgl_row_state* st = h->row;
   const int64_t C = h->C;
@@ -324,8 +307,26 @@ int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr) {
       const int64_t len = std::min<int64_t>(ROW_CH, cell_ptr[c + 1] - e);
       chunks.push_back(row_chunk{e, (int32_t)len, (int32_t)c});
     }
-  // full chunks keep their order (entry locality), tails follow by decreasing length
-  std::stable_sort(chunks.begin(), chunks.end(), [](const row_chunk& a, const row_chunk& b) { return a.len > b.len; });
+  // Launch order.  (1) non-increasing length, so that slot 0 of every wave carries the wave's trip count and the four
+  // slots of a wave finish together.  (2) among equally long chunks (all the full ones), ascending first SNP id:
+  // entries are SNP-sorted inside a cell, so workgroups that are resident at the same time then gather GP rows from
+  // the same window of the [S][V][3] tensor, which fits the 4 MiB per-XCD L2 (the whole tensor, 19 MB at config 1,
+  // does not).
+  if (entry_snp) {
+    std::vector<int32_t> first((size_t)chunks.size());
+    for (size_t i = 0; i < chunks.size(); ++i) first[i] = entry_snp[chunks[i].e0];
+    std::vector<size_t> ord(chunks.size());
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+      if (chunks[a].len != chunks[b].len) return chunks[a].len > chunks[b].len;
+      return first[a] < first[b];
+    });
+    std::vector<row_chunk> sorted(chunks.size());
+    for (size_t i = 0; i < ord.size(); ++i) sorted[i] = chunks[ord[i]];
+    chunks.swap(sorted);
+  } else {
+    std::stable_sort(chunks.begin(), chunks.end(), [](const row_chunk& a, const row_chunk& b) { return a.len > b.len; });
+  }
   const int64_t n = (int64_t)chunks.size();
   std::vector<int64_t> ccp((size_t)C + 1, 0);
   for (const row_chunk& ch : chunks) ccp[(size_t)ch.cell + 1]++;

@@ -1,27 +1,727 @@
-// fmx_kernels.hip -- freemuxlet hot path on gfx950 (cmd_cram_freemux2.cpp:117-160,277-288,375-597).
+// fmx_kernels.hip -- freemuxlet hot path on gfx950.
+//
+// Reference being replaced (statgen/popscle): calculate_snp_droplet_pileup (sc_drop_seq.cpp:452-509), the per-cell
+// singlet scores (cmd_cram_freemux2.cpp:117-160), the cluster pileup build (:277-288), and one EM iteration
+// (:375-597): E-step pair likelihoods (:383-456), scans (:458-513), re-assignment (:515-584) and the ordered,
+// clamped M-step (snp_droplet_pileup::merge, sc_drop_seq.h:77-101, driven by :590-596).
+//
+// Decomposition (new design; the reference is one thread walking std::maps):
+//   fmx_entry_kernel      lane <-> entry: 9 genotype-pair likelihoods + counts + log lk0/lk2 of the entry
+//   fmx_cell_score_kernel wave <-> cell: sums of the entry logs
+//   fmx_cgp_kernel        lane <-> (SNP, cluster): cluster genotype posterior row used by the E-step
+//   fmx_estep_row_kernel  K <= 16: the row-kernel scheme of demux_row.hip (slot of 16 lanes = one chunk of a cell,
+//                         lane = cluster, partner triples by DPP row rotation; the entry's 3x3 likelihood matrix is
+//                         symmetric, so 8 shifts cover all unordered pairs), product accumulators, one log per chunk
+//   fmx_estep_pair_kernel K > 16: workgroup <-> cell, lane <-> cluster pair (general fallback)
+//   fmx_call_kernel       lane <-> cell: scans, evidence, re-assignment, change counters
+//   fmx_mstep_kernel      lane <-> (SNP, cluster): walks the SNP's entries in ascending cell id (SNP-major view) and
+//                         applies merge() for the cells assigned to the cluster -- the exact sequential order of the
+//                         reference, parallel over the S*K independent chains
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 #include "common.hpp"
+
+namespace {
+
+constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
+
+// ------------------------------------------------------------------------------------------------ b1 / b2
+
+__global__ void __launch_bounds__(256)
+    fmx_entry_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
+                     const int32_t* __restrict__ entry_snp, const double* __restrict__ af,
+                     const double* __restrict__ lut_g, double* __restrict__ egls, int32_t* __restrict__ ecnt,
+                     double* __restrict__ l0, double* __restrict__ l2) {
+  __shared__ double lut[256];
+  lut[threadIdx.x] = lut_g[threadIdx.x];
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    double gls[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gls[i] = 1.0;
+    int32_t nreads = 0, nref = 0, nalt = 0;
+    const int64_t r1 = entry_rptr[e + 1];
+    for (int64_t r = entry_rptr[e]; r < r1; ++r) {
+      const uint32_t b = reads[r];
+      ++nreads;                               // sc_drop_seq.cpp:466
+      if (b == MUXGL_READ_OTHER) continue;    // :468
+      const uint32_t al = b >> 7, bq = b & 0x7f;
+      if (al == 0) ++nref;
+      else ++nalt;
+      const double mat = lut[128 + bq], e4 = lut[bq] / 4.;
+      // fraction of reference reads expected for genotype pair (g1,g2) at alpha = 0.5: 1 - (g1+g2)/4 (:472-491)
+      const double fr[9] = {1.0, .75, .5, .75, .5, .25, .5, .25, 0.0};
+      double tmp = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double f = (al == 0) ? fr[i] : fr[8 - i];
+        gls[i] *= (mat * f + e4);
+        tmp += gls[i];
+      }
+      const double inv = 1.0 / tmp;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gls[i] *= inv;
+    }
+    double tmp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (gls[i] < kMinNormGL) gls[i] = kMinNormGL;  // :498-501
+      tmp += gls[i];
+    }
+    const double inv = 1.0 / tmp;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      gls[i] *= inv;
+      egls[(size_t)e * 9 + i] = gls[i];
+    }
+    ecnt[(size_t)e * 3 + 0] = nreads;
+    ecnt[(size_t)e * 3 + 1] = nref;
+    ecnt[(size_t)e * 3 + 2] = nalt;
+    // cmd_cram_freemux2.cpp:138-149
+    const double a = af[entry_snp[e]];
+    const double gps[3] = {(1.0 - a) * (1.0 - a), 2.0 * a * (1.0 - a), a * a};
+    double lk0 = 0.0, lk2 = 0.0;
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+      lk2 += (gls[gi * 3 + gi] * gps[gi]);
+#pragma unroll
+      for (int gj = 0; gj < 3; ++gj) lk0 += (gls[gi * 3 + gj] * gps[gi] * gps[gj]);
+    }
+    l0[e] = log(lk0);
+    l2[e] = log(lk2);
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+    fmx_cell_score_kernel(const int64_t* __restrict__ cell_ptr, const double* __restrict__ l0,
+                          const double* __restrict__ l2, const int32_t* __restrict__ ecnt, double* __restrict__ llk0,
+                          double* __restrict__ llk2, int32_t* __restrict__ nsnps, int32_t* __restrict__ nreads) {
+  const int64_t c = blockIdx.x;
+  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  double s0 = 0.0, s2 = 0.0, nr = 0.0;
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 64) {
+    s0 += l0[e];
+    s2 += l2[e];
+    nr += (double)ecnt[(size_t)e * 3];
+  }
+  s0 = wave_sum(s0);
+  s2 = wave_sum(s2);
+  nr = wave_sum(nr);
+  if (threadIdx.x == 0) {
+    llk0[c] = s0;
+    llk2[c] = s2;
+    nsnps[c] = (int32_t)(e1 - e0);
+    nreads[c] = (int32_t)nr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cluster GP
+
+// cmd_cram_freemux2.cpp:402-415: gp = HWE(af) * diag(cluster gls), normalised, mixed with the prior by geno_error
+__global__ void __launch_bounds__(256)
+    fmx_cgp_kernel(int64_t S, int K, const double* __restrict__ af, const double* __restrict__ cgls, double geno_error,
+                   double* __restrict__ cgp) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= S * K) return;
+  const int64_t s = tid / K;
+  const int k = (int)(tid - s * K);
+  const double a = af[s];
+  const double* g = cgls + ((size_t)k * S + s) * 9;
+  const double p0 = (1.0 - a) * (1.0 - a), p1 = 2 * a * (1.0 - a), p2 = a * a;
+  double g0 = p0 * g[0], g1 = p1 * g[4], g2 = p2 * g[8];
+  const double sum = g0 + g1 + g2;
+  g0 /= sum;
+  g1 /= sum;
+  g2 /= sum;
+  if (geno_error > 0) {
+    g0 = (1 - geno_error) * g0 + geno_error * p0;
+    g1 = (1 - geno_error) * g1 + geno_error * p1;
+    g2 = (1 - geno_error) * g2 + geno_error * p2;
+  }
+  double* o = cgp + ((size_t)s * K + k) * 3;
+  o[0] = g0;
+  o[1] = g1;
+  o[2] = g2;
+}
+
+// ------------------------------------------------------------------------------------------------ E-step, K <= 16
+
+__device__ __forceinline__ double dpp_ror1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x121, 0xF, 0xF, false);  // row_ror:1
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x121, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int FX_PGS = 10;                    // 9 likelihoods + 1 pad (16-byte aligned rows)
+constexpr int FX_SLOT_STRIDE = 16 * FX_PGS + 4;
+constexpr int FX_NACC = 9;                    // [0] singlet, [1..8] shifts
+
+__global__ void __launch_bounds__(64)
+    fmx_estep_row_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
+                         const double* __restrict__ egls, const double* __restrict__ cgp, int K,
+                         double* __restrict__ part) {
+  __shared__ __align__(16) double gl[4 * FX_SLOT_STRIDE];
+  __shared__ int32_t snps[64];
+  const int lane = threadIdx.x;
+  const int slot = lane >> 4, j = lane & 15;
+  const int q = blockIdx.x * 4 + slot;
+  int64_t e0 = 0;
+  int len = 0;
+  if (q < n_chunks) {
+    e0 = chunks[q].e0;
+    len = chunks[q].len;
+  }
+  const int nb = (__builtin_amdgcn_readfirstlane(len) + 15) >> 4;
+  double acc[FX_NACC];
+  int32_t ex[FX_NACC];
+#pragma unroll
+  for (int a = 0; a < FX_NACC; ++a) {
+    acc[a] = 1.0;
+    ex[a] = 0;
+  }
+  const int K3 = K * 3;
+  const bool live = j < K;
+
+  for (int b = 0; b < nb; ++b) {
+    {  // phase 1: lane <-> entry, the 3x3 likelihoods of 64 entries into LDS
+      const int idx = b * 16 + j;
+      double* dst = gl + slot * FX_SLOT_STRIDE + j * FX_PGS;
+      int32_t s = -1;
+      if (idx < len) {
+        const int64_t e = e0 + idx;
+        s = entry_snp[e];
+        const double* src = egls + (size_t)e * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst[i] = src[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst[i] = 1.0;  // dead entry: with g = (1,0,0) every factor is exactly 1
+      }
+      snps[lane] = s;
+    }
+    __syncthreads();
+    int32_t s_next = snps[slot * 16];
+    double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+    if (s_next >= 0 && live) {
+      const double* row = cgp + (size_t)s_next * K3 + j * 3;
+      ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    }
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+      const double g0 = ng0, g1 = ng1, g2 = ng2;
+      ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+      if (i + 1 < 16) {
+        s_next = snps[slot * 16 + i + 1];
+        if (s_next >= 0 && live) {
+          const double* row = cgp + (size_t)s_next * K3 + j * 3;
+          ng0 = row[0], ng1 = row[1], ng2 = row[2];
+        }
+      }
+      const double* p = gl + slot * FX_SLOT_STRIDE + i * FX_PGS;
+      // singlet: sum_g glis[g,g] * gp_j[g]   (cmd_cram_freemux2.cpp:448-452)
+      acc[0] *= fma(g2, p[8], fma(g1, p[4], g0 * p[0]));
+      // pairs: sum_{g1,g2} glis[g1,g2] gp_j[g1] gp_k[g2]   (:440-446)
+      const double u0 = fma(g2, p[6], fma(g1, p[3], g0 * p[0]));
+      const double u1 = fma(g2, p[7], fma(g1, p[4], g0 * p[1]));
+      const double u2 = fma(g2, p[8], fma(g1, p[5], g0 * p[2]));
+      double r0 = g0, r1 = g1, r2 = g2;
+#pragma unroll
+      for (int t = 1; t <= 8; ++t) {
+        r0 = dpp_ror1(r0);
+        r1 = dpp_ror1(r1);
+        r2 = dpp_ror1(r2);
+        acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < FX_NACC; ++a) prodacc_renorm(acc[a], ex[a]);
+    __syncthreads();
+  }
+  if (q < n_chunks) {
+    double* out = part + (size_t)q * FX_NACC * 16;
+#pragma unroll
+    for (int a = 0; a < FX_NACC; ++a) out[a * 16 + j] = prodacc_log(acc[a], ex[a]);  // :454-455 as one log per chunk
+  }
+}
+
+__global__ void __launch_bounds__(192)
+    fmx_estep_row_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
+                                const double* __restrict__ part, const int32_t* __restrict__ kmap, int K,
+                                double* __restrict__ fll) {
+  const int64_t c = blockIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  const int npairs = K * (K + 1) / 2;
+  const int idx = threadIdx.x;
+  if (idx >= FX_NACC * 16) return;
+  const int a = idx >> 4, j = idx & 15;
+  if (j >= K) return;
+  const int k = (a == 0) ? j : kmap[a * 16 + j];
+  if (k >= K) return;
+  if (a == 8 && j < k) return;  // shift 8 visits every unordered pair twice
+  double s = 0.0;
+  for (int64_t ci = c0; ci < c1; ++ci) s += part[(size_t)cell_chunks[ci] * FX_NACC * 16 + idx];
+  const int hi = j > k ? j : k, lo = j > k ? k : j;
+  fll[(size_t)c * npairs + hi * (hi + 1) / 2 + lo] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ E-step, any K
+
+// workgroup <-> (cell, pair tile), lane <-> PPT pair slots; products with periodic renormalisation, one log at the end
+template <int PPT>
+__global__ void __launch_bounds__(256)
+    fmx_estep_pair_kernel(const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ entry_snp,
+                          const double* __restrict__ egls, const double* __restrict__ cgp, int K,
+                          double* __restrict__ fll) {
+  const int64_t c = blockIdx.x;
+  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  const int npairs = K * (K + 1) / 2;
+  const int T = blockDim.x;
+  int pj[PPT], pk[PPT];
+  double acc[PPT];
+  int32_t ex[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = blockIdx.y * T * PPT + threadIdx.x + i * T;
+    // invert p = j(j+1)/2 + k
+    int j = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while ((j + 1) * (j + 2) / 2 <= p) ++j;
+    while (j * (j + 1) / 2 > p) --j;
+    pj[i] = j;
+    pk[i] = p - j * (j + 1) / 2;
+    acc[i] = 1.0;
+    ex[i] = 0;
+  }
+  const int K3 = K * 3;
+  int cnt = 0;
+  for (int64_t e = e0; e < e1; ++e) {
+    const double* gl = egls + (size_t)e * 9;
+    const double* row = cgp + (size_t)entry_snp[e] * K3;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (blockIdx.y * T * PPT + threadIdx.x + i * T < npairs) {
+        const double* a = row + pj[i] * 3;
+        const double* b = row + pk[i] * 3;
+        double lk;
+        if (pj[i] == pk[i]) {
+          lk = fma(gl[8], a[2], fma(gl[4], a[1], gl[0] * a[0]));
+        } else {
+          const double u0 = fma(a[2], gl[6], fma(a[1], gl[3], a[0] * gl[0]));
+          const double u1 = fma(a[2], gl[7], fma(a[1], gl[4], a[0] * gl[1]));
+          const double u2 = fma(a[2], gl[8], fma(a[1], gl[5], a[0] * gl[2]));
+          lk = fma(b[2], u2, fma(b[1], u1, b[0] * u0));
+        }
+        acc[i] *= lk;
+      }
+    }
+    if (++cnt == 16) {
+      cnt = 0;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) prodacc_renorm(acc[i], ex[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = blockIdx.y * T * PPT + threadIdx.x + i * T;
+    if (p < npairs) fll[(size_t)c * npairs + p] = prodacc_log(acc[i], ex[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ scans + re-assignment
+
+// cmd_cram_freemux2.cpp:458-584 for one cell per lane; stat[0..2] = nsingle, namb, nchanged
+__global__ void __launch_bounds__(64)
+    fmx_call_kernel(int64_t C, int K, double doublet_prior, const double* __restrict__ fll,
+                    muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const int nSamples = K;
+  const int npairs = K * (K + 1) / 2;
+  const double log_single_prior = log((1.0 - doublet_prior) / nSamples);                // :379
+  const double log_double_prior = log(doublet_prior / nSamples / (nSamples - 1) * 2.0); // :380
+  const double* llks = fll + (size_t)i * npairs;
+  int32_t sBest = -1, sNext = -1, dBest1 = -1, dBest2 = -1, dNext1 = -1, dNext2 = -1;
+  double sngBestLLK = -1e300, sngNextLLK = -1e300, dblBestLLK = -1e300, dblNextLLK = -1e300;
+  double sumLLK = -1e300, sngLLK = -1e300;
+  for (int j = 0; j < nSamples; ++j) {  // :469-497
+    for (int k = 0; k < j; ++k) {
+      const double v = llks[j * (j + 1) / 2 + k];
+      if (v > dblBestLLK) {
+        dNext1 = dBest1;
+        dNext2 = dBest2;
+        dblNextLLK = dblBestLLK;
+        dBest1 = j;
+        dBest2 = k;
+        dblBestLLK = v;
+      } else if (v > dblNextLLK) {
+        dNext1 = j;
+        dNext2 = k;
+        dblNextLLK = v;
+      }
+      sumLLK = dev_logadd(sumLLK, v + log_double_prior);
+    }
+    const double v = llks[j * (j + 1) / 2 + j];
+    if (v > sngBestLLK) {
+      sNext = sBest;
+      sngNextLLK = sngBestLLK;
+      sBest = j;
+      sngBestLLK = v;
+    } else if (v > sngNextLLK) {
+      sNext = j;
+      sngNextLLK = v;
+    }
+    sumLLK = dev_logadd(sumLLK, v + log_single_prior);
+    sngLLK = dev_logadd(sngLLK, v + log_single_prior);
+  }
+  muxgl_fmx_cell c = cells[i];
+  c.sBest = sBest;
+  c.sngBestLLK = sngBestLLK;
+  c.sNext = sNext;
+  c.sngNextLLK = sngNextLLK;
+  c.dBest1 = dBest1;
+  c.dBest2 = dBest2;
+  c.dblBestLLK = dblBestLLK;
+  c.dNext1 = dNext1;
+  c.dNext2 = dNext2;
+  c.dblNextLLK = dblNextLLK;
+  c.sngPP = exp(sngLLK - sumLLK);
+  c.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);
+  c.sumLLK = sumLLK;
+
+  int32_t dsingle = 0, damb = 0, dchanged = 0;
+  c.clust = -1;                           // :520
+  if (dblBestLLK > sngBestLLK + 2) {      // :521
+    if (c.type != 1) dchanged = 1;
+    c.type = 1;
+    c.bestPP = (dblBestLLK + log_double_prior - sumLLK);
+    c.jBest = dBest1;
+    c.kBest = dBest2;
+    c.bestLLK = dblBestLLK;
+    if (dblNextLLK > sngBestLLK + 2) {
+      c.jNext = dNext1;
+      c.kNext = dNext2;
+      c.nextLLK = dblNextLLK;
+    } else {
+      c.jNext = c.kNext = sBest;
+      c.nextLLK = sngBestLLK;
+    }
+  } else if (sngBestLLK > sngNextLLK + 2) {  // :542
+    if ((c.type != 0) || (c.jBest != sBest) || (c.kBest != sBest)) dchanged = 1;
+    c.type = 0;
+    dsingle = 1;
+    c.bestPP = (sngBestLLK + log_single_prior - sumLLK);
+    c.jBest = c.kBest = sBest;
+    c.bestLLK = sngBestLLK;
+    c.clust = sBest;
+    if (dblBestLLK > sngNextLLK + 2) {
+      c.jNext = dBest1;
+      c.kNext = dBest2;
+      c.nextLLK = dblBestLLK;
+    } else {
+      c.jNext = c.kNext = sNext;
+      c.nextLLK = sngNextLLK;
+    }
+  } else {  // :565
+    if (c.type != 2) dchanged = 1;
+    c.type = 2;
+    damb = 1;
+    c.bestPP = (sngBestLLK + log_single_prior - sumLLK);
+    c.jBest = c.kBest = sBest;
+    c.bestLLK = sngBestLLK;
+    if (dblBestLLK > sngNextLLK + 2) {
+      c.jNext = dBest1;
+      c.kNext = dBest2;
+      c.nextLLK = dblNextLLK;  // sic, :577
+    } else {
+      c.jNext = c.kNext = sNext;
+      c.nextLLK = sngNextLLK;
+    }
+  }
+  cells[i] = c;
+  clust[i] = c.clust;
+  if (dsingle) atomicAdd(&stat[0], 1);
+  if (damb) atomicAdd(&stat[1], 1);
+  if (dchanged) atomicAdd(&stat[2], 1);
+}
+
+// ------------------------------------------------------------------------------------------------ M-step
+
+// snp_droplet_pileup::merge (sc_drop_seq.h:77-101), applied in ascending cell id for every (cluster, SNP) chain.
+// Division by the running sum is a multiplication by its reciprocal; logdenom is never read and is not kept.
+__global__ void __launch_bounds__(256)
+    fmx_mstep_kernel(int64_t S, int K, const int64_t* __restrict__ snp_ptr, const int64_t* __restrict__ snp_entry,
+                     const int32_t* __restrict__ entry_cell, const int32_t* __restrict__ clust,
+                     const double* __restrict__ egls, const int32_t* __restrict__ ecnt, double* __restrict__ cgls,
+                     int32_t* __restrict__ ccnt) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= S * K) return;
+  const int64_t s = tid / K;
+  const int k = (int)(tid - s * K);
+  double g[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) g[i] = 1.0;
+  int32_t nreads = 0, nref = 0, nalt = 0;
+  const int64_t p1 = snp_ptr[s + 1];
+  for (int64_t p = snp_ptr[s]; p < p1; ++p) {
+    const int64_t e = snp_entry[p];
+    if (clust[entry_cell[e]] != k) continue;
+    const double* o = egls + (size_t)e * 9;
+    const int32_t* oc = ecnt + (size_t)e * 3;
+    nreads += oc[0];
+    nref += oc[1];
+    nalt += oc[2];
+    double tmp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      g[i] *= o[i];
+      tmp += g[i];
+    }
+    double inv = 1.0 / tmp;
+    tmp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      g[i] *= inv;
+      if (g[i] < kMinNormGL) g[i] = kMinNormGL;
+      tmp += g[i];
+    }
+    inv = 1.0 / tmp;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] *= inv;
+  }
+  double* og = cgls + ((size_t)k * S + s) * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) og[i] = g[i];
+  int32_t* oc = ccnt + ((size_t)k * S + s) * 3;
+  oc[0] = nreads;
+  oc[1] = nref;
+  oc[2] = nalt;
+}
+
+}  // namespace
+
+static int fmx_mstep_launch(muxgl_handle* h) {
+  const int64_t n = h->S * h->K;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fmx_mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->K,
+                     h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_ecnt, h->d_cgls,
+                     h->d_ccnt);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
 
 extern "C" {
 
-int muxgl_fmx_prepare(muxgl_handle* h, const double*, double*, double*, int32_t*, int32_t*) {
+int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
+                      int32_t* cell_nreads) {
   if (!h) return 1;
-  MUXGL_FAIL(h, "muxgl_fmx_prepare: not implemented yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_cell_ptr) MUXGL_FAIL(h, "muxgl_fmx_prepare: no pileup set (muxgl_set_pileup)");
+  if (!af) MUXGL_FAIL(h, "muxgl_fmx_prepare: af is NULL");
+  clear_timing(h);
+  const int64_t C = h->C, S = h->S, nnz = h->nnz;
+  if (dev_alloc(h, &h->d_af, (size_t)S)) return 1;
+  if (S) HIPCHK(h, hipMemcpyAsync(h->d_af, af, sizeof(double) * S, hipMemcpyHostToDevice, h->stream));
+  if (dev_alloc(h, &h->d_egls, (size_t)nnz * 9)) return 1;
+  if (dev_alloc(h, &h->d_ecnt, (size_t)nnz * 3)) return 1;
+  double *d_l0 = nullptr, *d_l2 = nullptr, *d_c0 = nullptr, *d_c2 = nullptr;
+  int32_t *d_ns = nullptr, *d_nr = nullptr;
+  auto cleanup = [&]() {
+    dev_free(&d_l0);
+    dev_free(&d_l2);
+    dev_free(&d_c0);
+    dev_free(&d_c2);
+    dev_free(&d_ns);
+    dev_free(&d_nr);
+  };
+  if (dev_alloc(h, &d_l0, (size_t)nnz) || dev_alloc(h, &d_l2, (size_t)nnz) || dev_alloc(h, &d_c0, (size_t)C) ||
+      dev_alloc(h, &d_c2, (size_t)C) || dev_alloc(h, &d_ns, (size_t)C) || dev_alloc(h, &d_nr, (size_t)C)) {
+    cleanup();
+    return 1;
+  }
+  tic(h, MUXGL_T_FMX_ENTRY);
+  if (nnz) {
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fmx_entry_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_entry_rptr,
+                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, h->d_ecnt, d_l0, d_l2);
+  }
+  if (C)
+    hipLaunchKernelGGL(fmx_cell_score_kernel, dim3((unsigned)C), dim3(64), 0, h->stream, h->d_cell_ptr, d_l0, d_l2,
+                       h->d_ecnt, d_c0, d_c2, d_ns, d_nr);
+  toc(h, MUXGL_T_FMX_ENTRY);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess && C && cell_llk0) e = hipMemcpy(cell_llk0, d_c0, sizeof(double) * C, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && C && cell_llk2) e = hipMemcpy(cell_llk2, d_c2, sizeof(double) * C, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && C && cell_nsnps) e = hipMemcpy(cell_nsnps, d_ns, sizeof(int32_t) * C, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && C && cell_nreads) e = hipMemcpy(cell_nreads, d_nr, sizeof(int32_t) * C, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) MUXGL_FAIL(h, "muxgl_fmx_prepare: %s", hipGetErrorString(e));
+  collect_timing(h);
+
+  // SNP-major view of the entries (cells ascending inside each SNP) for the ordered M-step: stable counting sort of the
+  // CSR entries by SNP id.  Built once per pileup on the host from the device copy of the CSR arrays.
+  {
+    std::vector<int64_t> cp((size_t)C + 1);
+    std::vector<int32_t> es((size_t)nnz);
+    HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (C + 1), hipMemcpyDeviceToHost));
+    if (nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+    std::vector<int64_t> sp((size_t)S + 1, 0);
+    for (int64_t e2 = 0; e2 < nnz; ++e2) sp[(size_t)es[(size_t)e2] + 1]++;
+    for (int64_t s = 0; s < S; ++s) sp[(size_t)s + 1] += sp[(size_t)s];
+    std::vector<int64_t> fill(sp.begin(), sp.end() - 1);
+    std::vector<int64_t> se((size_t)nnz);
+    std::vector<int32_t> ec((size_t)nnz);
+    for (int64_t c = 0; c < C; ++c)
+      for (int64_t e2 = cp[(size_t)c]; e2 < cp[(size_t)c + 1]; ++e2) {
+        se[(size_t)fill[(size_t)es[(size_t)e2]]++] = e2;
+        ec[(size_t)e2] = (int32_t)c;
+      }
+    if (dev_alloc(h, &h->d_snp_ptr, (size_t)S + 1)) return 1;
+    if (dev_alloc(h, &h->d_snp_entry, (size_t)nnz)) return 1;
+    if (dev_alloc(h, &h->d_entry_cell, (size_t)nnz)) return 1;
+    HIPCHK(h, hipMemcpy(h->d_snp_ptr, sp.data(), sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice));
+    if (nnz) HIPCHK(h, hipMemcpy(h->d_snp_entry, se.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
+    if (nnz) HIPCHK(h, hipMemcpy(h->d_entry_cell, ec.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+  }
+  h->fmx_prepared = true;
+  h->K = 0;
+  return 0;
 }
-int muxgl_fmx_get_entry_gls(muxgl_handle* h, double*, int32_t*) {
+
+int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
   if (!h) return 1;
-  MUXGL_FAIL(h, "muxgl_fmx_get_entry_gls: not implemented yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_get_entry_gls: call muxgl_fmx_prepare first");
+  if (gls && h->nnz) HIPCHK(h, hipMemcpy(gls, h->d_egls, sizeof(double) * 9 * h->nnz, hipMemcpyDeviceToHost));
+  if (counts && h->nnz) HIPCHK(h, hipMemcpy(counts, h->d_ecnt, sizeof(int32_t) * 3 * h->nnz, hipMemcpyDeviceToHost));
+  return 0;
 }
-int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t, const int32_t*) {
+
+int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   if (!h) return 1;
-  MUXGL_FAIL(h, "muxgl_fmx_set_clusters: not implemented yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: call muxgl_fmx_prepare first");
+  if (K < 1 || K > 255) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: K=%d outside [1,255]", K);
+  if (!clust && h->C) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: clust is NULL");
+  const int64_t C = h->C, S = h->S;
+  for (int64_t i = 0; i < C; ++i)
+    if (clust[i] >= K) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: cell %lld has cluster %d >= K", (long long)i, clust[i]);
+  h->K = K;
+  if (dev_alloc(h, &h->d_cgls, (size_t)K * S * 9)) return 1;
+  if (dev_alloc(h, &h->d_ccnt, (size_t)K * S * 3)) return 1;
+  if (dev_alloc(h, &h->d_cgp, (size_t)S * K * 3)) return 1;
+  if (dev_alloc(h, &h->d_fll, (size_t)C * K * (K + 1) / 2)) return 1;
+  // state before the first iteration: cmd_cram_freemux2.cpp:191-194,213,244 and :345-367
+  std::vector<int32_t> cl((size_t)C);
+  for (int64_t i = 0; i < C; ++i) {
+    muxgl_fmx_cell& c = h->h_fcells[i];
+    memset(&c, 0, sizeof(c));
+    cl[(size_t)i] = clust[i] >= 0 ? clust[i] : -1;
+    c.type = (clust[i] >= 0) ? 0 : -1;
+    c.clust = cl[(size_t)i];
+    c.jBest = c.kBest = c.jNext = c.kNext = -1;
+    c.sBest = c.sNext = c.dBest1 = c.dBest2 = c.dNext1 = c.dNext2 = -1;
+    c.bestLLK = c.nextLLK = c.sngBestLLK = c.sngNextLLK = c.dblBestLLK = c.dblNextLLK = -1e300;
+    c.bestPP = c.sngPP = c.sngOnlyPP = c.sumLLK = -1e300;
+  }
+  if (C) {
+    HIPCHK(h, hipMemcpyAsync(h->d_fcells, h->h_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_clust, cl.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice, h->stream));
+  }
+  clear_timing(h);
+  tic(h, MUXGL_T_FMX_MSTEP);
+  if (fmx_mstep_launch(h)) return 1;  // :277-288: every assigned cell, ascending cell id
+  toc(h, MUXGL_T_FMX_MSTEP);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  return 0;
 }
-int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params*, muxgl_fmx_cell*, int32_t*, int32_t*, int32_t*, double*) {
+
+int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
+                      int32_t* nchanged, double* full_ll) {
   if (!h) return 1;
-  MUXGL_FAIL(h, "muxgl_fmx_iterate: not implemented yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!p) MUXGL_FAIL(h, "muxgl_fmx_iterate: params NULL");
+  if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iterate: call muxgl_fmx_prepare and muxgl_fmx_set_clusters first");
+  const int64_t C = h->C, S = h->S;
+  const int K = h->K;
+  const int npairs = K * (K + 1) / 2;
+  clear_timing(h);
+
+  tic(h, MUXGL_T_FMX_GP);
+  if (S) {
+    const int64_t n = S * K;
+    hipLaunchKernelGGL(fmx_cgp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S, K, h->d_af,
+                       h->d_cgls, p->geno_error, h->d_cgp);
+  }
+  toc(h, MUXGL_T_FMX_GP);
+
+  tic(h, MUXGL_T_FMX_ESTEP);
+  muxgl_row_state* st = h->row;
+  if (C) {
+    if (K <= 16 && st && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
+      const size_t need = (size_t)st->n_chunks * FX_NACC * 16;
+      if (need > st->part_cap) {
+        if (dev_alloc(h, &st->d_part, need)) return 1;
+        st->part_cap = need;
+      }
+      const unsigned blocks = (unsigned)((st->n_chunks + 3) / 4);
+      if (blocks)
+        hipLaunchKernelGGL(fmx_estep_row_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
+                           h->d_entry_snp, h->d_egls, h->d_cgp, K, st->d_part);
+      hipLaunchKernelGGL(fmx_estep_row_reduce_kernel, dim3((unsigned)C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                         st->d_cell_chunks, st->d_part, st->d_kmap, K, h->d_fll);
+    } else {
+      const int T = 256, PPT = 4;
+      const unsigned tiles = (unsigned)((npairs + T * PPT - 1) / (T * PPT));
+      hipLaunchKernelGGL(fmx_estep_pair_kernel<PPT>, dim3((unsigned)C, tiles), dim3(T), 0, h->stream, h->d_cell_ptr,
+                         h->d_entry_snp, h->d_egls, h->d_cgp, K, h->d_fll);
+    }
+  }
+  toc(h, MUXGL_T_FMX_ESTEP);
+
+  tic(h, MUXGL_T_FMX_CALL);
+  HIPCHK(h, hipMemsetAsync(h->d_fstat, 0, 4 * sizeof(int32_t), h->stream));
+  if (C)
+    hipLaunchKernelGGL(fmx_call_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, C, K, p->doublet_prior,
+                       h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+  toc(h, MUXGL_T_FMX_CALL);
+
+  tic(h, MUXGL_T_FMX_MSTEP);
+  if (fmx_mstep_launch(h)) return 1;  // :516-517 clear + :590-596 merge of the singlet cells, ascending cell id
+  toc(h, MUXGL_T_FMX_MSTEP);
+  HIPCHK(h, hipGetLastError());
+
+  int32_t stat[4] = {0, 0, 0, 0};
+  if (C) HIPCHK(h, hipMemcpyAsync(h->h_fcells, h->d_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(stat, h->d_fstat, sizeof(stat), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  if (out && C) memcpy(out, h->h_fcells, sizeof(muxgl_fmx_cell) * C);
+  if (nsingle) *nsingle = stat[0];
+  if (namb) *namb = stat[1];
+  if (nchanged) *nchanged = stat[2];
+  if (full_ll && C) HIPCHK(h, hipMemcpy(full_ll, h->d_fll, sizeof(double) * (size_t)C * npairs, hipMemcpyDeviceToHost));
+  return 0;
 }
-int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double*, int32_t*) {
+
+int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts) {
   if (!h) return 1;
-  MUXGL_FAIL(h, "muxgl_fmx_get_cluster_pileup: not implemented yet");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_get_cluster_pileup: no clusters set");
+  const size_t n = (size_t)h->K * h->S;
+  if (gls && n) HIPCHK(h, hipMemcpy(gls, h->d_cgls, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  if (counts && n) HIPCHK(h, hipMemcpy(counts, h->d_ccnt, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 }  // extern "C"

@@ -151,7 +151,7 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
     h->dcells_cap = C;
   }
   h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
-  if (demux_row_plan(h, cell_ptr)) return 1;
+  if (demux_row_plan(h, cell_ptr, entry_snp)) return 1;
   h->fmx_prepared = false;
   h->K = 0;
   HIPCHK(h, hipStreamSynchronize(h->stream));
