@@ -144,6 +144,16 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
  * counts[nnz][3] = nreads,nref,nalt.  Either may be NULL. */
 int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
 
+/* b3+b4: sort cells by singlet score (descending, ties by id descending: cmd_cram_freemux2.cpp:184-189 with the
+ * comparator sc_drop_seq.h:187-198) and run the greedy initial clustering (:217-261, distance =
+ * sc_dropseq_lib_t::calculate_droplet_clust_distance, sc_drop_seq.cpp:544-578).  scores[C] = cell_scores (llk2-llk0,
+ * possibly shuffled by --randomize-singlet-score on the caller side).  The procedure is sequential over cells by
+ * construction (each assignment changes the cluster pileups the next cell is scored against); this round it runs on
+ * the host inside the library, on the entry likelihoods muxgl_fmx_prepare computed on the device.
+ * clust_out[C] receives the cluster id, or -1 for cells skipped by frac_init_clust / singlet_score_thres. */
+int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,
+                          double singlet_score_thres, int32_t* clust_out);
+
 /* initial clusters (after --init-cluster or greedy init): builds the cluster pileups in ascending cell id
  * (cmd_cram_freemux2.cpp:277-288) and resets types/jBest/kBest (:263-265,349-350).  clust[C], -1 = unassigned. */
 int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust);

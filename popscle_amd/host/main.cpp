@@ -1,0 +1,405 @@
+// popscle-amd -- popscle-compatible front end for the demuxlet / freemuxlet genotype-likelihood path, with the hot path
+// running on an MI355X through the C-ABI of libmuxgl (include/muxgl.h).
+//
+//   popscle-amd demuxlet   --plp P --vcf V [--field GT|GP|PL] --out O [...]     mirrors cmdCramDemuxlet (cmd_cram_demuxlet.cpp)
+//   popscle-amd freemuxlet --plp P --nsample K --out O [...]                   mirrors cmdCramFreemux2 (cmd_cram_freemux2.cpp)
+//   popscle-amd dump-plp   --plp P [--vcf V --field F] --out FILE              loader only: packed pileup to a binary file
+//
+// Everything here is host plumbing: flag surface, loaders (plp.hpp, vcf.hpp), the sequential control flow of
+// the reference commands, and the text writers with the reference's printf formats.  All arithmetic of the path is
+// behind muxgl_* calls; there is no CPU implementation of it in this program.
+#include <cmath>
+
+#include "plp.hpp"
+
+using namespace pa;
+
+namespace {
+
+void check(muxgl_handle* h, int rc, const char* what) {
+  if (rc != 0) fatal("%s failed: %s", what, muxgl_last_error(h));
+}
+
+struct CommonFlags {
+  std::string plpPrefix, outPrefix, groupList;
+  LoadOptions lo;
+  int32_t device = 0;
+  void add(Args& a) {
+    a.add_string("plp", &plpPrefix);
+    a.add_string("out", &outPrefix);
+    a.add_int("cap-BQ", &lo.capBQ);
+    a.add_int("min-BQ", &lo.minBQ);
+    a.add_string("group-list", &lo.groupList);
+    a.add_int("min-total", &lo.minRead);
+    a.add_int("min-umi", &lo.minUMI);
+    a.add_int("min-snp", &lo.minSNP);
+    a.add_int("device", &device);
+  }
+};
+
+void upload(muxgl_handle* h, const Pileup& p) {
+  check(h, muxgl_set_pileup(h, p.C(), p.S(), p.nnz(), (int64_t)p.reads.size(), p.cell_ptr.data(), p.entry_snp.data(),
+                            p.entry_rptr.data(), p.reads.data()),
+        "muxgl_set_pileup");
+}
+
+const char* sid(const Pileup& p, int i) { return (i >= 0 && i < p.nv) ? p.sample_ids[(size_t)i].c_str() : "NA"; }
+
+// ------------------------------------------------------------------------------------------------ demuxlet
+int cmd_demuxlet(int argc, char** argv) {
+  CommonFlags cf;
+  VcfReader vr;
+  std::vector<std::string> smIDs;
+  std::string smList;
+  std::vector<double> gridAlpha;
+  double doublet_prior = 0.5;  // cmd_cram_demuxlet.cpp:32
+  std::string sam, tagGroup, tagUMI;
+  int32_t dummy_i = 0;
+  Args a;
+  cf.add(a);
+  a.add_string("vcf", &vr.path);
+  a.add_string("field", &cf.lo.field);
+  a.add_double("geno-error-offset", &cf.lo.genoErrorOffset);
+  a.add_double("geno-error-coeff", &cf.lo.genoErrorCoeffR2);
+  a.add_string("r2-info", &cf.lo.r2info);
+  a.add_int("min-mac", &vr.vfilt.minMAC);
+  a.add_double("min-callrate", &vr.vfilt.minCallRate);
+  a.add_multi_string("sm", &smIDs);
+  a.add_string("sm-list", &smList);
+  a.add_multi_double("alpha", &gridAlpha);
+  a.add_double("doublet-prior", &doublet_prior);
+  a.add_string("sam", &sam);  // BAM-direct mode needs htslib: accepted and rejected
+  a.add_string("tag-group", &tagGroup);
+  a.add_string("tag-UMI", &tagUMI);
+  a.add_int("sam-verbose", &dummy_i);
+  a.add_int("vcf-verbose", &dummy_i);
+  a.add_int("min-MQ", &dummy_i);
+  a.add_int("min-TD", &dummy_i);
+  a.add_int("excl-flag", &dummy_i);
+  a.parse(argc, argv);
+  if (!sam.empty()) fatal("--sam (BAM-direct mode) is not available in this build: run dsc-pileup first and pass --plp");
+  if (cf.plpPrefix.empty() || vr.path.empty() || cf.outPrefix.empty()) fatal("Missing required option(s) : --plp, --vcf, --out");
+  if (gridAlpha.empty()) {  // :85-89
+    gridAlpha.push_back(0);
+    gridAlpha.push_back(0.5);
+  }
+  if ((int)gridAlpha.size() > MUXGL_MAX_ALPHA) fatal("at most %d --alpha values are supported", MUXGL_MAX_ALPHA);
+  vr.wanted = smIDs;
+  if (!smList.empty()) {
+    TsvReader t(smList);
+    while (t.read_line() > 0) vr.wanted.push_back(t.str_field_at(0));
+  }
+  vr.init();
+  Pileup p;
+  load_from_plp(cf.plpPrefix, cf.lo, &vr, p);
+
+  muxgl_config cfg{cf.device, 0};
+  muxgl_handle* h = nullptr;
+  if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
+  upload(h, p);
+  check(h, muxgl_demux_set_gp(h, p.nv, p.gp.data(), p.has_gp.data()), "muxgl_demux_set_gp");
+  muxgl_demux_params dp;
+  memset(&dp, 0, sizeof(dp));
+  dp.n_alpha = (int32_t)gridAlpha.size();
+  for (size_t i = 0; i < gridAlpha.size(); ++i) dp.alpha[i] = gridAlpha[i];
+  dp.doublet_prior = doublet_prior;
+  notice("Starting to identify best matching individual IDs");
+  std::vector<muxgl_demux_cell> cells((size_t)p.C());
+  check(h, muxgl_demux_run(h, &dp, cells.data(), nullptr), "muxgl_demux_run");
+
+  // .best, cmd_cram_demuxlet.cpp:629,636-641,993-1013: rows in barcode-sorted order, INT_ID counts skipped cells too
+  OutFile w(cf.outPrefix + ".best", false);
+  w.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"
+           "DIFF.LLK.BEST.NEXT\tBEST.POSTERIOR\tSNG.POSTERIOR\tSNG.BEST.GUESS\tSNG.BEST.LLK\tSNG.NEXT.GUESS\t"
+           "SNG.NEXT.LLK\tSNG.ONLY.POSTERIOR\tDBL.BEST.GUESS\tDBL.BEST.LLK\tDIFF.LLK.SNG.DBL\n");
+  std::map<std::string, int32_t> bc_map;
+  for (int64_t i = 0; i < p.C(); ++i) bc_map[p.bcs[(size_t)i]] = (int32_t)i;
+  static const char* tname[3] = {"SNG", "DBL", "AMB"};
+  int ncells = 0;
+  for (auto it = bc_map.begin(); it != bc_map.end(); ++it, ++ncells) {
+    const int32_t i = it->second;
+    const muxgl_demux_cell& c = cells[(size_t)i];
+    if (p.cell_totl_reads[(size_t)i] < cf.lo.minRead || p.cell_uniq_reads[(size_t)i] < cf.lo.minUMI ||
+        c.nsnps < cf.lo.minSNP)
+      continue;  // :641
+    if (!c.valid) continue;  // :653
+    auto al = [&](int n) { return (n >= 0 && n < dp.n_alpha) ? dp.alpha[n] : NAN; };
+    w.printf("%d\t%s\t%u\t%d\t%s\t%s,%s,%.2lf\t%.2lf\t%s,%s,%.2lf\t%.2lf\t%.2lf\t%.2lg\t%.2lg\t%s\t%.2lf\t%s\t%.2lf\t"
+             "%.5lf\t%s,%s,%.2lf\t%.2lf\t%.2lf\n",
+             ncells, it->first.c_str(), (unsigned)c.nsnps, p.cell_uniq_reads[(size_t)i], tname[c.type],
+             sid(p, c.jBest), sid(p, c.kBest), al(c.aBest), c.bestLLK, sid(p, c.jNext), sid(p, c.kNext), al(c.aNext),
+             c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, sid(p, c.sBest), c.sngBestLLK, sid(p, c.sNext),
+             c.sngNextLLK, c.sngOnlyPP, sid(p, c.dBest1), sid(p, c.dBest2), al(c.dBestA), c.dblBestLLK,
+             c.sngBestLLK - c.dblBestLLK);
+  }
+  w.close();
+  notice("Finished writing output files");
+  muxgl_destroy(h);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ freemuxlet
+void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const std::vector<double>& gls,
+                       const std::vector<int32_t>& cnt, const std::vector<uint8_t>& snps_observed, const tm* ltm) {
+  // cmd_cram_freemux2.cpp:608-658
+  OutFile vc(path, true);
+  vc.printf("##fileformat=VCFv4.2\n");
+  vc.printf("##fileDate=%04d%02d%02d\n", 1970 + ltm->tm_year, 1 + ltm->tm_mon, ltm->tm_mday);  // sic: 1970+
+  vc.printf("##source=cramore-freemuxlet\n");
+  for (size_t i = 0; i < p.rid2chr.size(); ++i) vc.printf("##contig=<ID=%s>\n", p.rid2chr[i].c_str());
+  vc.printf("##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n");
+  vc.printf("##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
+  vc.printf("##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Phred-scale Genotype Quality\">\n");
+  vc.printf("##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Read Depth\">\n");
+  vc.printf("##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic Read Depth\">\n");
+  vc.printf("##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Phred-scale genotype likelihood\">\n");
+  vc.printf("##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Posterior probability using pooled allele frequencies\">\n");
+  vc.printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT");
+  for (int i = 0; i < K; ++i) vc.printf("\tCLUST%d", i);
+  vc.printf("\n");
+  const int64_t S = p.S();
+  for (int64_t v = 0; v < S; ++v) {
+    if (!snps_observed[(size_t)v]) continue;
+    const SnpInfo& s = p.snps[(size_t)v];
+    vc.printf("%s\t%d\t.\t%c\t%c\t.\tPASS\tAF=%.5lf\tGT:GQ:DP:AD:PL:GP", p.rid2chr[(size_t)s.rid].c_str(), s.pos, s.ref,
+              s.alt, s.af);
+    const double gps[3] = {(1. - s.af) * (1. - s.af), 2. * s.af * (1. - s.af), s.af * s.af};
+    for (int i = 0; i < K; ++i) {
+      const double* g = &gls[((size_t)i * S + v) * 9];
+      const int32_t* c = &cnt[((size_t)i * S + v) * 3];
+      double maxGL = g[0];
+      if (maxGL < g[4]) maxGL = g[4];
+      if (maxGL < g[8]) maxGL = g[8];
+      int32_t pls[3];
+      pls[0] = (int32_t)(-10.0 * log10(g[0] / maxGL));
+      pls[1] = (int32_t)(-10.0 * log10(g[4] / maxGL));
+      pls[2] = (int32_t)(-10.0 * log10(g[8] / maxGL));
+      double pps[3];
+      pps[0] = gps[0] * (g[0] / maxGL) + 1e-100;
+      pps[1] = gps[1] * (g[4] / maxGL) + 1e-100;
+      pps[2] = gps[2] * (g[8] / maxGL) + 1e-100;
+      const double sumPP = pps[0] + pps[1] + pps[2];
+      pps[0] /= sumPP;
+      pps[1] /= sumPP;
+      pps[2] /= sumPP;
+      const int bestG = (pps[0] > pps[1]) ? (pps[0] > pps[2] ? 0 : 2) : (pps[1] > pps[2] ? 1 : 2);
+      int32_t gq = (int32_t)(-10 * log10(1.0 - pps[bestG] + 1e-100));
+      if (gq > 255) gq = 255;
+      vc.printf("\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg", bestG == 2 ? 1 : 0, bestG > 0 ? 1 : 0, gq, c[0], c[1],
+                c[2], pls[0], pls[1], pls[2], pps[0], pps[1], pps[2]);
+    }
+    vc.printf("\n");
+  }
+  vc.close();
+}
+
+int cmd_freemuxlet(int argc, char** argv) {
+  CommonFlags cf;
+  std::string initClusterFile;
+  double doublet_prior = 0.5, geno_error = 0.1, bfThres = 5.41, fracInitClust = 1.0;  // cmd_cram_freemux2.cpp:19-28
+  double singletScoreThres = -1e300;
+  int32_t nSamples = 0, initIteration = 10, randomSeed = 0, verbose = 0, maxIter = 10;
+  bool auxFiles = false, keepInitMissing = false, randomizeSingletScore = false, noEarlyStop = false;
+  Args a;
+  cf.add(a);
+  a.add_string("init-cluster", &initClusterFile);
+  a.add_int("nsample", &nSamples);
+  a.add_bool("aux-files", &auxFiles);
+  a.add_int("verbose", &verbose);
+  a.add_double("doublet-prior", &doublet_prior);
+  a.add_double("geno-error", &geno_error);
+  a.add_double("bf-thres", &bfThres);              // accepted, unused (as in the reference)
+  a.add_double("frac-init-clust", &fracInitClust);
+  a.add_int("iter-init", &initIteration);          // accepted, unused
+  a.add_bool("keep-init-missing", &keepInitMissing);  // accepted, unused
+  a.add_bool("randomize-singlet-score", &randomizeSingletScore);
+  a.add_int("seed", &randomSeed);
+  a.add_int("max-iter", &maxIter);                 // extension: the reference hard-codes 10 (:372)
+  a.add_bool("no-early-stop", &noEarlyStop);       // extension for benchmarking fixed iteration counts
+  a.parse(argc, argv);
+  if (cf.plpPrefix.empty() || cf.outPrefix.empty() || nSamples == 0) fatal("Missing required option(s) : --plp, --out, --nsample");
+
+  Pileup p;
+  load_from_plp(cf.plpPrefix, cf.lo, nullptr, p);
+  const int64_t C = p.C(), S = p.S();
+  const int K = nSamples;
+
+  std::map<std::string, int32_t> initCluster;  // :90-104
+  if (!initClusterFile.empty()) {
+    TsvReader t(initClusterFile);
+    while (t.read_line() > 0) {
+      if (t.nfields != 2) fatal("ERROR: Initial clustering file %s has to have 2 columnes", initClusterFile.c_str());
+      const int32_t ic = t.int_field_at(1);
+      if (ic >= 0) {
+        if (ic >= K)
+          fatal("ERROR: --nsample %d parameter was set. The cluster ID must be between 0 to %d, or use negative values "
+                "to not assign initial cluster (not implemented yet)", K, K - 1);
+        initCluster[t.str_field_at(0)] = ic;
+      }
+    }
+  }
+
+  muxgl_config cfg{cf.device, 0};
+  muxgl_handle* h = nullptr;
+  if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
+  upload(h, p);
+  std::vector<double> af((size_t)S), llk0((size_t)C), llk2((size_t)C);
+  std::vector<int32_t> nSNPs((size_t)C), nReads((size_t)C);
+  for (int64_t s = 0; s < S; ++s) af[(size_t)s] = p.snps[(size_t)s].af;
+  check(h, muxgl_fmx_prepare(h, af.data(), llk0.data(), llk2.data(), nSNPs.data(), nReads.data()), "muxgl_fmx_prepare");
+
+  std::vector<double> scores((size_t)C);
+  {  // .lmix, :111-163
+    OutFile wmix(cf.outPrefix + ".lmix", false);
+    wmix.printf("INT_ID\tBARCODE\tNSNPs\tNREADs\tDBL.LLK\tSNG.LLK\tBF.SINGLET\tBF.SINGLET.PER.SNP\n");
+    for (int64_t i = 0; i < C; ++i) {
+      scores[(size_t)i] = llk2[(size_t)i] - llk0[(size_t)i];
+      wmix.printf("%d\t%s\t%d\t%d\t%.2lf\t%.2lf\t%.2lf\t%.4lf\n", (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i],
+                  nReads[(size_t)i], llk0[(size_t)i], llk2[(size_t)i], llk2[(size_t)i] - llk0[(size_t)i],
+                  (llk2[(size_t)i] - llk0[(size_t)i]) / nSNPs[(size_t)i]);
+    }
+  }
+  if (randomSeed == 0) srand((unsigned)std::time(0));  // :165-168
+  else srand((unsigned)randomSeed);
+  if (randomizeSingletScore) {  // :171-181
+    for (int64_t i = 0; i < C - 1; ++i) {
+      const int64_t j = i + rand() % (C - i);
+      if (i < j) std::swap(scores[(size_t)i], scores[(size_t)j]);
+    }
+  }
+
+  std::vector<int32_t> clusts((size_t)C, -1);
+  if (!initClusterFile.empty()) {  // :198-216
+    int32_t nmiss = 0;
+    for (int64_t i = 0; i < C; ++i) {
+      auto it = initCluster.find(p.bcs[(size_t)i]);
+      if (it == initCluster.end()) ++nmiss;
+      else clusts[(size_t)i] = it->second;
+    }
+    if (nmiss > 0) notice("WARNING: %d of %d droplets do not have initial cluster assignment", nmiss, (int)C);
+  } else {  // greedy clustering, :217-261
+    check(h, muxgl_fmx_greedy_init(h, K, scores.data(), fracInitClust, singletScoreThres, clusts.data()),
+          "muxgl_fmx_greedy_init");
+  }
+  notice("Finished assigning initial identity of the cluster..");
+  if (auxFiles) {  // :265-274
+    OutFile wc0(cf.outPrefix + ".clust0.samples.gz", true);
+    wc0.printf("INT_ID\tBARCODE\tCLUST0\n");
+    for (int64_t i = 0; i < C; ++i) wc0.printf("%d\t%s\t%d\n", (int)i, p.bcs[(size_t)i].c_str(), clusts[(size_t)i]);
+  }
+  std::vector<uint8_t> snps_observed((size_t)S, 0);  // :279-288
+  for (int64_t e = 0; e < p.nnz(); ++e) snps_observed[(size_t)p.entry_snp[(size_t)e]] = 1;
+  check(h, muxgl_fmx_set_clusters(h, K, clusts.data()), "muxgl_fmx_set_clusters");
+  time_t now = std::time(nullptr);
+  tm* ltm = localtime(&now);
+  std::vector<double> cgls((size_t)K * S * 9);
+  std::vector<int32_t> ccnt((size_t)K * S * 3);
+  if (auxFiles) {
+    check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
+    write_cluster_vcf(cf.outPrefix + ".clust0.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+  }
+
+  std::vector<muxgl_fmx_cell> cells((size_t)C);
+  muxgl_fmx_params fp{doublet_prior, geno_error};
+  for (int32_t iter = 0; iter < maxIter; ++iter) {  // :373-605
+    notice("Inferring doublets and refining clusters.., iter = %d", iter + 1);
+    int32_t nsingle = 0, namb = 0, nchanged = 0;
+    check(h, muxgl_fmx_iterate(h, &fp, cells.data(), &nsingle, &namb, &nchanged, nullptr), "muxgl_fmx_iterate");
+    notice("Refining per-cluster genotype likelihoods.... %d singlets, %d doublets, %d ambiguous, and %d changed", nsingle,
+           (int)C - nsingle - namb, namb, nchanged);
+    if (nchanged == 0 && !noEarlyStop) {
+      notice("No more changes in cluster assginment and singlet identities. Finishing iterations early");
+      break;
+    }
+  }
+  check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
+  write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+
+  OutFile wc1(cf.outPrefix + ".clust1.samples.gz", true);  // :660-665
+  wc1.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"
+             "DIFF.LLK.BEST.NEXT\tBEST.POSTERIOR\tSNG.POSTERIOR\tSNG.BEST.GUESS\tSNG.BEST.LLK\tSNG.NEXT.GUESS\t"
+             "SNG.NEXT.LLK\tSNG.ONLY.POSTERIOR\tDBL.BEST.GUESS\tDBL.BEST.LLK\tDIFF.LLK.SNG.DBL\n");
+  for (int64_t i = 0; i < C; ++i) {
+    const muxgl_fmx_cell& c = cells[(size_t)i];
+    wc1.printf("%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
+               "%.2lf\t%.2lf\n",
+               (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i], nReads[(size_t)i],
+               (c.type == 2) ? "AMB" : ((c.type == 0) ? "SNG" : "DBL"), c.jBest, c.kBest, c.bestLLK, c.jNext, c.kNext,
+               c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, c.sBest, c.sngBestLLK, c.sNext, c.sngNextLLK,
+               c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
+  }
+  wc1.close();
+  muxgl_destroy(h);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ dump-plp
+// loader-only command for the CPU tests: writes the packed pileup as a flat little-endian file
+//   magic "MUXGLPLP", int64 C,S,nnz,R,nv, then cell_ptr, entry_snp, entry_rptr, reads, af[S], has_gp[S], gp[S*nv*3],
+//   cell_totl_reads[C], cell_uniq_reads[C], then C barcodes and nv sample ids as NUL-terminated strings
+int cmd_dump_plp(int argc, char** argv) {
+  CommonFlags cf;
+  VcfReader vr;
+  std::vector<std::string> smIDs;
+  Args a;
+  cf.add(a);
+  a.add_string("vcf", &vr.path);
+  a.add_string("field", &cf.lo.field);
+  a.add_double("geno-error-offset", &cf.lo.genoErrorOffset);
+  a.add_double("geno-error-coeff", &cf.lo.genoErrorCoeffR2);
+  a.add_string("r2-info", &cf.lo.r2info);
+  a.add_int("min-mac", &vr.vfilt.minMAC);
+  a.add_double("min-callrate", &vr.vfilt.minCallRate);
+  a.add_multi_string("sm", &smIDs);
+  a.parse(argc, argv);
+  if (cf.plpPrefix.empty() || cf.outPrefix.empty()) fatal("Missing required option(s) : --plp, --out");
+  Pileup p;
+  if (!vr.path.empty()) {
+    vr.wanted = smIDs;
+    vr.init();
+    load_from_plp(cf.plpPrefix, cf.lo, &vr, p);
+  } else {
+    load_from_plp(cf.plpPrefix, cf.lo, nullptr, p);
+  }
+  FILE* f = fopen(cf.outPrefix.c_str(), "wb");
+  if (!f) fatal("Cannot open %s for writing", cf.outPrefix.c_str());
+  const int64_t hdr[5] = {p.C(), p.S(), p.nnz(), (int64_t)p.reads.size(), p.nv};
+  fwrite("MUXGLPLP", 1, 8, f);
+  fwrite(hdr, sizeof(int64_t), 5, f);
+  fwrite(p.cell_ptr.data(), sizeof(int64_t), p.cell_ptr.size(), f);
+  fwrite(p.entry_snp.data(), sizeof(int32_t), p.entry_snp.size(), f);
+  fwrite(p.entry_rptr.data(), sizeof(int64_t), p.entry_rptr.size(), f);
+  fwrite(p.reads.data(), 1, p.reads.size(), f);
+  std::vector<double> af((size_t)p.S());
+  for (int64_t s = 0; s < p.S(); ++s) af[(size_t)s] = p.snps[(size_t)s].af;
+  fwrite(af.data(), sizeof(double), af.size(), f);
+  std::vector<uint8_t> hg = p.has_gp;
+  hg.resize((size_t)p.S(), 0);
+  fwrite(hg.data(), 1, hg.size(), f);
+  fwrite(p.gp.data(), sizeof(double), p.gp.size(), f);
+  fwrite(p.cell_totl_reads.data(), sizeof(int32_t), p.cell_totl_reads.size(), f);
+  fwrite(p.cell_uniq_reads.data(), sizeof(int32_t), p.cell_uniq_reads.size(), f);
+  for (const std::string& s : p.bcs) fwrite(s.c_str(), 1, s.size() + 1, f);
+  for (const std::string& s : p.sample_ids) fwrite(s.c_str(), 1, s.size() + 1, f);
+  fclose(f);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: popscle-amd <demuxlet|freemuxlet|dump-plp> [options]\n");
+    return 1;
+  }
+  try {
+    const std::string cmd = argv[1];
+    if (cmd == "demuxlet") return cmd_demuxlet(argc - 2, argv + 2);
+    if (cmd == "freemuxlet") return cmd_freemuxlet(argc - 2, argv + 2);
+    if (cmd == "dump-plp") return cmd_dump_plp(argc - 2, argv + 2);
+    fprintf(stderr, "Cannot recognize the command %s\n", argv[1]);
+    return 1;
+  } catch (const std::exception&) {
+    return 1;
+  }
+}

@@ -1,0 +1,299 @@
+// plp.hpp -- CEL/VAR/PLP loader: the producer side of the libmuxgl boundary.
+//
+// Mirrors sc_dropseq_lib_t::load_from_plp (sc_drop_seq.cpp:103-384) but parses straight into the packed CSR pileup of
+// include/muxgl.h instead of the reference's map<cell, map<snp, map<string UMI, uint32>>> model:
+//   .cel.gz  header check (:143-151), --group-list / min-total / min-umi / min-snp filters (:164-180), dense ids in
+//            file order, DROPLET_ID consistency check (:184-185)
+//   .var.gz  header check (:210-217), SNP id = row index, chromosome index by first appearance (:228-233), merge-join
+//            with the VCF cursor (:258-327) and GP row construction (:287-315)
+//   .plp.gz  header check (:339-344), per base: bq = q-33, keep if bq >= minBQ, cap at capBQ, allele = digit (:350-370)
+// Read order inside an entry is the reference's std::map<std::string> iteration order: every kept base gets the UMI
+// sprintf("%x", numi++) (:361-368), i.e. reads are ordered by the hexadecimal STRING of a global kept-base counter.
+#pragma once
+
+#include <algorithm>
+#include <memory>
+
+#include "../../include/muxgl.h"
+#include "vcf.hpp"
+
+namespace pa {
+
+struct SnpInfo {
+  int32_t rid, pos;
+  char ref, alt;
+  double af;
+};
+
+struct Pileup {
+  // cells
+  std::vector<std::string> bcs;       // barcode of each cell id (file order of the kept cells)
+  std::vector<int32_t> cell_totl_reads, cell_uniq_reads;
+  // SNPs
+  std::vector<SnpInfo> snps;
+  std::vector<std::string> rid2chr;
+  // packed pileup
+  std::vector<int64_t> cell_ptr, entry_rptr;
+  std::vector<int32_t> entry_snp;
+  std::vector<uint8_t> reads;
+  // demuxlet only
+  int32_t nv = 0;
+  std::vector<std::string> sample_ids;
+  std::vector<double> gp;       // [S][nv][3]
+  std::vector<uint8_t> has_gp;  // [S]
+  int64_t C() const { return (int64_t)bcs.size(); }
+  int64_t S() const { return (int64_t)snps.size(); }
+  int64_t nnz() const { return (int64_t)entry_snp.size(); }
+};
+
+struct LoadOptions {
+  int32_t minRead = 0, minUMI = 0, minSNP = 0;  // --min-total --min-umi --min-snp
+  int32_t minBQ = 13, capBQ = 20;               // cmd_cram_demuxlet.cpp:17-18, cmd_cram_freemux2.cpp:16-17
+  std::string groupList;                        // --group-list
+  // VCF side (demuxlet)
+  std::string field = "GP";                     // --field
+  double genoErrorOffset = 0.10, genoErrorCoeffR2 = 0.0;
+  std::string r2info = "R2";
+};
+
+inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, VcfReader* pvr, Pileup& out) {
+  int nv = 0;
+  if (pvr) {
+    if (!pvr->read()) fatal("Cannot read any single variant from %s", pvr->path.c_str());
+    if (!pvr->parse_posteriors(opt.field))
+      fatal("Cannot parse posterior probability at %s:%d", pvr->chrom_name(pvr->rid), pvr->pos);
+    nv = pvr->nsamples();
+    out.nv = nv;
+    out.sample_ids = pvr->sample_ids;
+  }
+  std::set<std::string> valid_bcs;
+  if (!opt.groupList.empty()) {  // load_valid_barcodes, sc_drop_seq.cpp:93-101
+    TsvReader t(opt.groupList);
+    while (t.read_line() > 0) valid_bcs.insert(t.str_field_at(0));
+    notice("Loaded %zu valid barcodes from %s", valid_bcs.size(), opt.groupList.c_str());
+  }
+
+  notice("Loading pileup information with prefix %s", prefix.c_str());
+  // ---- .cel.gz
+  std::vector<int32_t> index_bcs, tmp_totl, tmp_uniq, tmp_nsnp;
+  {
+    TsvReader t(prefix + ".cel.gz");
+    if (t.read_line() > 0) {
+      if (t.nfields != 6 || strcmp("#DROPLET_ID", t.str_field_at(0)) || strcmp("BARCODE", t.str_field_at(1)) ||
+          strcmp("NUM.READ", t.str_field_at(2)) || strcmp("NUM.UMI", t.str_field_at(3)) ||
+          strcmp("NUM.UMIwSNP", t.str_field_at(4)) || strcmp("NUM.SNP", t.str_field_at(5)))
+        fatal("The header line of %s.cel.gz is malformed or outdated. Expecting #DROPLET_ID BARCODE NUM.READ NUM.UMI "
+              "NUM.UMIwSNP NUM.SNP", prefix.c_str());
+    } else {
+      fatal("Cannot read the first line of %s.cel.gz", prefix.c_str());
+    }
+    int32_t nskip = 0;
+    std::map<std::string, int32_t> bc_map;
+    while (t.read_line() > 0) {
+      if (t.nfields < 6) fatal("%s.cel.gz: line %d has %d fields", prefix.c_str(), t.nlines, t.nfields);
+      if (!valid_bcs.empty() && !valid_bcs.count(t.str_field_at(1))) {
+        ++nskip;
+        index_bcs.push_back(-1);
+        continue;
+      }
+      const int32_t n_reads = t.int_field_at(2), n_umis = t.int_field_at(3), n_umi_w_snps = t.int_field_at(4),
+                    n_snps = t.int_field_at(5);
+      if (n_reads < opt.minRead || n_umis < opt.minUMI || n_snps < opt.minSNP) {
+        index_bcs.push_back(-1);
+        ++nskip;
+        continue;
+      }
+      int32_t new_id;  // add_cell, sc_drop_seq.cpp:28-45
+      auto it = bc_map.find(t.str_field_at(1));
+      if (it == bc_map.end()) {
+        new_id = (int32_t)out.bcs.size();
+        bc_map[t.str_field_at(1)] = new_id;
+        out.bcs.push_back(t.str_field_at(1));
+      } else {
+        new_id = it->second;
+      }
+      index_bcs.push_back(new_id);
+      if (new_id + nskip != t.int_field_at(0))
+        fatal("Observed DROPLET_ID %d is different from expected DROPLET_ID %d. Did you modify the digital pileup "
+              "files by yourself?", t.int_field_at(0), new_id + nskip);
+      tmp_totl.push_back(n_reads);
+      tmp_uniq.push_back(n_umi_w_snps);
+      tmp_nsnp.push_back(n_snps);
+    }
+    notice("Finished loading %zu droplets, skipping %d", out.bcs.size(), nskip);
+  }
+  const int64_t C = out.C();
+
+  // ---- .var.gz (+ VCF merge-join)
+  {
+    TsvReader t(prefix + ".var.gz");
+    if (t.read_line() > 0) {
+      if (t.nfields != 6 || strcmp("#SNP_ID", t.str_field_at(0)) || strcmp("CHROM", t.str_field_at(1)) ||
+          strcmp("POS", t.str_field_at(2)) || strcmp("REF", t.str_field_at(3)) || strcmp("ALT", t.str_field_at(4)) ||
+          strcmp("AF", t.str_field_at(5)))
+        fatal("THe header line of %s.var.gz is malformed or outdated. Expecting #SNP_ID CHROM POS REF ALT AF",
+              prefix.c_str());
+    } else {
+      fatal("Cannot read the first line of %s.var.gz", prefix.c_str());
+    }
+    std::map<std::string, int32_t> chr2rid;
+    while (t.read_line() > 0) {
+      if (t.nfields < 6) fatal("%s.var.gz: line %d has %d fields", prefix.c_str(), t.nlines, t.nfields);
+      const char* chr = t.str_field_at(1);
+      if (!chr2rid.count(chr)) {
+        const int32_t newrid = (int32_t)chr2rid.size();
+        chr2rid[chr] = newrid;
+        out.rid2chr.push_back(chr);
+      }
+      SnpInfo s;
+      s.rid = chr2rid[chr];
+      s.pos = t.int_field_at(2);
+      s.ref = t.str_field_at(3)[0];
+      s.alt = t.str_field_at(4)[0];
+      s.af = t.double_field_at(5);
+      bool with_gp = false;
+      if (pvr) {
+        bool found = false, passed = false;  // sc_drop_seq.cpp:258-327
+        while (!(found || passed)) {
+          if (pvr->eof) {
+            passed = true;
+          } else if (pvr->rid > s.rid) {
+            passed = true;
+          } else if (pvr->rid == s.rid) {
+            if (pvr->pos > s.pos) {
+              passed = true;
+            } else if (pvr->pos == s.pos) {
+              const char vref = pvr->alleles[0].empty() ? '.' : pvr->alleles[0][0];
+              const char valt = pvr->alleles.size() > 1 && !pvr->alleles[1].empty() ? pvr->alleles[1][0] : '.';
+              if (vref != s.ref || valt != s.alt) passed = true;
+              else found = true;
+            }
+          }
+          if (passed) break;
+          if (found) {
+            if (!pvr->parse_posteriors(opt.field))
+              fatal("Cannot parse posterior probability at %s:%d", pvr->chrom_name(pvr->rid), pvr->pos);
+            std::vector<double> gps((size_t)nv * 3);
+            double avgGPs[3] = {1e-10, 1e-10, 1e-10};
+            for (int32_t i = 0; i < nv * 3; ++i) avgGPs[i % 3] += (gps[(size_t)i] = pvr->gps[(size_t)i]);
+            const double sumGP = avgGPs[0] + avgGPs[1] + avgGPs[2];
+            avgGPs[0] /= sumGP;
+            avgGPs[1] /= sumGP;
+            avgGPs[2] /= sumGP;
+            double err = opt.genoErrorOffset;
+            if (opt.genoErrorCoeffR2 > 0) {
+              float r2 = 0;
+              if (!pvr->info_float(opt.r2info, &r2))
+                fatal("Cannot extract %s (1 float value) from INFO field at %s:%d. Cannot use --geno-error-coeff",
+                      opt.r2info.c_str(), chr, s.pos);
+              err += (1 - opt.genoErrorOffset) * (1 - r2) * opt.genoErrorCoeffR2;
+            }
+            if (err > 0.999) err = 0.999;
+            if (err < 0) err = 0;
+            if (err > 0)
+              for (int32_t i = 0; i < nv * 3; ++i) gps[(size_t)i] = (1 - err) * gps[(size_t)i] + err * avgGPs[i % 3];
+            out.gp.insert(out.gp.end(), gps.begin(), gps.end());
+            with_gp = true;
+            break;
+          }
+          pvr->read();
+        }
+        if (!with_gp) out.gp.insert(out.gp.end(), (size_t)nv * 3, 0.0);
+        out.has_gp.push_back(with_gp ? 1 : 0);
+      }
+      out.snps.push_back(s);
+      if ((int)out.snps.size() + 1 != t.nlines)
+        fatal("Expected SNP nID = %d but observed %zu", t.nlines - 1, out.snps.size() - 1);
+    }
+    notice("Finished loading %zu variants..", out.snps.size());
+  }
+  const int64_t S = out.S();
+
+  // ---- .plp.gz
+  struct Rd {
+    int32_t cell, snp;
+    uint32_t numi;
+    uint8_t byte;
+  };
+  std::vector<Rd> rds;
+  out.cell_totl_reads.assign((size_t)C, 0);
+  out.cell_uniq_reads.assign((size_t)C, 0);
+  {
+    TsvReader t(prefix + ".plp.gz");
+    if (t.read_line() > 0) {
+      if (t.nfields != 4 || strcmp("#DROPLET_ID", t.str_field_at(0)) || strcmp("SNP_ID", t.str_field_at(1)) ||
+          strcmp("ALLELES", t.str_field_at(2)) || strcmp("BASEQS", t.str_field_at(3)))
+        fatal("THe header line of %s.plp.gz is malformed or outdated. Expecting #DROPLET_ID SNP_ID ALLELES BASEQS",
+              prefix.c_str());
+    } else {
+      fatal("Cannot read the first line of %s.plp.gz", prefix.c_str());
+    }
+    uint32_t numi = 0;
+    const int capBQ = opt.capBQ > 127 ? 127 : opt.capBQ;
+    while (t.read_line() > 0) {
+      if (t.nfields < 4) fatal("%s.plp.gz: line %d has %d fields", prefix.c_str(), t.nlines, t.nfields);
+      const int32_t did = t.int_field_at(0);
+      if (did < 0 || did >= (int32_t)index_bcs.size()) fatal("%s.plp.gz: DROPLET_ID %d out of range", prefix.c_str(), did);
+      const int32_t ibc = index_bcs[(size_t)did];
+      if (ibc < 0) continue;
+      const int32_t snp = t.int_field_at(1);
+      if (snp < 0 || snp >= S) fatal("%s.plp.gz: SNP_ID %d out of range", prefix.c_str(), snp);
+      const char* pa = t.str_field_at(2);
+      const char* pq = t.str_field_at(3);
+      const int32_t l = (int32_t)strlen(pq);
+      if ((int32_t)strlen(pa) != l) fatal("Length are different between %s and %s", pa, pq);
+      for (int32_t i = 0; i < l; ++i) {
+        const int bq0 = (int)(char)(pq[i] - (char)33);
+        if (bq0 >= opt.minBQ) {
+          const int bq = bq0 > capBQ ? capBQ : bq0;
+          const int al = (int)(char)(pa[i] - (char)'0');
+          const uint8_t byte = (al == 0) ? (uint8_t)bq : (al == 1) ? (uint8_t)(0x80 | bq) : (uint8_t)MUXGL_READ_OTHER;
+          rds.push_back(Rd{ibc, snp, numi++, byte});
+          ++out.cell_totl_reads[(size_t)ibc];
+          ++out.cell_uniq_reads[(size_t)ibc];  // every kept base is its own UMI (:361-368)
+        }
+      }
+    }
+    notice("Finished loading %u UMIs in total..", numi);
+  }
+  // order: cell, SNP, then the reference's std::map<std::string> order of the "%x" UMI strings
+  auto hexless = [](uint32_t a, uint32_t b) {
+    char sa[16], sb[16];
+    snprintf(sa, sizeof(sa), "%x", a);
+    snprintf(sb, sizeof(sb), "%x", b);
+    return strcmp(sa, sb) < 0;
+  };
+  std::sort(rds.begin(), rds.end(), [&](const Rd& a, const Rd& b) {
+    if (a.cell != b.cell) return a.cell < b.cell;
+    if (a.snp != b.snp) return a.snp < b.snp;
+    return a.numi < b.numi;
+  });
+  for (size_t b = 0; b < rds.size();) {  // entries are short: re-order each one by the "%x" string of its counters
+    size_t e = b + 1;
+    while (e < rds.size() && rds[e].cell == rds[b].cell && rds[e].snp == rds[b].snp) ++e;
+    if (e - b > 1)
+      std::sort(rds.begin() + (long)b, rds.begin() + (long)e, [&](const Rd& x, const Rd& y) { return hexless(x.numi, y.numi); });
+    b = e;
+  }
+  out.cell_ptr.assign((size_t)C + 1, 0);
+  out.entry_rptr.assign(1, 0);
+  out.reads.reserve(rds.size());
+  for (size_t i = 0; i < rds.size(); ++i) {
+    if (i == 0 || rds[i].cell != rds[i - 1].cell || rds[i].snp != rds[i - 1].snp) {
+      out.entry_snp.push_back(rds[i].snp);
+      out.entry_rptr.push_back(out.entry_rptr.back());
+      ++out.cell_ptr[(size_t)rds[i].cell + 1];
+    }
+    out.reads.push_back(rds[i].byte);
+    ++out.entry_rptr.back();
+  }
+  for (int64_t c = 0; c < C; ++c) out.cell_ptr[(size_t)c + 1] += out.cell_ptr[(size_t)c];
+  // sanity check on the observed counts (:375-380)
+  for (int64_t c = 0; c < C; ++c) {
+    const int64_t nent = out.cell_ptr[(size_t)c + 1] - out.cell_ptr[(size_t)c];
+    if (out.cell_uniq_reads[(size_t)c] == tmp_uniq[(size_t)c] && tmp_nsnp[(size_t)c] == (int32_t)nent)
+      out.cell_totl_reads[(size_t)c] = tmp_totl[(size_t)c];
+  }
+}
+
+}  // namespace pa

@@ -70,6 +70,7 @@ SYMBOLS = {
     "muxgl_demux_get_entry_pg": (C.c_int, [_VP, _VP]),
     "muxgl_fmx_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_entry_gls": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_fmx_greedy_init": (C.c_int, [_VP, C.c_int32, _VP, C.c_double, C.c_double, _VP]),
     "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
@@ -216,6 +217,15 @@ class Engine:
         cnt = np.zeros((self.nnz, 3), dtype=np.int32)
         self._check(self.lib.muxgl_fmx_get_entry_gls(self.h, _ptr(gls), _ptr(cnt)))
         return gls, cnt
+
+    def fmx_greedy_init(self, K, scores, frac_init_clust=1.0, singlet_score_thres=-1e300):
+        scores = _arr(scores, np.float64, "scores")
+        if scores.shape != (self.C,):
+            raise ValueError("scores must be [C]")
+        clust = np.zeros(self.C, dtype=np.int32)
+        self._check(self.lib.muxgl_fmx_greedy_init(self.h, int(K), _ptr(scores), float(frac_init_clust),
+                                                    float(singlet_score_thres), _ptr(clust)))
+        return clust
 
     def fmx_set_clusters(self, K, clust):
         clust = _arr(clust, np.int32, "clust")

@@ -104,6 +104,21 @@ def test_em_trajectory_vs_oracle(eng, K, C, S, ment, iters):
     assert worst < 1e-7
 
 
+@pytest.mark.parametrize("K,C,frac,thres", [(4, 150, 1.0, -1e300), (6, 100, 0.5, -1e300), (3, 100, 1.0, 5.0)])
+def test_greedy_init_vs_oracle(eng, K, C, frac, thres):
+    """b3+b4 of the product (muxgl_fmx_greedy_init, host code inside the library) vs the oracle's restatement"""
+    p = synth.make_pileup(C, 1500, K, seed=900 + K, mean_entries=200, min_entries=30, with_gp=False)
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    llk0, llk2, _, _ = eng.fmx_prepare(p.af)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0  # same scores on both sides: the sort must not depend on last-ulp differences of the GPU sums
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores), frac, thres)
+    got = eng.fmx_greedy_init(K, scores, frac, thres)
+    assert np.array_equal(got, want)
+    assert np.max(np.abs((llk2 - llk0) - scores)) < 1e-8
+
+
 def test_init_cluster_with_unassigned_cells_and_params(eng):
     """--init-cluster style start with some cells unassigned (-1), non-default priors, geno_error = 0"""
     K = 3

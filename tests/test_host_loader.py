@@ -1,0 +1,127 @@
+"""CPU tests of the host side (popscle_amd/host): the CEL/VAR/PLP loader and the VCF -> GP reader of the popscle-amd
+front end against an independent Python restatement of load_from_plp / parse_posteriors (tests/pyplp.py), on files of
+the real dsc-pileup format.  No GPU: `popscle-amd dump-plp` runs the loader only."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyplp
+from popscle_amd import plpio, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "popscle_amd", "bin", "popscle-amd")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(BIN):
+        from popscle_amd.build import build_lib
+
+        build_lib()
+        subprocess.run(["make", "-C", os.path.join(ROOT, "popscle_amd", "host")], check=True)
+    return BIN
+
+
+def dump(exe, prefix, out, *extra):
+    r = subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", out, *extra], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return plpio.read_dump(out)
+
+
+def same(got, want):
+    for k in ("C", "S", "nv", "bcs"):
+        assert got[k] == want[k], k
+    for k in ("cell_ptr", "entry_snp", "entry_rptr", "reads", "af", "has_gp", "cell_totl_reads", "cell_uniq_reads"):
+        assert np.array_equal(got[k], want[k]), k
+    assert got["gp"].shape == want["gp"].shape
+    assert np.array_equal(got["gp"], want["gp"]), "GP tensor differs (bit-exact expected)"
+
+
+def make_files(tmp_path, C=12, S=60, V=3, seed=3, deep=True):
+    p = synth.make_pileup(C, S, V, seed=seed, mean_entries=25, min_entries=5, reads_lambda=1.5 if deep else 0.3,
+                          other=0.05)
+    rng = np.random.default_rng(seed)
+    raw_bq = rng.integers(2, 41, size=p.R).astype(np.uint8)  # below min-BQ, between, above cap-BQ
+    prefix = str(tmp_path / "plp")
+    plpio.write_plp(prefix, p, raw_bq=raw_bq, seed=seed, extra_cells=2)
+    return p, prefix
+
+
+def test_loader_without_vcf(exe, tmp_path):
+    p, prefix = make_files(tmp_path)
+    got = dump(exe, prefix, str(tmp_path / "d.bin"))
+    want = pyplp.load(prefix)
+    same(got, want)
+    assert got["C"] == p.C + 2 and got["nnz"] <= p.nnz
+    # the UMI order is the order of the hex STRINGS of a global counter: with > 16 kept bases some entry must be
+    # affected ("10" < "9"); make sure the case is exercised
+    assert got["R"] > 16
+
+
+@pytest.mark.parametrize("minbq,capbq", [(13, 20), (2, 40), (30, 35)])
+def test_loader_bq_filters(exe, tmp_path, minbq, capbq):
+    p, prefix = make_files(tmp_path, seed=5)
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--min-BQ", str(minbq), "--cap-BQ", str(capbq))
+    same(got, pyplp.load(prefix, min_bq=minbq, cap_bq=capbq))
+    q = got["reads"][got["reads"] != 0xFF] & 0x7F
+    assert q.min() >= minbq and q.max() <= capbq
+
+
+def test_loader_cell_filters_and_group_list(exe, tmp_path):
+    p, prefix = make_files(tmp_path, seed=7)
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--min-snp", "1")
+    same(got, pyplp.load(prefix, min_snp=1))
+    assert got["C"] == p.C  # the two extra droplets have NUM.SNP = 0
+    bcs = pyplp.load(prefix)["bcs"]
+    keep = bcs[::2]
+    gl = tmp_path / "groups.txt"
+    gl.write_text("\n".join(keep) + "\n")
+    got = dump(exe, prefix, str(tmp_path / "d2.bin"), "--group-list", str(gl))
+    same(got, pyplp.load(prefix, group_list=keep))
+    assert got["bcs"] == keep
+
+
+@pytest.mark.parametrize("field", ["GT", "GP", "PL"])
+def test_loader_with_vcf(exe, tmp_path, field):
+    p, prefix = make_files(tmp_path, C=10, S=80, V=4, seed=11, deep=False)
+    G = p.truth["G"].astype(np.int64)
+    rng = np.random.default_rng(1)
+    gp = rng.dirichlet([0.3, 0.3, 0.3], size=G.shape)
+    pl = rng.integers(0, 60, size=G.shape + (3,))
+    vcf = str(tmp_path / "g.vcf.gz")
+    plpio.write_vcf(vcf, p, G, field=field, missing_frac=0.1, drop_snps=[3, 17, 18], gp=gp, pl=pl)
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--vcf", vcf, "--field", field)
+    want = pyplp.load(prefix, vcf=vcf, field=field)
+    same(got, want)
+    assert got["nv"] == 4 and got["sample_ids"] == ["S0", "S1", "S2", "S3"]
+    assert got["has_gp"][[3, 17, 18]].tolist() == [0, 0, 0]
+    assert 0 < got["has_gp"].sum() < p.S  # MAC / call-rate filters remove some monomorphic sites too
+    rows = got["gp"][got["has_gp"] == 1]
+    assert np.allclose(rows.sum(axis=2), 1.0, atol=1e-6)
+
+
+def test_loader_geno_error_flags(exe, tmp_path):
+    p, prefix = make_files(tmp_path, C=8, S=50, V=3, seed=13, deep=False)
+    vcf = str(tmp_path / "g.vcf")
+    plpio.write_vcf(vcf, p, p.truth["G"].astype(np.int64))
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--vcf", vcf, "--field", "GT", "--geno-error-offset", "0.05",
+               "--geno-error-coeff", "0.5", "--min-mac", "2", "--min-callrate", "0.9")
+    want = pyplp.load(prefix, vcf=vcf, field="GT", geno_error_offset=0.05, geno_error_coeff=0.5, min_mac=2,
+                      min_callrate=0.9)
+    same(got, want)
+
+
+def test_loader_rejects_malformed_header(exe, tmp_path):
+    import gzip
+
+    p, prefix = make_files(tmp_path, seed=17)
+    with gzip.open(prefix + ".cel.gz", "rt") as f:
+        lines = f.read().split("\n")
+    lines[0] = "#DROPLET_ID\tBARCODE\tNUM.READ\tNUM.UMI\tNUM.SNP"  # the outdated 5-column header
+    with gzip.open(prefix + ".cel.gz", "wt") as f:
+        f.write("\n".join(lines))
+    r = subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", str(tmp_path / "x.bin")], capture_output=True,
+                       text=True)
+    assert r.returncode != 0 and "malformed or outdated" in r.stderr
