@@ -36,7 +36,10 @@ def write_plp(prefix: str, p, bcs=None, raw_bq=None, chrom="1", seed: int = 0, e
     C, S = p.C, p.S
     bcs = list(bcs) if bcs is not None else barcodes(C + extra_cells, seed)
     al = np.where(p.reads == READ_OTHER, 2, p.reads >> 7).astype(np.uint8)
-    bq = (p.reads & 0x7F).astype(np.uint8) if raw_bq is None else np.asarray(raw_bq, dtype=np.uint8)
+    if raw_bq is None:
+        bq = np.where(p.reads == READ_OTHER, 20, p.reads & 0x7F).astype(np.uint8)  # 'other' bases carry no quality
+    else:
+        bq = np.asarray(raw_bq, dtype=np.uint8)
     nreads_e = np.diff(p.entry_rptr)
     with gzip.open(prefix + ".cel.gz", "wt") as f:
         f.write("#DROPLET_ID\tBARCODE\tNUM.READ\tNUM.UMI\tNUM.UMIwSNP\tNUM.SNP\n")
