@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (1 or 2)")
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the config's cells (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="functional test of the N>1 path on a 1-GPU box: every rank uses device 0 (use with gloo)")
     args = ap.parse_args()
 
     import torch
@@ -95,10 +98,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.dist_backend)
+    tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     cfg = synth.CONFIGS[args.config]
     alphas = tuple(cfg["alphas"])
@@ -108,7 +116,7 @@ def main():
     p = synth.make_pileup(C, cfg["S"], V, seed=synth.BASE_SEED + args.config + 1000 * rank,
                           donor_seed=synth.BASE_SEED + args.config)
 
-    eng = muxgl.Engine(local_rank)
+    eng = muxgl.Engine(dev)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.demux_set_gp(p.gp, p.has_gp)
 
@@ -128,10 +136,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(p.C), float(p.nnz)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(p.C), float(p.nnz)], dtype=torch.float64, device=tdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cells, total_entries = float(tot[0].item()), float(tot[1].item())
     else:

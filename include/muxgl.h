@@ -166,6 +166,23 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
 /* cluster pileups for the .clust1.vcf.gz writer (cmd_cram_freemux2.cpp:608-658): gls[K][S][9], counts[K][S][3] */
 int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
 
+/* ---- sharded EM (multi-GPU).  Every rank holds the whole pileup (muxgl_set_pileup + muxgl_fmx_prepare) and owns a
+ *      cell range [c0,c1) for the E-step/scans/re-assignment and a SNP range [s0,s1) for the cluster GP rows and the
+ *      ordered M-step.  One iteration = iter_gp -> all-gather MUXGL_BUF_CGP slices [s0*K*3, s1*K*3) -> iter_estep ->
+ *      all-gather MUXGL_BUF_CLUST slices [c0,c1) (+ all-reduce of the three counters) -> iter_mstep.  The collectives
+ *      are the caller's (RCCL over xGMI via torch.distributed in this repo); muxgl_fmx_buffer exposes the device
+ *      buffers they run on.  With the full ranges the phases reproduce muxgl_fmx_iterate bit for bit. ---------------- */
+enum { MUXGL_BUF_CGP = 0 /* f64[S][K][3] */, MUXGL_BUF_CLUST = 1 /* i32[C] */, MUXGL_BUF_CELLS = 2 /* muxgl_fmx_cell[C] */,
+       MUXGL_BUF_STAT = 3 /* i32[4]: nsingle, namb, nchanged of the local cell range */ };
+int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int64_t s1);
+int muxgl_fmx_iter_gp(muxgl_handle* h, const muxgl_fmx_params* p);
+int muxgl_fmx_iter_estep(muxgl_handle* h, const muxgl_fmx_params* p);
+int muxgl_fmx_iter_mstep(muxgl_handle* h);
+int muxgl_fmx_iter_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb, int32_t* nchanged,
+                         double* full_ll);
+int muxgl_fmx_buffer(muxgl_handle* h, int32_t which, void** dev_ptr, int64_t* n_elems);
+int muxgl_memcpy_dev(muxgl_handle* h, void* dst_dev, const void* src_dev, int64_t bytes);
+
 /* ---- measurement --------------------------------------------------------------------------------------------- */
 /* ms[MUXGL_T_COUNT]: hipEvent durations of the kernels of the most recent run/iterate call (0 where not run) */
 int muxgl_get_timing(const muxgl_handle* h, float* ms);

@@ -89,6 +89,8 @@ struct muxgl_handle {
   int64_t* d_snp_ptr = nullptr;   // [S+1]
   int64_t* d_snp_entry = nullptr; // [nnz] entry index
   bool fmx_prepared = false;
+  int64_t fc0 = 0, fc1 = 0, fs0 = 0, fs1 = 0;  // active cell / SNP shard of the EM phases (default: everything)
+  muxgl_row_state* frow = nullptr;             // chunk tables restricted to the cell shard
 
   hipEvent_t ev[2 * MUXGL_T_COUNT] = {};
   bool ev_used[MUXGL_T_COUNT] = {};
@@ -176,6 +178,9 @@ int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* 
 int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);
+int demux_row_build(muxgl_handle* h, muxgl_row_state** st, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t c0,
+                    int64_t c1);
+void demux_row_release(muxgl_row_state** st);
 int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
 int fmx_build_clusters_launch(muxgl_handle* h);
 int fmx_iterate_launch(muxgl_handle* h, const muxgl_fmx_params* p);

@@ -283,8 +283,8 @@ struct row_plan {
 
 }  // namespace
 
-void demux_row_free(muxgl_handle* h) {
-  muxgl_row_state* st = h->row;
+void demux_row_release(muxgl_row_state** pst) {
+  muxgl_row_state* st = *pst;
   if (!st) return;
   dev_free(&st->d_chunks);
   dev_free(&st->d_cell_chunk_ptr);
@@ -292,17 +292,28 @@ void demux_row_free(muxgl_handle* h) {
   dev_free(&st->d_kmap);
   dev_free(&st->d_part);
   delete st;
-  h->row = nullptr;
+  *pst = nullptr;
 }
 
-// builds the chunk tables from the host copy of cell_ptr (called by muxgl_set_pileup)
+void demux_row_free(muxgl_handle* h) {
+  demux_row_release(&h->row);
+  demux_row_release(&h->frow);
+}
+
+// builds the chunk tables of every cell from the host copy of the CSR arrays (called by muxgl_set_pileup)
 int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp) {
-  if (!h->row) h->row = new muxgl_row_state();
-  muxgl_row_state* st = h->row;
+  return demux_row_build(h, &h->row, cell_ptr, entry_snp, 0, h->C);
+}
+
+// chunk tables of the cells [cb, ce): cells outside the range own no chunk
+int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t cb,
+                    int64_t ce) {
+  if (!*pst) *pst = new muxgl_row_state();
+  muxgl_row_state* st = *pst;
   const int64_t C = h->C;
   std::vector<row_chunk> chunks;
-  chunks.reserve((size_t)(h->nnz / ROW_CH + C + 1));
-  for (int64_t c = 0; c < C; ++c)
+  chunks.reserve((size_t)((cell_ptr[ce] - cell_ptr[cb]) / ROW_CH + (ce - cb) + 1));
+  for (int64_t c = cb; c < ce; ++c)
     for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; e += ROW_CH) {
       const int64_t len = std::min<int64_t>(ROW_CH, cell_ptr[c + 1] - e);
       chunks.push_back(row_chunk{e, (int32_t)len, (int32_t)c});

@@ -127,12 +127,12 @@ __global__ void __launch_bounds__(64)
 
 // cmd_cram_freemux2.cpp:402-415: gp = HWE(af) * diag(cluster gls), normalised, mixed with the prior by geno_error
 __global__ void __launch_bounds__(256)
-    fmx_cgp_kernel(int64_t S, int K, const double* __restrict__ af, const double* __restrict__ cgls, double geno_error,
-                   double* __restrict__ cgp) {
+    fmx_cgp_kernel(int64_t S, int64_t s0, int64_t s1, int K, const double* __restrict__ af,
+                   const double* __restrict__ cgls, double geno_error, double* __restrict__ cgp) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= S * K) return;
-  const int64_t s = tid / K;
-  const int k = (int)(tid - s * K);
+  if (tid >= (s1 - s0) * K) return;
+  const int64_t s = s0 + tid / K;
+  const int k = (int)(tid % K);
   const double a = af[s];
   const double* g = cgls + ((size_t)k * S + s) * 9;
   const double p0 = (1.0 - a) * (1.0 - a), p1 = 2 * a * (1.0 - a), p2 = a * a;
@@ -256,8 +256,8 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(192)
     fmx_estep_row_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
                                 const double* __restrict__ part, const int32_t* __restrict__ kmap, int K,
-                                double* __restrict__ fll) {
-  const int64_t c = blockIdx.x;
+                                int64_t c_off, double* __restrict__ fll) {
+  const int64_t c = c_off + blockIdx.x;
   const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
   const int npairs = K * (K + 1) / 2;
   const int idx = threadIdx.x;
@@ -279,9 +279,9 @@ __global__ void __launch_bounds__(192)
 template <int PPT>
 __global__ void __launch_bounds__(256)
     fmx_estep_pair_kernel(const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ entry_snp,
-                          const double* __restrict__ egls, const double* __restrict__ cgp, int K,
+                          const double* __restrict__ egls, const double* __restrict__ cgp, int K, int64_t c_off,
                           double* __restrict__ fll) {
-  const int64_t c = blockIdx.x;
+  const int64_t c = c_off + blockIdx.x;
   const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
   const int npairs = K * (K + 1) / 2;
   const int T = blockDim.x;
@@ -339,10 +339,10 @@ __global__ void __launch_bounds__(256)
 
 // cmd_cram_freemux2.cpp:458-584 for one cell per lane; stat[0..2] = nsingle, namb, nchanged
 __global__ void __launch_bounds__(64)
-    fmx_call_kernel(int64_t C, int K, double doublet_prior, const double* __restrict__ fll,
+    fmx_call_kernel(int64_t c0, int64_t c1, int K, double doublet_prior, const double* __restrict__ fll,
                     muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C) return;
+  const int64_t i = c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c1) return;
   const int nSamples = K;
   const int npairs = K * (K + 1) / 2;
   const double log_single_prior = log((1.0 - doublet_prior) / nSamples);                // :379
@@ -457,14 +457,15 @@ __global__ void __launch_bounds__(64)
 // snp_droplet_pileup::merge (sc_drop_seq.h:77-101), applied in ascending cell id for every (cluster, SNP) chain.
 // Division by the running sum is a multiplication by its reciprocal; logdenom is never read and is not kept.
 __global__ void __launch_bounds__(256)
-    fmx_mstep_kernel(int64_t S, int K, const int64_t* __restrict__ snp_ptr, const int64_t* __restrict__ snp_entry,
+    fmx_mstep_kernel(int64_t S, int64_t s0, int64_t s1, int K, const int64_t* __restrict__ snp_ptr,
+                     const int64_t* __restrict__ snp_entry,
                      const int32_t* __restrict__ entry_cell, const int32_t* __restrict__ clust,
                      const double* __restrict__ egls, const int32_t* __restrict__ ecnt, double* __restrict__ cgls,
                      int32_t* __restrict__ ccnt) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= S * K) return;
-  const int64_t s = tid / K;
-  const int k = (int)(tid - s * K);
+  if (tid >= (s1 - s0) * K) return;
+  const int64_t s = s0 + tid / K;
+  const int k = (int)(tid % K);
   double g[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) g[i] = 1.0;
@@ -508,10 +509,10 @@ __global__ void __launch_bounds__(256)
 }  // namespace
 
 static int fmx_mstep_launch(muxgl_handle* h) {
-  const int64_t n = h->S * h->K;
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(fmx_mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->K,
-                     h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_ecnt, h->d_cgls,
+  const int64_t n = (h->fs1 - h->fs0) * h->K;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fmx_mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->fs0, h->fs1,
+                     h->K, h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_ecnt, h->d_cgls,
                      h->d_ccnt);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -594,6 +595,11 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   }
   h->fmx_prepared = true;
   h->K = 0;
+  h->fc0 = 0;
+  h->fc1 = C;
+  h->fs0 = 0;
+  h->fs1 = S;
+  demux_row_release(&h->frow);
   return 0;
 }
 
@@ -732,28 +738,32 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   return 0;
 }
 
-int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
-                      int32_t* nchanged, double* full_ll) {
-  if (!h) return 1;
-  HIPCHK(h, hipSetDevice(h->device));
-  if (!p) MUXGL_FAIL(h, "muxgl_fmx_iterate: params NULL");
-  if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iterate: call muxgl_fmx_prepare and muxgl_fmx_set_clusters first");
-  const int64_t C = h->C, S = h->S;
+static int fmx_check_iter(muxgl_handle* h, const muxgl_fmx_params* p, const char* who) {
+  if (!p) MUXGL_FAIL(h, "%s: params NULL", who);
+  if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "%s: call muxgl_fmx_prepare and muxgl_fmx_set_clusters first", who);
+  return 0;
+}
+
+// cluster genotype posteriors of the SNP shard [fs0,fs1) from the cluster pileups (cmd_cram_freemux2.cpp:402-415)
+static int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p) {
+  tic(h, MUXGL_T_FMX_GP);
+  const int64_t n = (h->fs1 - h->fs0) * h->K;
+  if (n > 0)
+    hipLaunchKernelGGL(fmx_cgp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->fs0, h->fs1,
+                       h->K, h->d_af, h->d_cgls, p->geno_error, h->d_cgp);
+  toc(h, MUXGL_T_FMX_GP);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+// E-step, scans and re-assignment of the cell shard [fc0,fc1) (:383-584); needs the whole cgp tensor
+static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
+  const int64_t c0 = h->fc0, c1 = h->fc1, nc = c1 - c0;
   const int K = h->K;
   const int npairs = K * (K + 1) / 2;
-  clear_timing(h);
-
-  tic(h, MUXGL_T_FMX_GP);
-  if (S) {
-    const int64_t n = S * K;
-    hipLaunchKernelGGL(fmx_cgp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S, K, h->d_af,
-                       h->d_cgls, p->geno_error, h->d_cgp);
-  }
-  toc(h, MUXGL_T_FMX_GP);
-
   tic(h, MUXGL_T_FMX_ESTEP);
-  muxgl_row_state* st = h->row;
-  if (C) {
+  muxgl_row_state* st = h->frow ? h->frow : h->row;
+  if (nc > 0) {
     if (K <= 16 && st && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
       const size_t need = (size_t)st->n_chunks * FX_NACC * 16;
       if (need > st->part_cap) {
@@ -764,39 +774,158 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
       if (blocks)
         hipLaunchKernelGGL(fmx_estep_row_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
                            h->d_entry_snp, h->d_egls, h->d_cgp, K, st->d_part);
-      hipLaunchKernelGGL(fmx_estep_row_reduce_kernel, dim3((unsigned)C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
-                         st->d_cell_chunks, st->d_part, st->d_kmap, K, h->d_fll);
+      hipLaunchKernelGGL(fmx_estep_row_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                         st->d_cell_chunks, st->d_part, st->d_kmap, K, c0, h->d_fll);
     } else {
       const int T = 256, PPT = 4;
       const unsigned tiles = (unsigned)((npairs + T * PPT - 1) / (T * PPT));
-      hipLaunchKernelGGL(fmx_estep_pair_kernel<PPT>, dim3((unsigned)C, tiles), dim3(T), 0, h->stream, h->d_cell_ptr,
-                         h->d_entry_snp, h->d_egls, h->d_cgp, K, h->d_fll);
+      hipLaunchKernelGGL(fmx_estep_pair_kernel<PPT>, dim3((unsigned)nc, tiles), dim3(T), 0, h->stream, h->d_cell_ptr,
+                         h->d_entry_snp, h->d_egls, h->d_cgp, K, c0, h->d_fll);
     }
   }
   toc(h, MUXGL_T_FMX_ESTEP);
-
   tic(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipMemsetAsync(h->d_fstat, 0, 4 * sizeof(int32_t), h->stream));
-  if (C)
-    hipLaunchKernelGGL(fmx_call_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, h->stream, C, K, p->doublet_prior,
-                       h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+  if (nc > 0)
+    hipLaunchKernelGGL(fmx_call_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, c0, c1, K,
+                       p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
   toc(h, MUXGL_T_FMX_CALL);
-
-  tic(h, MUXGL_T_FMX_MSTEP);
-  if (fmx_mstep_launch(h)) return 1;  // :516-517 clear + :590-596 merge of the singlet cells, ascending cell id
-  toc(h, MUXGL_T_FMX_MSTEP);
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
 
+// ordered clamped merge for the SNP shard [fs0,fs1) (:516-517 clear + :590-596); needs every cell's assignment
+static int fmx_phase_mstep(muxgl_handle* h) {
+  tic(h, MUXGL_T_FMX_MSTEP);
+  if (fmx_mstep_launch(h)) return 1;
+  toc(h, MUXGL_T_FMX_MSTEP);
+  return 0;
+}
+
+static int fmx_phase_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb, int32_t* nchanged,
+                           double* full_ll) {
+  const int64_t C = h->C;
+  const int npairs = h->K * (h->K + 1) / 2;
   int32_t stat[4] = {0, 0, 0, 0};
   if (C) HIPCHK(h, hipMemcpyAsync(h->h_fcells, h->d_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(stat, h->d_fstat, sizeof(stat), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  collect_timing(h);
   if (out && C) memcpy(out, h->h_fcells, sizeof(muxgl_fmx_cell) * C);
   if (nsingle) *nsingle = stat[0];
   if (namb) *namb = stat[1];
   if (nchanged) *nchanged = stat[2];
   if (full_ll && C) HIPCHK(h, hipMemcpy(full_ll, h->d_fll, sizeof(double) * (size_t)C * npairs, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
+                      int32_t* nchanged, double* full_ll) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (fmx_check_iter(h, p, "muxgl_fmx_iterate")) return 1;
+  if (h->fc0 != 0 || h->fc1 != h->C || h->fs0 != 0 || h->fs1 != h->S)
+    MUXGL_FAIL(h, "muxgl_fmx_iterate: handle is sharded (muxgl_fmx_set_shard); use the muxgl_fmx_iter_* phases");
+  clear_timing(h);
+  if (fmx_phase_gp(h, p) || fmx_phase_estep(h, p) || fmx_phase_mstep(h)) return 1;
+  if (fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll)) return 1;
+  collect_timing(h);
+  return 0;
+}
+
+// ---- sharded EM (multi-GPU): the same three phases, restricted to a cell range and a SNP range, with the exchanges
+//      (all-gather of the cluster-GP rows after iter_gp, of the assignments after iter_estep) left to the caller ------
+
+int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int64_t s1) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_set_shard: call muxgl_fmx_prepare first");
+  if (c0 < 0 || c1 < c0 || c1 > h->C || s0 < 0 || s1 < s0 || s1 > h->S) MUXGL_FAIL(h, "muxgl_fmx_set_shard: bad range");
+  h->fc0 = c0;
+  h->fc1 = c1;
+  h->fs0 = s0;
+  h->fs1 = s1;
+  demux_row_release(&h->frow);
+  if (c0 != 0 || c1 != h->C) {  // chunk tables of the cell shard for the row E-step
+    std::vector<int64_t> cp((size_t)h->C + 1);
+    std::vector<int32_t> es((size_t)h->nnz);
+    HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (h->C + 1), hipMemcpyDeviceToHost));
+    if (h->nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
+    if (demux_row_build(h, &h->frow, cp.data(), es.data(), c0, c1)) return 1;
+  }
+  return 0;
+}
+
+int muxgl_fmx_iter_gp(muxgl_handle* h, const muxgl_fmx_params* p) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (fmx_check_iter(h, p, "muxgl_fmx_iter_gp")) return 1;
+  clear_timing(h);
+  if (fmx_phase_gp(h, p)) return 1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  return 0;
+}
+
+int muxgl_fmx_iter_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (fmx_check_iter(h, p, "muxgl_fmx_iter_estep")) return 1;
+  clear_timing(h);
+  if (fmx_phase_estep(h, p)) return 1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  return 0;
+}
+
+int muxgl_fmx_iter_mstep(muxgl_handle* h) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iter_mstep: no clusters set");
+  clear_timing(h);
+  if (fmx_phase_mstep(h)) return 1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  return 0;
+}
+
+int muxgl_fmx_iter_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb, int32_t* nchanged,
+                         double* full_ll) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iter_fetch: no clusters set");
+  return fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll);
+}
+
+int muxgl_fmx_buffer(muxgl_handle* h, int32_t which, void** dev_ptr, int64_t* n_elems) {
+  if (!h) return 1;
+  if (!dev_ptr || !n_elems) MUXGL_FAIL(h, "muxgl_fmx_buffer: NULL output");
+  if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_buffer: no clusters set");
+  switch (which) {
+    case MUXGL_BUF_CGP:
+      *dev_ptr = h->d_cgp;
+      *n_elems = h->S * h->K * 3;
+      return 0;
+    case MUXGL_BUF_CLUST:
+      *dev_ptr = h->d_clust;
+      *n_elems = h->C;
+      return 0;
+    case MUXGL_BUF_CELLS:
+      *dev_ptr = h->d_fcells;
+      *n_elems = h->C;
+      return 0;
+    case MUXGL_BUF_STAT:
+      *dev_ptr = h->d_fstat;
+      *n_elems = 4;
+      return 0;
+    default:
+      MUXGL_FAIL(h, "muxgl_fmx_buffer: unknown buffer %d", which);
+  }
+}
+
+int muxgl_memcpy_dev(muxgl_handle* h, void* dst_dev, const void* src_dev, int64_t bytes) {
+  if (!h) return 1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (bytes > 0) HIPCHK(h, hipMemcpy(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice));
   return 0;
 }
 

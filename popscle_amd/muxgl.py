@@ -24,6 +24,7 @@ T_DEMUX_REDUCE, T_DEMUX_SWEEP, T_DEMUX_CALL, T_DEMUX_D2H = 0, 1, 2, 3
 FLAG_FORCE_TILE_SWEEP = 1
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
 T_COUNT = 16
+BUF_CGP, BUF_CLUST, BUF_CELLS, BUF_STAT = 0, 1, 2, 3
 
 DEMUX_CELL = np.dtype(
     [(n, np.int32) for n in ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA",
@@ -74,6 +75,13 @@ SYMBOLS = {
     "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_fmx_set_shard": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "muxgl_fmx_iter_gp": (C.c_int, [_VP, C.POINTER(_FmxParams)]),
+    "muxgl_fmx_iter_estep": (C.c_int, [_VP, C.POINTER(_FmxParams)]),
+    "muxgl_fmx_iter_mstep": (C.c_int, [_VP]),
+    "muxgl_fmx_iter_fetch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "muxgl_fmx_buffer": (C.c_int, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_int64)]),
+    "muxgl_memcpy_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64]),
     "muxgl_get_timing": (C.c_int, [_VP, _VP]),
 }
 
@@ -245,6 +253,40 @@ class Engine:
         if want_full_ll:
             return out, stats, full
         return out, stats
+
+    # ---- sharded EM phases (multi-GPU); the collectives between them belong to the caller (popscle_amd/freemuxlet.py)
+    def fmx_set_shard(self, c0, c1, s0, s1):
+        self._check(self.lib.muxgl_fmx_set_shard(self.h, int(c0), int(c1), int(s0), int(s1)))
+
+    def fmx_iter_gp(self, doublet_prior=0.5, geno_error=0.1):
+        p = _FmxParams(float(doublet_prior), float(geno_error))
+        self._check(self.lib.muxgl_fmx_iter_gp(self.h, C.byref(p)))
+
+    def fmx_iter_estep(self, doublet_prior=0.5, geno_error=0.1):
+        p = _FmxParams(float(doublet_prior), float(geno_error))
+        self._check(self.lib.muxgl_fmx_iter_estep(self.h, C.byref(p)))
+
+    def fmx_iter_mstep(self):
+        self._check(self.lib.muxgl_fmx_iter_mstep(self.h))
+
+    def fmx_iter_fetch(self, want_full_ll=False):
+        out = np.zeros(self.C, dtype=FMX_CELL)
+        full = np.zeros((self.C, self.K * (self.K + 1) // 2)) if want_full_ll else None
+        ns, na, nc = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.muxgl_fmx_iter_fetch(self.h, _ptr(out), C.byref(ns), C.byref(na), C.byref(nc), _ptr(full)))
+        stats = (ns.value, na.value, nc.value)
+        return (out, stats, full) if want_full_ll else (out, stats)
+
+    def fmx_buffer(self, which):
+        """(device pointer, element count) of an internal exchange buffer: BUF_CGP f64, BUF_CLUST i32, BUF_CELLS
+        records, BUF_STAT i32[4]"""
+        ptr = _VP()
+        n = C.c_int64()
+        self._check(self.lib.muxgl_fmx_buffer(self.h, int(which), C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def memcpy_dev(self, dst_ptr, src_ptr, nbytes):
+        self._check(self.lib.muxgl_memcpy_dev(self.h, _VP(dst_ptr), _VP(src_ptr), int(nbytes)))
 
     def fmx_cluster_pileup(self):
         gls = np.zeros((self.K, self.S, 9))

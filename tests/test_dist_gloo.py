@@ -1,0 +1,173 @@
+"""CPU tests of the N>1 path: world_size-2 runs over torch.distributed/gloo of the sharded demuxlet and freemuxlet
+drivers (popscle_amd/demuxlet.py, popscle_amd/freemuxlet.py) and of the shard planner.
+
+There is no GPU here, so the engines are oracle-backed stand-ins that implement exactly the phase interface of
+muxgl.Engine (range-restricted E-step, SNP-sharded ordered M-step, exchange buffers).  What is under test is the
+orchestration: shard planning, which slices travel, the order of phases and collectives, counter reduction, and the final
+gather -- the sharded run must reproduce the single-process oracle run bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_binding as ob
+from popscle_amd import demuxlet, freemuxlet, shard, synth
+
+
+def test_split_by_weight_properties():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 8):
+        w = rng.integers(0, 100, size=57)
+        r = shard.split_by_weight(w, n)
+        assert len(r) == n and r[0][0] == 0 and r[-1][1] == w.size
+        assert all(r[i][1] == r[i + 1][0] for i in range(n - 1))
+        sums = [w[b:e].sum() for b, e in r]
+        assert max(sums) <= w.sum() / n + w.max()
+    assert shard.split_by_weight([], 3) == [(0, 0), (0, 0), (0, 0)]
+    assert shard.split_by_weight([5, 5], 4)[-1][1] == 2
+
+
+def test_cell_and_snp_shards_cover_everything():
+    p = synth.make_pileup(50, 400, 3, seed=2, mean_entries=60, min_entries=5, with_gp=False)
+    cr = shard.cell_shards(p.cell_ptr, 4)
+    sr = shard.snp_shards(p.entry_snp, p.S, 4)
+    assert cr[0][0] == 0 and cr[-1][1] == p.C and sr[0][0] == 0 and sr[-1][1] == p.S
+    ent = [p.cell_ptr[e] - p.cell_ptr[b] for b, e in cr]
+    assert max(ent) < 1.6 * p.nnz / 4
+
+
+class FakeDemuxEngine:
+    def set_pileup(self, S, cell_ptr, entry_snp, entry_rptr, reads):
+        self.args = (S, cell_ptr, entry_snp, entry_rptr, reads)
+
+    def demux_set_gp(self, gp, has_gp):
+        self.gp, self.has_gp = gp, has_gp
+
+    def demux_run(self, alphas, doublet_prior):
+        S, cp, es, er, rd = self.args
+        q = synth.Pileup(cp.size - 1, S, cp, es, er, rd, np.zeros(S), self.gp, self.has_gp)
+        return ob.demux(q, alphas=alphas, doublet_prior=doublet_prior)
+
+
+class FakeFmxEngine:
+    """oracle-backed stand-in with muxgl.Engine's sharded-EM interface"""
+
+    def __init__(self, p):
+        self.p = p
+        self.C, self.S = p.C, p.S
+        self.e = ob.fmx_entry_pileup(p)
+
+    def fmx_set_shard(self, c0, c1, s0, s1):
+        self.c0, self.c1, self.s0, self.s1 = c0, c1, s0, s1
+
+    def _mstep(self):
+        full = ob.fmx_build_cluster_pileup(self.p, self.e, self.K, self.clust)
+        self.cplp[:, self.s0:self.s1] = full[:, self.s0:self.s1]
+
+    def fmx_set_clusters(self, K, clust):
+        self.K = K
+        self.clust = np.ascontiguousarray(clust, dtype=np.int32).copy()
+        self.cells = ob.fmx_init_cells(self.clust)
+        self.cplp = np.zeros((K, self.S), dtype=ob.PLP)
+        self.cplp["gls"] = np.nan  # rows of foreign SNP shards must arrive through the exchange
+        self.xg = np.full((self.S, K * 9), np.nan)
+        self._mstep()
+
+    def fmx_iter_gp(self, dp, ge):
+        self.xg[self.s0:self.s1] = self.cplp["gls"][:, self.s0:self.s1].transpose(1, 0, 2).reshape(-1, self.K * 9)
+
+    def fmx_iter_estep(self, dp, ge):
+        assert not np.isnan(self.xg).any(), "a cluster-GP slice was not exchanged"
+        cp = np.zeros((self.K, self.S), dtype=ob.PLP)
+        cp["gls"] = self.xg.reshape(self.S, self.K, 9).transpose(1, 0, 2)
+        cells_r = np.arange(self.c0, self.c1)
+        sub = self.p.subset_cells(cells_r)
+        e_sub = self.e[self.p.cell_ptr[self.c0]:self.p.cell_ptr[self.c1]].copy()
+        cs = self.cells[self.c0:self.c1].copy()
+        ns, na, nch = ob.fmx_iterate(sub, e_sub, self.K, cp, cs, dp, ge)
+        self.cells[self.c0:self.c1] = cs
+        self.clust[:] = -1000  # poison: every slice must come back through the exchange
+        self.clust[self.c0:self.c1] = cs["clust"]
+        self.stats = (ns, na, nch)
+
+    def fmx_iter_fetch(self):
+        return self.cells.copy(), self.stats
+
+    def fmx_iter_mstep(self):
+        assert (self.clust > -1000).all(), "an assignment slice was not exchanged"
+        self.cplp["gls"] = np.nan
+        self._mstep()
+        self.xg[:] = np.nan
+
+
+def fake_exchange_tensor(eng, which):
+    if which == freemuxlet.UNIT_CGP:
+        return torch.from_numpy(eng.xg)
+    return torch.from_numpy(eng.clust).view(-1, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, kind, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = freemuxlet.TorchExchange(dist, rank, world)
+    if kind == "demux":
+        p = synth.make_pileup(41, 600, 4, seed=33, mean_entries=80, min_entries=5)
+        out = demuxlet.run_sharded(FakeDemuxEngine, p, (0.0, 0.5), 0.5, exchange=ex)
+        np.save(os.path.join(outdir, f"demux_{rank}.npy"), out)
+    else:
+        K = 3
+        p = synth.make_pileup(60, 500, K, seed=44, mean_entries=120, min_entries=20, with_gp=False)
+        eng = FakeFmxEngine(p)
+        llk0, llk2, _, _ = ob.fmx_cell_scores(p, eng.e)
+        clust0 = ob.fmx_greedy_init(p, eng.e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
+        cells, hist = freemuxlet.run_em(eng, K, clust0, p.cell_ptr, p.entry_snp, 0.5, 0.1, max_iter=6, exchange=ex,
+                                        exchange_tensor=fake_exchange_tensor)
+        np.save(os.path.join(outdir, f"fmx_{rank}.npy"), cells)
+        np.save(os.path.join(outdir, f"fmxhist_{rank}.npy"), np.array(hist))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_demuxlet_gloo(tmp_path, world):
+    mp.spawn(_worker, args=(world, _free_port(), "demux", str(tmp_path)), nprocs=world, join=True)
+    p = synth.make_pileup(41, 600, 4, seed=33, mean_entries=80, min_entries=5)
+    want = ob.demux(p)
+    for r in range(world):
+        got = np.load(tmp_path / f"demux_{r}.npy")
+        assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_freemuxlet_gloo(tmp_path, world):
+    mp.spawn(_worker, args=(world, _free_port(), "fmx", str(tmp_path)), nprocs=world, join=True)
+    K = 3
+    p = synth.make_pileup(60, 500, K, seed=44, mean_entries=120, min_entries=20, with_gp=False)
+    e = ob.fmx_entry_pileup(p)
+    llk0, llk2, _, _ = ob.fmx_cell_scores(p, e)
+    clust0 = ob.fmx_greedy_init(p, e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
+    cplp = ob.fmx_build_cluster_pileup(p, e, K, clust0)
+    cells = ob.fmx_init_cells(clust0)
+    hist = []
+    for _ in range(6):
+        st = ob.fmx_iterate(p, e, K, cplp, cells)
+        hist.append(st)
+        if st[2] == 0:
+            break
+    for r in range(world):
+        got = np.load(tmp_path / f"fmx_{r}.npy")
+        assert got.tobytes() == cells.tobytes()
+        assert np.array_equal(np.load(tmp_path / f"fmxhist_{r}.npy"), np.array(hist))
