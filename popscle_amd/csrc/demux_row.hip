@@ -51,7 +51,7 @@ __global__ void row_kmap_kernel(int32_t* kmap /*[16][16] = [t][j]*/) {
 
 // cmd_cram_demuxlet.cpp:655-725 for one entry (same arithmetic as entry_pg<> in demux_kernels.hip)
 template <int NA>
-__device__ __forceinline__ void row_entry_pg(const uint8_t* __restrict__ reads, int64_t r0, int64_t r1,
+__device__ __forceinline__ void row_entry_pg(const uint8_t* __restrict__ reads, int64_t r0, int64_t r1, uint32_t first4,
                                              const double* __restrict__ alpha, const double* lut, double (&pG)[NA * 9]) {
   // The reference multiplies every element by pR*(1-p) + pA*p with p = 0.5*l + (m-l)*0.5*alpha (:673,685) and divides
   // by the running maximum after every read (:692-699).  Here:
@@ -64,7 +64,8 @@ __device__ __forceinline__ void row_entry_pg(const uint8_t* __restrict__ reads, 
   for (int i = 0; i < NA * 9; ++i) pG[i] = 1.0;
   int since_norm = 0;
   for (int64_t r = r0; r < r1; ++r) {
-    const uint32_t b = reads[r];
+    const int64_t kk = r - r0;
+    const uint32_t b = (kk < 4) ? ((first4 >> (8 * (int)kk)) & 0xffu) : (uint32_t)reads[r];  // first 4 come prefetched
     if (b == MUXGL_READ_OTHER) continue;  // :664
     const uint32_t al = b >> 7, bq = b & 0x7f;
     const double e3 = lut[bq] / 3.0, mt = lut[128 + bq];
@@ -121,7 +122,7 @@ struct row_layout {
 };
 
 template <int NNS, int NSY>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (NNS == 0 ? 2 : 1))
     demux_row_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
                      const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
                      const double* __restrict__ gp, const uint8_t* __restrict__ has_gp,
@@ -155,19 +156,53 @@ __global__ void __launch_bounds__(64)
   }
   const int V3 = V * 3;
   const bool live = j < V;
+
+  // Metadata of the batch to come is fetched one batch ahead, in two dependent stages, so that phase 1 never waits
+  // on HBM: (ps, pr0, pr1) at the top of the previous batch, then has_gp[ps] and the first four read bytes in the
+  // middle of the previous batch's phase 2.
+  int32_t ps = -1;
+  int64_t pr0 = 0, pr1 = 0;
+  uint32_t pbytes = 0;
+  int32_t phg = 0;
+  auto fetch_meta = [&](int b) {
+    const int idx = b * 16 + j;
+    ps = -1;
+    pr0 = pr1 = 0;
+    if (idx < len) {
+      const int64_t e = e0 + idx;
+      ps = entry_snp[e];
+      pr0 = entry_rptr[e];
+      pr1 = entry_rptr[e + 1];
+    }
+  };
+  auto fetch_dependent = [&]() {
+    phg = 0;
+    pbytes = 0;
+    if (ps >= 0) {
+      phg = has_gp[ps];
+      const int64_t n = pr1 - pr0;
+      if (n > 0) pbytes = reads[pr0];
+      if (n > 1) pbytes |= (uint32_t)reads[pr0 + 1] << 8;
+      if (n > 2) pbytes |= (uint32_t)reads[pr0 + 2] << 16;
+      if (n > 3) pbytes |= (uint32_t)reads[pr0 + 3] << 24;
+    }
+  };
+  fetch_meta(0);
+  fetch_dependent();
   __syncthreads();
 
   for (int b = 0; b < nb; ++b) {
     // ---- phase 1: lane <-> entry (a4, a5) ----
     {
-      const int idx = b * 16 + j;
       double pG[NA * 9];
-      int32_t s = -1;
-      if (idx < len) {
-        const int64_t e = e0 + idx;
-        s = entry_snp[e];
-        if (has_gp[s]) {
-          row_entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], al.a, lut, pG);
+      int32_t s = ps;
+      const int64_t r0 = pr0, r1 = pr1;
+      const uint32_t first4 = pbytes;
+      const int32_t hg = phg;
+      if (b + 1 < nb) fetch_meta(b + 1);  // stage 1 of the next batch: independent loads, issued now
+      if (s >= 0) {
+        if (hg) {
+          row_entry_pg<NA>(reads, r0, r1, first4, al.a, lut, pG);
         } else {
           s = -1;  // :733  marker without genotypes: contributes nothing
         }
@@ -196,6 +231,7 @@ __global__ void __launch_bounds__(64)
       const double g0 = ng0, g1 = ng1, g2 = ng2, h0 = nh0, h1 = nh1, h2 = nh2;
       // prefetch the next entry's triples
       ng0 = 1.0, ng1 = 0.0, ng2 = 0.0, nh0 = 1.0, nh1 = 0.0, nh2 = 0.0;
+      if (i == 8 && b + 1 < nb) fetch_dependent();  // stage 2 of the next batch
       if (i + 1 < 16) {
         s_next = snps[slot * 16 + i + 1];
         if (s_next >= 0) {
