@@ -68,7 +68,7 @@ __device__ __forceinline__ void row_entry_pg(const uint8_t* __restrict__ reads, 
     const uint32_t b = (kk < 4) ? ((first4 >> (8 * (int)kk)) & 0xffu) : (uint32_t)reads[r];  // first 4 come prefetched
     if (b == MUXGL_READ_OTHER) continue;  // :664
     const uint32_t al = b >> 7, bq = b & 0x7f;
-    const double e3 = lut[bq] / 3.0, mt = lut[128 + bq];
+    const double e3 = lut[256 + bq], mt = lut[128 + bq];  // Err/3.0, Mat
     const double pR = (al == 0) ? mt : e3;  // :666
     const double d = (al == 0) ? (e3 - mt) : (mt - e3);  // pA - pR (:667)
 #pragma unroll
@@ -129,13 +129,13 @@ __global__ void __launch_bounds__(64, (NNS == 0 ? 2 : 1))
                      const double* __restrict__ lut_g, int V, row_alpha al, double* __restrict__ part) {
   using L = row_layout<NNS, NSY>;
   constexpr int NA = L::NA, NACC = L::NACC, PGS = L::PGS;
-  __shared__ double lut[256];
+  __shared__ double lut[384];
   __shared__ __align__(16) double pgs[4 * L::SLOT_STRIDE];
   __shared__ int32_t snps[64];
 
   const int lane = threadIdx.x;
   const int slot = lane >> 4, j = lane & 15;
-  for (int i = lane; i < 256; i += 64) lut[i] = lut_g[i];
+  for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
 
   const int q = blockIdx.x * 4 + slot;
   int64_t e0 = 0;
@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(64, (NNS == 0 ? 2 : 1))
   }
   const int V3 = V * 3;
   const bool live = j < V;
+  const bool a0_zero = (al.a[0] == 0.0);  // wave-uniform
 
   // Metadata of the batch to come is fetched one batch ahead, in two dependent stages, so that phase 1 never waits
   // on HBM: (ps, pr0, pr1) at the top of the previous batch, then has_gp[ps] and the first four read bytes in the
@@ -242,7 +243,12 @@ __global__ void __launch_bounds__(64, (NNS == 0 ? 2 : 1))
       }
       const double* qn = pgs + slot * L::SLOT_STRIDE + i * PGS;
       // singlet slot: llksAB[j][0][0] (:806,828) = sum_{l,m} g_j[l] g_0[m] pG[0][l][m]
-      {
+      if (a0_zero) {
+        // alpha[0] == 0: p does not depend on m (:673), the three columns of pG[0] are the same numbers, and the sum
+        // factorises into (sum_l g_j[l] pG[0][l][0]) * (g_0[0] + g_0[1] + g_0[2])
+        const double u0 = fma(g2, qn[6], fma(g1, qn[3], g0 * qn[0]));
+        acc[0] *= u0 * (h0 + h1 + h2);
+      } else {
         const double u0 = fma(g2, qn[6], fma(g1, qn[3], g0 * qn[0]));
         const double u1 = fma(g2, qn[7], fma(g1, qn[4], g0 * qn[1]));
         const double u2 = fma(g2, qn[8], fma(g1, qn[5], g0 * qn[2]));

@@ -48,10 +48,12 @@ int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
 
   // Phred tables, PhredHelper.cpp:24-41: phred2Err[i] = (i > 1) ? pow(0.1, i*0.1) : 0.75; phred2Mat = 1 - Err.
   // The packed read byte carries 7 bits of quality, so 128 entries of each suffice.
-  double lut[256];
+  // [256..383] holds Err/3.0 (cmd_cram_demuxlet.cpp:666-667), divided here once, IEEE-exactly, instead of per read.
+  double lut[384];
   for (int i = 0; i < 128; ++i) {
     lut[i] = (i > 1) ? pow(0.1, i * 0.1) : 0.75;
     lut[128 + i] = 1. - lut[i];
+    lut[256 + i] = lut[i] / 3.0;
   }
   if ((e = hipMalloc((void**)&h->d_lut, sizeof(lut))) != hipSuccess) return fail("hipMalloc(lut)", e);
   if ((e = hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(lut)", e);
