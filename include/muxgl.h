@@ -41,7 +41,8 @@ extern "C" {
 enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 
 /* muxgl_config.flags */
-#define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row kernel (lets tests cover the general tile sweep) */
+#define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row/quad kernels (lets tests cover the general tile sweep) */
+#define MUXGL_FLAG_FORCE_ROW_KERNEL 2  /* never take the default-grid quad kernel (lets tests cover the row kernel) */
 
 typedef struct muxgl_handle muxgl_handle;
 

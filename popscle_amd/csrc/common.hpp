@@ -17,6 +17,9 @@ struct muxgl_counts {
   int32_t nreads, nref, nalt;
 };
 
+constexpr int MUXGL_ROW_CH = 128;   // entries per chunk of the row kernels (16-lane slots)
+constexpr int MUXGL_QUAD_CH = 64;  // entries per chunk of the quad kernel (4-lane slots)
+
 // one work unit of the row kernels (demux_row.hip, fmx_kernels.hip): <= 128 consecutive entries of one cell
 struct row_chunk {
   int64_t e0;
@@ -30,8 +33,10 @@ struct muxgl_row_state {
   int64_t* d_cell_chunk_ptr = nullptr;  // [C+1]
   int32_t* d_cell_chunks = nullptr;     // chunk positions of each cell in entry order
   int32_t* d_kmap = nullptr;            // [16][16]: sample held by lane j after t DPP row rotations
-  double* d_part = nullptr;             // per-chunk partial log-likelihoods
-  size_t part_cap = 0;
+  int32_t* d_tmap = nullptr;            // [2][4]: tile seen by a quad lane after row_ror:4 / row_ror:8
+  double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
+  int32_t* d_part_e = nullptr;          // per-chunk partial exponents (quad kernel)
+  size_t part_cap = 0, part_e_cap = 0;
   int64_t n_chunks = 0;
 };
 
@@ -56,6 +61,8 @@ struct muxgl_handle {
   int32_t V = 0;
   double* d_gp = nullptr;
   uint8_t* d_has_gp = nullptr;
+  double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_quad.hip)
+  double* d_gp0s = nullptr;  // V <= 16: per-SNP sum of sample 0's triple (the factor every singlet carries, :806)
   double* d_ll = nullptr;  // [C][V][V][A]
   size_t ll_cap = 0;
   bool ll_zeroed = false;
@@ -70,6 +77,7 @@ struct muxgl_handle {
   bool have_dp = false;
   bool pairs_valid = false;
   struct muxgl_row_state* row = nullptr;  // chunk tables of the V<=16 row kernel (demux_row.hip)
+  struct muxgl_row_state* qrow = nullptr; // chunk tables of the default-grid quad kernel (demux_quad.hip)
   int32_t flags = 0;
 
   // freemuxlet
@@ -166,6 +174,21 @@ __device__ __forceinline__ void prodacc_renorm(double& m, int32_t& e) {
 }
 __device__ __forceinline__ double prodacc_log(double m, int32_t e) { return log(m) + (double)e * 0.6931471805599453094; }
 
+// Workgroup -> work-unit index with XCD affinity.  The dispatcher is observed to place workgroup b on XCD b % 8
+// (MI355X_MICROARCH.md; used for speed only, nothing depends on it): the work list is cut into 8 contiguous blocks,
+// one per XCD, so that workgroups resident on one XCD walk neighbouring work units -- here neighbouring SNP windows of
+// the GP tensor, which then fit that XCD's 4 MiB L2.  n8 = ceil(n/8); the result may be >= n (caller checks).
+__device__ __forceinline__ int xcd_swizzle(int b, int n8) { return (b & 7) * n8 + (b >> 3); }
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 // sc_drop_seq.cpp:5-8
 __device__ __forceinline__ double dev_logadd(double la, double lb) {
   if (la > lb) return la + log(1.0 + exp(lb - la));
@@ -179,7 +202,8 @@ int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entr
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);
 int demux_row_build(muxgl_handle* h, muxgl_row_state** st, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t c0,
-                    int64_t c1);
+                    int64_t c1, int ch);
+int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_release(muxgl_row_state** st);
 int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
 int fmx_build_clusters_launch(muxgl_handle* h);

@@ -1,0 +1,415 @@
+// demux_quad.hip -- the demuxlet sweep for the reference's DEFAULT configuration: V <= 16 samples and the alpha grid
+// {0, 0.5} that cmdCramDemuxlet installs when no --alpha is given (cmd_cram_demuxlet.cpp:85-89).
+//
+// Reference being replaced: cmd_cram_demuxlet.cpp:655-747.  Same mathematics as demux_row.hip; what changes is the
+// register tiling, chosen because the row kernel turned out VALU-issue bound (94 % VALU busy) with 44 % of its vector
+// instructions being DPP moves and per-iteration bookkeeping rather than FP64 arithmetic:
+//
+//   * 4 lanes per entry instead of 16: lane r of a quad owns the FOUR samples 4r..4r+3 (12 doubles, one contiguous
+//     96-byte piece of the GP row), so a wave sweeps 16 entries per iteration instead of 4 and every per-iteration
+//     cost (LDS reads of the entry's likelihoods, address arithmetic, waits) is amortised over 4x more entries.
+//   * pairs inside a lane need no data movement (6 pairs); the other tiles arrive with two DPP rotations of the
+//     16-lane row (row_ror:4 -> neighbouring tile, 16 pairs; row_ror:8 -> opposite tile, 10 pairs with c <= d so that
+//     the two lanes facing each other split the tile pair) : 3 DPP moves per entry instead of 12.
+//   * the grid {0, 0.5} has structure the general code cannot assume: for alpha = 0 the mixing proportion is
+//     p = l/2, independent of m (3 distinct likelihoods per entry instead of 9), and for alpha = 0.5 it is
+//     p = (l+m)/4 (5 distinct instead of 9).  Phase 1 therefore carries 8 products per read instead of 18, and the
+//     singlet slot factorises into (sum_l g_j[l] q0[l]) * (g_0[0]+g_0[1]+g_0[2]).
+//   * products leave the kernel as (mantissa, exponent) pairs; demux_quad_reduce_kernel multiplies the chunk partials
+//     of a cell in chunk order and takes ONE log per hypothesis and cell (the row kernel took one per chunk).
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int QN_ACC = 36;      // per lane: 4 singlets, 6 in-lane pairs, 16 pairs with the neighbour tile, 10 with the opposite
+constexpr int Q_SLOT_STRIDE = 34;  // doubles: 4 entries x 8 likelihoods + 2 pad => the 16 slots of a wave hit distinct banks
+
+__device__ __forceinline__ double dpp_ror4(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, false);  // row_ror:4
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_ror8(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, false);  // row_ror:8
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// tile (= lane>>2 & 3) whose samples a lane sees after row_ror:4 / row_ror:8, measured rather than assumed
+__global__ void quad_tmap_kernel(int32_t* tmap /*[2][4]*/) {
+  const int lane = threadIdx.x;
+  int t = (lane >> 2) & 3;
+  const int t4 = __builtin_amdgcn_mov_dpp(t, 0x124, 0xF, 0xF, false);
+  const int t8 = __builtin_amdgcn_mov_dpp(t, 0x128, 0xF, 0xF, false);
+  if (lane < 16 && (lane & 3) == 0) {
+    tmap[t] = t4;
+    tmap[4 + t] = t8;
+  }
+}
+
+// accumulator index layout
+__host__ __device__ constexpr int q_acc_single(int c) { return c; }
+__host__ __device__ constexpr int q_acc_within(int c1, int c2) {  // c1 < c2
+  return 4 + (c1 == 0 ? c2 - 1 : (c1 == 1 ? 3 + c2 - 2 : 5));
+}
+__host__ __device__ constexpr int q_acc_t1(int c, int d) { return 10 + c * 4 + d; }
+__host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
+  return 26 + (c == 0 ? d : (c == 1 ? 4 + d - 1 : (c == 2 ? 7 + d - 2 : 9)));
+}
+
+__global__ void __launch_bounds__(64, 2)
+    demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
+                      const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
+                      const double* __restrict__ gpq, const double* __restrict__ gp0s,
+                      const uint8_t* __restrict__ has_gp, const double* __restrict__ lut_g, double* __restrict__ part_m,
+                      int32_t* __restrict__ part_e) {
+  __shared__ double lut[384];
+  __shared__ __align__(16) double pgs[16 * Q_SLOT_STRIDE];
+  __shared__ int32_t snps[64];
+
+  const int lane = threadIdx.x;
+  const int r = (lane >> 2) & 3;                       // tile: samples 4r..4r+3
+  const int slot = ((lane >> 4) << 2) | (lane & 3);    // 16 entry streams per wave
+  for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
+
+  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;
+  int64_t e0 = 0;
+  int len = 0;
+  if (q < n_chunks) {
+    e0 = chunks[q].e0;
+    len = chunks[q].len;
+  }
+  const int nb = (wave_max_i32(len) + 3) >> 2;  // trip count of the wave = its longest chunk
+
+  double acc[QN_ACC];
+  int32_t ex[QN_ACC];
+#pragma unroll
+  for (int a = 0; a < QN_ACC; ++a) {
+    acc[a] = 1.0;
+    ex[a] = 0;
+  }
+
+  // entry metadata of the batch to come, fetched one batch ahead in two dependent stages (see demux_row.hip)
+  int32_t ps = -1;
+  int64_t pr0 = 0, pr1 = 0;
+  uint32_t pbytes = 0;
+  int32_t phg = 0;
+  auto fetch_meta = [&](int b) {
+    const int idx = b * 4 + r;
+    ps = -1;
+    pr0 = pr1 = 0;
+    if (idx < len) {
+      const int64_t e = e0 + idx;
+      ps = entry_snp[e];
+      pr0 = entry_rptr[e];
+      pr1 = entry_rptr[e + 1];
+    }
+  };
+  auto fetch_dependent = [&]() {
+    phg = 0;
+    pbytes = 0;
+    if (ps >= 0) {
+      phg = has_gp[ps];
+      const int64_t n = pr1 - pr0;
+      if (n > 0) pbytes = reads[pr0];
+      if (n > 1) pbytes |= (uint32_t)reads[pr0 + 1] << 8;
+      if (n > 2) pbytes |= (uint32_t)reads[pr0 + 2] << 16;
+      if (n > 3) pbytes |= (uint32_t)reads[pr0 + 3] << 24;
+    }
+  };
+  fetch_meta(0);
+  fetch_dependent();
+  __syncthreads();
+
+  for (int b = 0; b < nb; ++b) {
+    // ---- phase 1: lane <-> entry.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
+    //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR ----
+    {
+      int32_t s = ps;
+      const int64_t r0 = pr0, r1 = pr1;
+      const uint32_t first4 = pbytes;
+      const int32_t hg = phg;
+      if (b + 1 < nb) fetch_meta(b + 1);
+      double q0[3] = {1.0, 1.0, 1.0}, q1[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
+      if (s >= 0 && !hg) s = -1;  // :733 marker without genotypes
+      if (s >= 0) {
+        int since = 0;
+        for (int64_t rr = r0; rr < r1; ++rr) {
+          const int64_t kk = rr - r0;
+          const uint32_t bb = (kk < 4) ? ((first4 >> (8 * (int)kk)) & 0xffu) : (uint32_t)reads[rr];
+          if (bb == MUXGL_READ_OTHER) continue;  // :664
+          const uint32_t al = bb >> 7, bq = bb & 0x7f;
+          const double e3 = lut[256 + bq], mt = lut[128 + bq];
+          const double pR = (al == 0) ? mt : e3, pA = (al == 0) ? e3 : mt;  // :666-667
+          const double d = pA - pR;
+          const double mid = fma(d, 0.5, pR);
+          q0[0] *= pR;
+          q0[1] *= mid;
+          q0[2] *= pA;
+          q1[0] *= pR;
+          q1[1] *= fma(d, 0.25, pR);
+          q1[2] *= mid;
+          q1[3] *= fma(d, 0.75, pR);
+          q1[4] *= pA;
+          if (++since == 32) {  // common rescaling, only against underflow (cancels in q/q_max)
+            since = 0;
+            double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) mx = fmax(mx, q1[t]);
+            const double inv = 1.0 / mx;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) q0[l] *= inv;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) q1[t] *= inv;
+          }
+        }
+        // (q/q_max + 1e-10) / (1 + 1e-10), :703-725; the maximum over all 18 elements is the maximum over these 8
+        double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) mx = fmax(mx, q1[t]);
+        const double cc = 1.0 / (1.0 + 1e-10);
+        const double sc = cc / mx, tt = 1e-10 * cc;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) q0[l] = fma(q0[l], sc, tt);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) q1[t] = fma(q1[t], sc, tt);
+      }
+      double* dst = pgs + slot * Q_SLOT_STRIDE + r * 8;
+      dst[0] = q0[0];
+      dst[1] = q0[1];
+      dst[2] = q0[2];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) dst[3 + t] = q1[t];
+      snps[slot * 4 + r] = s;
+    }
+    __syncthreads();
+
+    // ---- phase 2: lane <-> 4 samples, the 4 entries of the slot's batch one after the other ----
+    double nG[4][3], nhs = 1.0;
+    auto load_row = [&](int32_t s) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        nG[c][0] = 1.0;
+        nG[c][1] = 0.0;
+        nG[c][2] = 0.0;
+      }
+      nhs = 1.0;
+      if (s >= 0) {
+        nhs = gp0s[s];  // g_0[0]+g_0[1]+g_0[2]: sample 0's row multiplies every singlet (:806)
+        // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes
+        const double2* pc = reinterpret_cast<const double2*>(gpq + (size_t)s * 48) + r;
+        double f[12];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const double2 v = pc[t * 4];
+          f[2 * t] = v.x;
+          f[2 * t + 1] = v.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          nG[c][0] = f[3 * c];
+          nG[c][1] = f[3 * c + 1];
+          nG[c][2] = f[3 * c + 2];
+        }
+      }
+    };
+    load_row(snps[slot * 4]);
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      double G[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        G[c][0] = nG[c][0];
+        G[c][1] = nG[c][1];
+        G[c][2] = nG[c][2];
+      }
+      const double hs = nhs;
+      if (i == 2 && b + 1 < nb) fetch_dependent();
+      if (i + 1 < 4) load_row(snps[slot * 4 + i + 1]);  // prefetch the next entry's triples
+
+      const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
+      const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
+      const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
+      double u[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+        const double u0 = fma(G[c][2], a2, fma(G[c][1], a1, G[c][0] * a0));
+        acc[q_acc_single(c)] *= u0 * hs;
+        // u[c][m] = sum_l g_j[l] * pG[alpha=.5][l][m],  pG[l][m] = b[l+m]
+        u[c][0] = fma(G[c][2], b2, fma(G[c][1], b1, G[c][0] * b0));
+        u[c][1] = fma(G[c][2], b3, fma(G[c][1], b2, G[c][0] * b1));
+        u[c][2] = fma(G[c][2], b4, fma(G[c][1], b3, G[c][0] * b2));
+      }
+      // pairs inside the lane
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+        for (int c2 = c1 + 1; c2 < 4; ++c2)
+          acc[q_acc_within(c1, c2)] *= fma(G[c2][2], u[c1][2], fma(G[c2][1], u[c1][1], G[c2][0] * u[c1][0]));
+      // neighbouring tile
+      {
+        double P[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          P[d][0] = dpp_ror4(G[d][0]);
+          P[d][1] = dpp_ror4(G[d][1]);
+          P[d][2] = dpp_ror4(G[d][2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            acc[q_acc_t1(c, d)] *= fma(P[d][2], u[c][2], fma(P[d][1], u[c][1], P[d][0] * u[c][0]));  // :738-746
+      }
+      // opposite tile: the two lanes facing each other split the 16 pairs (c <= d here, d < c over there)
+      {
+        double Q[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          Q[d][0] = dpp_ror8(G[d][0]);
+          Q[d][1] = dpp_ror8(G[d][1]);
+          Q[d][2] = dpp_ror8(G[d][2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = c; d < 4; ++d)
+            acc[q_acc_t2(c, d)] *= fma(Q[d][2], u[c][2], fma(Q[d][1], u[c][1], Q[d][0] * u[c][0]));
+      }
+    }
+    if ((b & 3) == 3) {  // 16 entries per slot since the last renormalisation
+#pragma unroll
+      for (int a = 0; a < QN_ACC; ++a) prodacc_renorm(acc[a], ex[a]);
+    }
+    __syncthreads();
+  }
+
+  if (q < n_chunks) {
+#pragma unroll
+    for (int a = 0; a < QN_ACC; ++a) {
+      prodacc_renorm(acc[a], ex[a]);
+      part_m[((size_t)q * QN_ACC + a) * 4 + r] = acc[a];
+      part_e[((size_t)q * QN_ACC + a) * 4 + r] = ex[a];
+    }
+  }
+}
+
+// multiplies the chunk partials of one cell in chunk order and writes ll[c][j][k][n] (+ mirror): one log per hypothesis
+__global__ void __launch_bounds__(192)
+    demux_quad_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
+                             const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                             const int32_t* __restrict__ tmap, int V, int n0, int n1, int A, double* __restrict__ ll) {
+  const int64_t c = blockIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  const int idx = threadIdx.x;
+  if (c0 == c1 || idx >= QN_ACC * 4) return;
+  const int a = idx >> 2, r = idx & 3;
+  // which hypothesis is this accumulator?
+  int j, k, n = n1;
+  bool publish = true;
+  if (a < 4) {
+    j = 4 * r + a;
+    k = 0;
+    n = n0;
+  } else if (a < 10) {
+    int w = a - 4, c1i, c2i;
+    if (w < 3) {
+      c1i = 0;
+      c2i = w + 1;
+    } else if (w < 5) {
+      c1i = 1;
+      c2i = w - 1;
+    } else {
+      c1i = 2;
+      c2i = 3;
+    }
+    j = 4 * r + c2i;
+    k = 4 * r + c1i;
+  } else if (a < 26) {
+    const int cc = (a - 10) >> 2, dd = (a - 10) & 3;
+    j = 4 * r + cc;
+    k = 4 * tmap[r] + dd;
+  } else {
+    int w = a - 26, cc, dd;
+    if (w < 4) {
+      cc = 0;
+      dd = w;
+    } else if (w < 7) {
+      cc = 1;
+      dd = w - 3;
+    } else if (w < 9) {
+      cc = 2;
+      dd = w - 5;
+    } else {
+      cc = 3;
+      dd = 3;
+    }
+    const int ro = tmap[4 + r];
+    j = 4 * r + cc;
+    k = 4 * ro + dd;
+    if (cc == dd && r > ro) publish = false;  // the facing lane holds the same pair
+  }
+  if (!publish || j >= V || k >= V) return;
+  double m = 1.0;
+  int64_t e = 0;
+  int cnt = 0;
+  for (int64_t ci = c0; ci < c1; ++ci) {
+    const size_t o = (size_t)cell_chunks[ci] * QN_ACC * 4 + idx;
+    m *= part_m[o];
+    e += part_e[o];
+    if (++cnt == 512) {  // mantissas are in [0.5,1): 512 factors cannot underflow
+      cnt = 0;
+      int ee;
+      m = frexp(m, &ee);
+      e += ee;
+    }
+  }
+  const double v = log(m) + (double)e * 0.6931471805599453094;
+  double* out = ll + (size_t)c * V * V * A;
+  out[((size_t)j * V + k) * A + n] = v;
+  if (a >= 4) out[((size_t)k * V + j) * A + n] = v;
+}
+
+}  // namespace
+
+// returns -1 when the quad path does not apply, 0 ok, 1 error
+int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  if (h->V > 16 || !h->qrow || !h->d_gpq || h->C == 0) return -1;
+  if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL)) return -1;
+  if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
+  muxgl_row_state* st = h->qrow;
+  if (!st->d_tmap) {  // tile map of the two rotations
+    if (dev_alloc(h, &st->d_tmap, 8)) return 1;
+    hipLaunchKernelGGL(quad_tmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
+    HIPCHK(h, hipGetLastError());
+  }
+  const size_t need = (size_t)st->n_chunks * QN_ACC * 4;
+  if (need > st->part_cap) {
+    if (dev_alloc(h, &st->d_part, need)) return 1;
+    st->part_cap = need;
+  }
+  if (need > st->part_e_cap) {
+    if (dev_alloc(h, &st->d_part_e, need)) return 1;
+    st->part_e_cap = need;
+  }
+  tic(h, MUXGL_T_DEMUX_SWEEP);
+  const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
+  if (blocks) {
+    hipLaunchKernelGGL(demux_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
+                       h->d_entry_snp, h->d_entry_rptr, h->d_reads, h->d_gpq, h->d_gp0s, h->d_has_gp, h->d_lut,
+                       st->d_part, st->d_part_e);
+    HIPCHK(h, hipGetLastError());
+  }
+  toc(h, MUXGL_T_DEMUX_SWEEP);
+  tic(h, MUXGL_T_DEMUX_REDUCE);
+  hipLaunchKernelGGL(demux_quad_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                     st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, 0, 1, 2, h->d_ll);
+  HIPCHK(h, hipGetLastError());
+  toc(h, MUXGL_T_DEMUX_REDUCE);
+  return 0;
+}

@@ -24,7 +24,6 @@
 
 namespace {
 
-constexpr int ROW_CH = 128;  // entries per chunk
 
 struct row_alpha {
   double a[MUXGL_MAX_ALPHA];     // internal order: [0] = the singlet slot's alpha, then non-symmetric, then 0.5
@@ -137,15 +136,14 @@ __global__ void __launch_bounds__(64, (NNS == 0 ? 2 : 1))
   const int slot = lane >> 4, j = lane & 15;
   for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
 
-  const int q = blockIdx.x * 4 + slot;
+  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 4 + slot;
   int64_t e0 = 0;
   int len = 0;
   if (q < n_chunks) {
     e0 = chunks[q].e0;
     len = chunks[q].len;
   }
-  // chunks are ordered by non-increasing length, so slot 0 carries the wave's trip count
-  const int nb = (__builtin_amdgcn_readfirstlane(len) + 15) >> 4;
+  const int nb = (wave_max_i32(len) + 15) >> 4;  // trip count of the wave = its longest chunk
 
   double acc[NACC];
   int32_t ex[NACC];
@@ -345,7 +343,9 @@ void demux_row_release(muxgl_row_state** pst) {
   dev_free(&st->d_cell_chunk_ptr);
   dev_free(&st->d_cell_chunks);
   dev_free(&st->d_kmap);
+  dev_free(&st->d_tmap);
   dev_free(&st->d_part);
+  dev_free(&st->d_part_e);
   delete st;
   *pst = nullptr;
 }
@@ -353,38 +353,39 @@ void demux_row_release(muxgl_row_state** pst) {
 void demux_row_free(muxgl_handle* h) {
   demux_row_release(&h->row);
   demux_row_release(&h->frow);
+  demux_row_release(&h->qrow);
 }
 
 // builds the chunk tables of every cell from the host copy of the CSR arrays (called by muxgl_set_pileup)
 int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp) {
-  return demux_row_build(h, &h->row, cell_ptr, entry_snp, 0, h->C);
+  if (demux_row_build(h, &h->row, cell_ptr, entry_snp, 0, h->C, MUXGL_ROW_CH)) return 1;
+  return demux_row_build(h, &h->qrow, cell_ptr, entry_snp, 0, h->C, MUXGL_QUAD_CH);
 }
 
 // chunk tables of the cells [cb, ce): cells outside the range own no chunk
 int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t cb,
-                    int64_t ce) {
+                    int64_t ce, int ch) {
   if (!*pst) *pst = new muxgl_row_state();
   muxgl_row_state* st = *pst;
   const int64_t C = h->C;
   std::vector<row_chunk> chunks;
+  const int ROW_CH = ch;
   chunks.reserve((size_t)((cell_ptr[ce] - cell_ptr[cb]) / ROW_CH + (ce - cb) + 1));
   for (int64_t c = cb; c < ce; ++c)
     for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; e += ROW_CH) {
       const int64_t len = std::min<int64_t>(ROW_CH, cell_ptr[c + 1] - e);
       chunks.push_back(row_chunk{e, (int32_t)len, (int32_t)c});
     }
-  // Launch order.  (1) non-increasing length, so that slot 0 of every wave carries the wave's trip count and the four
-  // slots of a wave finish together.  (2) among equally long chunks (all the full ones), ascending first SNP id:
-  // entries are SNP-sorted inside a cell, so workgroups that are resident at the same time then gather GP rows from
-  // the same window of the [S][V][3] tensor, which fits the 4 MiB per-XCD L2 (the whole tensor, 19 MB at config 1,
-  // does not).
+  // Launch order: ascending first SNP id.  Entries are SNP-sorted inside a cell, so consecutive chunks of the launch
+  // list gather GP rows from neighbouring windows of the [S][V][3] tensor; xcd_swizzle() hands each XCD one contiguous
+  // eighth of the list, whose sliding window fits that XCD's 4 MiB L2 (the whole tensor, 19 MB at config 1, does not).
+  // Chunk lengths are then mixed inside a wave (the tails are ~6 % of the chunks): a wave runs for its longest chunk.
   if (entry_snp) {
     std::vector<int32_t> first((size_t)chunks.size());
     for (size_t i = 0; i < chunks.size(); ++i) first[i] = entry_snp[chunks[i].e0];
     std::vector<size_t> ord(chunks.size());
     for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
     std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
-      if (chunks[a].len != chunks[b].len) return chunks[a].len > chunks[b].len;
       return first[a] < first[b];
     });
     std::vector<row_chunk> sorted(chunks.size());
@@ -431,7 +432,7 @@ static int row_launch_t(muxgl_handle* h, const row_alpha& al, int A) {
     if (dev_alloc(h, &st->d_part, need)) return 1;
     st->part_cap = need;
   }
-  const unsigned blocks = (unsigned)((st->n_chunks + 3) / 4);
+  const unsigned blocks = (unsigned)((((st->n_chunks + 3) / 4) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL((demux_row_kernel<NNS, NSY>), dim3(blocks), dim3(64), 0, h->stream, st->d_chunks,
                        (int)st->n_chunks, h->d_entry_snp, h->d_entry_rptr, h->d_reads, h->d_gp, h->d_has_gp, h->d_lut,

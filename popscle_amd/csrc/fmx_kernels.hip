@@ -173,14 +173,14 @@ __global__ void __launch_bounds__(64)
   __shared__ int32_t snps[64];
   const int lane = threadIdx.x;
   const int slot = lane >> 4, j = lane & 15;
-  const int q = blockIdx.x * 4 + slot;
+  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 4 + slot;
   int64_t e0 = 0;
   int len = 0;
   if (q < n_chunks) {
     e0 = chunks[q].e0;
     len = chunks[q].len;
   }
-  const int nb = (__builtin_amdgcn_readfirstlane(len) + 15) >> 4;
+  const int nb = (wave_max_i32(len) + 15) >> 4;
   double acc[FX_NACC];
   int32_t ex[FX_NACC];
 #pragma unroll
@@ -770,7 +770,7 @@ static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
         if (dev_alloc(h, &st->d_part, need)) return 1;
         st->part_cap = need;
       }
-      const unsigned blocks = (unsigned)((st->n_chunks + 3) / 4);
+      const unsigned blocks = (unsigned)((((st->n_chunks + 3) / 4) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
       if (blocks)
         hipLaunchKernelGGL(fmx_estep_row_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
                            h->d_entry_snp, h->d_egls, h->d_cgp, K, st->d_part);
@@ -850,7 +850,7 @@ int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int
     std::vector<int32_t> es((size_t)h->nnz);
     HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (h->C + 1), hipMemcpyDeviceToHost));
     if (h->nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
-    if (demux_row_build(h, &h->frow, cp.data(), es.data(), c0, c1)) return 1;
+    if (demux_row_build(h, &h->frow, cp.data(), es.data(), c0, c1, MUXGL_ROW_CH)) return 1;
   }
   return 0;
 }

@@ -74,6 +74,8 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_lut);
   dev_free(&h->d_gp);
   dev_free(&h->d_has_gp);
+  dev_free(&h->d_gpq);
+  dev_free(&h->d_gp0s);
   dev_free(&h->d_ll);
   dev_free(&h->d_dcells);
   dev_free(&h->d_pairs);
@@ -171,6 +173,28 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   if (dev_alloc(h, &h->d_has_gp, (size_t)h->S)) return 1;
   if (n) HIPCHK(h, hipMemcpyAsync(h->d_gp, gp, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (h->S) HIPCHK(h, hipMemcpyAsync(h->d_has_gp, has_gp, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
+  dev_free(&h->d_gpq);
+  dev_free(&h->d_gp0s);
+  if (V <= 16 && h->S > 0) {
+    // Layout for the quad kernel (demux_quad.hip): lane r of a quad owns samples 4r..4r+3 = 12 doubles d = 3c+l, read as
+    // six 16-byte pieces; piece t of the four lanes is stored contiguously ([S][6][4][2]) so that one load instruction
+    // of a quad covers 64 consecutive bytes.  Samples >= V are padded with (1,0,0), which makes their factors exactly 1.
+    std::vector<double> q((size_t)h->S * 48), g0((size_t)h->S);
+    for (int64_t s = 0; s < h->S; ++s) {
+      const double* row = gp + (size_t)s * V * 3;
+      for (int r = 0; r < 4; ++r)
+        for (int d = 0; d < 12; ++d) {
+          const int j = 4 * r + d / 3, l = d % 3;
+          const double v = (j < V) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);
+          q[(size_t)s * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = v;
+        }
+      g0[(size_t)s] = (row[0] + row[1]) + row[2];
+    }
+    if (dev_alloc(h, &h->d_gpq, q.size())) return 1;
+    if (dev_alloc(h, &h->d_gp0s, g0.size())) return 1;
+    HIPCHK(h, hipMemcpy(h->d_gpq, q.data(), sizeof(double) * q.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_gp0s, g0.data(), sizeof(double) * g0.size(), hipMemcpyHostToDevice));
+  }
   h->V = V;
   h->have_dp = false;
   h->pairs_valid = false;
