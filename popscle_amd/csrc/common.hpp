@@ -20,6 +20,14 @@ struct muxgl_counts {
 constexpr int MUXGL_ROW_CH = 128;   // entries per chunk of the row kernels (16-lane slots)
 constexpr int MUXGL_QUAD_CH = 64;  // entries per chunk of the quad kernel (4-lane slots)
 
+// per-entry record of the quad kernel: everything phase 1 needs for an entry with <= 4 reads in ONE 16-byte load
+struct quad_entry {
+  int32_t snp;      // SNP id
+  uint32_t nreads;  // reads of the entry
+  uint32_t first4;  // its first four packed read bytes (byte k = read k)
+  uint32_t r0;      // offset of read 0 in the reads array (used only beyond four reads)
+};
+
 // one work unit of the row kernels (demux_row.hip, fmx_kernels.hip): <= 128 consecutive entries of one cell
 struct row_chunk {
   int64_t e0;
@@ -52,6 +60,7 @@ struct muxgl_handle {
   int64_t* d_entry_rptr = nullptr;
   uint8_t* d_reads = nullptr;
   int32_t* d_entry_cell = nullptr;  // cell id of each entry (for SNP-major views)
+  quad_entry* d_qent = nullptr;     // [nnz] packed records of the quad kernel (built when R < 2^32)
   int64_t max_cell_entries = 0;
 
   // Phred LUT: [0..127] = phred2Err, [128..255] = phred2Mat (bq is 7 bits in the packed read byte)

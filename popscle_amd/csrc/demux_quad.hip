@@ -62,10 +62,9 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
 }
 
 __global__ void __launch_bounds__(64, 2)
-    demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
-                      const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
-                      const double* __restrict__ gpq, const double* __restrict__ gp0s,
-                      const uint8_t* __restrict__ has_gp, const double* __restrict__ lut_g, double* __restrict__ part_m,
+    demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
+                      const uint8_t* __restrict__ reads, const double* __restrict__ gpq,
+                      const double* __restrict__ gp0s, const double* __restrict__ lut_g, double* __restrict__ part_m,
                       int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double pgs[16 * Q_SLOT_STRIDE];
@@ -93,49 +92,27 @@ __global__ void __launch_bounds__(64, 2)
     ex[a] = 0;
   }
 
-  // entry metadata of the batch to come, fetched one batch ahead in two dependent stages (see demux_row.hip)
-  int32_t ps = -1;
-  int64_t pr0 = 0, pr1 = 0;
-  uint32_t pbytes = 0;
-  int32_t phg = 0;
+  // the packed record of the batch to come (snp, read count, first four read bytes, read offset) is fetched one batch
+  // ahead with a single 16-byte load per lane
+  quad_entry prec = {-1, 0u, 0u, 0u};
   auto fetch_meta = [&](int b) {
     const int idx = b * 4 + r;
-    ps = -1;
-    pr0 = pr1 = 0;
-    if (idx < len) {
-      const int64_t e = e0 + idx;
-      ps = entry_snp[e];
-      pr0 = entry_rptr[e];
-      pr1 = entry_rptr[e + 1];
-    }
-  };
-  auto fetch_dependent = [&]() {
-    phg = 0;
-    pbytes = 0;
-    if (ps >= 0) {
-      phg = has_gp[ps];
-      const int64_t n = pr1 - pr0;
-      if (n > 0) pbytes = reads[pr0];
-      if (n > 1) pbytes |= (uint32_t)reads[pr0 + 1] << 8;
-      if (n > 2) pbytes |= (uint32_t)reads[pr0 + 2] << 16;
-      if (n > 3) pbytes |= (uint32_t)reads[pr0 + 3] << 24;
-    }
+    prec.snp = -1;
+    prec.nreads = 0;
+    if (idx < len) prec = qent[e0 + idx];
   };
   fetch_meta(0);
-  fetch_dependent();
   __syncthreads();
 
   for (int b = 0; b < nb; ++b) {
     // ---- phase 1: lane <-> entry.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
     //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR ----
     {
-      int32_t s = ps;
-      const int64_t r0 = pr0, r1 = pr1;
-      const uint32_t first4 = pbytes;
-      const int32_t hg = phg;
+      const int32_t s = prec.snp;
+      const int64_t r0 = prec.r0, r1 = (int64_t)prec.r0 + prec.nreads;
+      const uint32_t first4 = prec.first4;
       if (b + 1 < nb) fetch_meta(b + 1);
       double q0[3] = {1.0, 1.0, 1.0}, q1[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
-      if (s >= 0 && !hg) s = -1;  // :733 marker without genotypes
       if (s >= 0) {
         int since = 0;
         for (int64_t rr = r0; rr < r1; ++rr) {
@@ -227,13 +204,22 @@ __global__ void __launch_bounds__(64, 2)
         G[c][1] = nG[c][1];
         G[c][2] = nG[c][2];
       }
-      const double hs = nhs;
-      if (i == 2 && b + 1 < nb) fetch_dependent();
+      double hs = nhs;
       if (i + 1 < 4) load_row(snps[slot * 4 + i + 1]);  // prefetch the next entry's triples
 
       const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
-      const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
-      const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
+      double a0 = qq[0], a1 = qq[1], a2 = qq[2];
+      double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
+      if (hs < 0.0) {  // marker without genotypes (:733): every factor of the entry becomes exactly 1
+        hs = 1.0;
+        a0 = a1 = a2 = b0 = b1 = b2 = b3 = b4 = 1.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          G[c][0] = 1.0;
+          G[c][1] = 0.0;
+          G[c][2] = 0.0;
+        }
+      }
       double u[4][3];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -379,7 +365,7 @@ __global__ void __launch_bounds__(192)
 
 // returns -1 when the quad path does not apply, 0 ok, 1 error
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
-  if (h->V > 16 || !h->qrow || !h->d_gpq || h->C == 0) return -1;
+  if (h->V > 16 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
   if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL)) return -1;
   if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
   muxgl_row_state* st = h->qrow;
@@ -401,8 +387,7 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL(demux_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       h->d_entry_snp, h->d_entry_rptr, h->d_reads, h->d_gpq, h->d_gp0s, h->d_has_gp, h->d_lut,
-                       st->d_part, st->d_part_e);
+                       h->d_qent, h->d_reads, h->d_gpq, h->d_gp0s, h->d_lut, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);

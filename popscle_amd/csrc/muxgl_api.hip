@@ -71,6 +71,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_entry_rptr);
   dev_free(&h->d_reads);
   dev_free(&h->d_entry_cell);
+  dev_free(&h->d_qent);
   dev_free(&h->d_lut);
   dev_free(&h->d_gp);
   dev_free(&h->d_has_gp);
@@ -156,6 +157,18 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
   }
   h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
   if (demux_row_plan(h, cell_ptr, entry_snp)) return 1;
+  dev_free(&h->d_qent);
+  if (R < ((int64_t)1 << 32) && nnz > 0) {  // packed per-entry records of the quad kernel
+    std::vector<quad_entry> qe((size_t)nnz);
+    for (int64_t e = 0; e < nnz; ++e) {
+      const int64_t r0 = entry_rptr[e], n = entry_rptr[e + 1] - r0;
+      uint32_t f4 = 0;
+      for (int64_t k = 0; k < n && k < 4; ++k) f4 |= (uint32_t)reads[r0 + k] << (8 * k);
+      qe[(size_t)e] = quad_entry{entry_snp[e], (uint32_t)(n > 0xffffffffLL ? 0xffffffffLL : n), f4, (uint32_t)r0};
+    }
+    if (dev_alloc(h, &h->d_qent, (size_t)nnz)) return 1;
+    HIPCHK(h, hipMemcpy(h->d_qent, qe.data(), sizeof(quad_entry) * (size_t)nnz, hipMemcpyHostToDevice));
+  }
   h->fmx_prepared = false;
   h->K = 0;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -188,7 +201,8 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
           const double v = (j < V) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);
           q[(size_t)s * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = v;
         }
-      g0[(size_t)s] = (row[0] + row[1]) + row[2];
+      // a SNP without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) is marked by a negative sum
+      g0[(size_t)s] = has_gp[s] ? (row[0] + row[1]) + row[2] : -1.0;
     }
     if (dev_alloc(h, &h->d_gpq, q.size())) return 1;
     if (dev_alloc(h, &h->d_gp0s, g0.size())) return 1;
