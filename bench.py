@@ -174,7 +174,8 @@ def main():
             },
             "entries_per_s": total_entries / step_s,
             "cells_per_s": total_cells / step_s,
-            "kernel_ms": {"sweep": float(kern_ms[muxgl.T_DEMUX_SWEEP]), "call": float(kern_ms[muxgl.T_DEMUX_CALL]),
+            "kernel_ms": {"sweep": float(kern_ms[muxgl.T_DEMUX_SWEEP]), "reduce": float(kern_ms[muxgl.T_DEMUX_REDUCE]),
+                          "call": float(kern_ms[muxgl.T_DEMUX_CALL]),
                           "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},
             "roofline": {
                 "bound": "hbm", "kernel": "demux_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -18,7 +18,7 @@ struct muxgl_counts {
 };
 
 constexpr int MUXGL_ROW_CH = 128;   // entries per chunk of the row kernels (16-lane slots)
-constexpr int MUXGL_QUAD_CH = 64;  // entries per chunk of the quad kernel (4-lane slots)
+constexpr int MUXGL_QUAD_CH = 128;  // entries per chunk of the quad kernel (4-lane slots)
 
 // per-entry record of the quad kernel: everything phase 1 needs for an entry with <= 4 reads in ONE 16-byte load
 struct quad_entry {
@@ -213,6 +213,7 @@ void demux_row_free(muxgl_handle* h);
 int demux_row_build(muxgl_handle* h, muxgl_row_state** st, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t c0,
                     int64_t c1, int ch);
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
+int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_row_release(muxgl_row_state** st);
 int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
 int fmx_build_clusters_launch(muxgl_handle* h);

@@ -488,10 +488,14 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
 
   tic(h, MUXGL_T_DEMUX_CALL);
-  const unsigned blocks = (unsigned)((h->C + 63) / 64);
-  hipLaunchKernelGGL(demux_call_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
-                     A, al, p->doublet_prior, h->d_ll, h->d_dcells);
-  HIPCHK(h, hipGetLastError());
+  if (h->V <= 16 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
+    if (demux_call16_launch(h, p)) return 1;  // sixteen lanes per cell
+  } else {
+    const unsigned blocks = (unsigned)((h->C + 63) / 64);
+    hipLaunchKernelGGL(demux_call_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
+                       A, al, p->doublet_prior, h->d_ll, h->d_dcells);
+    HIPCHK(h, hipGetLastError());
+  }
   toc(h, MUXGL_T_DEMUX_CALL);
   return 0;
 }
