@@ -87,6 +87,7 @@ struct muxgl_handle {
   bool pairs_valid = false;
   struct muxgl_row_state* row = nullptr;  // chunk tables of the V<=16 row kernel (demux_row.hip)
   struct muxgl_row_state* qrow = nullptr; // chunk tables of the default-grid quad kernel (demux_quad.hip)
+  struct muxgl_wave_state* wave = nullptr; // cell order + pG table of the 16 < V <= 64 wave kernel (demux_wave.hip)
   int32_t flags = 0;
 
   // freemuxlet
@@ -214,6 +215,9 @@ int demux_row_build(muxgl_handle* h, muxgl_row_state** st, const int64_t* cell_p
                     int64_t c1, int ch);
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
+int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
+int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
+void demux_wave_free(muxgl_handle* h);
 void demux_row_release(muxgl_row_state** st);
 int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
 int fmx_build_clusters_launch(muxgl_handle* h);

@@ -473,6 +473,7 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 
   int rc = demux_quad_launch(h, p);          // V <= 16 and the reference's default grid {0, 0.5}: quad kernel
   if (rc < 0) rc = demux_row_launch(h, p);   // V <= 16, other grids: row kernel
+  if (rc < 0) rc = demux_wave_launch(h, p);  // 16 < V <= 64: one wave per cell, one lane per sample
   if (rc > 0) return rc;
   if (rc < 0) {                     // general tile sweep
     if (!h->pairs_valid) {

@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(192)
 // returns -1 when the quad path does not apply, 0 ok, 1 error
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (h->V > 16 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
-  if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL)) return -1;
+  if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL | MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;
   if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
   muxgl_row_state* st = h->qrow;
   if (!st->d_tmap) {  // tile map of the two rotations

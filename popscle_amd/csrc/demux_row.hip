@@ -452,7 +452,8 @@ static int row_launch_t(muxgl_handle* h, const row_alpha& al, int A) {
 
 // returns -1 when the row path does not apply (caller falls back to the tile sweep), 0 ok, 1 error
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p) {
-  if (h->V > 16 || !h->row || h->C == 0 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
+  if (h->V > 16 || !h->row || h->C == 0 || (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_WAVE_KERNEL)))
+    return -1;
   const int A = p->n_alpha;
   row_alpha al;
   int nns = 0, nsy = 0, pos = 0;

@@ -1,0 +1,190 @@
+// demux_wave.hip -- the demuxlet pair sweep for 16 < V <= 64 samples: one wave per cell, one lane per sample.
+//
+// Reference being replaced: cmd_cram_demuxlet.cpp:733-747 (pair sweep); the per-entry likelihoods pG (:655-725) come
+// from demux_entry_pg_kernel (demux_kernels.hip), written once per run for all alphas ([nnz][A][9] doubles).
+//
+// At V = 64 with six alphas an entry carries 18 208 hypotheses (179 kflop): the path is FP64-issue bound, not bandwidth
+// bound (SURVEY hard part 3), so the design minimises vector instructions per hypothesis:
+//   * lane j keeps sample j's triple g_j (loaded straight from the contiguous 1.5 KB GP row) and, per alpha,
+//     u[m] = sum_l g_j[l] * pG[alpha][l][m]; the entry's nine pG values are wave-uniform and are fetched through the
+//     scalar cache into SGPRs, so they cost no vector instruction and no LDS traffic;
+//   * the partner triple g_k reaches lane j by rotating the whole wave one lane per step (DPP wave_ror:1, 6 moves);
+//     after t steps lane j faces sample (j - t) mod 64: 3 FMA + 1 multiply per hypothesis;
+//   * one launch per doublet alpha keeps the accumulators in registers (63 per lane, 32 for alpha = 0.5 whose
+//     likelihood is symmetric in (j,k)); the singlet slot (j,0,n=0) rides along with the first launch;
+//   * products are kept as mantissa * 2^exponent and turned into one log per (cell, hypothesis).
+// Work unit = cell (100 k waves at BASELINE configs[2]); cells are launched longest first.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ double dpp_wror1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1 : lane j <- lane (j-1) mod 64
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise.  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
+template <int NSHIFT, bool WITH_SINGLET>
+__global__ void __launch_bounds__(64, 2)
+    demux_wave_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
+                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                      const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel,
+                      double* __restrict__ ll) {
+  if ((int64_t)blockIdx.x >= n_cells) return;
+  const int64_t c = order[blockIdx.x];
+  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if (e0 == e1) return;
+  const int j = threadIdx.x;
+  const bool live = j < V;
+  const int V3 = V * 3;
+  const int PG = nAlpha * 9;
+
+  double acc[NSHIFT], accS = 1.0;
+  int32_t ex[NSHIFT], exS = 0;
+#pragma unroll
+  for (int t = 0; t < NSHIFT; ++t) {
+    acc[t] = 1.0;
+    ex[t] = 0;
+  }
+
+  // software pipeline: triples of the next marker with genotypes are loaded while the current one is swept
+  int64_t e = e0;
+  while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
+  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+  if (e < e1 && live) {
+    const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+    ng0 = row[0], ng1 = row[1], ng2 = row[2];
+  }
+  int cnt = 0;
+  while (e < e1) {
+    const int64_t ecur = e;
+    const int32_t scur = entry_snp[ecur];
+    const double g0 = ng0, g1 = ng1, g2 = ng2;
+    ++e;
+    while (e < e1 && !has_gp[entry_snp[e]]) ++e;
+    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+    if (e < e1 && live) {
+      const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+      ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    }
+    // wave-uniform operands: the nine likelihoods of the selected alpha (and of alpha[0] for the singlet slot)
+    const double* q = pg + (size_t)ecur * PG + (size_t)n_sel * 9;
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
+    if (WITH_SINGLET) {
+      const double* s = pg + (size_t)ecur * PG;
+      const double* h = gp + (size_t)scur * V3;  // sample 0's triple multiplies every singlet (:806,828)
+      const double v0 = fma(g2, s[6], fma(g1, s[3], g0 * s[0]));
+      const double v1 = fma(g2, s[7], fma(g1, s[4], g0 * s[1]));
+      const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
+      accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
+    }
+    const double u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
+    const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
+    const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
+    double r0 = g0, r1 = g1, r2 = g2;
+#pragma unroll
+    for (int t = 0; t < NSHIFT; ++t) {
+      r0 = dpp_wror1(r0);
+      r1 = dpp_wror1(r1);
+      r2 = dpp_wror1(r2);
+      acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :738-746 as a product
+    }
+    if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
+      cnt = 0;
+#pragma unroll
+      for (int t = 0; t < NSHIFT; ++t) prodacc_renorm(acc[t], ex[t]);
+      if (WITH_SINGLET) prodacc_renorm(accS, exS);
+    }
+  }
+
+  // which sample does lane j face after t+1 rotations?  (measured with the same primitive)
+  double* out = ll + (size_t)c * V * V * nAlpha;
+  int kk = j;
+#pragma unroll
+  for (int t = 0; t < NSHIFT; ++t) {
+    kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
+    const double v = prodacc_log(acc[t], ex[t]);
+    if (n_sel > 0 && live && kk < V && kk != j) {
+      if (NSHIFT == 63) {
+        out[((size_t)j * V + kk) * nAlpha + n_sel] = v;
+      } else if (t < 31 || j > kk) {  // step 32 of 64 lanes meets every unordered pair twice: one writer
+        out[((size_t)j * V + kk) * nAlpha + n_sel] = v;
+        out[((size_t)kk * V + j) * nAlpha + n_sel] = v;
+      }
+    }
+  }
+  if (WITH_SINGLET && live) out[(size_t)j * V * nAlpha] = prodacc_log(accS, exS);
+}
+
+}  // namespace
+
+struct muxgl_wave_state {
+  int32_t* d_order = nullptr;  // cells, longest first
+  double* d_pg = nullptr;      // [nnz][A][9]
+  size_t pg_cap = 0;
+};
+
+void demux_wave_free(muxgl_handle* h) {
+  muxgl_wave_state* st = h->wave;
+  if (!st) return;
+  dev_free(&st->d_order);
+  dev_free(&st->d_pg);
+  delete st;
+  h->wave = nullptr;
+}
+
+int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr) {
+  if (!h->wave) h->wave = new muxgl_wave_state();
+  muxgl_wave_state* st = h->wave;
+  std::vector<int32_t> order((size_t)h->C);
+  for (int64_t c = 0; c < h->C; ++c) order[(size_t)c] = (int32_t)c;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    return cell_ptr[a + 1] - cell_ptr[a] > cell_ptr[b + 1] - cell_ptr[b];
+  });
+  if (dev_alloc(h, &st->d_order, (size_t)h->C)) return 1;
+  if (h->C) HIPCHK(h, hipMemcpy(st->d_order, order.data(), sizeof(int32_t) * h->C, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// returns -1 when the wave path does not apply, 0 ok, 1 error
+int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  if (h->V > 64 || !h->wave || h->C == 0 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
+  if (h->V <= 16 && !(h->flags & MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;  // the row/quad kernels are better there
+  muxgl_wave_state* st = h->wave;
+  const int A = p->n_alpha;
+  const size_t need = (size_t)h->nnz * A * 9;
+  if ((double)need * 8.0 > 96e9) return -1;  // pG table would not fit comfortably: tile sweep
+  if (need > st->pg_cap) {
+    if (dev_alloc(h, &st->d_pg, need)) return 1;
+    st->pg_cap = need;
+  }
+  tic(h, MUXGL_T_DEMUX_SWEEP);
+  if (demux_entry_pg_launch(h, p, st->d_pg)) return 1;
+  const unsigned blocks = (unsigned)h->C;
+  bool first = true;
+  for (int n = 1; n < A; ++n) {
+    const bool sym = (p->alpha[n] == 0.5);
+#define WAVE_LAUNCH(NS, WS)                                                                                          \
+  hipLaunchKernelGGL((demux_wave_kernel<NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,             \
+                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, n, h->d_ll)
+    if (sym && first) WAVE_LAUNCH(32, true);
+    else if (sym) WAVE_LAUNCH(32, false);
+    else if (first) WAVE_LAUNCH(63, true);
+    else WAVE_LAUNCH(63, false);
+#undef WAVE_LAUNCH
+    HIPCHK(h, hipGetLastError());
+    first = false;
+  }
+  if (first) {  // nAlpha == 1: singlets only; run the symmetric kernel on alpha[0] and let the call kernel ignore n >= 1
+    hipLaunchKernelGGL((demux_wave_kernel<32, true>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,
+                       h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, 0, h->d_ll);
+    HIPCHK(h, hipGetLastError());
+  }
+  toc(h, MUXGL_T_DEMUX_SWEEP);
+  return 0;
+}

@@ -93,6 +93,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_snp_ptr);
   dev_free(&h->d_snp_entry);
   demux_row_free(h);
+  demux_wave_free(h);
   if (h->h_dcells) (void)hipHostFree(h->h_dcells);
   if (h->h_fcells) (void)hipHostFree(h->h_fcells);
   for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
@@ -157,6 +158,7 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
   }
   h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
   if (demux_row_plan(h, cell_ptr, entry_snp)) return 1;
+  if (demux_wave_plan(h, cell_ptr)) return 1;
   dev_free(&h->d_qent);
   if (R < ((int64_t)1 << 32) && nnz > 0) {  // packed per-entry records of the quad kernel
     std::vector<quad_entry> qe((size_t)nnz);
