@@ -81,12 +81,13 @@ __device__ __forceinline__ top2 top2_xor(const top2& t, int m) {
   return o;
 }
 
+template <int G>  // lanes per cell: 16 (V <= 16) or 64 (V <= 64)
 __global__ void __launch_bounds__(64)
-    demux_call16_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
+    demux_callg_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
                         double doublet_prior, const double* __restrict__ ll, muxgl_demux_cell* __restrict__ out) {
   const int lane = threadIdx.x;
-  const int j = lane & 15;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (lane >> 4);
+  const int j = lane & (G - 1);
+  const int64_t i = (int64_t)blockIdx.x * (64 / G) + lane / G;
   const bool cell_ok = i < C;
   const bool live = cell_ok && j < nv;
   const double* gridAlpha = al.a;
@@ -119,13 +120,13 @@ __global__ void __launch_bounds__(64)
   }
   // merge the sixteen rows
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
+  for (int m = 1; m < G; m <<= 1) {
     sng = top2_merge(sng, top2_xor(sng, m));
     dbl = top2_merge(dbl, top2_xor(dbl, m));
   }
   double sumLLK = -1e-300, sngLLK = -1e-300;  // :791 (sic)
-  const int base = lane & 48;
-  for (int t = 0; t < 16; ++t) {
+  const int base = lane & ~(G - 1);
+  for (int t = 0; t < G; ++t) {
     const double rs = __shfl(rowsum, base + t, 64);
     const double st = __shfl(sterm, base + t, 64);
     const int hv = __shfl((int)have, base + t, 64);
@@ -233,9 +234,15 @@ __global__ void __launch_bounds__(64)
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   call_alpha al;
   for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
-  const unsigned blocks = (unsigned)((h->C + 3) / 4);
-  hipLaunchKernelGGL(demux_call16_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
-                     p->n_alpha, al, p->doublet_prior, h->d_ll, h->d_dcells);
+  if (h->V <= 16) {
+    const unsigned blocks = (unsigned)((h->C + 3) / 4);
+    hipLaunchKernelGGL(demux_callg_kernel<16>, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr,
+                       h->V, p->n_alpha, al, p->doublet_prior, h->d_ll, h->d_dcells);
+  } else {
+    const unsigned blocks = (unsigned)h->C;
+    hipLaunchKernelGGL(demux_callg_kernel<64>, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr,
+                       h->V, p->n_alpha, al, p->doublet_prior, h->d_ll, h->d_dcells);
+  }
   HIPCHK(h, hipGetLastError());
   return 0;
 }

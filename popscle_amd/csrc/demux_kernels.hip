@@ -489,8 +489,8 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
 
   tic(h, MUXGL_T_DEMUX_CALL);
-  if (h->V <= 16 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
-    if (demux_call16_launch(h, p)) return 1;  // sixteen lanes per cell
+  if (h->V <= 64 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
+    if (demux_call16_launch(h, p)) return 1;  // 16 or 64 lanes per cell
   } else {
     const unsigned blocks = (unsigned)((h->C + 63) / 64);
     hipLaunchKernelGGL(demux_call_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
