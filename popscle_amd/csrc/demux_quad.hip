@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64, 2)
                       int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double pgs[16 * Q_SLOT_STRIDE];
-  __shared__ int32_t snps[64];
+  __shared__ int32_t snps[64], snps_nx[64];
 
   const int lane = threadIdx.x;
   const int r = (lane >> 2) & 3;                       // tile: samples 4r..4r+3
@@ -102,7 +102,40 @@ __global__ void __launch_bounds__(64, 2)
     if (idx < len) prec = qent[e0 + idx];
   };
   fetch_meta(0);
+
+  // GP triples of the entry to come are always one entry ahead, across batch boundaries too: the first entry of the
+  // next batch is known from the prefetched records (snps_nx)
+  double nG[4][3], nhs = 1.0;
+  auto load_row = [&](int32_t s) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      nG[c][0] = 1.0;
+      nG[c][1] = 0.0;
+      nG[c][2] = 0.0;
+    }
+    nhs = 1.0;
+    if (s >= 0) {
+      nhs = gp0s[s];  // g_0[0]+g_0[1]+g_0[2]: sample 0's row multiplies every singlet (:806)
+      // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes
+      const double2* pc = reinterpret_cast<const double2*>(gpq + (size_t)s * 48) + r;
+      double f[12];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const double2 v = pc[t * 4];
+        f[2 * t] = v.x;
+        f[2 * t + 1] = v.y;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        nG[c][0] = f[3 * c];
+        nG[c][1] = f[3 * c + 1];
+        nG[c][2] = f[3 * c + 2];
+      }
+    }
+  };
+  snps_nx[slot * 4 + r] = prec.snp;
   __syncthreads();
+  load_row(snps_nx[slot * 4]);
 
   for (int b = 0; b < nb; ++b) {
     // ---- phase 1: lane <-> entry.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
@@ -166,35 +199,6 @@ __global__ void __launch_bounds__(64, 2)
     __syncthreads();
 
     // ---- phase 2: lane <-> 4 samples, the 4 entries of the slot's batch one after the other ----
-    double nG[4][3], nhs = 1.0;
-    auto load_row = [&](int32_t s) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        nG[c][0] = 1.0;
-        nG[c][1] = 0.0;
-        nG[c][2] = 0.0;
-      }
-      nhs = 1.0;
-      if (s >= 0) {
-        nhs = gp0s[s];  // g_0[0]+g_0[1]+g_0[2]: sample 0's row multiplies every singlet (:806)
-        // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes
-        const double2* pc = reinterpret_cast<const double2*>(gpq + (size_t)s * 48) + r;
-        double f[12];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          const double2 v = pc[t * 4];
-          f[2 * t] = v.x;
-          f[2 * t + 1] = v.y;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          nG[c][0] = f[3 * c];
-          nG[c][1] = f[3 * c + 1];
-          nG[c][2] = f[3 * c + 2];
-        }
-      }
-    };
-    load_row(snps[slot * 4]);
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
       double G[4][3];
@@ -205,7 +209,9 @@ __global__ void __launch_bounds__(64, 2)
         G[c][2] = nG[c][2];
       }
       double hs = nhs;
+      if (i == 2 && b + 1 < nb) snps_nx[slot * 4 + r] = prec.snp;  // the next batch's records have long arrived
       if (i + 1 < 4) load_row(snps[slot * 4 + i + 1]);  // prefetch the next entry's triples
+      else if (b + 1 < nb) load_row(snps_nx[slot * 4]);  // ... including the first entry of the next batch
 
       const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
       double a0 = qq[0], a1 = qq[1], a2 = qq[2];
