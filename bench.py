@@ -43,6 +43,17 @@ def algorithmic_flops_per_entry(V: int, A: int, reads_per_entry: float) -> float
     return A * (18.0 * V + 7.0 * V * V) + reads_per_entry * A * 27.0
 
 
+def sweep_kernel_name(V, alphas):
+    """the kernel libmuxgl dispatches for this shape (popscle_amd/csrc/demux_kernels.hip: demux_launch)"""
+    if V <= 16 and tuple(alphas) == (0.0, 0.5):
+        return "demux_quad_kernel"
+    if V <= 16 and sum(1 for a in alphas[1:] if a != 0.5) <= 5 and sum(1 for a in alphas[1:] if a == 0.5) <= 1:
+        return "demux_row_kernel"
+    if V <= 64:
+        return "demux_wave_kernel"
+    return "demux_sweep_kernel"
+
+
 def cpu_baseline(p, alphas, gpu_cells, budget_s=15.0):
     """The CPU oracle (the restatement of the reference's loop, kind "port") timed on this host's cores on a bounded
     sample of the same workload.  Also used as a last parity check of the GPU records for the sampled cells."""
@@ -178,7 +189,7 @@ def main():
                           "call": float(kern_ms[muxgl.T_DEMUX_CALL]),
                           "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},
             "roofline": {
-                "bound": "hbm", "kernel": "demux_sweep_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": sweep_kernel_name(V, alphas), "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": abytes,
                 "fp64_valu": {"achieved": aflops / sweep_s / 1e12 if sweep_s > 0 else 0.0, "peak": FP64_PEAK_TFLOPS,
