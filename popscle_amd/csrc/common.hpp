@@ -106,6 +106,9 @@ struct muxgl_handle {
   // SNP-major (CSC) view of the entries, cells ascending inside each SNP: M-step walks it
   int64_t* d_snp_ptr = nullptr;   // [S+1]
   int64_t* d_snp_entry = nullptr; // [nnz] entry index
+  int32_t* d_snp_cell = nullptr;  // [nnz] cell id of the same SNP-major element
+  double* d_segls = nullptr;      // [nnz][9] entry likelihoods in SNP-major order (the M-step streams them)
+  int32_t* d_secnt = nullptr;     // [nnz][3] entry counts in SNP-major order
   bool fmx_prepared = false;
   int64_t fc0 = 0, fc1 = 0, fs0 = 0, fs1 = 0;  // active cell / SNP shard of the EM phases (default: everything)
   muxgl_row_state* frow = nullptr;             // chunk tables restricted to the cell shard

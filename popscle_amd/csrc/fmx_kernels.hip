@@ -506,11 +506,135 @@ __global__ void __launch_bounds__(256)
   oc[2] = nalt;
 }
 
+// nreads / nref / nalt of the cluster pileups (the integer part of merge(), sc_drop_seq.h:78-80): order-independent
+// sums over the entries of the cells currently assigned to a cluster, entry-parallel with integer atomics
+__global__ void __launch_bounds__(256)
+    fmx_counts_kernel(int64_t nnz, int64_t S, const int32_t* __restrict__ entry_snp,
+                      const int32_t* __restrict__ entry_cell, const int32_t* __restrict__ clust,
+                      const int32_t* __restrict__ ecnt, int32_t* __restrict__ ccnt) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t k = clust[entry_cell[e]];
+    if (k < 0) continue;
+    int32_t* oc = ccnt + ((size_t)k * S + entry_snp[e]) * 3;
+    atomicAdd(oc, ecnt[(size_t)e * 3]);
+    atomicAdd(oc + 1, ecnt[(size_t)e * 3 + 1]);
+    atomicAdd(oc + 2, ecnt[(size_t)e * 3 + 2]);
+  }
+}
+
+// one-time gather of the entry likelihoods and counts into SNP-major order
+__global__ void __launch_bounds__(256)
+    fmx_snp_major_kernel(int64_t nnz, const int64_t* __restrict__ snp_entry, const double* __restrict__ egls,
+                         const int32_t* __restrict__ ecnt, double* __restrict__ segls, int32_t* __restrict__ secnt) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = snp_entry[p];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) segls[(size_t)p * 9 + i] = egls[(size_t)e * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) secnt[(size_t)p * 3 + i] = ecnt[(size_t)e * 3 + i];
+  }
+}
+
+// The same chains with one lane per SNP: the lane walks its SNP's entries once (ascending cell id) and keeps the K
+// cluster states of that SNP in LDS, so every list element costs one merge on a fully populated wave instead of a
+// K-fold masked one.  Loads are software-pipelined one element ahead (entry id and cell are SNP-major and sequential;
+// the assignment lookup and the 72-byte likelihood gather of the next element fly during the current merge).
+// The read counts of the cluster pileups are plain sums and are not needed by the EM: fmx_counts_kernel computes
+// them on demand (muxgl_fmx_get_cluster_pileup).  Needs 64*(9K+1)*8 B of LDS.
+__global__ void __launch_bounds__(64)
+    fmx_mstep_snp_kernel(int64_t S, int64_t s0, int64_t s1, int K, const int64_t* __restrict__ snp_ptr,
+                         const int32_t* __restrict__ snp_cell, const int32_t* __restrict__ clust,
+                         const double* __restrict__ segls, double* __restrict__ cgls) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x;
+  const int STR = K * 9 + 1;
+  double* st = sm + (size_t)lane * STR;
+  for (int i = 0; i < K * 9; ++i) st[i] = 1.0;
+  const int64_t s = s0 + (int64_t)blockIdx.x * 64 + lane;
+  int64_t p = 0, p1 = 0;
+  if (s < s1) {
+    p = snp_ptr[s];
+    p1 = snp_ptr[s + 1];
+  }
+  // pipeline registers: element "cur" is complete, element "nx" has its id and cell
+  int32_t k_cur = -1;
+  double g[9];
+  int64_t e_nx = 0;
+  int32_t c_nx = 0;
+  bool have_cur = false, have_nx = false;
+  auto load_ids = [&]() {
+    have_nx = p < p1;
+    if (have_nx) {
+      e_nx = p;  // position in the SNP-major arrays
+      c_nx = snp_cell[p];
+      ++p;
+    }
+  };
+  auto promote = [&]() {  // nx -> cur: assignment lookup + likelihood gather
+    have_cur = have_nx;
+    k_cur = -1;
+    if (have_nx) {
+      k_cur = clust[c_nx];
+      const double* o = segls + (size_t)e_nx * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) g[i] = o[i];
+    }
+  };
+  load_ids();
+  promote();
+  load_ids();
+  while (__any(have_cur)) {
+    const int32_t k = k_cur;
+    const bool doit = have_cur && k >= 0;
+    double o[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = g[i];
+    promote();   // loads of the next element overlap the merge below
+    load_ids();
+    if (doit) {
+      double* q = st + k * 9;
+      double v[9], tmp = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        v[i] = q[i] * o[i];
+        tmp += v[i];
+      }
+      double inv = 1.0 / tmp;
+      tmp = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        v[i] *= inv;
+        if (v[i] < kMinNormGL) v[i] = kMinNormGL;
+        tmp += v[i];
+      }
+      inv = 1.0 / tmp;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q[i] = v[i] * inv;
+    }
+  }
+  if (s < s1) {
+    for (int k = 0; k < K; ++k) {
+      double* og = cgls + ((size_t)k * S + s) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) og[i] = st[k * 9 + i];
+    }
+  }
+}
+
 }  // namespace
 
 static int fmx_mstep_launch(muxgl_handle* h) {
   const int64_t n = (h->fs1 - h->fs0) * h->K;
   if (n <= 0) return 0;
+  const size_t lds = (size_t)64 * (h->K * 9 + 1) * sizeof(double);
+  if (lds <= 150 * 1024 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // one lane per SNP, cluster states in LDS
+    const int64_t ns = h->fs1 - h->fs0;
+    HIPCHK(h, hipFuncSetAttribute((const void*)fmx_mstep_snp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fmx_mstep_snp_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), lds, h->stream, h->S, h->fs0,
+                       h->fs1, h->K, h->d_snp_ptr, h->d_snp_cell, h->d_clust, h->d_segls, h->d_cgls);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(fmx_mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->fs0, h->fs1,
                      h->K, h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_ecnt, h->d_cgls,
                      h->d_ccnt);
@@ -580,18 +704,32 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
     for (int64_t s = 0; s < S; ++s) sp[(size_t)s + 1] += sp[(size_t)s];
     std::vector<int64_t> fill(sp.begin(), sp.end() - 1);
     std::vector<int64_t> se((size_t)nnz);
-    std::vector<int32_t> ec((size_t)nnz);
+    std::vector<int32_t> ec((size_t)nnz), sc((size_t)nnz);
     for (int64_t c = 0; c < C; ++c)
       for (int64_t e2 = cp[(size_t)c]; e2 < cp[(size_t)c + 1]; ++e2) {
-        se[(size_t)fill[(size_t)es[(size_t)e2]]++] = e2;
+        const int64_t pos = fill[(size_t)es[(size_t)e2]]++;
+        se[(size_t)pos] = e2;
+        sc[(size_t)pos] = (int32_t)c;
         ec[(size_t)e2] = (int32_t)c;
       }
     if (dev_alloc(h, &h->d_snp_ptr, (size_t)S + 1)) return 1;
     if (dev_alloc(h, &h->d_snp_entry, (size_t)nnz)) return 1;
     if (dev_alloc(h, &h->d_entry_cell, (size_t)nnz)) return 1;
+    if (dev_alloc(h, &h->d_snp_cell, (size_t)nnz)) return 1;
     HIPCHK(h, hipMemcpy(h->d_snp_ptr, sp.data(), sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice));
     if (nnz) HIPCHK(h, hipMemcpy(h->d_snp_entry, se.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
     if (nnz) HIPCHK(h, hipMemcpy(h->d_entry_cell, ec.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    if (nnz) HIPCHK(h, hipMemcpy(h->d_snp_cell, sc.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
+    if (dev_alloc(h, &h->d_secnt, (size_t)nnz * 3)) return 1;
+    if (nnz) {
+      int64_t blocks = (nnz + 255) / 256;
+      if (blocks > 16384) blocks = 16384;
+      hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
+                         h->d_egls, h->d_ecnt, h->d_segls, h->d_secnt);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
   }
   h->fmx_prepared = true;
   h->K = 0;
@@ -935,7 +1073,18 @@ int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts) 
   if (h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_get_cluster_pileup: no clusters set");
   const size_t n = (size_t)h->K * h->S;
   if (gls && n) HIPCHK(h, hipMemcpy(gls, h->d_cgls, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
-  if (counts && n) HIPCHK(h, hipMemcpy(counts, h->d_ccnt, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+  if (counts && n) {
+    HIPCHK(h, hipMemsetAsync(h->d_ccnt, 0, sizeof(int32_t) * 3 * n, h->stream));
+    if (h->nnz) {
+      int64_t blocks = (h->nnz + 255) / 256;
+      if (blocks > 16384) blocks = 16384;
+      hipLaunchKernelGGL(fmx_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->nnz, h->S, h->d_entry_snp,
+                         h->d_entry_cell, h->d_clust, h->d_ecnt, h->d_ccnt);
+      HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(counts, h->d_ccnt, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 

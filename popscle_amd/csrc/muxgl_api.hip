@@ -92,6 +92,9 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_fstat);
   dev_free(&h->d_snp_ptr);
   dev_free(&h->d_snp_entry);
+  dev_free(&h->d_snp_cell);
+  dev_free(&h->d_segls);
+  dev_free(&h->d_secnt);
   demux_row_free(h);
   demux_wave_free(h);
   if (h->h_dcells) (void)hipHostFree(h->h_dcells);
