@@ -10,13 +10,6 @@
 
 #include "../../include/muxgl.h"
 
-#define MUXGL_WAVE 64
-
-// device-side per-(cell,SNP) or per-(cluster,SNP) pileup counts; gls are kept in separate SoA/AoS arrays
-struct muxgl_counts {
-  int32_t nreads, nref, nalt;
-};
-
 constexpr int MUXGL_ROW_CH = 128;   // entries per chunk of the row kernels (16-lane slots)
 constexpr int MUXGL_QUAD_CH = 128;  // entries per chunk of the quad kernel (4-lane slots)
 
@@ -75,7 +68,6 @@ struct muxgl_handle {
   double* d_ll = nullptr;  // [C][V][V][A]
   size_t ll_cap = 0;
   bool ll_zeroed = false;
-  int32_t ll_V = 0, ll_A = 0;
   muxgl_demux_cell* d_dcells = nullptr;
   muxgl_demux_cell* h_dcells = nullptr;  // pinned
   int64_t dcells_cap = 0;
@@ -108,10 +100,14 @@ struct muxgl_handle {
   int64_t* d_snp_entry = nullptr; // [nnz] entry index
   int32_t* d_snp_cell = nullptr;  // [nnz] cell id of the same SNP-major element
   double* d_segls = nullptr;      // [nnz][9] entry likelihoods in SNP-major order (the M-step streams them)
+  double* d_egls6 = nullptr;      // [nnz][6] the six distinct likelihoods {00,11,22,01,02,12} (quad E-step)
   int32_t* d_secnt = nullptr;     // [nnz][3] entry counts in SNP-major order
   bool fmx_prepared = false;
   int64_t fc0 = 0, fc1 = 0, fs0 = 0, fs1 = 0;  // active cell / SNP shard of the EM phases (default: everything)
   muxgl_row_state* frow = nullptr;             // chunk tables restricted to the cell shard
+  muxgl_row_state* fqrow = nullptr;            // same for the quad E-step
+  double* d_cgpq = nullptr;                    // [S][6][4][2] cluster-GP rows re-laid per quad (fmx_quad.hip)
+  size_t cgpq_cap = 0;
 
   hipEvent_t ev[2 * MUXGL_T_COUNT] = {};
   bool ev_used[MUXGL_T_COUNT] = {};
@@ -218,10 +214,8 @@ int demux_row_build(muxgl_handle* h, muxgl_row_state** st, const int64_t* cell_p
                     int64_t c1, int ch);
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
+int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_wave_free(muxgl_handle* h);
 void demux_row_release(muxgl_row_state** st);
-int fmx_prepare_launch(muxgl_handle* h, double* d_llk0, double* d_llk2, int32_t* d_nsnps, int32_t* d_nreads);
-int fmx_build_clusters_launch(muxgl_handle* h);
-int fmx_iterate_launch(muxgl_handle* h, const muxgl_fmx_params* p);

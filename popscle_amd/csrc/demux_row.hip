@@ -353,6 +353,7 @@ void demux_row_release(muxgl_row_state** pst) {
 void demux_row_free(muxgl_handle* h) {
   demux_row_release(&h->row);
   demux_row_release(&h->frow);
+  demux_row_release(&h->fqrow);
   demux_row_release(&h->qrow);
 }
 

@@ -32,8 +32,8 @@ constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
 __global__ void __launch_bounds__(256)
     fmx_entry_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
                      const int32_t* __restrict__ entry_snp, const double* __restrict__ af,
-                     const double* __restrict__ lut_g, double* __restrict__ egls, int32_t* __restrict__ ecnt,
-                     double* __restrict__ l0, double* __restrict__ l2) {
+                     const double* __restrict__ lut_g, double* __restrict__ egls, double* __restrict__ egls6,
+                     int32_t* __restrict__ ecnt, double* __restrict__ l0, double* __restrict__ l2) {
   __shared__ double lut[256];
   lut[threadIdx.x] = lut_g[threadIdx.x];
   __syncthreads();
@@ -76,6 +76,13 @@ __global__ void __launch_bounds__(256)
       gls[i] *= inv;
       egls[(size_t)e * 9 + i] = gls[i];
     }
+    // the matrix is symmetric (fraction 1-(g1+g2)/4 depends on g1+g2 only): six distinct values for the quad E-step
+    egls6[(size_t)e * 6 + 0] = gls[0];
+    egls6[(size_t)e * 6 + 1] = gls[4];
+    egls6[(size_t)e * 6 + 2] = gls[8];
+    egls6[(size_t)e * 6 + 3] = gls[1];
+    egls6[(size_t)e * 6 + 4] = gls[2];
+    egls6[(size_t)e * 6 + 5] = gls[5];
     ecnt[(size_t)e * 3 + 0] = nreads;
     ecnt[(size_t)e * 3 + 1] = nref;
     ecnt[(size_t)e * 3 + 2] = nalt;
@@ -656,6 +663,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   if (S) HIPCHK(h, hipMemcpyAsync(h->d_af, af, sizeof(double) * S, hipMemcpyHostToDevice, h->stream));
   if (dev_alloc(h, &h->d_egls, (size_t)nnz * 9)) return 1;
   if (dev_alloc(h, &h->d_ecnt, (size_t)nnz * 3)) return 1;
+  if (dev_alloc(h, &h->d_egls6, (size_t)nnz * 6)) return 1;
   double *d_l0 = nullptr, *d_l2 = nullptr, *d_c0 = nullptr, *d_c2 = nullptr;
   int32_t *d_ns = nullptr, *d_nr = nullptr;
   auto cleanup = [&]() {
@@ -676,7 +684,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(fmx_entry_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_entry_rptr,
-                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, h->d_ecnt, d_l0, d_l2);
+                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, h->d_egls6, h->d_ecnt, d_l0, d_l2);
   }
   if (C)
     hipLaunchKernelGGL(fmx_cell_score_kernel, dim3((unsigned)C), dim3(64), 0, h->stream, h->d_cell_ptr, d_l0, d_l2,
@@ -738,6 +746,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   h->fs0 = 0;
   h->fs1 = S;
   demux_row_release(&h->frow);
+  demux_row_release(&h->fqrow);
   return 0;
 }
 
@@ -901,7 +910,10 @@ static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   const int npairs = K * (K + 1) / 2;
   tic(h, MUXGL_T_FMX_ESTEP);
   muxgl_row_state* st = h->frow ? h->frow : h->row;
-  if (nc > 0) {
+  int qrc = -1;
+  if (nc > 0) qrc = fmx_quad_estep_launch(h, h->fqrow ? h->fqrow : h->qrow, c0, nc);  // K <= 16: quad tiling
+  if (qrc > 0) return 1;
+  if (nc > 0 && qrc < 0) {
     if (K <= 16 && st && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
       const size_t need = (size_t)st->n_chunks * FX_NACC * 16;
       if (need > st->part_cap) {
@@ -983,12 +995,14 @@ int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int
   h->fs0 = s0;
   h->fs1 = s1;
   demux_row_release(&h->frow);
+  demux_row_release(&h->fqrow);
   if (c0 != 0 || c1 != h->C) {  // chunk tables of the cell shard for the row E-step
     std::vector<int64_t> cp((size_t)h->C + 1);
     std::vector<int32_t> es((size_t)h->nnz);
     HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (h->C + 1), hipMemcpyDeviceToHost));
     if (h->nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
     if (demux_row_build(h, &h->frow, cp.data(), es.data(), c0, c1, MUXGL_ROW_CH)) return 1;
+    if (demux_row_build(h, &h->fqrow, cp.data(), es.data(), c0, c1, MUXGL_QUAD_CH)) return 1;
   }
   return 0;
 }

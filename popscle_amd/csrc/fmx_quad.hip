@@ -1,0 +1,305 @@
+// fmx_quad.hip -- freemuxlet E-step (cmd_cram_freemux2.cpp:383-456) for K <= 16 clusters with the quad tiling of
+// demux_quad.hip: 4 lanes per entry, lane r owns clusters 4r..4r+3, 16 entries per wave iteration.
+//
+// Per entry the reference evaluates, for every cluster pair k < j,  lk = sum_{g1,g2} glis[g1][g2] gp_j[g1] gp_k[g2]
+// (:440-446) and for every cluster  lk = sum_g glis[g][g] gp_j[g]  (:448-452), and adds log(lk) to llks (:454-455).
+// glis (calculate_snp_droplet_pileup, alpha = 0.5) is symmetric, so unordered pairs suffice.  Here:
+//   u[c][m] = sum_l gp_c[l] * glis[l][m]  for the lane's four clusters, then every pair costs 3 FMA + 1 multiply into a
+//   product accumulator (6 pairs inside the lane, 16 with the neighbouring tile via row_ror:4, 10 with the opposite tile
+//   via row_ror:8).  Products leave as (mantissa, exponent) per chunk; fmx_quad_reduce_kernel takes one log per
+//   (cell, pair).  The cluster-GP rows are re-laid per quad ([S][6][4][2], fmx_cgpq_kernel) once per iteration.
+#include "common.hpp"
+
+namespace {
+
+constexpr int FQ_ACC = 36;          // 4 singlets, 6 in-lane pairs, 16 + 10 cross-tile pairs
+constexpr int FQ_ENTRY = 6;         // doubles per entry in LDS: the six distinct likelihoods {00,11,22,01,02,12}
+constexpr int FQ_SLOT_STRIDE = 26;  // 4 entries x 6 + 2: slot regions 208 B apart => distinct LDS banks for 16 slots
+
+__device__ __forceinline__ double fq_ror4(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x124, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x124, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fq_ror8(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x128, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x128, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__global__ void fq_tmap_kernel(int32_t* tmap /*[2][4]*/) {
+  const int lane = threadIdx.x;
+  const int t = (lane >> 2) & 3;
+  const int t4 = __builtin_amdgcn_mov_dpp(t, 0x124, 0xF, 0xF, false);
+  const int t8 = __builtin_amdgcn_mov_dpp(t, 0x128, 0xF, 0xF, false);
+  if (lane < 16 && (lane & 3) == 0) {
+    tmap[t] = t4;
+    tmap[4 + t] = t8;
+  }
+}
+
+__host__ __device__ constexpr int fq_within(int c1, int c2) { return 4 + (c1 == 0 ? c2 - 1 : (c1 == 1 ? 3 + c2 - 2 : 5)); }
+__host__ __device__ constexpr int fq_t1(int c, int d) { return 10 + c * 4 + d; }
+__host__ __device__ constexpr int fq_t2(int c, int d) { return 26 + (c == 0 ? d : (c == 1 ? 4 + d - 1 : (c == 2 ? 7 + d - 2 : 9))); }
+
+// cluster-GP rows [S][K][3] -> [S][6][4][2]; clusters >= K are padded with (1,0,0) (their factors are exactly 1)
+__global__ void __launch_bounds__(256)
+    fmx_cgpq_kernel(int64_t S, int K, const double* __restrict__ cgp, double* __restrict__ cgpq) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= S * 48) return;
+  const int64_t s = tid / 48;
+  const int w = (int)(tid - s * 48);  // position inside the quad row: ((t*4 + r)*2 + half)
+  const int half = w & 1, r = (w >> 1) & 3, t = w >> 3;
+  const int d = 2 * t + half, j = 4 * r + d / 3, l = d % 3;
+  cgpq[tid] = (j < K) ? cgp[((size_t)s * K + j) * 3 + l] : (l == 0 ? 1.0 : 0.0);
+}
+
+__global__ void __launch_bounds__(64, 2)
+    fmx_estep_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
+                          const double* __restrict__ egls6, const double* __restrict__ cgpq, double* __restrict__ part_m,
+                          int32_t* __restrict__ part_e) {
+  __shared__ __align__(16) double gl[16 * FQ_SLOT_STRIDE];
+  __shared__ int32_t snps[64], snps_nx[64];
+
+  const int lane = threadIdx.x;
+  const int r = (lane >> 2) & 3;
+  const int slot = ((lane >> 4) << 2) | (lane & 3);
+  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;
+  int64_t e0 = 0;
+  int len = 0;
+  if (q < n_chunks) {
+    e0 = chunks[q].e0;
+    len = chunks[q].len;
+  }
+  const int nb = (wave_max_i32(len) + 3) >> 2;
+
+  double acc[FQ_ACC];
+  int32_t ex[FQ_ACC];
+#pragma unroll
+  for (int a = 0; a < FQ_ACC; ++a) {
+    acc[a] = 1.0;
+    ex[a] = 0;
+  }
+
+  // the entry of the batch to come (SNP id + its nine likelihoods) is fetched one batch ahead
+  int32_t psnp = -1;
+  double pgl[6];
+  auto fetch_entry = [&](int b) {
+    const int idx = b * 4 + r;
+    psnp = -1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pgl[i] = 1.0;  // dead entry: with g = (1,0,0) every factor is exactly 1
+    if (idx < len) {
+      const int64_t e = e0 + idx;
+      psnp = entry_snp[e];
+      const double2* src = reinterpret_cast<const double2*>(egls6 + (size_t)e * 6);  // 48 B, 16-byte aligned
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double2 v = src[i];
+        pgl[2 * i] = v.x;
+        pgl[2 * i + 1] = v.y;
+      }
+    }
+  };
+  double nG[4][3];
+  auto load_row = [&](int32_t s) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      nG[c][0] = 1.0;
+      nG[c][1] = 0.0;
+      nG[c][2] = 0.0;
+    }
+    if (s >= 0) {
+      const double2* pc = reinterpret_cast<const double2*>(cgpq + (size_t)s * 48) + r;
+      double f[12];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const double2 v = pc[t * 4];
+        f[2 * t] = v.x;
+        f[2 * t + 1] = v.y;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        nG[c][0] = f[3 * c];
+        nG[c][1] = f[3 * c + 1];
+        nG[c][2] = f[3 * c + 2];
+      }
+    }
+  };
+  fetch_entry(0);
+  snps_nx[slot * 4 + r] = psnp;
+  __syncthreads();
+  load_row(snps_nx[slot * 4]);
+
+  for (int b = 0; b < nb; ++b) {
+    {  // phase 1: lane <-> entry, likelihoods of 64 entries into LDS
+      double* dst = gl + slot * FQ_SLOT_STRIDE + r * FQ_ENTRY;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dst[i] = pgl[i];
+      snps[slot * 4 + r] = psnp;
+      if (b + 1 < nb) fetch_entry(b + 1);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      double G[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        G[c][0] = nG[c][0];
+        G[c][1] = nG[c][1];
+        G[c][2] = nG[c][2];
+      }
+      if (i == 2 && b + 1 < nb) snps_nx[slot * 4 + r] = psnp;
+      if (i + 1 < 4) load_row(snps[slot * 4 + i + 1]);
+      else if (b + 1 < nb) load_row(snps_nx[slot * 4]);
+
+      const double* p = gl + slot * FQ_SLOT_STRIDE + i * FQ_ENTRY;
+      const double p0 = p[0], p4 = p[1], p8 = p[2], p1 = p[3], p2 = p[4], p5 = p[5];
+      const double p3 = p1, p6 = p2, p7 = p5;  // glis[g1][g2] == glis[g2][g1]
+      double u[4][3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[c] *= fma(G[c][2], p8, fma(G[c][1], p4, G[c][0] * p0));  // singlet (:448-452)
+        u[c][0] = fma(G[c][2], p6, fma(G[c][1], p3, G[c][0] * p0));
+        u[c][1] = fma(G[c][2], p7, fma(G[c][1], p4, G[c][0] * p1));
+        u[c][2] = fma(G[c][2], p8, fma(G[c][1], p5, G[c][0] * p2));
+      }
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+        for (int c2 = c1 + 1; c2 < 4; ++c2)
+          acc[fq_within(c1, c2)] *= fma(G[c2][2], u[c1][2], fma(G[c2][1], u[c1][1], G[c2][0] * u[c1][0]));
+      {
+        double P[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          P[d][0] = fq_ror4(G[d][0]);
+          P[d][1] = fq_ror4(G[d][1]);
+          P[d][2] = fq_ror4(G[d][2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            acc[fq_t1(c, d)] *= fma(P[d][2], u[c][2], fma(P[d][1], u[c][1], P[d][0] * u[c][0]));  // :440-446
+      }
+      {
+        double Q[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          Q[d][0] = fq_ror8(G[d][0]);
+          Q[d][1] = fq_ror8(G[d][1]);
+          Q[d][2] = fq_ror8(G[d][2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = c; d < 4; ++d)
+            acc[fq_t2(c, d)] *= fma(Q[d][2], u[c][2], fma(Q[d][1], u[c][1], Q[d][0] * u[c][0]));
+      }
+    }
+    if ((b & 3) == 3) {
+#pragma unroll
+      for (int a = 0; a < FQ_ACC; ++a) prodacc_renorm(acc[a], ex[a]);
+    }
+    __syncthreads();
+  }
+  if (q < n_chunks) {
+#pragma unroll
+    for (int a = 0; a < FQ_ACC; ++a) {
+      prodacc_renorm(acc[a], ex[a]);
+      part_m[((size_t)q * FQ_ACC + a) * 4 + r] = acc[a];
+      part_e[((size_t)q * FQ_ACC + a) * 4 + r] = ex[a];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(192)
+    fmx_quad_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
+                           const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                           const int32_t* __restrict__ tmap, int K, int64_t c_off, double* __restrict__ fll) {
+  const int64_t c = c_off + blockIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  const int npairs = K * (K + 1) / 2;
+  const int idx = threadIdx.x;
+  if (idx >= FQ_ACC * 4) return;
+  const int a = idx >> 2, r = idx & 3;
+  int j, k;
+  bool publish = true;
+  if (a < 4) {
+    j = k = 4 * r + a;
+  } else if (a < 10) {
+    const int w = a - 4;
+    const int c1i = w < 3 ? 0 : (w < 5 ? 1 : 2);
+    const int c2i = w < 3 ? w + 1 : (w < 5 ? w - 1 : 3);
+    j = 4 * r + c2i;
+    k = 4 * r + c1i;
+  } else if (a < 26) {
+    j = 4 * r + ((a - 10) >> 2);
+    k = 4 * tmap[r] + ((a - 10) & 3);
+  } else {
+    const int w = a - 26;
+    const int cc = w < 4 ? 0 : (w < 7 ? 1 : (w < 9 ? 2 : 3));
+    const int dd = w < 4 ? w : (w < 7 ? w - 3 : (w < 9 ? w - 5 : 3));
+    const int ro = tmap[4 + r];
+    j = 4 * r + cc;
+    k = 4 * ro + dd;
+    if (cc == dd && r > ro) publish = false;
+  }
+  if (!publish || j >= K || k >= K) return;
+  double m = 1.0;
+  int64_t e = 0;
+  int cnt = 0;
+  for (int64_t ci = c0; ci < c1; ++ci) {
+    const size_t o = (size_t)cell_chunks[ci] * FQ_ACC * 4 + idx;
+    m *= part_m[o];
+    e += part_e[o];
+    if (++cnt == 512) {
+      cnt = 0;
+      int ee;
+      m = frexp(m, &ee);
+      e += ee;
+    }
+  }
+  const int hi = j > k ? j : k, lo = j > k ? k : j;
+  fll[(size_t)c * npairs + hi * (hi + 1) / 2 + lo] = (c0 == c1) ? 0.0 : log(m) + (double)e * 0.6931471805599453094;
+}
+
+}  // namespace
+
+// quad E-step for the cell shard [c0, c0+nc) described by the chunk tables st; -1 if not applicable
+int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc) {
+  if (h->K > 16 || !st || (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL))) return -1;
+  if (!st->d_tmap) {
+    if (dev_alloc(h, &st->d_tmap, 8)) return 1;
+    hipLaunchKernelGGL(fq_tmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
+    HIPCHK(h, hipGetLastError());
+  }
+  const size_t need = (size_t)st->n_chunks * FQ_ACC * 4;
+  if (need > st->part_cap) {
+    if (dev_alloc(h, &st->d_part, need)) return 1;
+    st->part_cap = need;
+  }
+  if (need > st->part_e_cap) {
+    if (dev_alloc(h, &st->d_part_e, need)) return 1;
+    st->part_e_cap = need;
+  }
+  const size_t nq = (size_t)h->S * 48;
+  if (nq > h->cgpq_cap) {
+    if (dev_alloc(h, &h->d_cgpq, nq)) return 1;
+    h->cgpq_cap = nq;
+  }
+  if (nq)
+    hipLaunchKernelGGL(fmx_cgpq_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, h->S, h->K, h->d_cgp,
+                       h->d_cgpq);
+  const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);
+  if (blocks)
+    hipLaunchKernelGGL(fmx_estep_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
+                       h->d_entry_snp, h->d_egls6, h->d_cgpq, st->d_part, st->d_part_e);
+  if (nc > 0)
+    hipLaunchKernelGGL(fmx_quad_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                       st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->K, c0, h->d_fll);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}

@@ -94,6 +94,8 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_snp_entry);
   dev_free(&h->d_snp_cell);
   dev_free(&h->d_segls);
+  dev_free(&h->d_egls6);
+  dev_free(&h->d_cgpq);
   dev_free(&h->d_secnt);
   demux_row_free(h);
   demux_wave_free(h);

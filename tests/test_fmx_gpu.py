@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(scope="module", params=["row", "pair"])
+@pytest.fixture(scope="module", params=["default", "row", "pair"])
 def eng(request):
-    """'row' = default dispatch (row E-step for K <= 16), 'pair' = the general pair kernel forced for every K"""
-    e = muxgl.Engine(0, muxgl.FLAG_FORCE_TILE_SWEEP if request.param == "pair" else 0)
+    """'default' = normal dispatch (quad E-step for K <= 16), 'row' = quad disabled (row E-step), 'pair' = the general
+    pair kernel and the (SNP, cluster)-parallel M-step forced for every K"""
+    flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "pair": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
+    e = muxgl.Engine(0, flags)
     yield e
     e.close()
 
