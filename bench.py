@@ -185,6 +185,8 @@ def main():
             },
             "entries_per_s": total_entries / step_s,
             "cells_per_s": total_cells / step_s,
+            # quad path: "reduce" is the fused finish kernel (chunk reduction + call + records written to pinned host
+            # memory), "call" and "d2h" are then 0; other paths run them as separate launches
             "kernel_ms": {"sweep": float(kern_ms[muxgl.T_DEMUX_SWEEP]), "reduce": float(kern_ms[muxgl.T_DEMUX_REDUCE]),
                           "call": float(kern_ms[muxgl.T_DEMUX_CALL]),
                           "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},

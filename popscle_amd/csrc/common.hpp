@@ -69,7 +69,9 @@ struct muxgl_handle {
   size_t ll_cap = 0;
   bool ll_zeroed = false;
   muxgl_demux_cell* d_dcells = nullptr;
-  muxgl_demux_cell* h_dcells = nullptr;  // pinned
+  muxgl_demux_cell* h_dcells = nullptr;  // pinned, device-visible
+  bool want_full_ll = false;     // this run must leave the LL tensor in d_ll
+  bool records_on_host = false;  // the launch wrote the records into h_dcells itself (no D2H copy needed)
   int64_t dcells_cap = 0;
   uint32_t* d_pairs = nullptr;  // packed (j | k<<8 | nmask<<16) work list of the sweep
   int32_t n_pairs = 0;

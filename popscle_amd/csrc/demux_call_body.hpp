@@ -1,0 +1,241 @@
+// demux_call_body.hpp -- the per-cell call (evidence sums, best/next scans, SNG/DBL/AMB decision;
+// cmd_cram_demuxlet.cpp:788-991) as a device function over G lanes, shared by demux_callg_kernel (LL tensor in HBM)
+// and the fused finish kernel of the quad path (LL tile in LDS).  See demux_call16.hip for the argument why the
+// lane-parallel scans and evidence chains give the reference's result.
+#pragma once
+#include "common.hpp"
+
+namespace muxgl_call {
+
+struct call_alpha {
+  double a[MUXGL_MAX_ALPHA];
+};
+
+struct top2 {
+  double bv, nv;  // best / next value
+  int32_t bp, np; // scan positions (-1: none); position encodes the hypothesis
+};
+
+// reference update rule for one more element at a later position
+__device__ __forceinline__ void top2_push(top2& t, double v, int32_t pos) {
+  if (t.bv < v) {
+    t.nv = t.bv;
+    t.np = t.bp;
+    t.bv = v;
+    t.bp = pos;
+  } else if (t.nv < v) {
+    t.nv = v;
+    t.np = pos;
+  }
+}
+
+// key order: value descending, then position ascending; "none" entries (pos < 0) carry -1e300 and never win
+__device__ __forceinline__ bool key_before(double va, int32_t pa, double vb, int32_t pb) {
+  if (pb < 0) return true;
+  if (pa < 0) return false;
+  if (va > vb) return true;
+  if (va < vb) return false;
+  return pa < pb;
+}
+
+__device__ __forceinline__ top2 top2_merge(const top2& a, const top2& b) {
+  top2 r;
+  if (key_before(a.bv, a.bp, b.bv, b.bp)) {
+    r.bv = a.bv;
+    r.bp = a.bp;
+    if (key_before(a.nv, a.np, b.bv, b.bp)) {
+      r.nv = a.nv;
+      r.np = a.np;
+    } else {
+      r.nv = b.bv;
+      r.np = b.bp;
+    }
+  } else {
+    r.bv = b.bv;
+    r.bp = b.bp;
+    if (key_before(b.nv, b.np, a.bv, a.bp)) {
+      r.nv = b.nv;
+      r.np = b.np;
+    } else {
+      r.nv = a.bv;
+      r.np = a.bp;
+    }
+  }
+  return r;
+}
+
+__device__ __forceinline__ top2 top2_xor(const top2& t, int m) {
+  top2 o;
+  o.bv = __shfl_xor(t.bv, m, 64);
+  o.nv = __shfl_xor(t.nv, m, 64);
+  o.bp = __shfl_xor(t.bp, m, 64);
+  o.np = __shfl_xor(t.np, m, 64);
+  return o;
+}
+
+// lane = lane id in the wave; lanes [base, base+G) with base = lane & ~(G-1) work on one cell.  ll_cell points at that
+// cell's [nv][nv][nAlpha] hypotheses (global or LDS); lane base+0 writes *out when cell_ok.
+template <int G>
+__device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
+                                                 const double* gridAlpha, double doublet_prior, const double* ll_cell,
+                                                 muxgl_demux_cell* out) {
+  const int j = lane & (G - 1);
+  const bool live = cell_ok && j < nv;
+  const double log_single_prior = log((1.0 - doublet_prior) / nv);
+  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
+  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
+
+  top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
+  const double NEG_INF = -__builtin_huge_val();
+  double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0;
+  if (live) {
+    const double* row = ll_cell + (size_t)j * nv * nAlpha;
+    const double s = row[0];  // llksAB[j][0][0]
+    top2_push(sng, s, j);
+    sterm = s + log_single_prior;
+    rowmax = sterm;
+    // pass 1: scans, and the largest evidence term of the row
+    for (int k = 0; k < nv; ++k) {
+      if (k == j) continue;
+      for (int n = 1; n < nAlpha; ++n) {
+        const double v = row[k * nAlpha + n];
+        if (gridAlpha[n] == 0.5) {
+          if (k < j) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
+        } else {
+          rowmax = fmax(rowmax, v + log_doublet_prior1);
+        }
+        top2_push(dbl, v, (j * nv + k) * nAlpha + n);
+      }
+    }
+    // pass 2: the row's evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
+    if (rowmax > NEG_INF) {
+      racc = exp(sterm - rowmax);
+      for (int k = 0; k < nv; ++k) {
+        if (k == j) continue;
+        for (int n = 1; n < nAlpha; ++n) {
+          const double v = row[k * nAlpha + n];
+          if (gridAlpha[n] == 0.5) {
+            if (k < j) racc += exp(v + log_doublet_prior2 - rowmax);
+          } else {
+            racc += exp(v + log_doublet_prior1 - rowmax);
+          }
+        }
+      }
+    }
+  }
+  // merge the G rows: top-2 lists, maxima, then the scaled sums
+  double M = rowmax, Ms = sterm;
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    sng = top2_merge(sng, top2_xor(sng, m));
+    dbl = top2_merge(dbl, top2_xor(dbl, m));
+    M = fmax(M, __shfl_xor(M, m, 64));
+    Ms = fmax(Ms, __shfl_xor(Ms, m, 64));
+  }
+  double S = (racc > 0.0) ? racc * exp(rowmax - M) : 0.0;
+  double Ss = (sterm > NEG_INF) ? exp(sterm - Ms) : 0.0;
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    S += __shfl_xor(S, m, 64);
+    Ss += __shfl_xor(Ss, m, 64);
+  }
+  // :791 (sic): the reference starts both sums at -1e-300, i.e. with one more term exp(-1e-300)
+  double sumLLK = -1e-300, sngLLK = -1e-300;
+  if (S > 0.0) sumLLK = dev_logadd(sumLLK, M + log(S));
+  if (Ss > 0.0) sngLLK = dev_logadd(sngLLK, Ms + log(Ss));
+  if (!cell_ok || j != 0) return;
+
+  muxgl_demux_cell o;
+  memset(&o, 0, sizeof(o));
+  o.nsnps = nsnps;
+  if (o.nsnps == 0) {  // :653
+    *out = o;
+    return;
+  }
+  o.valid = 1;
+  const int32_t sBest = sng.bp, sNext = sng.np;
+  const double sngBestLLK = sng.bv, sngNextLLK = sng.nv;
+  const double dblBestLLK = dbl.bv, dblNextLLK = dbl.nv;
+  int32_t dBest1 = -1, dBest2 = -1, dblBestAlpha = -1, dNext1 = -1, dNext2 = -1, dblNextAlpha = -1;
+  if (dbl.bp >= 0) {
+    dblBestAlpha = dbl.bp % nAlpha;
+    dBest2 = (dbl.bp / nAlpha) % nv;
+    dBest1 = dbl.bp / (nAlpha * nv);
+  }
+  if (dbl.np >= 0) {
+    dblNextAlpha = dbl.np % nAlpha;
+    dNext2 = (dbl.np / nAlpha) % nv;
+    dNext1 = dbl.np / (nAlpha * nv);
+  }
+  int32_t bestType, nextType, jBest, kBest, jNext, kNext, alphaBest, alphaNext;
+  double bestLLK, nextLLK, bestPP;
+  if (dblBestLLK > sngBestLLK + 2) {  // :925
+    bestType = MUXGL_DBL;
+    bestPP = exp(dblBestLLK + ((gridAlpha[dblBestAlpha] == 0.5) ? log_doublet_prior2 : log_doublet_prior1) - sumLLK);
+    jBest = dBest1;
+    kBest = dBest2;
+    bestLLK = dblBestLLK;
+    alphaBest = dblBestAlpha;
+    if (dblNextLLK > sngBestLLK + 2) {
+      nextType = MUXGL_DBL;
+      jNext = dNext1;
+      kNext = dNext2;
+      nextLLK = dblNextLLK;
+      alphaNext = dblNextAlpha;
+    } else {
+      nextType = MUXGL_SNG;
+      jNext = kNext = sBest;
+      nextLLK = sngBestLLK;
+      alphaNext = 0;
+    }
+  } else {
+    bestType = (sngBestLLK > sngNextLLK + 2) ? MUXGL_SNG : MUXGL_AMB;  // :947 / :968
+    bestPP = sngBestLLK + log_single_prior - sumLLK;                   // log value, as the reference (:949,970)
+    jBest = kBest = sBest;
+    bestLLK = sngBestLLK;
+    alphaBest = 0;
+    if (dblBestLLK > sngNextLLK + 2) {
+      nextType = MUXGL_DBL;
+      jNext = dBest1;
+      kNext = dBest2;
+      nextLLK = dblBestLLK;
+      alphaNext = dblBestAlpha;
+    } else {
+      nextType = MUXGL_SNG;
+      jNext = kNext = sNext;
+      nextLLK = sngNextLLK;
+      alphaNext = 0;
+    }
+  }
+  o.type = bestType;
+  o.next_type = nextType;
+  o.sBest = sBest;
+  o.sNext = sNext;
+  o.dBest1 = dBest1;
+  o.dBest2 = dBest2;
+  o.dBestA = dblBestAlpha;
+  o.dNext1 = dNext1;
+  o.dNext2 = dNext2;
+  o.dNextA = dblNextAlpha;
+  o.jBest = jBest;
+  o.kBest = kBest;
+  o.aBest = alphaBest;
+  o.jNext = jNext;
+  o.kNext = kNext;
+  o.aNext = alphaNext;
+  o.sngBestLLK = sngBestLLK;
+  o.sngNextLLK = sngNextLLK;
+  o.dblBestLLK = dblBestLLK;
+  o.dblNextLLK = dblNextLLK;
+  o.sumLLK = sumLLK;
+  o.sngLLK = sngLLK;
+  o.bestLLK = bestLLK;
+  o.nextLLK = nextLLK;
+  o.bestPP = bestPP;
+  o.sngPP = exp(sngLLK - sumLLK);                             // :990
+  o.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);  // :991
+  *out = o;
+}
+
+
+}  // namespace muxgl_call

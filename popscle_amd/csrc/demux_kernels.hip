@@ -471,7 +471,9 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     h->ll_zeroed = true;
   }
 
+  h->records_on_host = false;
   int rc = demux_quad_launch(h, p);          // V <= 16 and the reference's default grid {0, 0.5}: quad kernel
+  if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the quad path's finish kernel
   if (rc < 0) rc = demux_row_launch(h, p);   // V <= 16, other grids: row kernel
   if (rc < 0) rc = demux_wave_launch(h, p);  // 16 < V <= 64: one wave per cell, one lane per sample
   if (rc > 0) return rc;

@@ -19,7 +19,7 @@
 //     of a cell in chunk order and takes ONE log per hypothesis and cell (the row kernel took one per chunk).
 #include <vector>
 
-#include "common.hpp"
+#include "demux_call_body.hpp"
 
 namespace {
 
@@ -291,23 +291,16 @@ __global__ void __launch_bounds__(64, 2)
   }
 }
 
-// multiplies the chunk partials of one cell in chunk order and writes ll[c][j][k][n] (+ mirror): one log per hypothesis
-__global__ void __launch_bounds__(192)
-    demux_quad_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
-                             const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
-                             const int32_t* __restrict__ tmap, int V, int n0, int n1, int A, double* __restrict__ ll) {
-  const int64_t c = blockIdx.x;
-  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
-  const int idx = threadIdx.x;
-  if (c0 == c1 || idx >= QN_ACC * 4) return;
+// Decodes accumulator idx = a*4 + r of the quad kernel into its hypothesis (j, k) and multiplies the chunk partials of
+// one cell in chunk order: ONE log per hypothesis.  Returns false for slots nobody reads (mirrors held twice, j/k >= V).
+__device__ __forceinline__ bool quad_hypothesis(int idx, int64_t c0, int64_t c1, const int32_t* __restrict__ cell_chunks,
+                                                const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                                                const int32_t* __restrict__ tmap, int V, int& j, int& k, double& v) {
   const int a = idx >> 2, r = idx & 3;
-  // which hypothesis is this accumulator?
-  int j, k, n = n1;
   bool publish = true;
   if (a < 4) {
     j = 4 * r + a;
     k = 0;
-    n = n0;
   } else if (a < 10) {
     int w = a - 4, c1i, c2i;
     if (w < 3) {
@@ -346,25 +339,103 @@ __global__ void __launch_bounds__(192)
     k = 4 * ro + dd;
     if (cc == dd && r > ro) publish = false;  // the facing lane holds the same pair
   }
-  if (!publish || j >= V || k >= V) return;
+  if (!publish || j >= V || k >= V) return false;
+  // eight chunks per trip: the sixteen loads are independent and in flight together, the products stay in chunk order
   double m = 1.0;
   int64_t e = 0;
   int cnt = 0;
-  for (int64_t ci = c0; ci < c1; ++ci) {
-    const size_t o = (size_t)cell_chunks[ci] * QN_ACC * 4 + idx;
-    m *= part_m[o];
-    e += part_e[o];
-    if (++cnt == 512) {  // mantissas are in [0.5,1): 512 factors cannot underflow
+  for (int64_t ci = c0; ci < c1; ci += 8) {
+    double pm[8];
+    int32_t pe[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = ci + u < c1;
+      const size_t o = (size_t)cell_chunks[ok ? ci + u : c0] * QN_ACC * 4 + idx;
+      pm[u] = ok ? part_m[o] : 1.0;
+      pe[u] = ok ? part_e[o] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      m *= pm[u];
+      e += pe[u];
+    }
+    if (++cnt == 64) {  // mantissas are in [0.5,1): 512 factors cannot underflow
       cnt = 0;
       int ee;
       m = frexp(m, &ee);
       e += ee;
     }
   }
-  const double v = log(m) + (double)e * 0.6931471805599453094;
-  double* out = ll + (size_t)c * V * V * A;
-  out[((size_t)j * V + k) * A + n] = v;
-  if (a >= 4) out[((size_t)k * V + j) * A + n] = v;
+  v = log(m) + (double)e * 0.6931471805599453094;
+  return true;
+}
+
+// writes ll[c][j][k][n] (+ mirror) of one cell to the LL tensor in HBM (needed when the caller asks for the tensor)
+__global__ void __launch_bounds__(192)
+    demux_quad_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
+                             const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                             const int32_t* __restrict__ tmap, int V, double* __restrict__ ll) {
+  const int64_t c = blockIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  const int idx = threadIdx.x;
+  if (c0 == c1 || idx >= QN_ACC * 4) return;
+  int j, k;
+  double v;
+  if (!quad_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, tmap, V, j, k, v)) return;
+  double* out = ll + (size_t)c * V * V * 2;
+  if (idx < 16) {
+    out[((size_t)j * V + k) * 2 + 0] = v;  // singlet: alpha index 0
+  } else {
+    out[((size_t)j * V + k) * 2 + 1] = v;
+    out[((size_t)k * V + j) * 2 + 1] = v;
+  }
+}
+
+// The same reduction, but the hypotheses of four cells stay in LDS and the call (demux_call_body.hpp) follows at once,
+// sixteen lanes per cell in wave 0: no LL tensor round trip through HBM, one launch less, and the 160-byte records go
+// straight to the caller's pinned host buffer (16-byte stores of consecutive lanes), which removes the separate
+// device-to-host copy.
+constexpr int QF_CELLS = 4;
+__global__ void __launch_bounds__(256)
+    demux_quad_finish_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, const int64_t* __restrict__ cell_chunk_ptr,
+                             const int32_t* __restrict__ cell_chunks, const double* __restrict__ part_m,
+                             const int32_t* __restrict__ part_e, const int32_t* __restrict__ tmap, int V,
+                             muxgl_call::call_alpha al, double doublet_prior, muxgl_demux_cell* __restrict__ out) {
+  __shared__ double llt[QF_CELLS][16 * 16 * 2];
+  __shared__ __align__(16) muxgl_demux_cell rec[QF_CELLS];
+  static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
+  const int64_t cbase = (int64_t)blockIdx.x * QF_CELLS;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < QF_CELLS * 512; t += 256) (&llt[0][0])[t] = 0.0;
+  __syncthreads();
+  for (int w = tid; w < QF_CELLS * QN_ACC * 4; w += 256) {
+    const int lc = w / (QN_ACC * 4), idx = w - lc * (QN_ACC * 4);
+    const int64_t c = cbase + lc;
+    if (c >= C) break;
+    const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+    int j, k;
+    double v;
+    if (c0 != c1 && quad_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, tmap, V, j, k, v)) {
+      if (idx < 16) {
+        llt[lc][(j * V + k) * 2 + 0] = v;
+      } else {
+        llt[lc][(j * V + k) * 2 + 1] = v;
+        llt[lc][(k * V + j) * 2 + 1] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lc = tid >> 4;
+    const int64_t c = cbase + lc;
+    const bool ok = c < C;
+    muxgl_call::demux_call_group<16>(tid, ok, ok ? (int32_t)(cell_ptr[c + 1] - cell_ptr[c]) : 0, V, 2, al.a,
+                                     doublet_prior, llt[lc], &rec[lc]);
+  }
+  __syncthreads();
+  constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
+  if (tid < QF_CELLS * NQ && cbase + tid / NQ < C)
+    reinterpret_cast<uint4*>(out + cbase)[tid] = reinterpret_cast<const uint4*>(&rec[0])[tid];
 }
 
 }  // namespace
@@ -398,8 +469,17 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);
   tic(h, MUXGL_T_DEMUX_REDUCE);
-  hipLaunchKernelGGL(demux_quad_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
-                     st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, 0, 1, 2, h->d_ll);
+  if (h->want_full_ll) {
+    hipLaunchKernelGGL(demux_quad_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                       st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);
+  } else {  // reduce + call fused, records written to the pinned host buffer
+    muxgl_call::call_alpha al;
+    for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+    hipLaunchKernelGGL(demux_quad_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(256), 0,
+                       h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
+                       p->doublet_prior, h->h_dcells);
+    h->records_on_host = true;
+  }
   HIPCHK(h, hipGetLastError());
   toc(h, MUXGL_T_DEMUX_REDUCE);
   return 0;

@@ -372,11 +372,18 @@ int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, const int64_t* cell_
   std::vector<row_chunk> chunks;
   const int ROW_CH = ch;
   chunks.reserve((size_t)((cell_ptr[ce] - cell_ptr[cb]) / ROW_CH + (ce - cb) + 1));
-  for (int64_t c = cb; c < ce; ++c)
-    for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; e += ROW_CH) {
-      const int64_t len = std::min<int64_t>(ROW_CH, cell_ptr[c + 1] - e);
+  // a cell is cut into the fewest chunks of <= ROW_CH entries, of (nearly) equal length rounded up to the kernels'
+  // batch of four entries: the slots of a wave then finish together instead of waiting for the full-length ones
+  for (int64_t c = cb; c < ce; ++c) {
+    const int64_t n = cell_ptr[c + 1] - cell_ptr[c];
+    if (n == 0) continue;
+    const int64_t nch = (n + ROW_CH - 1) / ROW_CH;
+    const int64_t step = std::min<int64_t>(ROW_CH, ((n + nch - 1) / nch + 3) / 4 * 4);
+    for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; e += step) {
+      const int64_t len = std::min<int64_t>(step, cell_ptr[c + 1] - e);
       chunks.push_back(row_chunk{e, (int32_t)len, (int32_t)c});
     }
+  }
   // Launch order: ascending first SNP id.  Entries are SNP-sorted inside a cell, so consecutive chunks of the launch
   // list gather GP rows from neighbouring windows of the [S][V][3] tensor; xcd_swizzle() hands each XCD one contiguous
   // eighth of the list, whose sliding window fits that XCD's 4 MiB L2 (the whole tensor, 19 MB at config 1, does not).

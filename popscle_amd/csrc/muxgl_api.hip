@@ -239,11 +239,14 @@ int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_ce
   if (check_demux_params(h, p)) return 1;
   clear_timing(h);
   if (h->C > 0) {
+    h->want_full_ll = full_ll != nullptr;
     if (demux_launch(h, p)) return 1;
-    tic(h, MUXGL_T_DEMUX_D2H);
-    HIPCHK(h, hipMemcpyAsync(h->h_dcells, h->d_dcells, sizeof(muxgl_demux_cell) * (size_t)h->C, hipMemcpyDeviceToHost,
-                             h->stream));
-    toc(h, MUXGL_T_DEMUX_D2H);
+    if (!h->records_on_host) {
+      tic(h, MUXGL_T_DEMUX_D2H);
+      HIPCHK(h, hipMemcpyAsync(h->h_dcells, h->d_dcells, sizeof(muxgl_demux_cell) * (size_t)h->C,
+                               hipMemcpyDeviceToHost, h->stream));
+      toc(h, MUXGL_T_DEMUX_D2H);
+    }
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
