@@ -15,6 +15,7 @@
 #include <memory>
 
 #include "../../include/muxgl.h"
+#include "plp_fast.hpp"
 #include "vcf.hpp"
 
 namespace pa {
@@ -74,6 +75,7 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
   }
 
   notice("Loading pileup information with prefix %s", prefix.c_str());
+  StageTimer tm;
   // ---- .cel.gz
   std::vector<int32_t> index_bcs, tmp_totl, tmp_uniq, tmp_nsnp;
   {
@@ -209,85 +211,34 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
   }
   const int64_t S = out.S();
 
-  // ---- .plp.gz
-  struct Rd {
-    int32_t cell, snp;
-    uint32_t numi;
-    uint8_t byte;
-  };
-  std::vector<Rd> rds;
+  tm.lap("cel+var(+vcf)");
+  // ---- .plp.gz: the big file.  One thread inflates, the others parse line-aligned slices of each inflated block
+  // (plp_fast.hpp); rows come back in file order with the global kept-base counter that names each read's UMI.
+  std::vector<PlpRead> rds;
   out.cell_totl_reads.assign((size_t)C, 0);
   out.cell_uniq_reads.assign((size_t)C, 0);
+  bool sorted = true;
   {
-    TsvReader t(prefix + ".plp.gz");
-    if (t.read_line() > 0) {
-      if (t.nfields != 4 || strcmp("#DROPLET_ID", t.str_field_at(0)) || strcmp("SNP_ID", t.str_field_at(1)) ||
-          strcmp("ALLELES", t.str_field_at(2)) || strcmp("BASEQS", t.str_field_at(3)))
-        fatal("THe header line of %s.plp.gz is malformed or outdated. Expecting #DROPLET_ID SNP_ID ALLELES BASEQS",
-              prefix.c_str());
-    } else {
-      fatal("Cannot read the first line of %s.plp.gz", prefix.c_str());
+    PlpParseOptions po;
+    po.minBQ = opt.minBQ;
+    po.capBQ = opt.capBQ > 127 ? 127 : opt.capBQ;
+    po.S = (int32_t)S;
+    po.index_bcs = &index_bcs;
+    const uint64_t numi = parse_plp_gz(prefix, po, rds, &sorted);
+    tm.lap("plp inflate+parse");
+    for (const PlpRead& r : rds) {
+      ++out.cell_totl_reads[(size_t)r.cell];
+      ++out.cell_uniq_reads[(size_t)r.cell];  // every kept base is its own UMI (:361-368)
     }
-    uint32_t numi = 0;
-    const int capBQ = opt.capBQ > 127 ? 127 : opt.capBQ;
-    while (t.read_line() > 0) {
-      if (t.nfields < 4) fatal("%s.plp.gz: line %d has %d fields", prefix.c_str(), t.nlines, t.nfields);
-      const int32_t did = t.int_field_at(0);
-      if (did < 0 || did >= (int32_t)index_bcs.size()) fatal("%s.plp.gz: DROPLET_ID %d out of range", prefix.c_str(), did);
-      const int32_t ibc = index_bcs[(size_t)did];
-      if (ibc < 0) continue;
-      const int32_t snp = t.int_field_at(1);
-      if (snp < 0 || snp >= S) fatal("%s.plp.gz: SNP_ID %d out of range", prefix.c_str(), snp);
-      const char* pa = t.str_field_at(2);
-      const char* pq = t.str_field_at(3);
-      const int32_t l = (int32_t)strlen(pq);
-      if ((int32_t)strlen(pa) != l) fatal("Length are different between %s and %s", pa, pq);
-      for (int32_t i = 0; i < l; ++i) {
-        const int bq0 = (int)(char)(pq[i] - (char)33);
-        if (bq0 >= opt.minBQ) {
-          const int bq = bq0 > capBQ ? capBQ : bq0;
-          const int al = (int)(char)(pa[i] - (char)'0');
-          const uint8_t byte = (al == 0) ? (uint8_t)bq : (al == 1) ? (uint8_t)(0x80 | bq) : (uint8_t)MUXGL_READ_OTHER;
-          rds.push_back(Rd{ibc, snp, numi++, byte});
-          ++out.cell_totl_reads[(size_t)ibc];
-          ++out.cell_uniq_reads[(size_t)ibc];  // every kept base is its own UMI (:361-368)
-        }
-      }
-    }
-    notice("Finished loading %u UMIs in total..", numi);
+    notice("Finished loading %llu UMIs in total..", (unsigned long long)numi);
   }
   // order: cell, SNP, then the reference's std::map<std::string> order of the "%x" UMI strings
-  auto hexless = [](uint32_t a, uint32_t b) {
-    char sa[16], sb[16];
-    snprintf(sa, sizeof(sa), "%x", a);
-    snprintf(sb, sizeof(sb), "%x", b);
-    return strcmp(sa, sb) < 0;
-  };
-  std::sort(rds.begin(), rds.end(), [&](const Rd& a, const Rd& b) {
-    if (a.cell != b.cell) return a.cell < b.cell;
-    if (a.snp != b.snp) return a.snp < b.snp;
-    return a.numi < b.numi;
-  });
-  for (size_t b = 0; b < rds.size();) {  // entries are short: re-order each one by the "%x" string of its counters
-    size_t e = b + 1;
-    while (e < rds.size() && rds[e].cell == rds[b].cell && rds[e].snp == rds[b].snp) ++e;
-    if (e - b > 1)
-      std::sort(rds.begin() + (long)b, rds.begin() + (long)e, [&](const Rd& x, const Rd& y) { return hexless(x.numi, y.numi); });
-    b = e;
-  }
-  out.cell_ptr.assign((size_t)C + 1, 0);
-  out.entry_rptr.assign(1, 0);
-  out.reads.reserve(rds.size());
-  for (size_t i = 0; i < rds.size(); ++i) {
-    if (i == 0 || rds[i].cell != rds[i - 1].cell || rds[i].snp != rds[i - 1].snp) {
-      out.entry_snp.push_back(rds[i].snp);
-      out.entry_rptr.push_back(out.entry_rptr.back());
-      ++out.cell_ptr[(size_t)rds[i].cell + 1];
-    }
-    out.reads.push_back(rds[i].byte);
-    ++out.entry_rptr.back();
-  }
-  for (int64_t c = 0; c < C; ++c) out.cell_ptr[(size_t)c + 1] += out.cell_ptr[(size_t)c];
+  tm.lap("plp counts");
+  std::vector<int64_t> cell_rd0;  // first read of every cell in the ordered list
+  plp_order_by_cell(rds, C, sorted, cell_rd0);
+  tm.lap("plp order");
+  plp_pack(rds, C, cell_rd0, out.cell_ptr, out.entry_snp, out.entry_rptr, out.reads);
+  tm.lap("plp pack");
   // sanity check on the observed counts (:375-380)
   for (int64_t c = 0; c < C; ++c) {
     const int64_t nent = out.cell_ptr[(size_t)c + 1] - out.cell_ptr[(size_t)c];

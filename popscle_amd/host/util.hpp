@@ -40,6 +40,22 @@ inline void notice(const char* fmt, ...) {  // Error.cpp notice(): timestamped s
   fputc('\n', stderr);
 }
 
+// stage timer: prints "TIMING <what> <seconds>" to stderr when POPSCLE_AMD_TIMING is set
+class StageTimer {
+ public:
+  StageTimer() : on_(getenv("POPSCLE_AMD_TIMING") != nullptr) { clock_gettime(CLOCK_MONOTONIC, &t0_); }
+  void lap(const char* what) {
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (on_) fprintf(stderr, "TIMING %-28s %.3f s\n", what, (double)(t1.tv_sec - t0_.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0_.tv_nsec));
+    t0_ = t1;
+  }
+
+ private:
+  bool on_;
+  timespec t0_;
+};
+
 // Line reader over plain or gzip text with the field semantics of the reference's tsv_reader (tsv_reader.cpp:28-51):
 // fields are split on runs of whitespace (ksplit with delimiter 0), int fields are atoi, double fields are atof, and
 // read_line() returns the number of fields, 0 at end of file.  A blank line therefore ends the file, as it does in the
