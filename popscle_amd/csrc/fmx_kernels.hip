@@ -759,92 +759,6 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
   return 0;
 }
 
-int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,
-                          double singlet_score_thres, int32_t* clust_out) {
-  if (!h) return 1;
-  HIPCHK(h, hipSetDevice(h->device));
-  if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_greedy_init: call muxgl_fmx_prepare first");
-  if (K < 1 || K > 255) MUXGL_FAIL(h, "muxgl_fmx_greedy_init: K=%d outside [1,255]", K);
-  if ((!scores || !clust_out) && h->C) MUXGL_FAIL(h, "muxgl_fmx_greedy_init: NULL array");
-  const int64_t C = h->C, S = h->S, nnz = h->nnz;
-  std::vector<int64_t> cp((size_t)C + 1);
-  std::vector<int32_t> es((size_t)nnz);
-  std::vector<double> egls((size_t)nnz * 9), af((size_t)S);
-  HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (C + 1), hipMemcpyDeviceToHost));
-  if (nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
-  if (nnz) HIPCHK(h, hipMemcpy(egls.data(), h->d_egls, sizeof(double) * 9 * nnz, hipMemcpyDeviceToHost));
-  if (S) HIPCHK(h, hipMemcpy(af.data(), h->d_af, sizeof(double) * S, hipMemcpyDeviceToHost));
-
-  // sort: score descending, ties by id descending (sc_drop_seq.h:187-198)
-  std::vector<int32_t> order((size_t)C);
-  for (int64_t i = 0; i < C; ++i) order[(size_t)i] = (int32_t)i;
-  std::sort(order.begin(), order.end(), [&](int32_t lhs, int32_t rhs) {
-    const double cmp = scores[lhs] - scores[rhs];
-    if (cmp != 0) return cmp > 0;
-    return lhs > rhs;
-  });
-
-  // cluster pileups: diagonal likelihoods only are ever read by the distance (sc_drop_seq.cpp:563-568), but merge()
-  // normalises over all nine, so all nine are kept.  present <=> the (cluster, SNP) key exists in the reference's map.
-  std::vector<double> cg((size_t)K * S * 9, 1.0);
-  std::vector<uint8_t> present((size_t)K * S, 0);
-  std::vector<double> d2((size_t)K), d0((size_t)K);
-  for (int64_t i = 0; i < C; ++i) clust_out[i] = -1;
-  for (int64_t i = 0; i < C; ++i) {
-    const int32_t si = order[(size_t)i];
-    if ((double)i > (double)C * frac_init_clust) continue;   // cmd_cram_freemux2.cpp:222
-    if (scores[si] < singlet_score_thres) continue;          // :223
-    for (int j = 0; j < K; ++j) {                            // :227-230
-      double llk0 = 0, llk2 = 0;
-      for (int64_t e = cp[(size_t)si]; e < cp[(size_t)si + 1]; ++e) {
-        const int32_t snp = es[(size_t)e];
-        const size_t ci = (size_t)j * S + snp;
-        if (!present[ci]) continue;                          // sc_drop_seq.cpp:549-550
-        const double a = af[(size_t)snp];
-        const double gps[3] = {(1.0 - a) * (1.0 - a), 2.0 * a * (1.0 - a), a * a};
-        const double* glis = &egls[(size_t)e * 9];
-        const double* gljs = &cg[ci * 9];
-        double lk0 = 0, lk2 = 0;
-        for (int gi = 0; gi < 3; ++gi) {
-          lk2 += (glis[gi * 3 + gi] * gljs[gi * 3 + gi] * gps[gi]);
-          for (int gj = 0; gj < 3; ++gj) lk0 += (glis[gi * 3 + gi] * gljs[gj * 3 + gj] * gps[gi] * gps[gj]);
-        }
-        llk2 += log(lk2);
-        llk0 += log(lk0);
-      }
-      d2[(size_t)j] = llk2;
-      d0[(size_t)j] = llk0;
-    }
-    int maxClust = 0;                                        // :233-242
-    double maxScore = d2[0] - d0[0];
-    for (int j = 1; j < K; ++j)
-      if (d2[(size_t)j] - d0[(size_t)j] > maxScore) {
-        maxClust = j;
-        maxScore = d2[(size_t)j] - d0[(size_t)j];
-      }
-    clust_out[si] = maxClust;
-    for (int64_t e = cp[(size_t)si]; e < cp[(size_t)si + 1]; ++e) {  // :248-251, merge() of sc_drop_seq.h:77-101
-      const size_t ci = (size_t)maxClust * S + es[(size_t)e];
-      double* g = &cg[ci * 9];
-      const double* o = &egls[(size_t)e * 9];
-      double tmp = 0;
-      for (int q = 0; q < 9; ++q) {
-        g[q] *= o[q];
-        tmp += g[q];
-      }
-      for (int q = 0; q < 9; ++q) g[q] /= tmp;
-      tmp = 0;
-      for (int q = 0; q < 9; ++q) {
-        if (g[q] < kMinNormGL) g[q] = kMinNormGL;
-        tmp += g[q];
-      }
-      for (int q = 0; q < 9; ++q) g[q] /= tmp;
-      present[ci] = 1;
-    }
-  }
-  return 0;
-}
-
 int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   if (!h) return 1;
   HIPCHK(h, hipSetDevice(h->device));

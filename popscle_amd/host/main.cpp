@@ -91,13 +91,17 @@ int cmd_demuxlet(int argc, char** argv) {
   }
   vr.init();
   Pileup p;
+  StageTimer tm;
   load_from_plp(cf.plpPrefix, cf.lo, &vr, p);
+  tm.lap("demuxlet: load");
 
   muxgl_config cfg{cf.device, 0};
   muxgl_handle* h = nullptr;
   if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
+  tm.lap("demuxlet: device init");
   upload(h, p);
   check(h, muxgl_demux_set_gp(h, p.nv, p.gp.data(), p.has_gp.data()), "muxgl_demux_set_gp");
+  tm.lap("demuxlet: hand-over (H2D+plans)");
   muxgl_demux_params dp;
   memset(&dp, 0, sizeof(dp));
   dp.n_alpha = (int32_t)gridAlpha.size();
@@ -106,6 +110,7 @@ int cmd_demuxlet(int argc, char** argv) {
   notice("Starting to identify best matching individual IDs");
   std::vector<muxgl_demux_cell> cells((size_t)p.C());
   check(h, muxgl_demux_run(h, &dp, cells.data(), nullptr), "muxgl_demux_run");
+  tm.lap("demuxlet: muxgl_demux_run");
 
   // .best, cmd_cram_demuxlet.cpp:629,636-641,993-1013: rows in barcode-sorted order, INT_ID counts skipped cells too
   OutFile w(cf.outPrefix + ".best", false);
@@ -133,6 +138,7 @@ int cmd_demuxlet(int argc, char** argv) {
              c.sngBestLLK - c.dblBestLLK);
   }
   w.close();
+  tm.lap("demuxlet: write .best");
   notice("Finished writing output files");
   muxgl_destroy(h);
   return 0;
@@ -158,11 +164,16 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const st
   for (int i = 0; i < K; ++i) vc.printf("\tCLUST%d", i);
   vc.printf("\n");
   const int64_t S = p.S();
-  for (int64_t v = 0; v < S; ++v) {
-    if (!snps_observed[(size_t)v]) continue;
+  // rows are formatted by the worker pool in batches of SNPs and written in order
+  auto appendf = [](std::string& o, const char* fmt, auto... args) {
+    char buf[512];
+    const int n = snprintf(buf, sizeof(buf), fmt, args...);
+    o.append(buf, (size_t)(n < (int)sizeof(buf) ? n : (int)sizeof(buf) - 1));
+  };
+  auto format_snp = [&](int64_t v, std::string& o) {
     const SnpInfo& s = p.snps[(size_t)v];
-    vc.printf("%s\t%d\t.\t%c\t%c\t.\tPASS\tAF=%.5lf\tGT:GQ:DP:AD:PL:GP", p.rid2chr[(size_t)s.rid].c_str(), s.pos, s.ref,
-              s.alt, s.af);
+    appendf(o, "%s\t%d\t.\t%c\t%c\t.\tPASS\tAF=%.5lf\tGT:GQ:DP:AD:PL:GP", p.rid2chr[(size_t)s.rid].c_str(), s.pos,
+            s.ref, s.alt, s.af);
     const double gps[3] = {(1. - s.af) * (1. - s.af), 2. * s.af * (1. - s.af), s.af * s.af};
     for (int i = 0; i < K; ++i) {
       const double* g = &gls[((size_t)i * S + v) * 9];
@@ -185,10 +196,23 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const st
       const int bestG = (pps[0] > pps[1]) ? (pps[0] > pps[2] ? 0 : 2) : (pps[1] > pps[2] ? 1 : 2);
       int32_t gq = (int32_t)(-10 * log10(1.0 - pps[bestG] + 1e-100));
       if (gq > 255) gq = 255;
-      vc.printf("\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg", bestG == 2 ? 1 : 0, bestG > 0 ? 1 : 0, gq, c[0], c[1],
-                c[2], pls[0], pls[1], pls[2], pps[0], pps[1], pps[2]);
+      appendf(o, "\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg", bestG == 2 ? 1 : 0, bestG > 0 ? 1 : 0, gq, c[0], c[1],
+              c[2], pls[0], pls[1], pls[2], pps[0], pps[1], pps[2]);
     }
-    vc.printf("\n");
+    o.push_back('\n');
+  };
+  constexpr int64_t GRAIN = 256, BATCH = 64;  // SNPs per work item, work items per batch
+  std::vector<std::string> parts((size_t)BATCH);
+  for (int64_t v0 = 0; v0 < S; v0 += GRAIN * BATCH) {
+    const int64_t nparts = std::min<int64_t>(BATCH, (S - v0 + GRAIN - 1) / GRAIN);
+    parallel_for(nparts, plp_threads(), [&](int64_t i) {
+      std::string& o = parts[(size_t)i];
+      o.clear();
+      const int64_t vb = v0 + i * GRAIN, ve = std::min(S, vb + GRAIN);
+      for (int64_t v = vb; v < ve; ++v)
+        if (snps_observed[(size_t)v]) format_snp(v, o);
+    });
+    for (int64_t i = 0; i < nparts; ++i) vc.write(parts[(size_t)i].data(), parts[(size_t)i].size());
   }
   vc.close();
 }
@@ -220,7 +244,9 @@ int cmd_freemuxlet(int argc, char** argv) {
   if (cf.plpPrefix.empty() || cf.outPrefix.empty() || nSamples == 0) fatal("Missing required option(s) : --plp, --out, --nsample");
 
   Pileup p;
+  StageTimer tmr;
   load_from_plp(cf.plpPrefix, cf.lo, nullptr, p);
+  tmr.lap("freemuxlet: load");
   const int64_t C = p.C(), S = p.S();
   const int K = nSamples;
 
@@ -246,7 +272,9 @@ int cmd_freemuxlet(int argc, char** argv) {
   std::vector<double> af((size_t)S), llk0((size_t)C), llk2((size_t)C);
   std::vector<int32_t> nSNPs((size_t)C), nReads((size_t)C);
   for (int64_t s = 0; s < S; ++s) af[(size_t)s] = p.snps[(size_t)s].af;
+  tmr.lap("freemuxlet: device init+hand-over");
   check(h, muxgl_fmx_prepare(h, af.data(), llk0.data(), llk2.data(), nSNPs.data(), nReads.data()), "muxgl_fmx_prepare");
+  tmr.lap("freemuxlet: muxgl_fmx_prepare");
 
   std::vector<double> scores((size_t)C);
   {  // .lmix, :111-163
@@ -281,6 +309,7 @@ int cmd_freemuxlet(int argc, char** argv) {
     check(h, muxgl_fmx_greedy_init(h, K, scores.data(), fracInitClust, singletScoreThres, clusts.data()),
           "muxgl_fmx_greedy_init");
   }
+  tmr.lap("freemuxlet: .lmix + initial clusters");
   notice("Finished assigning initial identity of the cluster..");
   if (auxFiles) {  // :265-274
     OutFile wc0(cf.outPrefix + ".clust0.samples.gz", true);
@@ -301,6 +330,7 @@ int cmd_freemuxlet(int argc, char** argv) {
 
   std::vector<muxgl_fmx_cell> cells((size_t)C);
   muxgl_fmx_params fp{doublet_prior, geno_error};
+  tmr.lap("freemuxlet: set_clusters");
   for (int32_t iter = 0; iter < maxIter; ++iter) {  // :373-605
     notice("Inferring doublets and refining clusters.., iter = %d", iter + 1);
     int32_t nsingle = 0, namb = 0, nchanged = 0;
@@ -312,8 +342,10 @@ int cmd_freemuxlet(int argc, char** argv) {
       break;
     }
   }
+  tmr.lap("freemuxlet: EM iterations");
   check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
   write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+  tmr.lap("freemuxlet: write .clust1.vcf.gz");
 
   OutFile wc1(cf.outPrefix + ".clust1.samples.gz", true);  // :660-665
   wc1.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"
@@ -329,6 +361,7 @@ int cmd_freemuxlet(int argc, char** argv) {
                c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
   }
   wc1.close();
+  tmr.lap("freemuxlet: write .clust1.samples.gz");
   muxgl_destroy(h);
   return 0;
 }
@@ -385,6 +418,27 @@ int cmd_dump_plp(int argc, char** argv) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ bgzf
+// writer-only command for the CPU tests: copies a file through the BGZF writer of util.hpp (line by line, as the
+// commands' printf calls do)
+int cmd_bgzf(int argc, char** argv) {
+  std::string in, outp;
+  Args a;
+  a.add_string("in", &in);
+  a.add_string("out", &outp);
+  a.parse(argc, argv);
+  if (in.empty() || outp.empty()) fatal("Missing required option(s) : --in, --out");
+  FILE* f = fopen(in.c_str(), "rb");
+  if (!f) fatal("Cannot open %s for reading", in.c_str());
+  OutFile w(outp, true);
+  char buf[1 << 16];
+  size_t n;
+  while ((n = fread(buf, 1, 777, f)) > 0) w.write(buf, n);  // odd-sized pieces across block borders
+  fclose(f);
+  w.close();
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -397,6 +451,7 @@ int main(int argc, char** argv) {
     if (cmd == "demuxlet") return cmd_demuxlet(argc - 2, argv + 2);
     if (cmd == "freemuxlet") return cmd_freemuxlet(argc - 2, argv + 2);
     if (cmd == "dump-plp") return cmd_dump_plp(argc - 2, argv + 2);
+    if (cmd == "bgzf") return cmd_bgzf(argc - 2, argv + 2);
     fprintf(stderr, "Cannot recognize the command %s\n", argv[1]);
     return 1;
   } catch (const std::exception&) {

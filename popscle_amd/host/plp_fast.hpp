@@ -11,11 +11,6 @@
 // cuts every block into line-aligned slices, parses them with OpenMP, and appends the slices in file order.
 #pragma once
 
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <atomic>
-#include <functional>
 
 #include "util.hpp"
 
@@ -40,93 +35,6 @@ inline bool hex_string_less(uint32_t a, uint32_t b) {
   const uint64_t xa = (uint64_t)a << (4 * (8 - la)), xb = (uint64_t)b << (4 * (8 - lb));
   if (xa != xb) return xa < xb;
   return la < lb;
-}
-
-inline int plp_threads() {
-  if (const char* ev = getenv("POPSCLE_AMD_THREADS")) return std::max(1, atoi(ev));
-  const unsigned hc = std::thread::hardware_concurrency();
-  return (int)std::min(16u, std::max(1u, hc));
-}
-
-// fn(i) for i in [0, n), items handed out one at a time to the threads of a persistent pool.  The workers sleep on a
-// condition variable between calls (OpenMP's spinning workers starve the inflating thread when every core is taken;
-// threads spawned per call are not spread over the cores before a 5 ms job is over).
-class WorkerPool {
- public:
-  static WorkerPool& get() {
-    static WorkerPool p;
-    return p;
-  }
-  void run(int64_t n, int nth, const std::function<void(int64_t)>& fn) {
-    if (n <= 0) return;
-    nth = (int)std::min<int64_t>(nth, n);
-    if (nth <= 1) {
-      for (int64_t i = 0; i < n; ++i) fn(i);
-      return;
-    }
-    std::lock_guard<std::mutex> serial(run_m_);
-    {
-      std::lock_guard<std::mutex> g(m_);
-      while ((int)th_.size() < nth - 1) th_.emplace_back([this] { loop(); });
-      fn_ = &fn;
-      n_ = n;
-      next_.store(0);
-      busy_ = std::min<int>((int)th_.size(), nth - 1);
-      want_ = busy_;
-      ++gen_;
-    }
-    cv_.notify_all();
-    for (int64_t i; (i = next_.fetch_add(1)) < n;) fn(i);
-    std::unique_lock<std::mutex> g(m_);
-    done_.wait(g, [this] { return busy_ == 0; });
-    fn_ = nullptr;
-  }
-  ~WorkerPool() {
-    {
-      std::lock_guard<std::mutex> g(m_);
-      quit_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-  }
-
- private:
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      std::unique_lock<std::mutex> g(m_);
-      cv_.wait(g, [&] { return quit_ || (gen_ != seen && want_ > 0); });
-      if (quit_) return;
-      seen = gen_;
-      --want_;
-      const std::function<void(int64_t)>* fn = fn_;
-      const int64_t n = n_;
-      g.unlock();
-      for (int64_t i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
-      g.lock();
-      if (--busy_ == 0) done_.notify_all();
-    }
-  }
-  std::mutex m_, run_m_;
-  std::condition_variable cv_, done_;
-  std::vector<std::thread> th_;
-  const std::function<void(int64_t)>* fn_ = nullptr;
-  std::atomic<int64_t> next_{0};
-  int64_t n_ = 0;
-  int busy_ = 0, want_ = 0;
-  uint64_t gen_ = 0;
-  bool quit_ = false;
-};
-
-inline void parallel_for(int64_t n, int nth, const std::function<void(int64_t)>& fn) { WorkerPool::get().run(n, nth, fn); }
-
-// fn(c) for c in [0, n) in blocks of `grain`
-inline void parallel_for_blocked(int64_t n, int64_t grain, int nth, const std::function<void(int64_t)>& fn) {
-  const int64_t nb = (n + grain - 1) / grain;
-  parallel_for(nb, nth, [&](int64_t b) {
-    const int64_t e = std::min(n, (b + 1) * grain);
-    for (int64_t c = b * grain; c < e; ++c) fn(c);
-  });
 }
 
 namespace detail {

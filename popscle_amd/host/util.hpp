@@ -4,6 +4,12 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -113,17 +119,104 @@ class TsvReader {
   std::vector<std::pair<size_t, size_t>> fields_;
 };
 
-// hprintf()-style writer: plain file for mode "w", gzip for "wz" (the reference writes BGZF, which is a gzip stream)
+// worker threads of the host side (loader, writers); POPSCLE_AMD_THREADS overrides
+inline int plp_threads() {
+  if (const char* ev = getenv("POPSCLE_AMD_THREADS")) return std::max(1, atoi(ev));
+  const unsigned hc = std::thread::hardware_concurrency();
+  return (int)std::min(16u, std::max(1u, hc));
+}
+
+// fn(i) for i in [0, n), items handed out one at a time to the threads of a persistent pool.  The workers sleep on a
+// condition variable between calls (OpenMP's spinning workers starve the inflating thread when every core is taken;
+// threads spawned per call are not spread over the cores before a 5 ms job is over).
+class WorkerPool {
+ public:
+  static WorkerPool& get() {
+    static WorkerPool p;
+    return p;
+  }
+  void run(int64_t n, int nth, const std::function<void(int64_t)>& fn) {
+    if (n <= 0) return;
+    nth = (int)std::min<int64_t>(nth, n);
+    if (nth <= 1) {
+      for (int64_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    std::lock_guard<std::mutex> serial(run_m_);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      while ((int)th_.size() < nth - 1) th_.emplace_back([this] { loop(); });
+      fn_ = &fn;
+      n_ = n;
+      next_.store(0);
+      busy_ = std::min<int>((int)th_.size(), nth - 1);
+      want_ = busy_;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (int64_t i; (i = next_.fetch_add(1)) < n;) fn(i);
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return busy_ == 0; });
+    fn_ = nullptr;
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+
+ private:
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> g(m_);
+      cv_.wait(g, [&] { return quit_ || (gen_ != seen && want_ > 0); });
+      if (quit_) return;
+      seen = gen_;
+      --want_;
+      const std::function<void(int64_t)>* fn = fn_;
+      const int64_t n = n_;
+      g.unlock();
+      for (int64_t i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+      g.lock();
+      if (--busy_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex m_, run_m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void(int64_t)>* fn_ = nullptr;
+  std::atomic<int64_t> next_{0};
+  int64_t n_ = 0;
+  int busy_ = 0, want_ = 0;
+  uint64_t gen_ = 0;
+  bool quit_ = false;
+};
+
+inline void parallel_for(int64_t n, int nth, const std::function<void(int64_t)>& fn) { WorkerPool::get().run(n, nth, fn); }
+
+// fn(c) for c in [0, n) in blocks of `grain`
+inline void parallel_for_blocked(int64_t n, int64_t grain, int nth, const std::function<void(int64_t)>& fn) {
+  const int64_t nb = (n + grain - 1) / grain;
+  parallel_for(nb, nth, [&](int64_t b) {
+    const int64_t e = std::min(n, (b + 1) * grain);
+    for (int64_t c = b * grain; c < e; ++c) fn(c);
+  });
+}
+
+// hprintf()-style writer: plain file for mode "w", BGZF for "wz" -- what the reference's hts_open(..., "wz") produces:
+// a series of independent gzip members of <= 64 KiB input each, with the BC extra field holding the member size and an
+// empty member as end marker (SAM spec 4.1).  Independent members are also what makes the compression parallel: text is
+// collected in 4 MiB batches whose blocks are deflated by the worker pool and written in order.
 class OutFile {
  public:
   OutFile(const std::string& path, bool gz) : gz_(gz) {
-    if (gz) {
-      g_ = gzopen(path.c_str(), "wb");
-      if (!g_) fatal("Cannot open %s for writing", path.c_str());
-    } else {
-      f_ = fopen(path.c_str(), "w");
-      if (!f_) fatal("Cannot open %s for writing", path.c_str());
-    }
+    f_ = fopen(path.c_str(), gz ? "wb" : "w");
+    if (!f_) fatal("Cannot open %s for writing", path.c_str());
+    if (gz) buf_.reserve(kBatch + kBlock);
   }
   ~OutFile() { close(); }
   void printf(const char* fmt, ...) {
@@ -143,24 +236,76 @@ class OutFile {
     }
     va_end(ap2);
   }
+  void write(const char* p, size_t n) {
+    if (!gz_) {
+      if (fwrite(p, 1, n, f_) != n) fatal("write failed");
+      return;
+    }
+    buf_.insert(buf_.end(), p, p + n);
+    if (buf_.size() >= kBatch) flush_blocks(false);
+  }
   void close() {
-    if (g_) gzclose(g_);
-    if (f_) fclose(f_);
-    g_ = nullptr;
+    if (!f_) return;
+    if (gz_) {
+      flush_blocks(true);
+      static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                                            0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (fwrite(eof, 1, sizeof(eof), f_) != sizeof(eof)) fatal("write failed");
+    }
+    if (fclose(f_) != 0) fatal("write failed");
     f_ = nullptr;
   }
 
  private:
-  void write(const char* p, size_t n) {
-    if (gz_) {
-      if (gzwrite(g_, p, (unsigned)n) != (int)n) fatal("write failed");
-    } else if (fwrite(p, 1, n, f_) != n) {
-      fatal("write failed");
-    }
+  static constexpr size_t kBlock = 0xff00;   // input bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
+  static constexpr size_t kBatch = 4u << 20;
+  // deflates whole blocks of buf_ (all of it when `all`), keeps the tail
+  void flush_blocks(bool all) {
+    const size_t nb = all ? (buf_.size() + kBlock - 1) / kBlock : buf_.size() / kBlock;
+    if (nb == 0) return;
+    std::vector<std::vector<unsigned char>> out(nb);
+    std::atomic<bool> bad(false);
+    parallel_for((int64_t)nb, plp_threads(), [&](int64_t i) {
+      const size_t o = (size_t)i * kBlock, len = std::min(kBlock, buf_.size() - o);
+      std::vector<unsigned char>& dst = out[(size_t)i];
+      dst.resize(18 + compressBound((uLong)len) + 8);
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+        bad = true;
+        return;
+      }
+      zs.next_in = (Bytef*)(buf_.data() + o);
+      zs.avail_in = (uInt)len;
+      zs.next_out = dst.data() + 18;
+      zs.avail_out = (uInt)(dst.size() - 18 - 8);
+      const int rc = deflate(&zs, Z_FINISH);
+      const size_t clen = zs.total_out;
+      deflateEnd(&zs);
+      if (rc != Z_STREAM_END || 18 + clen + 8 > 0x10000) {
+        bad = true;
+        return;
+      }
+      static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+      memcpy(dst.data(), hdr, 16);
+      const size_t bsize = 18 + clen + 8 - 1;
+      dst[16] = (unsigned char)(bsize & 0xff);
+      dst[17] = (unsigned char)(bsize >> 8);
+      const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(buf_.data() + o), (uInt)len);
+      unsigned char* tl = dst.data() + 18 + clen;
+      for (int k = 0; k < 4; ++k) tl[k] = (unsigned char)(crc >> (8 * k));
+      for (int k = 0; k < 4; ++k) tl[4 + k] = (unsigned char)((uint32_t)len >> (8 * k));
+      dst.resize(18 + clen + 8);
+    });
+    if (bad) fatal("BGZF compression failed");
+    for (const auto& d : out)
+      if (fwrite(d.data(), 1, d.size(), f_) != d.size()) fatal("write failed");
+    const size_t used = std::min(buf_.size(), nb * kBlock);
+    buf_.erase(buf_.begin(), buf_.begin() + (long)used);
   }
   bool gz_;
-  gzFile g_ = nullptr;
   FILE* f_ = nullptr;
+  std::vector<char> buf_;
 };
 
 // `--flag value` parser with the reference's conventions (params.cpp:167-171,449-485): long options only, boolean

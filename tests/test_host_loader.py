@@ -225,3 +225,37 @@ def test_loader_threads_and_blocks(exe, tmp_path):
     assert np.array_equal(got["cell_ptr"], p.cell_ptr[: p.C + 1]) and np.array_equal(got["entry_snp"], p.entry_snp)
     # reads: same multiset per entry (the order inside an entry follows the "%x" rule, pinned by the small tests)
     assert got["R"] == p.R and np.array_equal(got["entry_rptr"], p.entry_rptr)
+
+
+# ---- the BGZF writer behind every "wz" output (.clust1.vcf.gz, .clust1.samples.gz) ------------------------------------
+
+@pytest.mark.parametrize("size", [0, 1, 65279, 65280, 65281, 9_000_000])
+def test_bgzf_writer(exe, tmp_path, size):
+    """hts_open(..., "wz") writes BGZF: independent gzip members with the BC extra field and an empty end marker.
+    The payload must survive, every member must be a valid BGZF block of <= 64 KiB, and the file must end with the
+    28-byte EOF block (SAM spec 4.1.2)."""
+    import gzip
+    import struct
+
+    rng = np.random.default_rng(size)
+    words = np.array([b"CLUST", b"0/1", b"\t", b"255,0,12", b"\n", b"0.99999", b":"], dtype=object)
+    data = b"".join(words[rng.integers(0, len(words), size=size // 2 + 1)])[:size]
+    assert len(data) == size
+    src, dst = tmp_path / "in.txt", tmp_path / "out.gz"
+    src.write_bytes(data)
+    r = subprocess.run([exe, "bgzf", "--in", str(src), "--out", str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = dst.read_bytes()
+    assert gzip.decompress(raw) == data
+    eof = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    assert raw.endswith(eof)
+    off, total, nblocks = 0, 0, 0
+    while off < len(raw):
+        assert raw[off:off + 4] == b"\x1f\x8b\x08\x04" and raw[off + 12:off + 16] == b"BC\x02\x00"
+        bsize = struct.unpack("<H", raw[off + 16:off + 18])[0] + 1
+        isize = struct.unpack("<I", raw[off + bsize - 4:off + bsize])[0]
+        assert isize <= 0xff00
+        total += isize
+        off += bsize
+        nblocks += 1
+    assert off == len(raw) and total == size and nblocks == (size + 0xff00 - 1) // 0xff00 + 1

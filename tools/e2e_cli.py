@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""End-to-end wall time of the popscle-amd front end on files of the real dsc-pileup format (the
+loader bounds the end-to-end time).  Writes a synthetic CEL/VAR/PLP (+VCF) of the given shape to a scratch directory,
+runs `popscle-amd demuxlet` and/or `freemuxlet` with POPSCLE_AMD_TIMING=1 and prints the stage times.
+
+    python tools/e2e_cli.py --cells 10000 --snps 50000 --samples 16 [--freemuxlet K] [--dir /tmp/e2e]
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from popscle_amd import plpio, synth  # noqa: E402
+
+BIN = os.path.join(ROOT, "popscle_amd", "bin", "popscle-amd")
+
+
+def run(cmd):
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, POPSCLE_AMD_TIMING="1"))
+    dt = time.perf_counter() - t0
+    if r.returncode != 0:
+        print(r.stderr[-2000:])
+        raise SystemExit(f"{cmd[1]} failed")
+    for line in r.stderr.splitlines():
+        if line.startswith("TIMING"):
+            print("   ", line)
+    print(f"    TOTAL wall {dt:.3f} s")
+    return dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=10000)
+    ap.add_argument("--snps", type=int, default=50000)
+    ap.add_argument("--samples", type=int, default=16)
+    ap.add_argument("--freemuxlet", type=int, default=0, help="also run freemuxlet with this many clusters")
+    ap.add_argument("--dir", default="/tmp/e2e")
+    a = ap.parse_args()
+    os.makedirs(a.dir, exist_ok=True)
+    prefix = os.path.join(a.dir, "plp")
+    t0 = time.perf_counter()
+    p = synth.make_pileup(a.cells, a.snps, a.samples, seed=synth.BASE_SEED + 1)
+    plpio.write_plp(prefix, p)
+    vcf = os.path.join(a.dir, "donors.vcf.gz")
+    plpio.write_vcf(vcf, p, p.truth["G"].astype(np.int64))
+    rows = int((np.diff(p.entry_rptr) > 0).sum())
+    print(f"wrote {prefix}.* in {time.perf_counter() - t0:.1f} s: {a.cells} droplets, {a.snps} SNPs, {rows} PLP rows, "
+          f"{p.R} bases, plp.gz {os.path.getsize(prefix + '.plp.gz') / 1e6:.1f} MB")
+    print("demuxlet --field GT:")
+    dt = run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", os.path.join(a.dir, "dmx")])
+    print(f"    => {rows / dt / 1e6:.2f} M PLP rows/s end to end")
+    if a.freemuxlet:
+        print(f"freemuxlet --nsample {a.freemuxlet}:")
+        run([BIN, "freemuxlet", "--plp", prefix, "--nsample", str(a.freemuxlet), "--out", os.path.join(a.dir, "fmx")])
+
+
+if __name__ == "__main__":
+    main()
