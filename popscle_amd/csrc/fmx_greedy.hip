@@ -5,17 +5,22 @@
 // sum_snp [log lk2 - log lk0] against the pileups built from cells 0..i-1, and is merged into it before cell i+1 is
 // looked at.  What is parallel is the inside of one step -- L entries x K clusters independent likelihood terms, then L
 // independent merges -- so ONE persistent 1024-thread workgroup walks the cell list (a grid-wide barrier per cell
-// would cost more than the step itself):
-//   * distance: thread = (cluster j, entry stripe); the K diagonal triples of a SNP sit in one 32*K-byte row of a
-//     SNP-major table, so an entry costs K/4 cache lines instead of K gathers into [K][S][9]; per-thread products
-//     (mantissa, exponent) instead of two log's per term, a tree over the stripes in LDS, two log's per cluster;
+// would cost as much as the step itself).  Per cell:
+//   * stage (thread = entry): SNP id, allele frequency and the entry-only factors w_g = gl_i[g,g] * hwe[g] to LDS
+//     (A = w_0 + w_1 + w_2), from registers that were loaded during the previous cell's step;
+//   * distance (thread = (cluster j, entry stripe)): one 32-byte gather per term from the SNP-major table
+//     diag[snp][j] = {gl_j[0,0], gl_j[1,1], gl_j[2,2], B} with B = sum_g gl_j[g,g] * hwe[g] kept up to date by the
+//     merge (B > 0 doubles as "the (cluster, SNP) key exists", sc_drop_seq.cpp:549-550).  The K rows of a SNP are
+//     contiguous, eight gathers per thread are in flight.  lk2 = sum_g w_g gl_j[g,g]; the reference's nine-term lk0
+//     (:563-568) factorises exactly into A * B (same value up to the rounding of a different association).  Products
+//     are kept as (mantissa, exponent) instead of two log's per term; stripes are combined with wave shuffles and one
+//     pass through LDS; two log's per cluster;
 //   * argmax: strict `>` from cluster 0 (:235-242);
-//   * merge: thread = entry, the full nine-value state of (SNP, winner) is updated in the reference's operation order
-//     (multiply, normalise, clamp at 1e-6, normalise) and its diagonal copied to the distance table.
+//   * merge (thread = entry): the nine-value state of (SNP, winner) is updated in the reference's operation order
+//     (multiply, normalise, clamp at 1e-6, normalise; divisions as reciprocal multiplies), B refreshed, five 16-byte
+//     accesses each way.
 // The per-(cluster, SNP) states built here are discarded afterwards, exactly as in the reference, which rebuilds the
 // cluster pileups from the assignment in ascending cell order (:277-288 -> muxgl_fmx_set_clusters).
-//
-// Measured on MI355X: 10 k cells x 16 clusters (9.5 M entries) ...  see DESIGN.md section 4.2.
 #include <algorithm>
 #include <vector>
 
@@ -23,119 +28,226 @@
 
 namespace {
 
+// workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
 constexpr int GT = 1024;             // threads of the persistent workgroup
+constexpr int GU = 6;                // gathers a thread has in flight in the distance phase
+constexpr int ST = GT;               // entries staged in LDS per pass (one per thread)
 
-// diag[snp][j] = {gl00, gl11, gl22, present}; full[snp][j][9]
 __global__ void __launch_bounds__(GT)
-    fmx_greedy_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ cell_ptr,
-                      const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
+    fmx_greedy_kernel(const int64_t* __restrict__ hdr_e0, const int32_t* __restrict__ hdr_len,
+                      const int32_t* __restrict__ hdr_cell, int64_t n_order, const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
                       const double* __restrict__ af, int K, int Kp /* K rounded up to a power of two */,
-                      double* diag, double* full, int32_t* __restrict__ clust) {
-  __shared__ double sm2[GT], sm0[GT];
-  __shared__ int32_t se2[GT], se0[GT];
-  __shared__ double score[256];
+                      double* diag, double* offd, int32_t* __restrict__ clust) {
+  __shared__ int32_t s_snp[ST];
+  __shared__ __align__(16) double s_w[ST][4];  // w0, w1, w2, allele frequency
+  __shared__ double p_m2[GT], p_m0[GT];
+  __shared__ int32_t p_x2[GT], p_x0[GT];
   __shared__ int winner;
   const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
   const int j = t & (Kp - 1);
   const int stripe = t / Kp, nstripes = GT / Kp;
+  const bool small = Kp <= 64;                      // a wave holds 64/Kp whole stripes
+  const int ngroups = small ? GT / 64 : nstripes;   // partials per cluster after the in-wave step
+  // Software pipeline over the cell list, so that a step starts with its inputs already on chip.  Barriers inside a
+  // step synchronise LDS only (lds_barrier): a full __syncthreads() drains every outstanding global access, which
+  // would put each prefetch back on the critical path; the one full barrier per step is the one that publishes the
+  // merged states, and the prefetches ride along with its store drain.
+  //   * headers {first entry, length, cell id} of 64 steps sit in one register per lane of every wave (read with a
+  //     wave-uniform shuffle), the next 64 are loaded a batch ahead;
+  //   * the first ST entries' SNP ids of the next cell are requested at the start of a step, what hangs off them
+  //     (allele frequency, the entry's diagonal likelihoods) before the merge.
+  int64_t b_e0 = hdr_e0[lane], nb_e0 = hdr_e0[64 + lane];  // the host pads the header arrays to a multiple of 64, +64
+  int32_t b_len = hdr_len[lane], nb_len = hdr_len[64 + lane];
+  int32_t b_cell = hdr_cell[lane], nb_cell = hdr_cell[64 + lane];
+  int64_t e0_n1 = __shfl(b_e0, 0, 64);
+  int64_t e1_n1 = e0_n1 + __shfl(b_len, 0, 64);
+  int32_t cell_n1 = __shfl(b_cell, 0, 64);
+  int32_t pf_snp = 0;
+  double pf_a = 0, pf_g0 = 0, pf_g4 = 0, pf_g8 = 0;
+  if (e0_n1 + t < e1_n1) {
+    pf_snp = entry_snp[e0_n1 + t];
+    pf_a = af[pf_snp];
+    const double* gl = egls + (size_t)(e0_n1 + t) * 9;
+    pf_g0 = gl[0];
+    pf_g4 = gl[4];
+    pf_g8 = gl[8];
+  }
   for (int64_t oi = 0; oi < n_order; ++oi) {
-    const int32_t cell = order[oi];
-    const int64_t e0 = cell_ptr[cell], e1 = cell_ptr[cell + 1];
+    const int32_t cell = cell_n1;
+    const int64_t e0 = e0_n1, e1 = e1_n1;
+    {  // header of step oi + 1
+      const int l = (int)((oi + 1) & 63);
+      if (l == 0) {  // batch boundary: the batch loaded 64 steps ago becomes current, the one after it is requested
+        b_e0 = nb_e0;
+        b_len = nb_len;
+        b_cell = nb_cell;
+        const int64_t nb = oi + 1 + 64 + lane;
+        nb_e0 = hdr_e0[nb];
+        nb_len = hdr_len[nb];
+        nb_cell = hdr_cell[nb];
+      }
+      e0_n1 = __shfl(b_e0, l, 64);
+      e1_n1 = e0_n1 + __shfl(b_len, l, 64);
+      cell_n1 = __shfl(b_cell, l, 64);
+    }
+    const bool have_next = oi + 1 < n_order;
+    const int32_t nx_snp = (have_next && e0_n1 + t < e1_n1) ? entry_snp[e0_n1 + t] : 0;
     // ---- distance to every cluster
     double m2 = 1.0, m0 = 1.0;
     int32_t x2 = 0, x0 = 0;
-    if (j < K) {
-      int cnt = 0;
-      for (int64_t e = e0 + stripe; e < e1; e += nstripes) {
-        const int32_t snp = entry_snp[e];
-        const double4 d = *reinterpret_cast<const double4*>(diag + ((size_t)snp * K + j) * 4);
-        if (d.w == 0.0) continue;  // the (cluster, SNP) key does not exist yet (sc_drop_seq.cpp:549-550)
-        const double a = af[snp];
-        const double gps[3] = {(1.0 - a) * (1.0 - a), 2.0 * a * (1.0 - a), a * a};
-        const double* gl = egls + (size_t)e * 9;
-        const double gi[3] = {gl[0], gl[4], gl[8]};
-        const double gj[3] = {d.x, d.y, d.z};
-        double lk0 = 0, lk2 = 0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          lk2 += (gi[p] * gj[p] * gps[p]);
-#pragma unroll
-          for (int q = 0; q < 3; ++q) lk0 += (gi[p] * gj[q] * gps[p] * gps[q]);
+    for (int64_t cb = e0; cb < e1; cb += ST) {
+      const int n = (int)((e1 - cb < ST) ? (e1 - cb) : ST);
+      if (cb != e0) lds_barrier();  // the previous pass has been consumed
+      for (int i = t; i < n; i += GT) {  // ST == GT: one entry per thread
+        int32_t snp;
+        double a, g0, g4, g8;
+        if (cb == e0) {
+          snp = pf_snp;
+          a = pf_a;
+          g0 = pf_g0;
+          g4 = pf_g4;
+          g8 = pf_g8;
+        } else {
+          const int64_t e = cb + i;
+          snp = entry_snp[e];
+          a = af[snp];
+          const double* gl = egls + (size_t)e * 9;
+          g0 = gl[0];
+          g4 = gl[4];
+          g8 = gl[8];
         }
-        m2 *= lk2;
-        m0 *= lk0;
-        if (++cnt == 4) {  // a term is >= ~1e-30 (clamped likelihoods x HWE priors): four cannot underflow
-          cnt = 0;
-          prodacc_renorm(m2, x2);
-          prodacc_renorm(m0, x0);
+        s_snp[i] = snp;
+        *reinterpret_cast<double4*>(s_w[i]) =
+            make_double4(g0 * ((1.0 - a) * (1.0 - a)), g4 * (2.0 * a * (1.0 - a)), g8 * (a * a), a);
+      }
+      lds_barrier();
+      if (j < K) {
+        for (int ib = stripe; ib < n; ib += nstripes * GU) {
+          double4 d[GU];
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            const int i = ib + u * nstripes;
+            d[u] = (i < n) ? *reinterpret_cast<const double4*>(diag + ((size_t)s_snp[i] * K + j) * 4)
+                           : make_double4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            if (d[u].w == 0.0) continue;  // no such (cluster, SNP) yet, or past the end
+            const double4 w = *reinterpret_cast<const double4*>(s_w[ib + u * nstripes]);
+            m2 *= (w.x * d[u].x + w.y * d[u].y) + w.z * d[u].z;
+            m0 *= ((w.x + w.y) + w.z) * d[u].w;
+            if ((u & 3) == 3) {  // a term is >= ~1e-30 (clamped likelihoods x HWE priors): four cannot underflow
+              prodacc_renorm(m2, x2);
+              prodacc_renorm(m0, x0);
+            }
+          }
         }
+      }
+    }
+    if (have_next && e0_n1 + t < e1_n1) {  // second half of the next cell's prefetch
+      pf_snp = nx_snp;
+      pf_a = af[nx_snp];
+      const double* gl = egls + (size_t)(e0_n1 + t) * 9;
+      pf_g0 = gl[0];
+      pf_g4 = gl[4];
+      pf_g8 = gl[8];
+    }
+    prodacc_renorm(m2, x2);
+    prodacc_renorm(m0, x0);
+    if (small) {  // stripes of one wave: lanes Kp apart
+      for (int off = Kp; off < 64; off <<= 1) {
+        m2 *= __shfl_xor(m2, off, 64);
+        m0 *= __shfl_xor(m0, off, 64);
+        x2 += __shfl_xor(x2, off, 64);
+        x0 += __shfl_xor(x0, off, 64);
       }
       prodacc_renorm(m2, x2);
       prodacc_renorm(m0, x0);
     }
-    sm2[t] = m2;
-    sm0[t] = m0;
-    se2[t] = x2;
-    se0[t] = x0;
-    __syncthreads();
-    for (int s = nstripes >> 1; s > 0; s >>= 1) {  // stripes of one cluster are Kp threads apart
-      if (stripe < s) {
-        const int o = t + s * Kp;
-        double a2 = sm2[t] * sm2[o], a0 = sm0[t] * sm0[o];
-        int32_t b2 = se2[t] + se2[o], b0 = se0[t] + se0[o];
-        prodacc_renorm(a2, b2);
-        prodacc_renorm(a0, b0);
-        sm2[t] = a2;
-        sm0[t] = a0;
-        se2[t] = b2;
-        se0[t] = b0;
-      }
-      __syncthreads();
+    if (!small || lane < Kp) {
+      const int g = small ? wave : stripe;
+      p_m2[g * Kp + j] = m2;
+      p_m0[g * Kp + j] = m0;
+      p_x2[g * Kp + j] = x2;
+      p_x0[g * Kp + j] = x0;
     }
-    if (t < K) score[t] = prodacc_log(sm2[t], se2[t]) - prodacc_log(sm0[t], se0[t]);
-    __syncthreads();
-    if (t == 0) {  // :233-242
-      int best = 0;
-      double bs = score[0];
-      for (int c = 1; c < K; ++c)
-        if (score[c] > bs) {
-          best = c;
-          bs = score[c];
+    lds_barrier();
+    if (t < 64) {  // wave 0: scores of clusters t, t+64, ...; running argmax with strict `>` in cluster order (:233-242)
+      double bs = 0.0;
+      int best = -1;
+      for (int c = t; c < K; c += 64) {
+        double a2 = 1.0, a0 = 1.0;
+        int32_t b2 = 0, b0 = 0;
+        for (int g = 0; g < ngroups; ++g) {  // <= 16 mantissas in [0.5,1): no underflow
+          a2 *= p_m2[g * Kp + c];
+          a0 *= p_m0[g * Kp + c];
+          b2 += p_x2[g * Kp + c];
+          b0 += p_x0[g * Kp + c];
         }
-      winner = best;
-      clust[cell] = best;
+        const double sc = prodacc_log(a2, b2) - prodacc_log(a0, b0);
+        if (best < 0 || sc > bs) {
+          bs = sc;
+          best = c;
+        }
+      }
+      // the first maximum in cluster order == largest value, smallest index among equals
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double os = __shfl_xor(bs, off, 64);
+        const int ob = __shfl_xor(best, off, 64);
+        if (ob >= 0 && (best < 0 || os > bs || (os == bs && ob < best))) {
+          bs = os;
+          best = ob;
+        }
+      }
+      if (t == 0) {
+        winner = best;
+        clust[cell] = best;
+      }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- merge the cell into the winner (:248-251)
     const int w = winner;
+    const bool staged = e1 - e0 <= ST;  // SNP id and allele frequency are still in LDS
     for (int64_t e = e0 + t; e < e1; e += GT) {
-      const int32_t snp = entry_snp[e];
-      double* dg = diag + ((size_t)snp * K + w) * 4;
-      double* g = full + ((size_t)snp * K + w) * 9;
+      const int32_t snp = staged ? s_snp[e - e0] : entry_snp[e];
+      // diag[snp][w] = {g00, g11, g22, B} (what the distance phase gathers), offd[snp][w] = {g01, g02, g10, g12, g20,
+      // g21}: 16-byte accesses, five each way.  One CU moves 64 B per clock to and from L2, and that -- not latency --
+      // bounds a step, so the tables are as compact as the arithmetic allows.
+      double2* dg = reinterpret_cast<double2*>(diag + ((size_t)snp * K + w) * 4);
+      double2* od = reinterpret_cast<double2*>(offd + ((size_t)snp * K + w) * 6);
       const double* o = egls + (size_t)e * 9;
-      const bool present = dg[3] != 0.0;
-      double v[9];
+      const double a = staged ? s_w[e - e0][3] : af[snp];
+      const double2 r0 = dg[0], r1 = dg[1], r2 = od[0], r3 = od[1], r4 = od[2];
+      const bool present = r1.y != 0.0;
+      double v[9] = {r0.x, r2.x, r2.y, r3.x, r0.y, r3.y, r4.x, r4.y, r1.x};  // gls[g1*3+g2] order
       double tmp = 0;
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        v[q] = (present ? g[q] : 1.0) * o[q];
+        v[q] = (present ? v[q] : 1.0) * o[q];
         tmp += v[q];
       }
-#pragma unroll
-      for (int q = 0; q < 9; ++q) v[q] /= tmp;
+      double r = 1.0 / tmp;
       tmp = 0;
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
+        v[q] *= r;
         if (v[q] < kMinNormGL) v[q] = kMinNormGL;
         tmp += v[q];
       }
+      r = 1.0 / tmp;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        v[q] /= tmp;
-        g[q] = v[q];
-      }
-      *reinterpret_cast<double4*>(dg) = make_double4(v[0], v[4], v[8], 1.0);
+      for (int q = 0; q < 9; ++q) v[q] *= r;
+      const double B = (v[0] * ((1.0 - a) * (1.0 - a)) + v[4] * (2.0 * a * (1.0 - a))) + v[8] * (a * a);
+      dg[0] = make_double2(v[0], v[4]);
+      dg[1] = make_double2(v[8], B);
+      od[0] = make_double2(v[1], v[2]);
+      od[1] = make_double2(v[3], v[5]);
+      od[2] = make_double2(v[6], v[7]);
     }
     __syncthreads();  // the workgroup's stores are visible to its own later loads (one CU, one L1)
   }
@@ -172,20 +284,34 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
 
   int Kp = 1;
   while (Kp < K) Kp <<= 1;
-  int32_t *d_order = nullptr, *d_clust = nullptr;
-  double *d_diag = nullptr, *d_full = nullptr;
+  // step headers in processing order, padded so that the kernel's batch prefetch never reads past the end
+  const size_t n = todo.size(), npad = (n + 63) / 64 * 64 + 128;
+  std::vector<int64_t> cp((size_t)C + 1);
+  HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (size_t)(C + 1), hipMemcpyDeviceToHost));
+  std::vector<int64_t> he0(npad, 0);
+  std::vector<int32_t> hlen(npad, 0), hcell(npad, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t c = todo[i];
+    he0[i] = cp[(size_t)c];
+    hlen[i] = (int32_t)(cp[(size_t)c + 1] - cp[(size_t)c]);
+    hcell[i] = c;
+  }
+  int64_t* d_he0 = nullptr;
+  int32_t *d_hlen = nullptr, *d_hcell = nullptr, *d_clust = nullptr;
+  double *d_diag = nullptr, *d_offd = nullptr;  // [S][K][4], [S][K][6]
   int rc = 1;
   do {
-    if (dev_alloc(h, &d_order, todo.size())) break;
+    if (dev_alloc(h, &d_he0, npad) || dev_alloc(h, &d_hlen, npad) || dev_alloc(h, &d_hcell, npad)) break;
     if (dev_alloc(h, &d_clust, (size_t)C)) break;
-    if (dev_alloc(h, &d_diag, (size_t)S * K * 4)) break;
-    if (dev_alloc(h, &d_full, (size_t)S * K * 9)) break;
-    hipError_t e = hipMemcpyAsync(d_order, todo.data(), sizeof(int32_t) * todo.size(), hipMemcpyHostToDevice, h->stream);
+    if (dev_alloc(h, &d_diag, (size_t)S * K * 4) || dev_alloc(h, &d_offd, (size_t)S * K * 6)) break;
+    hipError_t e = hipMemcpyAsync(d_he0, he0.data(), sizeof(int64_t) * npad, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hlen, hlen.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hcell, hcell.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_clust, 0xFF, sizeof(int32_t) * (size_t)C, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_diag, 0, sizeof(double) * (size_t)S * K * 4, h->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(fmx_greedy_kernel, dim3(1), dim3(GT), 0, h->stream, d_order, (int64_t)todo.size(),
-                         h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_af, (int)K, Kp, d_diag, d_full, d_clust);
+      hipLaunchKernelGGL(fmx_greedy_kernel, dim3(1), dim3(GT), 0, h->stream, d_he0, d_hlen, d_hcell, (int64_t)n,
+                         h->d_entry_snp, h->d_egls, h->d_af, (int)K, Kp, d_diag, d_offd, d_clust);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(clust_out, d_clust, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, h->stream);
@@ -196,9 +322,11 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
     }
     rc = 0;
   } while (0);
-  dev_free(&d_order);
+  dev_free(&d_he0);
+  dev_free(&d_hlen);
+  dev_free(&d_hcell);
   dev_free(&d_clust);
   dev_free(&d_diag);
-  dev_free(&d_full);
+  dev_free(&d_offd);
   return rc;
 }
