@@ -214,7 +214,7 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
   tm.lap("cel+var(+vcf)");
   // ---- .plp.gz: the big file.  One thread inflates, the others parse line-aligned slices of each inflated block
   // (plp_fast.hpp); rows come back in file order with the global kept-base counter that names each read's UMI.
-  std::vector<PlpRead> rds;
+  PlpReadVec rds;
   out.cell_totl_reads.assign((size_t)C, 0);
   out.cell_uniq_reads.assign((size_t)C, 0);
   bool sorted = true;

@@ -12,6 +12,8 @@
 #pragma once
 
 
+#include <memory>
+
 #include "util.hpp"
 
 namespace pa {
@@ -20,6 +22,58 @@ struct PlpRead {
   int32_t cell, snp;
   uint32_t numi;  // global kept-base counter
   uint8_t byte;   // allele<<7 | capped bq, or MUXGL_READ_OTHER
+};
+
+// Growable array of PlpRead without value-initialisation: a std::vector zero-fills on resize, and that single-threaded
+// first touch of a few hundred MB (page faults) was a third of the load time; here the parallel copies touch the pages.
+class PlpReadVec {
+ public:
+  PlpReadVec() {}
+  explicit PlpReadVec(size_t n) { resize(n); }
+  PlpReadVec(const PlpReadVec&) = delete;
+  PlpReadVec& operator=(const PlpReadVec&) = delete;
+  ~PlpReadVec() { free(p_); }
+  size_t size() const { return n_; }
+  size_t capacity() const { return cap_; }
+  bool empty() const { return n_ == 0; }
+  PlpRead* data() { return p_; }
+  const PlpRead* data() const { return p_; }
+  PlpRead* begin() { return p_; }
+  PlpRead* end() { return p_ + n_; }
+  const PlpRead* begin() const { return p_; }
+  const PlpRead* end() const { return p_ + n_; }
+  PlpRead& operator[](size_t i) { return p_[i]; }
+  const PlpRead& operator[](size_t i) const { return p_[i]; }
+  void reserve(size_t c) {
+    if (c <= cap_) return;
+    PlpRead* q = (PlpRead*)malloc(c * sizeof(PlpRead));
+    if (!q) fatal("out of memory (%zu reads)", c);
+    if (n_) {  // rare (the size hint normally covers the file): copy with all threads
+      const size_t nb = (n_ + (1u << 16) - 1) >> 16;
+      PlpRead* src = p_;
+      const size_t n = n_;
+      parallel_for((int64_t)nb, plp_threads(), [&](int64_t b) {
+        const size_t o = (size_t)b << 16;
+        memcpy((void*)(q + o), (const void*)(src + o), std::min<size_t>(1u << 16, n - o) * sizeof(PlpRead));
+      });
+    }
+    free(p_);
+    p_ = q;
+    cap_ = c;
+  }
+  void resize(size_t n) {  // new elements are NOT initialised
+    if (n > cap_) reserve(std::max(n, cap_ * 2));
+    n_ = n;
+  }
+  void swap(PlpReadVec& o) {
+    std::swap(p_, o.p_);
+    std::swap(n_, o.n_);
+    std::swap(cap_, o.cap_);
+  }
+
+ private:
+  PlpRead* p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
 };
 
 struct PlpParseOptions {
@@ -136,8 +190,14 @@ inline void parse_slice(Slice& sl, const PlpParseOptions& po, const char* prefix
   }
 }
 
-// inflates `path` into blocks that end at a newline (the last block of the file may lack one)
-class GzBlockReader {
+// source of inflated text blocks that end at a newline (the last block of the file may lack one)
+struct BlockSource {
+  virtual ~BlockSource() {}
+  virtual bool next(std::vector<char>& blk) = 0;  // false at end of file
+};
+
+// plain gzip stream: one thread inflates (a gzip member cannot be split), the parser runs beside it
+class GzBlockReader : public BlockSource {
  public:
   static constexpr size_t BLK = 8u << 20;
   explicit GzBlockReader(const std::string& path) {
@@ -156,7 +216,7 @@ class GzBlockReader {
     if (fp_) gzclose(fp_);
   }
   // next block, false at end of file; the buffer stays valid until the following call
-  bool next(std::vector<char>& blk) {
+  bool next(std::vector<char>& blk) override {
     std::unique_lock<std::mutex> g(m_);
     cv_.wait(g, [this] { return have_ || done_; });
     if (!have_) {
@@ -222,11 +282,132 @@ class GzBlockReader {
   std::string err_;
 };
 
+// BGZF (what dsc-pileup writes through hts_open(..., "wz"), cmd_cram_dsc_pileup.cpp:438-440): a chain of independent
+// gzip members of <= 64 KiB, each announcing its compressed size in the BC extra field and its inflated size in the
+// trailer -- so a batch of members is inflated by the whole worker pool straight to its place in the text block.
+class BgzfBlockReader : public BlockSource {
+ public:
+  static constexpr size_t TEXT = 16u << 20;  // inflated bytes per block (about)
+  static bool is_bgzf(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    unsigned char h[18];
+    const bool ok = fread(h, 1, 18, f) == 18 && member_size(h, 18) > 0;
+    fclose(f);
+    return ok;
+  }
+  explicit BgzfBlockReader(const std::string& path) : path_(path) {
+    f_ = fopen(path.c_str(), "rb");
+    if (!f_) fatal("Cannot open %s for reading", path.c_str());
+  }
+  ~BgzfBlockReader() override {
+    if (f_) fclose(f_);
+  }
+  bool next(std::vector<char>& blk) override {
+    if (finished_) return false;
+    struct Member {
+      size_t off, csize, out;
+      uint32_t isize;
+    };
+    std::vector<Member> mem;
+    size_t text = carry_.size();
+    fpos_ += cpos_;  // drop what the previous call consumed; from here on the buffer only grows (members keep offsets)
+    cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (long)cpos_);
+    cpos_ = 0;
+    // gather whole members until the block is large enough
+    for (;;) {
+      if (cbuf_.size() - cpos_ < 18 && !refill()) break;
+      if (cbuf_.size() - cpos_ == 0) break;
+      const unsigned char* p = (const unsigned char*)cbuf_.data() + cpos_;
+      const size_t avail = cbuf_.size() - cpos_;
+      const long ms = avail >= 18 ? member_size(p, avail) : -1;
+      if (ms <= 0) fatal("%s: not a BGZF member at compressed offset %zu", path_.c_str(), fpos_ + cpos_);
+      if ((size_t)ms > avail) {
+        if (!refill()) fatal("%s: truncated BGZF member", path_.c_str());
+        continue;
+      }
+      const uint32_t isize = (uint32_t)p[ms - 4] | ((uint32_t)p[ms - 3] << 8) | ((uint32_t)p[ms - 2] << 16) |
+                             ((uint32_t)p[ms - 1] << 24);
+      if (isize > 0x10000) fatal("%s: BGZF member claims %u bytes", path_.c_str(), isize);
+      mem.push_back(Member{cpos_, (size_t)ms, text, isize});
+      text += isize;
+      cpos_ += (size_t)ms;
+      if (text >= TEXT) break;
+    }
+    blk.resize(text);
+    if (!carry_.empty()) memcpy(blk.data(), carry_.data(), carry_.size());
+    std::atomic<bool> bad(false);
+    const unsigned char* base = (const unsigned char*)cbuf_.data();
+    parallel_for_blocked((int64_t)mem.size(), 8, plp_threads(), [&](int64_t i) {
+      const Member& m = mem[(size_t)i];
+      if (m.isize == 0) return;  // e.g. the end-of-file marker
+      const unsigned char* p = base + m.off;
+      const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) {
+        bad = true;
+        return;
+      }
+      zs.next_in = (Bytef*)(p + 12 + xlen);
+      zs.avail_in = (uInt)(m.csize - 12 - xlen - 8);
+      zs.next_out = (Bytef*)(blk.data() + m.out);
+      zs.avail_out = m.isize;
+      const int rc = inflate(&zs, Z_FINISH);
+      const bool ok = rc == Z_STREAM_END && zs.total_out == m.isize;
+      inflateEnd(&zs);
+      const uint32_t want = (uint32_t)p[m.csize - 8] | ((uint32_t)p[m.csize - 7] << 8) |
+                            ((uint32_t)p[m.csize - 6] << 16) | ((uint32_t)p[m.csize - 5] << 24);
+      if (!ok || (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(blk.data() + m.out), m.isize) != want) bad = true;
+    });
+    if (bad) fatal("%s: corrupt BGZF member", path_.c_str());
+    const bool eof = cbuf_.size() == cpos_ && feof_;
+    size_t cut = blk.size();
+    if (!eof) {
+      while (cut > 0 && blk[cut - 1] != '\n') --cut;
+    }
+    carry_.assign(blk.begin() + (long)cut, blk.end());
+    blk.resize(cut);
+    if (eof) finished_ = true;
+    if (blk.empty()) return eof ? false : next(blk);
+    return true;
+  }
+
+ private:
+  // size of the gzip member starting at p if it is a BGZF block (gzip header with FEXTRA and a BC subfield), else -1
+  static long member_size(const unsigned char* p, size_t avail) {
+    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return -1;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+    if (avail < 12 + xlen) return xlen <= 0xffff ? 0x10000 : -1;  // need more bytes to see the subfields
+    for (size_t o = 12; o + 4 <= 12 + xlen;) {
+      const size_t slen = (size_t)p[o + 2] | ((size_t)p[o + 3] << 8);
+      if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen)
+        return (long)((size_t)p[o + 4] | ((size_t)p[o + 5] << 8)) + 1;
+      o += 4 + slen;
+    }
+    return -1;
+  }
+  bool refill() {  // append the next chunk of the file
+    if (feof_) return false;
+    const size_t old = cbuf_.size(), want = 8u << 20;
+    cbuf_.resize(old + want);
+    const size_t n = fread(cbuf_.data() + old, 1, want, f_);
+    cbuf_.resize(old + n);
+    if (n < want) feof_ = true;
+    return n > 0;
+  }
+  std::string path_;
+  FILE* f_ = nullptr;
+  std::vector<char> cbuf_, carry_;
+  size_t cpos_ = 0, fpos_ = 0;
+  bool feof_ = false, finished_ = false;
+};
+
 }  // namespace detail
 
 // Parses <prefix>.plp.gz; appends the kept bases to `rds` in file order, returns their number; *sorted tells whether the
 // rows came in (cell, SNP) order.
-inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& po, std::vector<PlpRead>& rds,
+inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& po, PlpReadVec& rds,
                              bool* sorted) {
   using namespace detail;
   {  // size hint: the gzip trailer holds the uncompressed length (mod 2^32); a kept base costs >= ~9 bytes of text
@@ -238,7 +419,12 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
     }
     if (f) fclose(f);
   }
-  GzBlockReader rd(prefix + ".plp.gz");
+  std::unique_ptr<BlockSource> src;
+  if (BgzfBlockReader::is_bgzf(prefix + ".plp.gz"))
+    src.reset(new BgzfBlockReader(prefix + ".plp.gz"));
+  else
+    src.reset(new GzBlockReader(prefix + ".plp.gz"));
+  BlockSource& rd = *src;
   const int nth = plp_threads();
   std::vector<char> blk;
   std::vector<Slice> sl;  // reused from block to block: their buffers stay warm
@@ -297,7 +483,6 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
     std::vector<size_t> off((size_t)want + 1, rds.size());
     {  // copy the slices' reads to their places (numi made global), in parallel
       for (size_t i = 0; i < (size_t)want; ++i) off[i + 1] = off[i] + sl[i].rds.size();
-      if (off.back() > rds.capacity()) rds.reserve(std::max(off.back(), rds.capacity() * 2));
       rds.resize(off.back());
       const uint64_t base0 = numi - off[0];
       parallel_for(want, nth, [&](int64_t i) {
@@ -334,7 +519,7 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
     }
     tA = now(); t_app += tA - tC;
   }
-  if (getenv("POPSCLE_AMD_TIMING")) fprintf(stderr, "TIMING   plp: wait %.3f parse %.3f append %.3f sorted %d threads %d\n", t_wait, t_parse, t_app, (int)file_sorted, nth);
+  if (getenv("POPSCLE_AMD_TIMING")) fprintf(stderr, "TIMING   plp: wait %.3f parse %.3f append %.3f sorted %d threads %d bgzf %d\n", t_wait, t_parse, t_app, (int)file_sorted, nth, (int)(dynamic_cast<BgzfBlockReader*>(src.get()) != nullptr));
   if (!header) fatal("Cannot read the first line of %s.plp.gz", prefix.c_str());
   *sorted = file_sorted;
   return numi;
@@ -343,7 +528,7 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
 // Brings the reads (file order) into (cell, SNP, "%x"-string of numi) order.  dsc-pileup writes the table SNP-major
 // (cmd_cram_dsc_pileup.cpp:497-518), so the general case is a transpose: a stable bucket pass by cell keeps the file's
 // SNP order inside every cell; a cell whose rows were not SNP-ascending in the file is sorted on its own.
-inline void plp_order_by_cell(std::vector<PlpRead>& rds, int64_t C, bool already_sorted, std::vector<int64_t>& cell_rd0) {
+inline void plp_order_by_cell(PlpReadVec& rds, int64_t C, bool already_sorted, std::vector<int64_t>& cell_rd0) {
   const int64_t n = (int64_t)rds.size();
   const int nth = plp_threads();
   const int64_t P = std::max<int64_t>(1, std::min<int64_t>(nth, n / (1 << 16) + 1));  // input parts
@@ -364,7 +549,7 @@ inline void plp_order_by_cell(std::vector<PlpRead>& rds, int64_t C, bool already
       }
     }
     cell_rd0[(size_t)C] = run;
-    std::vector<PlpRead> dst((size_t)n);
+    PlpReadVec dst((size_t)n);
     parallel_for(P, nth, [&](int64_t t) {
       int64_t* c = cnt.data() + t * C;
       for (int64_t i = n * t / P; i < n * (t + 1) / P; ++i) dst[(size_t)c[rds[(size_t)i].cell]++] = rds[(size_t)i];
@@ -395,7 +580,7 @@ inline void plp_order_by_cell(std::vector<PlpRead>& rds, int64_t C, bool already
 }
 
 // ordered reads -> CSR (cell_ptr, entry_snp, entry_rptr, reads)
-inline void plp_pack(const std::vector<PlpRead>& rds, int64_t C, const std::vector<int64_t>& cell_rd0,
+inline void plp_pack(const PlpReadVec& rds, int64_t C, const std::vector<int64_t>& cell_rd0,
                      std::vector<int64_t>& cell_ptr, std::vector<int32_t>& entry_snp, std::vector<int64_t>& entry_rptr,
                      std::vector<uint8_t>& reads) {
   const int nth = plp_threads();

@@ -259,3 +259,37 @@ def test_bgzf_writer(exe, tmp_path, size):
         off += bsize
         nblocks += 1
     assert off == len(raw) and total == size and nblocks == (size + 0xff00 - 1) // 0xff00 + 1
+
+
+def test_loader_bgzf_input(exe, tmp_path):
+    """dsc-pileup writes its tables as BGZF (hts_open "wz"); the loader inflates the blocks in parallel.  Same table as
+    plain gzip and as BGZF (re-compressed with the front end's own BGZF writer) must load to the same bytes."""
+    import gzip
+    import shutil
+
+    p = synth.make_pileup(500, 20000, 2, seed=47, mean_entries=900, min_entries=100, reads_lambda=0.6, other=0.02)
+    prefix = str(tmp_path / "gz")
+    plpio.write_plp(prefix, p, seed=1)
+    ref = str(tmp_path / "ref.bin")
+    assert subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", ref]).returncode == 0
+    bprefix = str(tmp_path / "bgzf")
+    for ext in (".cel.gz", ".var.gz"):
+        shutil.copy(prefix + ext, bprefix + ext)
+    txt = tmp_path / "plp.txt"
+    txt.write_bytes(gzip.open(prefix + ".plp.gz", "rb").read())
+    assert txt.stat().st_size > 3 * (1 << 20)  # dozens of 64 KiB blocks
+    assert subprocess.run([exe, "bgzf", "--in", str(txt), "--out", bprefix + ".plp.gz"]).returncode == 0
+    for nt in (1, 5):
+        out = str(tmp_path / f"b{nt}.bin")
+        r = subprocess.run([exe, "dump-plp", "--plp", bprefix, "--out", out], capture_output=True, text=True,
+                           env=dict(os.environ, POPSCLE_AMD_THREADS=str(nt), POPSCLE_AMD_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert "bgzf 1" in r.stderr
+        assert open(out, "rb").read() == open(ref, "rb").read()
+    # a corrupted block is detected (CRC), not parsed
+    raw = bytearray(open(bprefix + ".plp.gz", "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    open(bprefix + ".plp.gz", "wb").write(bytes(raw))
+    r = subprocess.run([exe, "dump-plp", "--plp", bprefix, "--out", str(tmp_path / "x.bin")], capture_output=True,
+                       text=True)
+    assert r.returncode != 0

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--samples", type=int, default=16)
     ap.add_argument("--freemuxlet", type=int, default=0, help="also run freemuxlet with this many clusters")
     ap.add_argument("--dir", default="/tmp/e2e")
+    ap.add_argument("--bgzf", action="store_true", help="store the PLP table as BGZF, as dsc-pileup does")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
     prefix = os.path.join(a.dir, "plp")
@@ -52,6 +53,15 @@ def main():
     rows = int((np.diff(p.entry_rptr) > 0).sum())
     print(f"wrote {prefix}.* in {time.perf_counter() - t0:.1f} s: {a.cells} droplets, {a.snps} SNPs, {rows} PLP rows, "
           f"{p.R} bases, plp.gz {os.path.getsize(prefix + '.plp.gz') / 1e6:.1f} MB")
+    if a.bgzf:  # what dsc-pileup itself writes (hts_open "wz"): blocks inflate in parallel
+        import gzip
+        import shutil
+
+        with gzip.open(prefix + ".plp.gz", "rb") as f, open(prefix + ".plp.txt", "wb") as g:
+            shutil.copyfileobj(f, g, 1 << 24)
+        subprocess.run([BIN, "bgzf", "--in", prefix + ".plp.txt", "--out", prefix + ".plp.gz"], check=True)
+        os.remove(prefix + ".plp.txt")
+        print(f"re-compressed as BGZF: plp.gz {os.path.getsize(prefix + '.plp.gz') / 1e6:.1f} MB")
     print("demuxlet --field GT:")
     dt = run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", os.path.join(a.dir, "dmx")])
     print(f"    => {rows / dt / 1e6:.2f} M PLP rows/s end to end")
