@@ -24,7 +24,8 @@
 namespace {
 
 constexpr int QN_ACC = 36;      // per lane: 4 singlets, 6 in-lane pairs, 16 pairs with the neighbour tile, 10 with the opposite
-constexpr int Q_SLOT_STRIDE = 34;  // doubles: 4 entries x 8 likelihoods + 2 pad => the 16 slots of a wave hit distinct banks
+constexpr int Q_SLOT_STRIDE = 38;  // doubles: 4 entries x 8 likelihoods + 4 singlet factors + 2 pad => the 16 slots of a
+                                   // wave hit distinct banks (76 dwords apart)
 
 __device__ __forceinline__ double dpp_ror4(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -64,8 +65,8 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
 __global__ void __launch_bounds__(64, 2)
     demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
                       const uint8_t* __restrict__ reads, const double* __restrict__ gpq,
-                      const double* __restrict__ gp0s, const double* __restrict__ lut_g, double* __restrict__ part_m,
-                      int32_t* __restrict__ part_e) {
+                      const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
+                      double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double pgs[16 * Q_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
@@ -104,36 +105,30 @@ __global__ void __launch_bounds__(64, 2)
   fetch_meta(0);
 
   // GP triples of the entry to come are always one entry ahead, across batch boundaries too: the first entry of the
-  // next batch is known from the prefetched records (snps_nx)
-  double nG[4][3], nhs = 1.0;
+  // next batch is known from the prefetched records (snps_nx).  Rows are loaded unconditionally: padding entries and
+  // markers without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) point at the dummy row S_dummy = (1,0,0 | 1),
+  // which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1.
+  double nG[4][3];
   auto load_row = [&](int32_t s) {
+    // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes
+    const double2* pc = reinterpret_cast<const double2*>(gpq + (size_t)s * 48) + r;
+    double f[12];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const double2 v = pc[t * 4];
+      f[2 * t] = v.x;
+      f[2 * t + 1] = v.y;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      nG[c][0] = 1.0;
-      nG[c][1] = 0.0;
-      nG[c][2] = 0.0;
-    }
-    nhs = 1.0;
-    if (s >= 0) {
-      nhs = gp0s[s];  // g_0[0]+g_0[1]+g_0[2]: sample 0's row multiplies every singlet (:806)
-      // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes
-      const double2* pc = reinterpret_cast<const double2*>(gpq + (size_t)s * 48) + r;
-      double f[12];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const double2 v = pc[t * 4];
-        f[2 * t] = v.x;
-        f[2 * t + 1] = v.y;
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        nG[c][0] = f[3 * c];
-        nG[c][1] = f[3 * c + 1];
-        nG[c][2] = f[3 * c + 2];
-      }
+      nG[c][0] = f[3 * c];
+      nG[c][1] = f[3 * c + 1];
+      nG[c][2] = f[3 * c + 2];
     }
   };
-  snps_nx[slot * 4 + r] = prec.snp;
+  // sum of the lane's OWN entry of the batch to come (phase 1 mapping), fetched with the record: negative = no genotypes
+  double hs_own = (prec.snp >= 0) ? gp0s[prec.snp] : 1.0;
+  snps_nx[slot * 4 + r] = (prec.snp >= 0 && hs_own >= 0.0) ? prec.snp : S_dummy;
   __syncthreads();
   load_row(snps_nx[slot * 4]);
 
@@ -141,10 +136,14 @@ __global__ void __launch_bounds__(64, 2)
     // ---- phase 1: lane <-> entry.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
     //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR ----
     {
-      const int32_t s = prec.snp;
+      const int32_t s = (hs_own >= 0.0) ? prec.snp : -1;  // no genotypes: the entry is skipped (:733)
+      // g_0[0]+g_0[1]+g_0[2]: sample 0's row multiplies every singlet (:806); handed to phase 2 through LDS
+      const double hs_cur = (s >= 0) ? hs_own : 1.0;
       const int64_t r0 = prec.r0, r1 = (int64_t)prec.r0 + prec.nreads;
       const uint32_t first4 = prec.first4;
-      if (b + 1 < nb) fetch_meta(b + 1);
+      fetch_meta(b + 1);  // past the end of the chunk this yields snp = -1
+      const int32_t s_nx = prec.snp;
+      hs_own = (s_nx >= 0) ? gp0s[s_nx] : 1.0;
       double q0[3] = {1.0, 1.0, 1.0}, q1[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
       if (s >= 0) {
         int since = 0;
@@ -194,7 +193,8 @@ __global__ void __launch_bounds__(64, 2)
       dst[2] = q0[2];
 #pragma unroll
       for (int t = 0; t < 5; ++t) dst[3 + t] = q1[t];
-      snps[slot * 4 + r] = s;
+      pgs[slot * Q_SLOT_STRIDE + 32 + r] = hs_cur;
+      snps[slot * 4 + r] = (s >= 0) ? s : S_dummy;
     }
     __syncthreads();
 
@@ -208,24 +208,14 @@ __global__ void __launch_bounds__(64, 2)
         G[c][1] = nG[c][1];
         G[c][2] = nG[c][2];
       }
-      double hs = nhs;
-      if (i == 2 && b + 1 < nb) snps_nx[slot * 4 + r] = prec.snp;  // the next batch's records have long arrived
-      if (i + 1 < 4) load_row(snps[slot * 4 + i + 1]);  // prefetch the next entry's triples
-      else if (b + 1 < nb) load_row(snps_nx[slot * 4]);  // ... including the first entry of the next batch
+      // the next batch's records (and the sums hanging off them) have long arrived
+      if (i == 2) snps_nx[slot * 4 + r] = (prec.snp >= 0 && hs_own >= 0.0) ? prec.snp : S_dummy;
+      load_row((i + 1 < 4) ? snps[slot * 4 + i + 1] : snps_nx[slot * 4]);  // next entry's triples, next batch included
 
       const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
-      double a0 = qq[0], a1 = qq[1], a2 = qq[2];
-      double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
-      if (hs < 0.0) {  // marker without genotypes (:733): every factor of the entry becomes exactly 1
-        hs = 1.0;
-        a0 = a1 = a2 = b0 = b1 = b2 = b3 = b4 = 1.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          G[c][0] = 1.0;
-          G[c][1] = 0.0;
-          G[c][2] = 0.0;
-        }
-      }
+      const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
+      const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
+      const double hs = pgs[slot * Q_SLOT_STRIDE + 32 + i];
       double u[4][3];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -464,7 +454,7 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL(demux_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       h->d_qent, h->d_reads, h->d_gpq, h->d_gp0s, h->d_lut, st->d_part, st->d_part_e);
+                       h->d_qent, h->d_reads, h->d_gpq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);

@@ -199,7 +199,9 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
     // Layout for the quad kernel (demux_quad.hip): lane r of a quad owns samples 4r..4r+3 = 12 doubles d = 3c+l, read as
     // six 16-byte pieces; piece t of the four lanes is stored contiguously ([S][6][4][2]) so that one load instruction
     // of a quad covers 64 consecutive bytes.  Samples >= V are padded with (1,0,0), which makes their factors exactly 1.
-    std::vector<double> q((size_t)h->S * 48), g0((size_t)h->S);
+    // Row S is a dummy marker, (1,0,0) for every sample and sum 1: padding entries and markers without genotypes are
+    // pointed at it, so the kernel loads rows unconditionally.
+    std::vector<double> q((size_t)(h->S + 1) * 48), g0((size_t)h->S + 1);
     for (int64_t s = 0; s < h->S; ++s) {
       const double* row = gp + (size_t)s * V * 3;
       for (int r = 0; r < 4; ++r)
@@ -211,6 +213,13 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
       // a SNP without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) is marked by a negative sum
       g0[(size_t)s] = has_gp[s] ? (row[0] + row[1]) + row[2] : -1.0;
     }
+    for (int t = 0; t < 48; ++t) q[(size_t)h->S * 48 + t] = 0.0;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        const int d = 3 * c;  // l == 0 of sample c
+        q[(size_t)h->S * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = 1.0;
+      }
+    g0[(size_t)h->S] = 1.0;
     if (dev_alloc(h, &h->d_gpq, q.size())) return 1;
     if (dev_alloc(h, &h->d_gp0s, g0.size())) return 1;
     HIPCHK(h, hipMemcpy(h->d_gpq, q.data(), sizeof(double) * q.size(), hipMemcpyHostToDevice));
