@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the demuxlet hot path on MI355X -- BASELINE.json's metric on BASELINE.json's configs[1].
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -90,8 +90,11 @@ def cpu_baseline(p, alphas, gpu_cells, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--ramp-seconds", type=float, default=1.0,
+                    help="untimed passes before the W warmup steps, until the engine clock has ramped up (a 0.6 ms step "
+                         "repeated 20 times runs ~10 %% below the sustained clock)")
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (1 or 2)")
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the config's cells (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,6 +139,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        eng.demux_run(alphas, 0.5, want_cells=False)
     for _ in range(args.warmup):
         eng.demux_run(alphas, 0.5, want_cells=False)
     barrier()

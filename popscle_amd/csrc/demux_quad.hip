@@ -62,19 +62,34 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
   return 26 + (c == 0 ? d : (c == 1 ? 4 + d - 1 : (c == 2 ? 7 + d - 2 : 9)));
 }
 
+// The sweep kernel.  GP rows are requested TWO entries ahead into three register sets that rotate without copies (a
+// copy would wait for the load it copies); four entries per batch against three sets gives a period of twelve entries,
+// so three batches are written out, each starting one set later.  The 36 integer exponents of the accumulators live in
+// LDS (touched once per 16 entries) to make room for the third set.  The (empty) asm statements pin program order:
+// everything that reads a set is complete before the set is reloaded, and a reload is issued before the sweep behind
+// it -- otherwise the scheduler renames registers to hoist loads, runs out of VGPRs and spills.
+//
+// What the time is made of (config 1, ablations of this kernel on MI355X): FP64 arithmetic alone 0.28 ms, + DPP moves
+// 0.06, + phase 1 0.09, + row gathers 0.12 = 0.55 ms at the clocks of a 20-launch run (0.49 ms sustained).  The parts
+// add up instead of overlapping, and neither a fifth fewer instructions (dummy row instead of predicated loads), nor
+// deeper prefetch, nor a branch-free phase 1 moved the total by more than 2 %: the launch behaves as if limited by the
+// work itself (energy per entry under the power cap), not by latency or issue slots.
 __global__ void __launch_bounds__(64, 2)
     demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
-                      const uint8_t* __restrict__ reads, const double* __restrict__ gpq,
-                      const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
-                      double* __restrict__ part_m, int32_t* __restrict__ part_e) {
+                       const uint8_t* __restrict__ reads, const double* __restrict__ gpq,
+                       const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
+                       double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double pgs[16 * Q_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
+  __shared__ int32_t exs[QN_ACC][64];
 
   const int lane = threadIdx.x;
   const int r = (lane >> 2) & 3;                       // tile: samples 4r..4r+3
   const int slot = ((lane >> 4) << 2) | (lane & 3);    // 16 entry streams per wave
   for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
+#pragma unroll
+  for (int a = 0; a < QN_ACC; ++a) exs[a][lane] = 0;
 
   const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;
   int64_t e0 = 0;
@@ -86,31 +101,30 @@ __global__ void __launch_bounds__(64, 2)
   const int nb = (wave_max_i32(len) + 3) >> 2;  // trip count of the wave = its longest chunk
 
   double acc[QN_ACC];
-  int32_t ex[QN_ACC];
 #pragma unroll
-  for (int a = 0; a < QN_ACC; ++a) {
-    acc[a] = 1.0;
-    ex[a] = 0;
-  }
+  for (int a = 0; a < QN_ACC; ++a) acc[a] = 1.0;
 
-  // the packed record of the batch to come (snp, read count, first four read bytes, read offset) is fetched one batch
-  // ahead with a single 16-byte load per lane
-  quad_entry prec = {-1, 0u, 0u, 0u};
+  // records {snp, read count, first four read bytes, read offset} of the lane's own entry: batch b in precA, b+1 in
+  // precB, b+2 requested during phase 1 of batch b
+  // (loaded unconditionally from a clamped index and invalidated where it is used: a predicated load followed by a
+  // merge with the defaults makes the compiler wait for the load on the spot)
+  const int last = len > 0 ? len - 1 : 0;
   auto fetch_meta = [&](int b) {
     const int idx = b * 4 + r;
-    prec.snp = -1;
-    prec.nreads = 0;
-    if (idx < len) prec = qent[e0 + idx];
+    return qent[e0 + (idx < last ? idx : last)];
   };
-  fetch_meta(0);
+  auto snp_of = [&](const quad_entry& p, int b) { return (b * 4 + r < len) ? p.snp : -1; };
+  quad_entry precA = fetch_meta(0), precB = fetch_meta(1);
+  // sum of sample 0's triple at the lane's own entry (negative: marker without genotypes), one batch ahead as well
+  double hs_cur = gp0s[precA.snp];
 
-  // GP triples of the entry to come are always one entry ahead, across batch boundaries too: the first entry of the
-  // next batch is known from the prefetched records (snps_nx).  Rows are loaded unconditionally: padding entries and
-  // markers without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) point at the dummy row S_dummy = (1,0,0 | 1),
-  // which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1.
-  double nG[4][3];
-  auto load_row = [&](int32_t s) {
-    // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes
+  struct row_t {
+    double G[4][3];
+  };
+  auto load_row = [&](row_t& R, int32_t s) {
+    // six 16-byte pieces of this lane's 12 doubles; piece t of the quad's four lanes is 64 contiguous bytes.  Rows of
+    // padding entries and of markers without genotypes are (1,0,0) -- the dummy row S_dummy resp. the host's fill --
+    // which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1 (:733).
     const double2* pc = reinterpret_cast<const double2*>(gpq + (size_t)s * 48) + r;
     double f[12];
 #pragma unroll
@@ -121,39 +135,74 @@ __global__ void __launch_bounds__(64, 2)
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      nG[c][0] = f[3 * c];
-      nG[c][1] = f[3 * c + 1];
-      nG[c][2] = f[3 * c + 2];
+      R.G[c][0] = f[3 * c];
+      R.G[c][1] = f[3 * c + 1];
+      R.G[c][2] = f[3 * c + 2];
     }
   };
-  // sum of the lane's OWN entry of the batch to come (phase 1 mapping), fetched with the record: negative = no genotypes
-  double hs_own = (prec.snp >= 0) ? gp0s[prec.snp] : 1.0;
-  snps_nx[slot * 4 + r] = (prec.snp >= 0 && hs_own >= 0.0) ? prec.snp : S_dummy;
-  __syncthreads();
-  load_row(snps_nx[slot * 4]);
 
-  for (int b = 0; b < nb; ++b) {
-    // ---- phase 1: lane <-> entry.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
-    //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR ----
+  // ---- phase 1 of a batch: lane <-> entry.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
+  //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR ----
+  auto phase1 = [&](int b) {
+    const int32_t sa = snp_of(precA, b);
+    const int32_t s = (hs_cur >= 0.0) ? sa : -1;  // no genotypes: the entry is skipped (:733)
+    const double hs_out = (s >= 0) ? hs_cur : 1.0;       // multiplies every singlet (:806)
+    const int64_t r0 = precA.r0, r1 = (int64_t)precA.r0 + precA.nreads;
+    const uint32_t first4 = precA.first4;
+    precA = precB;
+    precB = fetch_meta(b + 2);
+    hs_cur = gp0s[precA.snp];
+    // The first four reads (all of them for > 99 % of the entries) come out of the record and are handled without a
+    // branch: a read that does not exist, an allele other than 0/1 (:664) or a skipped entry multiplies by exactly 1
+    // (pR = pA = 1).  The eight LUT reads are issued together.  Measured: the branchy read loop made phase 1 two
+    // fifths of the kernel time at a seventh of its instructions -- per-read LDS round trips on a divergent path.
+    double q0[3], q1[5];
     {
-      const int32_t s = (hs_own >= 0.0) ? prec.snp : -1;  // no genotypes: the entry is skipped (:733)
-      // g_0[0]+g_0[1]+g_0[2]: sample 0's row multiplies every singlet (:806); handed to phase 2 through LDS
-      const double hs_cur = (s >= 0) ? hs_own : 1.0;
-      const int64_t r0 = prec.r0, r1 = (int64_t)prec.r0 + prec.nreads;
-      const uint32_t first4 = prec.first4;
-      fetch_meta(b + 1);  // past the end of the chunk this yields snp = -1
-      const int32_t s_nx = prec.snp;
-      hs_own = (s_nx >= 0) ? gp0s[s_nx] : 1.0;
-      double q0[3] = {1.0, 1.0, 1.0}, q1[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
-      if (s >= 0) {
-        int since = 0;
-        for (int64_t rr = r0; rr < r1; ++rr) {
-          const int64_t kk = rr - r0;
-          const uint32_t bb = (kk < 4) ? ((first4 >> (8 * (int)kk)) & 0xffu) : (uint32_t)reads[rr];
+      double pRk[4], pAk[4];
+      const uint32_t nr = (s >= 0) ? (uint32_t)(r1 - r0) : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t bb = (first4 >> (8 * k)) & 0xffu;
+        const uint32_t bq = bb & 0x7f;
+        const double e3 = lut[256 + bq], mt = lut[128 + bq];
+        const bool use = (uint32_t)k < nr && bb != MUXGL_READ_OTHER;
+        const bool ref = (bb >> 7) == 0;
+        pRk[k] = use ? (ref ? mt : e3) : 1.0;  // :666-667
+        pAk[k] = use ? (ref ? e3 : mt) : 1.0;
+      }
+      {
+        const double d = pAk[0] - pRk[0];
+        const double mid = fma(d, 0.5, pRk[0]);
+        q0[0] = pRk[0];
+        q0[1] = mid;
+        q0[2] = pAk[0];
+        q1[0] = pRk[0];
+        q1[1] = fma(d, 0.25, pRk[0]);
+        q1[2] = mid;
+        q1[3] = fma(d, 0.75, pRk[0]);
+        q1[4] = pAk[0];
+      }
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const double d = pAk[k] - pRk[k];
+        const double mid = fma(d, 0.5, pRk[k]);
+        q0[0] *= pRk[k];
+        q0[1] *= mid;
+        q0[2] *= pAk[k];
+        q1[0] *= pRk[k];
+        q1[1] *= fma(d, 0.25, pRk[k]);
+        q1[2] *= mid;
+        q1[3] *= fma(d, 0.75, pRk[k]);
+        q1[4] *= pAk[k];
+      }
+      if (nr > 4) {  // deep entries: the rest from the read array
+        int since = 4;
+        for (int64_t rr = r0 + 4; rr < r1; ++rr) {
+          const uint32_t bb = (uint32_t)reads[rr];
           if (bb == MUXGL_READ_OTHER) continue;  // :664
           const uint32_t al = bb >> 7, bq = bb & 0x7f;
           const double e3 = lut[256 + bq], mt = lut[128 + bq];
-          const double pR = (al == 0) ? mt : e3, pA = (al == 0) ? e3 : mt;  // :666-667
+          const double pR = (al == 0) ? mt : e3, pA = (al == 0) ? e3 : mt;
           const double d = pA - pR;
           const double mid = fma(d, 0.5, pR);
           q0[0] *= pR;
@@ -164,7 +213,7 @@ __global__ void __launch_bounds__(64, 2)
           q1[2] *= mid;
           q1[3] *= fma(d, 0.75, pR);
           q1[4] *= pA;
-          if (++since == 32) {  // common rescaling, only against underflow (cancels in q/q_max)
+          if (++since >= 32) {  // common rescaling, only against underflow (cancels in q/q_max)
             since = 0;
             double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
 #pragma unroll
@@ -176,107 +225,151 @@ __global__ void __launch_bounds__(64, 2)
             for (int t = 0; t < 5; ++t) q1[t] *= inv;
           }
         }
-        // (q/q_max + 1e-10) / (1 + 1e-10), :703-725; the maximum over all 18 elements is the maximum over these 8
-        double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
-#pragma unroll
-        for (int t = 0; t < 5; ++t) mx = fmax(mx, q1[t]);
-        const double cc = 1.0 / (1.0 + 1e-10);
-        const double sc = cc / mx, tt = 1e-10 * cc;
-#pragma unroll
-        for (int l = 0; l < 3; ++l) q0[l] = fma(q0[l], sc, tt);
-#pragma unroll
-        for (int t = 0; t < 5; ++t) q1[t] = fma(q1[t], sc, tt);
       }
-      double* dst = pgs + slot * Q_SLOT_STRIDE + r * 8;
-      dst[0] = q0[0];
-      dst[1] = q0[1];
-      dst[2] = q0[2];
+      // (q/q_max + 1e-10) / (1 + 1e-10), :703-725; the maximum over all 18 elements is the maximum over these 8.
+      // 1/q_max by v_rcp_f64 and two Newton steps (<= 1 ulp; the factor is common to the entry's likelihoods).  For
+      // a skipped entry everything is 1 and must stay exactly 1.
+      double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
 #pragma unroll
-      for (int t = 0; t < 5; ++t) dst[3 + t] = q1[t];
-      pgs[slot * Q_SLOT_STRIDE + 32 + r] = hs_cur;
-      snps[slot * 4 + r] = (s >= 0) ? s : S_dummy;
+      for (int t = 0; t < 5; ++t) mx = fmax(mx, q1[t]);
+      double x = __builtin_amdgcn_rcp(mx);
+      x = fma(x, fma(-mx, x, 1.0), x);
+      x = fma(x, fma(-mx, x, 1.0), x);
+      const double cc = 1.0 / (1.0 + 1e-10);
+      const double sc = (s >= 0) ? cc * x : 1.0, tt = (s >= 0) ? 1e-10 * cc : 0.0;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) q0[l] = fma(q0[l], sc, tt);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) q1[t] = fma(q1[t], sc, tt);
     }
-    __syncthreads();
+    double* dst = pgs + slot * Q_SLOT_STRIDE + r * 8;
+    dst[0] = q0[0];
+    dst[1] = q0[1];
+    dst[2] = q0[2];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) dst[3 + t] = q1[t];
+    pgs[slot * Q_SLOT_STRIDE + 32 + r] = hs_out;
+    snps[slot * 4 + r] = (s >= 0) ? s : S_dummy;
+    const int32_t sn = snp_of(precA, b + 1);
+    snps_nx[slot * 4 + r] = (sn >= 0) ? sn : S_dummy;  // next batch; its no-genotype rows are (1,0,0)
+  };
 
-    // ---- phase 2: lane <-> 4 samples, the 4 entries of the slot's batch one after the other ----
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-      double G[4][3];
+  // ---- phase 2 for entry i of the slot's batch: lane <-> 4 samples ----
+  auto sweep_entry = [&](const row_t& R, int i) {
+    const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
+    const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
+    const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
+    const double hs = pgs[slot * Q_SLOT_STRIDE + 32 + i];
+    double u[4][3];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        G[c][0] = nG[c][0];
-        G[c][1] = nG[c][1];
-        G[c][2] = nG[c][2];
+    for (int c = 0; c < 4; ++c) {
+      // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+      const double u0 = fma(R.G[c][2], a2, fma(R.G[c][1], a1, R.G[c][0] * a0));
+      acc[q_acc_single(c)] *= u0 * hs;
+      // u[c][m] = sum_l g_j[l] * pG[alpha=.5][l][m],  pG[l][m] = b[l+m]
+      u[c][0] = fma(R.G[c][2], b2, fma(R.G[c][1], b1, R.G[c][0] * b0));
+      u[c][1] = fma(R.G[c][2], b3, fma(R.G[c][1], b2, R.G[c][0] * b1));
+      u[c][2] = fma(R.G[c][2], b4, fma(R.G[c][1], b3, R.G[c][0] * b2));
+    }
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1)  // pairs inside the lane
+#pragma unroll
+      for (int c2 = c1 + 1; c2 < 4; ++c2)
+        acc[q_acc_within(c1, c2)] *= fma(R.G[c2][2], u[c1][2], fma(R.G[c2][1], u[c1][1], R.G[c2][0] * u[c1][0]));
+    {  // neighbouring tile
+      double P[4][3];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        P[d][0] = dpp_ror4(R.G[d][0]);
+        P[d][1] = dpp_ror4(R.G[d][1]);
+        P[d][2] = dpp_ror4(R.G[d][2]);
       }
-      // the next batch's records (and the sums hanging off them) have long arrived
-      if (i == 2) snps_nx[slot * 4 + r] = (prec.snp >= 0 && hs_own >= 0.0) ? prec.snp : S_dummy;
-      load_row((i + 1 < 4) ? snps[slot * 4 + i + 1] : snps_nx[slot * 4]);  // next entry's triples, next batch included
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          acc[q_acc_t1(c, d)] *= fma(P[d][2], u[c][2], fma(P[d][1], u[c][1], P[d][0] * u[c][0]));  // :738-746
+    }
+    {  // opposite tile: the two lanes facing each other split the 16 pairs (c <= d here, d < c over there)
+      double Q[4][3];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        Q[d][0] = dpp_ror8(R.G[d][0]);
+        Q[d][1] = dpp_ror8(R.G[d][1]);
+        Q[d][2] = dpp_ror8(R.G[d][2]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = c; d < 4; ++d)
+          acc[q_acc_t2(c, d)] *= fma(Q[d][2], u[c][2], fma(Q[d][1], u[c][1], Q[d][0] * u[c][0]));
+    }
+  };
+  auto pin = [&]() {  // all accumulator updates so far are in program order before what follows
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                 "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]));
+    asm volatile("" : "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17]),
+                 "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]));
+    asm volatile("" : "+v"(acc[24]), "+v"(acc[25]), "+v"(acc[26]), "+v"(acc[27]), "+v"(acc[28]), "+v"(acc[29]),
+                 "+v"(acc[30]), "+v"(acc[31]), "+v"(acc[32]), "+v"(acc[33]), "+v"(acc[34]), "+v"(acc[35])
+                 :
+                 : "memory");
+  };
+  auto renorm = [&]() {
+#pragma unroll
+    for (int a = 0; a < QN_ACC; ++a) {
+      int e;
+      acc[a] = frexp(acc[a], &e);
+      exs[a][lane] += e;
+    }
+  };
 
-      const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
-      const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
-      const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
-      const double hs = pgs[slot * Q_SLOT_STRIDE + 32 + i];
-      double u[4][3];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
-        const double u0 = fma(G[c][2], a2, fma(G[c][1], a1, G[c][0] * a0));
-        acc[q_acc_single(c)] *= u0 * hs;
-        // u[c][m] = sum_l g_j[l] * pG[alpha=.5][l][m],  pG[l][m] = b[l+m]
-        u[c][0] = fma(G[c][2], b2, fma(G[c][1], b1, G[c][0] * b0));
-        u[c][1] = fma(G[c][2], b3, fma(G[c][1], b2, G[c][0] * b1));
-        u[c][2] = fma(G[c][2], b4, fma(G[c][1], b3, G[c][0] * b2));
-      }
-      // pairs inside the lane
-#pragma unroll
-      for (int c1 = 0; c1 < 4; ++c1)
-#pragma unroll
-        for (int c2 = c1 + 1; c2 < 4; ++c2)
-          acc[q_acc_within(c1, c2)] *= fma(G[c2][2], u[c1][2], fma(G[c2][1], u[c1][1], G[c2][0] * u[c1][0]));
-      // neighbouring tile
-      {
-        double P[4][3];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          P[d][0] = dpp_ror4(G[d][0]);
-          P[d][1] = dpp_ror4(G[d][1]);
-          P[d][2] = dpp_ror4(G[d][2]);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int d = 0; d < 4; ++d)
-            acc[q_acc_t1(c, d)] *= fma(P[d][2], u[c][2], fma(P[d][1], u[c][1], P[d][0] * u[c][0]));  // :738-746
-      }
-      // opposite tile: the two lanes facing each other split the 16 pairs (c <= d here, d < c over there)
-      {
-        double Q[4][3];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          Q[d][0] = dpp_ror8(G[d][0]);
-          Q[d][1] = dpp_ror8(G[d][1]);
-          Q[d][2] = dpp_ror8(G[d][2]);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int d = c; d < 4; ++d)
-            acc[q_acc_t2(c, d)] *= fma(Q[d][2], u[c][2], fma(Q[d][1], u[c][1], Q[d][0] * u[c][0]));
-      }
-    }
-    if ((b & 3) == 3) {  // 16 entries per slot since the last renormalisation
-#pragma unroll
-      for (int a = 0; a < QN_ACC; ++a) prodacc_renorm(acc[a], ex[a]);
-    }
+  // One batch: phase 1, then its four entries.  X holds the row of entry 0, Y of entry 1 (both requested earlier); Z is
+  // free.  Entry i is swept while the row of stream position i+2 is requested into the set that was swept last.
+  auto batch = [&](int b, row_t& X, row_t& Y, row_t& Z) {
+    phase1(b);
     __syncthreads();
+    load_row(Z, snps[slot * 4 + 2]);
+    asm volatile("" ::: "memory");
+    sweep_entry(X, 0);
+    pin();
+    load_row(X, snps[slot * 4 + 3]);
+    asm volatile("" ::: "memory");
+    sweep_entry(Y, 1);
+    pin();
+    load_row(Y, snps_nx[slot * 4 + 0]);
+    asm volatile("" ::: "memory");
+    sweep_entry(Z, 2);
+    pin();
+    load_row(Z, snps_nx[slot * 4 + 1]);
+    asm volatile("" ::: "memory");
+    sweep_entry(X, 3);
+    pin();
+    if ((b & 3) == 3) renorm();  // 16 entries per slot since the last renormalisation
+    __syncthreads();
+  };
+
+  row_t R0, R1, R2;
+  snps_nx[slot * 4 + r] = (snp_of(precA, 0) >= 0) ? precA.snp : S_dummy;
+  __syncthreads();
+  load_row(R0, snps_nx[slot * 4 + 0]);
+  load_row(R1, snps_nx[slot * 4 + 1]);
+  __syncthreads();
+  for (int b = 0; b < nb; b += 3) {
+    batch(b, R0, R1, R2);  // leaves entry 0 of the next batch in R1, entry 1 in R2
+    if (b + 1 >= nb) break;
+    batch(b + 1, R1, R2, R0);
+    if (b + 2 >= nb) break;
+    batch(b + 2, R2, R0, R1);
   }
 
   if (q < n_chunks) {
 #pragma unroll
     for (int a = 0; a < QN_ACC; ++a) {
-      prodacc_renorm(acc[a], ex[a]);
+      int e;
+      acc[a] = frexp(acc[a], &e);
       part_m[((size_t)q * QN_ACC + a) * 4 + r] = acc[a];
-      part_e[((size_t)q * QN_ACC + a) * 4 + r] = ex[a];
+      part_e[((size_t)q * QN_ACC + a) * 4 + r] = exs[a][lane] + e;
     }
   }
 }

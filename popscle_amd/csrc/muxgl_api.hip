@@ -207,7 +207,7 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
       for (int r = 0; r < 4; ++r)
         for (int d = 0; d < 12; ++d) {
           const int j = 4 * r + d / 3, l = d % 3;
-          const double v = (j < V) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);
+          const double v = (j < V && has_gp[s]) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);  // no genotypes: neutral row
           q[(size_t)s * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = v;
         }
       // a SNP without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) is marked by a negative sum
