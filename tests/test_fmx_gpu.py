@@ -106,10 +106,17 @@ def test_em_trajectory_vs_oracle(eng, K, C, S, ment, iters):
     assert worst < 1e-7
 
 
-@pytest.mark.parametrize("K,C,frac,thres", [(4, 150, 1.0, -1e300), (6, 100, 0.5, -1e300), (3, 100, 1.0, 5.0)])
+@pytest.mark.parametrize("K,C,frac,thres", [
+    (4, 150, 1.0, -1e300), (6, 100, 0.5, -1e300), (3, 100, 1.0, 5.0),
+    (1, 40, 1.0, -1e300),      # a single cluster
+    (20, 160, 1.0, -1e300),    # 32 lanes per entry stripe
+    (64, 200, 1.0, -1e300),    # one stripe per wave
+    (100, 260, 1.0, -1e300),   # clusters spread over two waves
+])
 def test_greedy_init_vs_oracle(eng, K, C, frac, thres):
-    """b3+b4 of the product (muxgl_fmx_greedy_init, host code inside the library) vs the oracle's restatement"""
-    p = synth.make_pileup(C, 1500, K, seed=900 + K, mean_entries=200, min_entries=30, with_gp=False)
+    """b3+b4 of the product (muxgl_fmx_greedy_init: host sort + the persistent-workgroup kernel of fmx_greedy.hip) vs
+    the oracle's restatement of cmd_cram_freemux2.cpp:217-261"""
+    p = synth.make_pileup(C, 1500, min(K, 16), seed=900 + K, mean_entries=200, min_entries=30, with_gp=False)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     llk0, llk2, _, _ = eng.fmx_prepare(p.af)
     e = ob.fmx_entry_pileup(p)
@@ -119,6 +126,20 @@ def test_greedy_init_vs_oracle(eng, K, C, frac, thres):
     got = eng.fmx_greedy_init(K, scores, frac, thres)
     assert np.array_equal(got, want)
     assert np.max(np.abs((llk2 - llk0) - scores)) < 1e-8
+
+
+def test_greedy_init_deep_cells(eng):
+    """cells with more entries than one staging pass of the kernel (1024), next to empty and tiny ones"""
+    K = 5
+    p = synth.make_pileup(60, 6000, K, seed=77, mean_entries=1500, min_entries=0, with_gp=False)
+    assert np.diff(p.cell_ptr).max() > 1024
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    eng.fmx_prepare(p.af)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    assert np.array_equal(eng.fmx_greedy_init(K, scores), want)
 
 
 def test_init_cluster_with_unassigned_cells_and_params(eng):
