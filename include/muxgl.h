@@ -142,7 +142,7 @@ int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg);
 int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
                       int32_t* cell_nreads);
 
-/* entry pileups for host-side greedy init (cmd_cram_freemux2.cpp:217-261) and parity: gls[nnz][9],
+/* entry pileups (for parity checks and callers that want them): gls[nnz][9],
  * counts[nnz][3] = nreads,nref,nalt.  Either may be NULL. */
 int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
 
@@ -150,8 +150,8 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
  * comparator sc_drop_seq.h:187-198) and run the greedy initial clustering (:217-261, distance =
  * sc_dropseq_lib_t::calculate_droplet_clust_distance, sc_drop_seq.cpp:544-578).  scores[C] = cell_scores (llk2-llk0,
  * possibly shuffled by --randomize-singlet-score on the caller side).  The procedure is sequential over cells by
- * construction (each assignment changes the cluster pileups the next cell is scored against); this round it runs on
- * the host inside the library, on the entry likelihoods muxgl_fmx_prepare computed on the device.
+ * construction (each assignment changes the cluster pileups the next cell is scored against): the cells are sorted on
+ * the host, then one persistent workgroup on the device walks them in order (fmx_greedy.hip), parallel inside a step.
  * clust_out[C] receives the cluster id, or -1 for cells skipped by frac_init_clust / singlet_score_thres. */
 int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,
                           double singlet_score_thres, int32_t* clust_out);
