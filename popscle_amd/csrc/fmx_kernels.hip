@@ -27,6 +27,13 @@ namespace {
 
 constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
 
+// 1/x by v_rcp_f64 and two Newton steps: within 1 ulp of the division at a fifth of its instructions
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+
 // ------------------------------------------------------------------------------------------------ b1 / b2
 
 __global__ void __launch_bounds__(256)
@@ -563,61 +570,73 @@ __global__ void __launch_bounds__(64)
     p = snp_ptr[s];
     p1 = snp_ptr[s + 1];
   }
-  // pipeline registers: element "cur" is complete, element "nx" has its id and cell
-  int32_t k_cur = -1;
-  double g[9];
-  int64_t e_nx = 0;
-  int32_t c_nx = 0;
-  bool have_cur = false, have_nx = false;
-  auto load_ids = [&]() {
-    have_nx = p < p1;
-    if (have_nx) {
-      e_nx = p;  // position in the SNP-major arrays
-      c_nx = snp_cell[p];
-      ++p;
+  // Software pipeline in blocks of MU entries, two register sets: while block n is merged (a strictly sequential chain
+  // through the LDS states), the likelihoods and assignments of block n+1 and the cell ids of block n+2 are in flight.
+  // The number of chains in flight is capped by LDS (K*72 B per marker, ~140 markers per CU), so the time per chain
+  // step is what counts: it was one full memory round trip with a single entry of look-ahead.
+  // (all loads are unconditional from clamped positions: a predicated load merged with a default makes the compiler
+  // wait for it on the spot)
+  constexpr int MU = 4;
+  struct blk_t {
+    int32_t k[MU];
+    double g[MU][9];
+  };
+  const int64_t plast = (p1 > p) ? p1 - 1 : 0;
+  auto load_ids = [&](int32_t (&c)[MU], int64_t base) {
+#pragma unroll
+    for (int u = 0; u < MU; ++u) c[u] = snp_cell[(base + u < p1) ? base + u : plast];
+  };
+  auto load_data = [&](blk_t& B, const int32_t (&c)[MU], int64_t base) {
+#pragma unroll
+    for (int u = 0; u < MU; ++u) {
+      const int64_t e = (base + u < p1) ? base + u : plast;
+      B.k[u] = clust[c[u]];
+      const double* o = segls + (size_t)e * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) B.g[u][i] = o[i];
     }
   };
-  auto promote = [&]() {  // nx -> cur: assignment lookup + likelihood gather
-    have_cur = have_nx;
-    k_cur = -1;
-    if (have_nx) {
-      k_cur = clust[c_nx];
-      const double* o = segls + (size_t)e_nx * 9;
+  auto merge_blk = [&](const blk_t& B, int64_t base) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) g[i] = o[i];
+    for (int u = 0; u < MU; ++u) {
+      const int32_t k = B.k[u];
+      if (base + u < p1 && k >= 0) {  // only cells called singlets carry a cluster (b8, :590-596)
+        double* q = st + k * 9;
+        double v[9], tmp = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          v[i] = q[i] * B.g[u][i];
+          tmp += v[i];
+        }
+        double inv = fast_rcp(tmp);
+        tmp = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          v[i] *= inv;
+          if (v[i] < kMinNormGL) v[i] = kMinNormGL;
+          tmp += v[i];
+        }
+        inv = fast_rcp(tmp);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) q[i] = v[i] * inv;
+      }
     }
   };
-  load_ids();
-  promote();
-  load_ids();
-  while (__any(have_cur)) {
-    const int32_t k = k_cur;
-    const bool doit = have_cur && k >= 0;
-    double o[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o[i] = g[i];
-    promote();   // loads of the next element overlap the merge below
-    load_ids();
-    if (doit) {
-      double* q = st + k * 9;
-      double v[9], tmp = 0.0;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        v[i] = q[i] * o[i];
-        tmp += v[i];
-      }
-      double inv = 1.0 / tmp;
-      tmp = 0.0;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        v[i] *= inv;
-        if (v[i] < kMinNormGL) v[i] = kMinNormGL;
-        tmp += v[i];
-      }
-      inv = 1.0 / tmp;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) q[i] = v[i] * inv;
-    }
+  blk_t A, B;
+  int32_t ca[MU], cb[MU];
+  load_ids(ca, p);
+  load_ids(cb, p + MU);
+  load_data(A, ca, p);
+  while (__any(p < p1)) {
+    load_data(B, cb, p + MU);
+    load_ids(ca, p + 2 * MU);
+    merge_blk(A, p);
+    p += MU;
+    if (!__any(p < p1)) break;
+    load_data(A, ca, p + MU);
+    load_ids(cb, p + 2 * MU);
+    merge_blk(B, p);
+    p += MU;
   }
   if (s < s1) {
     for (int k = 0; k < K; ++k) {
