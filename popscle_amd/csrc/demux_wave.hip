@@ -10,8 +10,10 @@
 //     scalar cache into SGPRs, so they cost no vector instruction and no LDS traffic;
 //   * the partner triple g_k reaches lane j by rotating the whole wave one lane per step (DPP wave_ror:1, 6 moves);
 //     after t steps lane j faces sample (j - t) mod 64: 3 FMA + 1 multiply per hypothesis;
-//   * one launch per doublet alpha keeps the accumulators in registers (63 per lane, 32 for alpha = 0.5 whose
-//     likelihood is symmetric in (j,k)); the singlet slot (j,0,n=0) rides along with the first launch;
+//   * 64 accumulators per lane: alpha = 0.5 (symmetric in (j,k): 32 steps) and a lone alpha (63 steps) get a launch of
+//     their own, other alphas go four (or two) at a time with 16 (32) of the rotation steps per launch
+//     (demux_wave_multi_kernel: the rotation is paid once for all of them); the singlet slot (j,0,n=0) rides along
+//     with the first launch;
 //   * products are kept as mantissa * 2^exponent and turned into one log per (cell, hypothesis).
 // Work unit = cell (100 k waves at BASELINE configs[2]); cells are launched longest first.
 #include <algorithm>
@@ -121,6 +123,116 @@ __global__ void __launch_bounds__(64, 2)
   if (WITH_SINGLET && live) out[(size_t)j * V * nAlpha] = prodacc_log(accS, exS);
 }
 
+// Several non-symmetric alphas in one launch.  The partner rotation (six DPP moves per step) does not depend on alpha,
+// only u does: with NA alphas per launch a step costs 6 + 4*NA vector instructions for NA hypotheses instead of 10 for
+// one.  The accumulator budget (64 per lane) is kept by giving a launch NS = 64/NA of the 63 rotation steps, starting
+// at offset s0 (one cross-lane permute per entry brings the triple to lane j - s0 first).
+struct wave_sel {
+  int32_t n[4];
+};
+template <int NA, int NS, bool WITH_SINGLET>
+__global__ void __launch_bounds__(64, 2)
+    demux_wave_multi_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
+                            const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                            const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
+                            wave_sel sel, int s0, double* __restrict__ ll) {
+  if ((int64_t)blockIdx.x >= n_cells) return;
+  const int64_t c = order[blockIdx.x];
+  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if (e0 == e1) return;
+  const int j = threadIdx.x;
+  const bool live = j < V;
+  const int V3 = V * 3;
+  const int PG = nAlpha * 9;
+  const int src = (j - s0) & 63;  // lane whose triple this lane starts from
+
+  // 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
+  __shared__ int32_t exs[NA * NS][64];
+  double acc[NA * NS], accS = 1.0;
+  int32_t exS = 0;
+#pragma unroll
+  for (int t = 0; t < NA * NS; ++t) {
+    acc[t] = 1.0;
+    exs[t][j] = 0;
+  }
+
+  int64_t e = e0;
+  while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
+  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+  if (e < e1 && live) {
+    const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+    ng0 = row[0], ng1 = row[1], ng2 = row[2];
+  }
+  int cnt = 0;
+  while (e < e1) {
+    const int64_t ecur = e;
+    const int32_t scur = entry_snp[ecur];
+    const double g0 = ng0, g1 = ng1, g2 = ng2;
+    ++e;
+    while (e < e1 && !has_gp[entry_snp[e]]) ++e;
+    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+    if (e < e1 && live) {
+      const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+      ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    }
+    if (WITH_SINGLET) {
+      const double* s = pg + (size_t)ecur * PG;
+      const double* h = gp + (size_t)scur * V3;  // sample 0's triple multiplies every singlet (:806,828)
+      const double v0 = fma(g2, s[6], fma(g1, s[3], g0 * s[0]));
+      const double v1 = fma(g2, s[7], fma(g1, s[4], g0 * s[1]));
+      const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
+      accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
+    }
+    double u[NA][3];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {  // wave-uniform likelihoods through the scalar cache
+      const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
+      u[a][0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
+      u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
+      u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
+    }
+    double r0 = g0, r1 = g1, r2 = g2;
+    if (s0) {
+      r0 = __shfl(r0, src, 64);
+      r1 = __shfl(r1, src, 64);
+      r2 = __shfl(r2, src, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      r0 = dpp_wror1(r0);
+      r1 = dpp_wror1(r1);
+      r2 = dpp_wror1(r2);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, u[a][2], fma(r1, u[a][1], r0 * u[a][0]));  // :738-746
+    }
+    if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
+      cnt = 0;
+#pragma unroll
+      for (int t = 0; t < NA * NS; ++t) {
+        int ee;
+        acc[t] = frexp(acc[t], &ee);
+        exs[t][j] += ee;
+      }
+      if (WITH_SINGLET) prodacc_renorm(accS, exS);
+    }
+  }
+
+  // which sample does lane j face after the offset and t+1 rotations?  (measured with the same primitives)
+  double* out = ll + (size_t)c * V * V * nAlpha;
+  int kk = j;
+  if (s0) kk = __shfl(kk, src, 64);
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
+    if (live && kk < V && kk != j) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        out[((size_t)j * V + kk) * nAlpha + sel.n[a]] = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
+    }
+  }
+  if (WITH_SINGLET && live) out[(size_t)j * V * nAlpha] = prodacc_log(accS, exS);
+}
+
 }  // namespace
 
 struct muxgl_wave_state {
@@ -167,8 +279,38 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (demux_entry_pg_launch(h, p, st->d_pg)) return 1;
   const unsigned blocks = (unsigned)h->C;
   bool first = true;
+  // non-symmetric alphas four (or two) at a time, see demux_wave_multi_kernel; the rest one per launch
+  std::vector<int> plain;
+  for (int n = 1; n < A; ++n)
+    if (p->alpha[n] != 0.5) plain.push_back(n);
+#define MULTI_LAUNCH(NA, NS, WS, S0)                                                                                  \
+  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,   \
+                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, sel, S0, h->d_ll)
+  size_t done = 0;
+  while (plain.size() - done >= 4) {
+    wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
+    if (first) MULTI_LAUNCH(4, 16, true, 0);
+    else MULTI_LAUNCH(4, 16, false, 0);
+    MULTI_LAUNCH(4, 16, false, 16);
+    MULTI_LAUNCH(4, 16, false, 32);
+    MULTI_LAUNCH(4, 16, false, 48);
+    HIPCHK(h, hipGetLastError());
+    first = false;
+    done += 4;
+  }
+  while (plain.size() - done >= 2) {
+    wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
+    if (first) MULTI_LAUNCH(2, 32, true, 0);
+    else MULTI_LAUNCH(2, 32, false, 0);
+    MULTI_LAUNCH(2, 32, false, 32);
+    HIPCHK(h, hipGetLastError());
+    first = false;
+    done += 2;
+  }
+#undef MULTI_LAUNCH
   for (int n = 1; n < A; ++n) {
     const bool sym = (p->alpha[n] == 0.5);
+    if (!sym && !(done < plain.size() && plain[done] == n)) continue;  // already covered by a multi-alpha launch
 #define WAVE_LAUNCH(NS, WS)                                                                                          \
   hipLaunchKernelGGL((demux_wave_kernel<NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,             \
                      h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, n, h->d_ll)
@@ -179,6 +321,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 #undef WAVE_LAUNCH
     HIPCHK(h, hipGetLastError());
     first = false;
+    if (!sym) ++done;
   }
   if (first) {  // nAlpha == 1: singlets only; run the symmetric kernel on alpha[0] and let the call kernel ignore n >= 1
     hipLaunchKernelGGL((demux_wave_kernel<32, true>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,
