@@ -66,6 +66,9 @@ struct muxgl_handle {
   double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_quad.hip)
   double* d_gp0s = nullptr;  // V <= 16: per-SNP sum of sample 0's triple (the factor every singlet carries, :806)
   double* d_ll = nullptr;  // [C][V][V][A]
+  double* d_llw = nullptr; // wave path: [C][A][64 rotation steps][64 lanes], see demux_wave.hip
+  size_t llw_cap = 0;
+  bool ll_wave = false;    // the last sweep left its result in d_llw
   size_t ll_cap = 0;
   bool ll_zeroed = false;
   muxgl_demux_cell* d_dcells = nullptr;
@@ -219,5 +222,7 @@ int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
+int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p);  // standard LL tensor allocated and zeroed
+int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);
 void demux_row_release(muxgl_row_state** st);

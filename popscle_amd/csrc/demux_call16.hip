@@ -32,7 +32,77 @@ __global__ void __launch_bounds__(64)
                       doublet_prior, ll + (size_t)ic * nv * nv * nAlpha, out + ic);
 }
 
+// The call on the wave layout llw[c][n][step t][lane j] (demux_wave.hip): lane j owns row j; at step t it faces sample
+// k = j - t - 1 mod 64 (re-derived with the rotation the sweep used), so every read of the wave is one contiguous 512-byte
+// line run instead of 64 lines 3 KB apart.  Rows are scanned in step order, not in k order: the top-2 lists are kept
+// with the position-aware insertion, the evidence sums do not depend on the order.
+__global__ void __launch_bounds__(64)
+    demux_call_wave_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
+                           double doublet_prior, const double* __restrict__ llw, muxgl_demux_cell* __restrict__ out) {
+  const int64_t i = blockIdx.x;
+  const int j = threadIdx.x;
+  const bool live = j < nv;
+  const double* in = llw + (size_t)i * nAlpha * 4096;
+  const double log_single_prior = log((1.0 - doublet_prior) / nv);
+  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
+  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
+  const int32_t nsnps = (int32_t)(cell_ptr[i + 1] - cell_ptr[i]);
+  top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
+  const double NEG_INF = -__builtin_huge_val();
+  double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0;
+  if (nsnps > 0) {  // (an empty cell leaves no LL behind; its record is all zeros, :653)
+    if (live) {
+      const double s = in[j];  // llksAB[j][0][0]
+      top2_push(sng, s, j);
+      sterm = s + log_single_prior;
+      rowmax = sterm;
+    }
+    // pass 1: scans, and the largest evidence term of the row
+    for (int n = 1; n < nAlpha; ++n) {
+      const bool sym = al.a[n] == 0.5;
+      int k = j;
+      for (int t = 0; t < 63; ++t) {
+        k = __builtin_amdgcn_mov_dpp(k, 0x13C, 0xF, 0xF, false);
+        if (!live || k >= nv) continue;
+        const double v = in[((size_t)n * 64 + t) * 64 + j];
+        if (sym) {
+          if (k < j) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
+        } else {
+          rowmax = fmax(rowmax, v + log_doublet_prior1);
+        }
+        top2_insert(dbl, v, (j * nv + k) * nAlpha + n);
+      }
+    }
+    // pass 2: the row's evidence terms relative to that maximum
+    if (rowmax > NEG_INF) racc = exp(sterm - rowmax);
+    for (int n = 1; n < nAlpha; ++n) {
+      const bool sym = al.a[n] == 0.5;
+      int k = j;
+      for (int t = 0; t < 63; ++t) {
+        k = __builtin_amdgcn_mov_dpp(k, 0x13C, 0xF, 0xF, false);
+        if (!live || k >= nv || !(rowmax > NEG_INF)) continue;
+        const double v = in[((size_t)n * 64 + t) * 64 + j];
+        if (sym) {
+          if (k < j) racc += exp(v + log_doublet_prior2 - rowmax);
+        } else {
+          racc += exp(v + log_doublet_prior1 - rowmax);
+        }
+      }
+    }
+  }
+  demux_call_finish<64>(j, true, nsnps, nv, nAlpha, al.a, doublet_prior, sng, dbl, sterm, rowmax, racc, out + i);
+}
+
 }  // namespace
+
+int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  call_alpha al;
+  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+  hipLaunchKernelGGL(demux_call_wave_kernel, dim3((unsigned)h->C), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
+                     p->n_alpha, al, p->doublet_prior, h->d_llw, h->d_dcells);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
 
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   call_alpha al;

@@ -73,56 +73,30 @@ __device__ __forceinline__ top2 top2_xor(const top2& t, int m) {
   return o;
 }
 
-// lane = lane id in the wave; lanes [base, base+G) with base = lane & ~(G-1) work on one cell.  ll_cell points at that
-// cell's [nv][nv][nAlpha] hypotheses (global or LDS); lane base+0 writes *out when cell_ok.
+// order-independent insertion (the scans above rely on ascending positions; this one does not)
+__device__ __forceinline__ void top2_insert(top2& t, double v, int32_t pos) {
+  if (key_before(v, pos, t.bv, t.bp)) {
+    t.nv = t.bv;
+    t.np = t.bp;
+    t.bv = v;
+    t.bp = pos;
+  } else if (key_before(v, pos, t.nv, t.np)) {
+    t.nv = v;
+    t.np = pos;
+  }
+}
+
+// Second half of the call: merges the per-lane row results (top-2 lists, the row's largest evidence term rowmax, its
+// evidence sum racc relative to rowmax, the singlet term sterm) over the G lanes of the cell and makes the decision.
 template <int G>
-__device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
-                                                 const double* gridAlpha, double doublet_prior, const double* ll_cell,
-                                                 muxgl_demux_cell* out) {
+__device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
+                                                  const double* gridAlpha, double doublet_prior, top2 sng, top2 dbl,
+                                                  double sterm, double rowmax, double racc, muxgl_demux_cell* out) {
   const int j = lane & (G - 1);
-  const bool live = cell_ok && j < nv;
+  const double NEG_INF = -__builtin_huge_val();
   const double log_single_prior = log((1.0 - doublet_prior) / nv);
   const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
   const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
-
-  top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
-  const double NEG_INF = -__builtin_huge_val();
-  double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0;
-  if (live) {
-    const double* row = ll_cell + (size_t)j * nv * nAlpha;
-    const double s = row[0];  // llksAB[j][0][0]
-    top2_push(sng, s, j);
-    sterm = s + log_single_prior;
-    rowmax = sterm;
-    // pass 1: scans, and the largest evidence term of the row
-    for (int k = 0; k < nv; ++k) {
-      if (k == j) continue;
-      for (int n = 1; n < nAlpha; ++n) {
-        const double v = row[k * nAlpha + n];
-        if (gridAlpha[n] == 0.5) {
-          if (k < j) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
-        } else {
-          rowmax = fmax(rowmax, v + log_doublet_prior1);
-        }
-        top2_push(dbl, v, (j * nv + k) * nAlpha + n);
-      }
-    }
-    // pass 2: the row's evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
-    if (rowmax > NEG_INF) {
-      racc = exp(sterm - rowmax);
-      for (int k = 0; k < nv; ++k) {
-        if (k == j) continue;
-        for (int n = 1; n < nAlpha; ++n) {
-          const double v = row[k * nAlpha + n];
-          if (gridAlpha[n] == 0.5) {
-            if (k < j) racc += exp(v + log_doublet_prior2 - rowmax);
-          } else {
-            racc += exp(v + log_doublet_prior1 - rowmax);
-          }
-        }
-      }
-    }
-  }
   // merge the G rows: top-2 lists, maxima, then the scaled sums
   double M = rowmax, Ms = sterm;
 #pragma unroll
@@ -237,5 +211,59 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
   *out = o;
 }
 
+
+
+// lane = lane id in the wave; lanes [base, base+G) with base = lane & ~(G-1) work on one cell.  ll_cell points at that
+// cell's [nv][nv][nAlpha] hypotheses (global or LDS); lane base+0 writes *out when cell_ok.
+template <int G>
+__device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
+                                                 const double* gridAlpha, double doublet_prior, const double* ll_cell,
+                                                 muxgl_demux_cell* out) {
+  const int j = lane & (G - 1);
+  const bool live = cell_ok && j < nv;
+  const double log_single_prior = log((1.0 - doublet_prior) / nv);
+  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
+  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
+
+  top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
+  const double NEG_INF = -__builtin_huge_val();
+  double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0;
+  if (live) {
+    const double* row = ll_cell + (size_t)j * nv * nAlpha;
+    const double s = row[0];  // llksAB[j][0][0]
+    top2_push(sng, s, j);
+    sterm = s + log_single_prior;
+    rowmax = sterm;
+    // pass 1: scans, and the largest evidence term of the row
+    for (int k = 0; k < nv; ++k) {
+      if (k == j) continue;
+      for (int n = 1; n < nAlpha; ++n) {
+        const double v = row[k * nAlpha + n];
+        if (gridAlpha[n] == 0.5) {
+          if (k < j) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
+        } else {
+          rowmax = fmax(rowmax, v + log_doublet_prior1);
+        }
+        top2_push(dbl, v, (j * nv + k) * nAlpha + n);
+      }
+    }
+    // pass 2: the row's evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
+    if (rowmax > NEG_INF) {
+      racc = exp(sterm - rowmax);
+      for (int k = 0; k < nv; ++k) {
+        if (k == j) continue;
+        for (int n = 1; n < nAlpha; ++n) {
+          const double v = row[k * nAlpha + n];
+          if (gridAlpha[n] == 0.5) {
+            if (k < j) racc += exp(v + log_doublet_prior2 - rowmax);
+          } else {
+            racc += exp(v + log_doublet_prior1 - rowmax);
+          }
+        }
+      }
+    }
+  }
+  demux_call_finish<G>(lane, cell_ok, nsnps, nv, nAlpha, gridAlpha, doublet_prior, sng, dbl, sterm, rowmax, racc, out);
+}
 
 }  // namespace muxgl_call

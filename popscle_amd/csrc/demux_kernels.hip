@@ -446,6 +446,21 @@ static bool same_params(const muxgl_demux_params& a, const muxgl_demux_params& b
   return true;
 }
 
+// LL tensor [C][V][V][A]; slots the sweep never writes must read 0
+int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p) {
+  const size_t need = (size_t)h->C * h->V * h->V * p->n_alpha;
+  if (need > h->ll_cap) {
+    if (dev_alloc(h, &h->d_ll, need)) return 1;
+    h->ll_cap = need;
+    h->ll_zeroed = false;
+  }
+  if (!h->ll_zeroed) {
+    HIPCHK(h, hipMemsetAsync(h->d_ll, 0, sizeof(double) * (need ? need : 1), h->stream));
+    h->ll_zeroed = true;
+  }
+  return 0;
+}
+
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const int A = p->n_alpha;
   alpha_args al;
@@ -459,25 +474,19 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     h->pairs_valid = false;
     h->ll_zeroed = false;
   }
-  // LL tensor [C][V][V][A]; slots the sweep never writes must read 0
-  const size_t need = (size_t)h->C * h->V * h->V * A;
-  if (need > h->ll_cap) {
-    if (dev_alloc(h, &h->d_ll, need)) return 1;
-    h->ll_cap = need;
-    h->ll_zeroed = false;
-  }
-  if (!h->ll_zeroed) {
-    HIPCHK(h, hipMemsetAsync(h->d_ll, 0, sizeof(double) * (need ? need : 1), h->stream));
-    h->ll_zeroed = true;
-  }
-
   h->records_on_host = false;
-  int rc = demux_quad_launch(h, p);          // V <= 16 and the reference's default grid {0, 0.5}: quad kernel
-  if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the quad path's finish kernel
-  if (rc < 0) rc = demux_row_launch(h, p);   // V <= 16, other grids: row kernel
-  if (rc < 0) rc = demux_wave_launch(h, p);  // 16 < V <= 64: one wave per cell, one lane per sample
+  h->ll_wave = false;
+  int rc = -1;
+  if (h->V <= 16) {
+    if (demux_ensure_ll(h, p)) return 1;
+    rc = demux_quad_launch(h, p);               // the reference's default grid {0, 0.5}: quad kernel
+    if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the quad path's finish kernel
+    if (rc < 0) rc = demux_row_launch(h, p);    // other grids: row kernel
+  }
+  if (rc < 0) rc = demux_wave_launch(h, p);  // V <= 64: one wave per cell, one lane per sample (own LL layout)
   if (rc > 0) return rc;
   if (rc < 0) {                     // general tile sweep
+    if (demux_ensure_ll(h, p)) return 1;
     if (!h->pairs_valid) {
       if (build_pairs(h, p, &symmask)) return 1;
       h->pairs_valid = true;
@@ -491,7 +500,9 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
 
   tic(h, MUXGL_T_DEMUX_CALL);
-  if (h->V <= 64 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
+  if (h->ll_wave) {
+    if (demux_call_wave_launch(h, p)) return 1;
+  } else if (h->V <= 64 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
     if (demux_call16_launch(h, p)) return 1;  // 16 or 64 lanes per cell
   } else {
     const unsigned blocks = (unsigned)((h->C + 63) / 64);

@@ -104,23 +104,25 @@ __global__ void __launch_bounds__(64, 2)
     }
   }
 
-  // which sample does lane j face after t+1 rotations?  (measured with the same primitive)
-  double* out = ll + (size_t)c * V * V * nAlpha;
+  // Results go to the wave layout llw[c][n][step t][lane j] (coalesced; the partner of (t, j) is re-derived by the
+  // readers with the same rotation): lane j, step t holds the hypothesis (j, k = j - t - 1 mod 64).  Alpha = 0.5 fills
+  // the mirrored half too: the pair met at step t by lane j is met at step 62 - t by lane k.
+  double* out = ll + (size_t)c * nAlpha * 4096;
   int kk = j;
 #pragma unroll
   for (int t = 0; t < NSHIFT; ++t) {
     kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
     const double v = prodacc_log(acc[t], ex[t]);
-    if (n_sel > 0 && live && kk < V && kk != j) {
+    if (n_sel > 0) {
       if (NSHIFT == 63) {
-        out[((size_t)j * V + kk) * nAlpha + n_sel] = v;
+        out[((size_t)n_sel * 64 + t) * 64 + j] = v;
       } else if (t < 31 || j > kk) {  // step 32 of 64 lanes meets every unordered pair twice: one writer
-        out[((size_t)j * V + kk) * nAlpha + n_sel] = v;
-        out[((size_t)kk * V + j) * nAlpha + n_sel] = v;
+        out[((size_t)n_sel * 64 + t) * 64 + j] = v;
+        out[((size_t)n_sel * 64 + (62 - t)) * 64 + kk] = v;
       }
     }
   }
-  if (WITH_SINGLET && live) out[(size_t)j * V * nAlpha] = prodacc_log(accS, exS);
+  if (WITH_SINGLET) out[j] = prodacc_log(accS, exS);  // llw[c][0][0][j]
 }
 
 // Several non-symmetric alphas in one launch.  The partner rotation (six DPP moves per step) does not depend on alpha,
@@ -217,20 +219,32 @@ __global__ void __launch_bounds__(64, 2)
     }
   }
 
-  // which sample does lane j face after the offset and t+1 rotations?  (measured with the same primitives)
-  double* out = ll + (size_t)c * V * V * nAlpha;
-  int kk = j;
-  if (s0) kk = __shfl(kk, src, 64);
+  double* out = ll + (size_t)c * nAlpha * 4096;  // wave layout, see demux_wave_kernel
 #pragma unroll
-  for (int t = 0; t < NS; ++t) {
-    kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
-    if (live && kk < V && kk != j) {
+  for (int t = 0; t < NS; ++t)
+    if (s0 + t < 63) {
 #pragma unroll
       for (int a = 0; a < NA; ++a)
-        out[((size_t)j * V + kk) * nAlpha + sel.n[a]] = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
+        out[((size_t)sel.n[a] * 64 + s0 + t) * 64 + j] = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
     }
-  }
-  if (WITH_SINGLET && live) out[(size_t)j * V * nAlpha] = prodacc_log(accS, exS);
+  if (WITH_SINGLET) out[j] = prodacc_log(accS, exS);
+}
+
+// wave layout -> the ABI's [C][V][V][A] tensor (only when the caller asks for it)
+__global__ void __launch_bounds__(64)
+    demux_wave_to_full_kernel(const double* __restrict__ llw, const int64_t* __restrict__ cell_ptr, int V, int nAlpha,
+                              double* __restrict__ ll) {
+  const int64_t c = blockIdx.x;
+  const int j = threadIdx.x;
+  if (j >= V || cell_ptr[c] == cell_ptr[c + 1]) return;  // the sweep leaves nothing behind for an empty cell
+  const double* in = llw + (size_t)c * nAlpha * 4096;
+  double* out = ll + (size_t)c * V * V * nAlpha;
+  out[(size_t)j * V * nAlpha] = in[j];
+  for (int n = 1; n < nAlpha; ++n)
+    for (int t = 0; t < 63; ++t) {
+      const int k = (j - t - 1) & 63;  // wave_ror:1 brings lane j the value of lane j - 1
+      if (k < V) out[((size_t)j * V + k) * nAlpha + n] = in[((size_t)n * 64 + t) * 64 + j];
+    }
 }
 
 }  // namespace
@@ -266,6 +280,7 @@ int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr) {
 // returns -1 when the wave path does not apply, 0 ok, 1 error
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (h->V > 64 || !h->wave || h->C == 0 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
+  if (p->n_alpha < 2) return -1;  // singlets only: left to the general path
   if (h->V <= 16 && !(h->flags & MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;  // the row/quad kernels are better there
   muxgl_wave_state* st = h->wave;
   const int A = p->n_alpha;
@@ -274,6 +289,11 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (need > st->pg_cap) {
     if (dev_alloc(h, &st->d_pg, need)) return 1;
     st->pg_cap = need;
+  }
+  const size_t llw_need = (size_t)h->C * A * 4096;
+  if (llw_need > h->llw_cap) {
+    if (dev_alloc(h, &h->d_llw, llw_need)) return 1;
+    h->llw_cap = llw_need;
   }
   tic(h, MUXGL_T_DEMUX_SWEEP);
   if (demux_entry_pg_launch(h, p, st->d_pg)) return 1;
@@ -285,7 +305,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (p->alpha[n] != 0.5) plain.push_back(n);
 #define MULTI_LAUNCH(NA, NS, WS, S0)                                                                                  \
   hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,   \
-                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, sel, S0, h->d_ll)
+                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, sel, S0, h->d_llw)
   size_t done = 0;
   while (plain.size() - done >= 4) {
     wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
@@ -313,7 +333,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (!sym && !(done < plain.size() && plain[done] == n)) continue;  // already covered by a multi-alpha launch
 #define WAVE_LAUNCH(NS, WS)                                                                                          \
   hipLaunchKernelGGL((demux_wave_kernel<NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,             \
-                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, n, h->d_ll)
+                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, n, h->d_llw)
     if (sym && first) WAVE_LAUNCH(32, true);
     else if (sym) WAVE_LAUNCH(32, false);
     else if (first) WAVE_LAUNCH(63, true);
@@ -323,9 +343,10 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     first = false;
     if (!sym) ++done;
   }
-  if (first) {  // nAlpha == 1: singlets only; run the symmetric kernel on alpha[0] and let the call kernel ignore n >= 1
-    hipLaunchKernelGGL((demux_wave_kernel<32, true>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,
-                       h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, 0, h->d_ll);
+  h->ll_wave = true;
+  if (h->want_full_ll) {
+    if (demux_ensure_ll(h, p)) return 1;
+    hipLaunchKernelGGL(demux_wave_to_full_kernel, dim3(blocks), dim3(64), 0, h->stream, h->d_llw, h->d_cell_ptr, h->V, A, h->d_ll);
     HIPCHK(h, hipGetLastError());
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);

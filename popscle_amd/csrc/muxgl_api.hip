@@ -79,6 +79,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_gp0s);
   dev_free(&h->d_ll);
   dev_free(&h->d_dcells);
+  dev_free(&h->d_llw);
   dev_free(&h->d_pairs);
   dev_free(&h->d_af);
   dev_free(&h->d_egls);
