@@ -222,6 +222,8 @@ int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
+const int32_t* demux_wave_order(const muxgl_handle* h);  // cells, longest first (device)
+int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc);  // 16 < K <= 64; -1: not applicable
 int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p);  // standard LL tensor allocated and zeroed
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);

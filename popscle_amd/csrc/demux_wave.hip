@@ -255,6 +255,8 @@ struct muxgl_wave_state {
   size_t pg_cap = 0;
 };
 
+const int32_t* demux_wave_order(const muxgl_handle* h) { return h->wave ? h->wave->d_order : nullptr; }
+
 void demux_wave_free(muxgl_handle* h) {
   muxgl_wave_state* st = h->wave;
   if (!st) return;

@@ -554,17 +554,22 @@ __global__ void __launch_bounds__(256)
 // K-fold masked one.  Loads are software-pipelined one element ahead (entry id and cell are SNP-major and sequential;
 // the assignment lookup and the 72-byte likelihood gather of the next element fly during the current merge).
 // The read counts of the cluster pileups are plain sums and are not needed by the EM: fmx_counts_kernel computes
-// them on demand (muxgl_fmx_get_cluster_pileup).  Needs 64*(9K+1)*8 B of LDS.
+// them on demand (muxgl_fmx_get_cluster_pileup).
+// For K > 16 a marker is shared by P = 2 or 4 lanes, each holding KL = K/P (<= 16) of its cluster states: the lanes of a
+// marker read the same list (identical addresses, one fetch) and only the lane that owns the entry's cluster merges.
+// Needs 64*(9*KL+1)*8 B of LDS.
 __global__ void __launch_bounds__(64)
-    fmx_mstep_snp_kernel(int64_t S, int64_t s0, int64_t s1, int K, const int64_t* __restrict__ snp_ptr,
+    fmx_mstep_snp_kernel(int64_t S, int64_t s0, int64_t s1, int K, int P, int KL, const int64_t* __restrict__ snp_ptr,
                          const int32_t* __restrict__ snp_cell, const int32_t* __restrict__ clust,
                          const double* __restrict__ segls, double* __restrict__ cgls) {
   extern __shared__ double sm[];
   const int lane = threadIdx.x;
-  const int STR = K * 9 + 1;
+  const int STR = KL * 9 + 1;
   double* st = sm + (size_t)lane * STR;
-  for (int i = 0; i < K * 9; ++i) st[i] = 1.0;
-  const int64_t s = s0 + (int64_t)blockIdx.x * 64 + lane;
+  for (int i = 0; i < KL * 9; ++i) st[i] = 1.0;
+  const int per = 64 / P;                       // markers per wave
+  const int part = lane / per;                  // this lane owns clusters [part*KL, part*KL + KL)
+  const int64_t s = s0 + (int64_t)blockIdx.x * per + (lane - part * per);
   int64_t p = 0, p1 = 0;
   if (s < s1) {
     p = snp_ptr[s];
@@ -599,8 +604,8 @@ __global__ void __launch_bounds__(64)
   auto merge_blk = [&](const blk_t& B, int64_t base) {
 #pragma unroll
     for (int u = 0; u < MU; ++u) {
-      const int32_t k = B.k[u];
-      if (base + u < p1 && k >= 0) {  // only cells called singlets carry a cluster (b8, :590-596)
+      const int32_t k = B.k[u] - part * KL;
+      if (base + u < p1 && k >= 0 && k < KL) {  // only cells called singlets carry a cluster (b8, :590-596)
         double* q = st + k * 9;
         double v[9], tmp = 0.0;
 #pragma unroll
@@ -639,8 +644,8 @@ __global__ void __launch_bounds__(64)
     p += MU;
   }
   if (s < s1) {
-    for (int k = 0; k < K; ++k) {
-      double* og = cgls + ((size_t)k * S + s) * 9;
+    for (int k = 0; k < KL && part * KL + k < K; ++k) {
+      double* og = cgls + ((size_t)(part * KL + k) * S + s) * 9;
 #pragma unroll
       for (int i = 0; i < 9; ++i) og[i] = st[k * 9 + i];
     }
@@ -652,12 +657,14 @@ __global__ void __launch_bounds__(64)
 static int fmx_mstep_launch(muxgl_handle* h) {
   const int64_t n = (h->fs1 - h->fs0) * h->K;
   if (n <= 0) return 0;
-  const size_t lds = (size_t)64 * (h->K * 9 + 1) * sizeof(double);
-  if (lds <= 150 * 1024 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // one lane per SNP, cluster states in LDS
+  const int P = h->K <= 16 ? 1 : (h->K <= 32 ? 2 : 4), KL = (h->K + P - 1) / P;
+  const size_t lds = (size_t)64 * (KL * 9 + 1) * sizeof(double);
+  if (h->K <= 64 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // lane(s) per SNP, cluster states in LDS
     const int64_t ns = h->fs1 - h->fs0;
+    const int per = 64 / P;
     HIPCHK(h, hipFuncSetAttribute((const void*)fmx_mstep_snp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fmx_mstep_snp_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), lds, h->stream, h->S, h->fs0,
-                       h->fs1, h->K, h->d_snp_ptr, h->d_snp_cell, h->d_clust, h->d_segls, h->d_cgls);
+    hipLaunchKernelGGL(fmx_mstep_snp_kernel, dim3((unsigned)((ns + per - 1) / per)), dim3(64), lds, h->stream, h->S,
+                       h->fs0, h->fs1, h->K, P, KL, h->d_snp_ptr, h->d_snp_cell, h->d_clust, h->d_segls, h->d_cgls);
     HIPCHK(h, hipGetLastError());
     return 0;
   }
@@ -845,6 +852,7 @@ static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   muxgl_row_state* st = h->frow ? h->frow : h->row;
   int qrc = -1;
   if (nc > 0) qrc = fmx_quad_estep_launch(h, h->fqrow ? h->fqrow : h->qrow, c0, nc);  // K <= 16: quad tiling
+  if (nc > 0 && qrc < 0) qrc = fmx_wave_estep_launch(h, c0, nc);  // 16 < K <= 64: one wave per cell
   if (qrc > 0) return 1;
   if (nc > 0 && qrc < 0) {
     if (K <= 16 && st && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
