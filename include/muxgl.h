@@ -107,6 +107,8 @@ enum {
   MUXGL_T_FMX_ESTEP = 6,   /* E-step pair sweep (b6) */
   MUXGL_T_FMX_CALL = 7,    /* scans + re-assignment (b7,b8 classification) */
   MUXGL_T_FMX_MSTEP = 8,   /* ordered clamped merge (b5,b8) */
+  MUXGL_T_FMXOLD_PAIR = 9, /* freemuxlet-old: pairwise droplet distance matrix (c1) */
+  MUXGL_T_FMXOLD_VOTE = 10, /* freemuxlet-old: one voting pass (c1) */
   MUXGL_T_COUNT = 16
 };
 
@@ -167,6 +169,39 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
 
 /* cluster pileups for the .clust1.vcf.gz writer (cmd_cram_freemux2.cpp:608-658): gls[K][S][9], counts[K][S][3] */
 int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
+
+/* ---- freemuxlet-old (`popscle freemuxlet-old`, cmd_cram_freemuxlet.cpp): the parts that differ from freemux2.  The
+ *      entry pileups, scores and the EM loop are the calls above (geno_error = 0 except in the tenth and last
+ *      iteration, no early stop: cmd_cram_freemuxlet.cpp:457,485,500); what is particular to the old command is its
+ *      initial clustering from a pairwise droplet distance matrix.  rand() and std::random_shuffle stay with the
+ *      caller, which passes the visiting orders and the vote jitters in the reference's drawing order. ------------- */
+
+/* dropD (sc_drop_seq.h:45-52) of the cell pair a > b, stored at a(a-1)/2 + b */
+typedef struct {
+  int32_t nsnps, nread1, nread2, _pad;
+  double llk0, llk2;
+} muxgl_dropd;
+
+/* pairwise distance matrix, cmd_cram_freemuxlet.cpp:176-221, after muxgl_fmx_prepare.  The device keeps one vote sign
+ * per ordered pair (+1: llk2 - llk0 > bf_thres, -1: llk0 - llk2 > bf_thres, :273-278,312-313; C^2 bytes).
+ * full: NULL or [C(C-1)/2] records (what --aux-files prints to .ldist.gz, :264, and what parity tests compare). */
+int muxgl_fmxold_pair_dist(muxgl_handle* h, double bf_thres, muxgl_dropd* full);
+
+/* the sign matrix as [C][C] bytes (tests) */
+int muxgl_fmxold_get_signs(muxgl_handle* h, int8_t* out);
+
+/* first-pass voting, cmd_cram_freemuxlet.cpp:245-291.  order[C] = drops_srted (muxgl_fmx_greedy_init's sort order:
+ * score descending, ties by id descending); jitter[n_visited][K] = the values `rand()/(RAND_MAX+1.)/1000.` drawn for
+ * the visited cells (:257-259).  clust_out[C]: cluster, or -1 for cells beyond frac_init_clust; ccounts: NULL or [K].
+ * K <= 64. */
+int muxgl_fmxold_vote_init(muxgl_handle* h, int32_t K, const int32_t* order, const double* jitter,
+                           double frac_init_clust, int32_t* clust_out, int32_t* ccounts);
+
+/* one refinement pass, cmd_cram_freemuxlet.cpp:297-343 (one value of `iter`).  order[C] = orand after
+ * std::random_shuffle (:301-302), jitter[C][K] in visiting order.  clust_inout[C] is updated in place; changed and
+ * ccounts[K] as the reference reports them (:346-349). */
+int muxgl_fmxold_vote_refine(muxgl_handle* h, int32_t K, const int32_t* order, const double* jitter,
+                             int32_t keep_init_missing, int32_t* clust_inout, int32_t* changed, int32_t* ccounts);
 
 /* ---- sharded EM (multi-GPU).  Every rank holds the whole pileup (muxgl_set_pileup + muxgl_fmx_prepare) and owns a
  *      cell range [c0,c1) for the E-step/scans/re-assignment and a SNP range [s0,s1) for the cluster GP rows and the

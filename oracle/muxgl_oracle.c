@@ -673,3 +673,133 @@ int32_t oracle_fmx_iterate(int64_t C, int64_t S, int32_t K, const int64_t* cell_
   *namb_out = namb;
   return nchanged;
 }
+
+/* ---------------------------------------------------------------------------------------- freemuxlet-old deltas */
+
+/* cmd_cram_freemuxlet.cpp:187-221 */
+void oracle_fmxold_pair_dist(int64_t C, int64_t S, const int64_t* cell_ptr, const int32_t* entry_snp,
+                             const oracle_plp* eplp, const double* afs, oracle_dropd* out) {
+  memset(out, 0, sizeof(oracle_dropd) * (size_t)(C * (C - 1) / 2));
+  /* snp_cell_plps[v] : std::map<cell, plp*> (:113,135) == the entries of SNP v in ascending cell id */
+  int64_t nnz = cell_ptr[C];
+  int64_t* sp = (int64_t*)calloc((size_t)S + 1, sizeof(int64_t));
+  for (int64_t e = 0; e < nnz; ++e) ++sp[entry_snp[e] + 1];
+  for (int64_t v = 0; v < S; ++v) sp[v + 1] += sp[v];
+  int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)S);
+  memcpy(fill, sp, sizeof(int64_t) * (size_t)S);
+  int64_t* sent = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nnz ? nnz : 1));
+  int32_t* scell = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+  for (int64_t i = 0; i < C; ++i)
+    for (int64_t e = cell_ptr[i]; e < cell_ptr[i + 1]; ++e) {
+      int64_t p = fill[entry_snp[e]]++;
+      sent[p] = e;
+      scell[p] = (int32_t)i;
+    }
+  for (int64_t v = 0; v < S; ++v) {
+    for (int64_t p = sp[v]; p < sp[v + 1]; ++p) {
+      const oracle_plp* pi = &eplp[sent[p]];
+      const double* glis = pi->gls;
+      for (int64_t q = sp[v]; q < p; ++q) {
+        const oracle_plp* pj = &eplp[sent[q]];
+        const double* gljs = pj->gls;
+        double af = afs[v];
+        double lk0 = 0, lk2 = 0;
+        double gps[3];
+        gps[0] = (1.0 - af) * (1.0 - af);
+        gps[1] = 2.0 * af * (1.0 - af);
+        gps[2] = af * af;
+        for (int32_t gi = 0; gi < 3; ++gi) { /* :203-208 */
+          lk2 += (glis[gi * 3 + gi] * gljs[gi * 3 + gi] * gps[gi]);
+          for (int32_t gj = 0; gj < 3; ++gj) {
+            lk0 += (glis[gi * 3 + gi] * gljs[gj * 3 + gj] * gps[gi] * gps[gj]);
+          }
+        }
+        int64_t a = scell[p], b = scell[q];
+        oracle_dropd* d = &out[a * (a - 1) / 2 + b]; /* dropDs[it->first][jt->first] (:210) */
+        ++d->nsnps;
+        d->nread1 += pi->nreads;
+        d->nread2 += pj->nreads;
+        d->llk2 += log(lk2);
+        d->llk0 += log(lk0);
+      }
+    }
+  }
+  free(sp);
+  free(fill);
+  free(sent);
+  free(scell);
+}
+
+static const oracle_dropd* dd_at(const oracle_dropd* dd, int64_t a, int64_t b) {
+  return (a > b) ? &dd[a * (a - 1) / 2 + b] : &dd[b * (b - 1) / 2 + a];
+}
+
+/* cmd_cram_freemuxlet.cpp:245-291 */
+void oracle_fmxold_vote_init(int64_t C, int32_t K, const oracle_dropd* dd, const int32_t* order, const double* jitter,
+                             double bfThres, double fracInitClust, int32_t* clusts, int32_t* ccounts) {
+  double* votes = (double*)malloc(sizeof(double) * (size_t)K);
+  for (int64_t i = 0; i < C; ++i) clusts[i] = -1;
+  for (int32_t j = 0; j < K; ++j) ccounts[j] = 0;
+  int64_t t = 0;
+  for (int64_t i = 0; i < C; ++i) {
+    int32_t si = order[i];
+    if (i > C * fracInitClust) continue; /* :248 */
+    for (int32_t j = 0; j < K; ++j) votes[j] = jitter[t * K + j]; /* :257-259 */
+    ++t;
+    for (int64_t j = 0; j < i; ++j) {
+      int32_t sj = order[j];
+      const oracle_dropd* d = dd_at(dd, si, sj);
+      if (d->llk0 - d->llk2 > bfThres) votes[clusts[sj]] -= 1.0;      /* :273-275 */
+      else if (d->llk2 - d->llk0 > bfThres) votes[clusts[sj]] += 1.0; /* :276-278 */
+    }
+    int32_t elected = 0;
+    double maxvote = votes[0];
+    for (int32_t j = 1; j < K; ++j) {
+      if (maxvote < votes[j]) {
+        elected = j;
+        maxvote = votes[j];
+      }
+    }
+    clusts[si] = elected;
+    ++ccounts[elected];
+  }
+  free(votes);
+}
+
+/* cmd_cram_freemuxlet.cpp:297-343, one value of iter */
+int32_t oracle_fmxold_vote_refine(int64_t C, int32_t K, const oracle_dropd* dd, const int32_t* order,
+                                  const double* jitter, double bfThres, int32_t keepInitMissing, int32_t* clusts,
+                                  int32_t* ccounts) {
+  double* votes = (double*)malloc(sizeof(double) * (size_t)K);
+  int32_t changed = 0;
+  for (int32_t j = 0; j < K; ++j) ccounts[j] = 0;
+  for (int64_t i = 0; i < C; ++i) {
+    int32_t si = order[i];
+    for (int32_t j = 0; j < K; ++j) votes[j] = jitter[i * K + j];
+    for (int64_t j = 0; j < C; ++j) {
+      if (si != j) {
+        const oracle_dropd* d = dd_at(dd, si, j);
+        double bf = d->llk2 - d->llk0;
+        if (clusts[j] >= 0) {
+          if (bf > bfThres) ++votes[clusts[j]];
+          else if (bf < 0 - bfThres) --votes[clusts[j]];
+        }
+      }
+    }
+    int32_t elected = 0;
+    double maxvote = votes[0];
+    for (int32_t j = 1; j < K; ++j) {
+      if (maxvote < votes[j]) {
+        elected = j;
+        maxvote = votes[j];
+      }
+    }
+    if ((clusts[si] >= 0) || (keepInitMissing == 0)) { /* :333-337 */
+      if (clusts[si] != elected) ++changed;
+      clusts[si] = elected;
+      ++ccounts[elected];
+    }
+  }
+  free(votes);
+  return changed;
+}

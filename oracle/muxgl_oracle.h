@@ -122,6 +122,32 @@ int32_t oracle_fmx_iterate(int64_t C, int64_t S, int32_t K, const int64_t* cell_
 /* state before the first iteration: types[i] = 0 if clust[i]>=0 else -1 (:194,213,244), jBest=kBest=-1 (:349-350) */
 void oracle_fmx_init_cells(int64_t C, const int32_t* clust, oracle_fmx_cell* cells);
 
+/* ---- freemuxlet-old (cmd_cram_freemuxlet.cpp), the rows that differ from freemux2 ------------------------------- */
+
+/* dropD of cmd_cram_freemuxlet.cpp:176-221 (struct in sc_drop_seq.h): one record per cell pair a > b, stored at
+ * a(a-1)/2 + b */
+typedef struct {
+  int32_t nsnps, nread1, nread2, _pad;
+  double llk0, llk2;
+} oracle_dropd;
+
+/* pairwise distance matrix, cmd_cram_freemuxlet.cpp:187-221: SNPs ascending, then cell pairs (a, b < a) of the SNP's
+ * std::map order.  out = [C(C-1)/2], zero-initialised here. */
+void oracle_fmxold_pair_dist(int64_t C, int64_t S, const int64_t* cell_ptr, const int32_t* entry_snp,
+                             const oracle_plp* eplp, const double* af, oracle_dropd* out);
+
+/* first-pass voting, cmd_cram_freemuxlet.cpp:245-291.  order[C] = drops_srted; jitter[n_visited][K] holds the values
+ * `rand()/(RAND_MAX+1.)/1000.` the reference draws for the visited cells, in drawing order (the RNG stays with the
+ * caller).  clust[C] is set to -1 and then filled for the visited cells; ccounts[K] receives the cluster sizes. */
+void oracle_fmxold_vote_init(int64_t C, int32_t K, const oracle_dropd* dd, const int32_t* order, const double* jitter,
+                             double bf_thres, double frac_init_clust, int32_t* clust, int32_t* ccounts);
+
+/* one refinement pass, cmd_cram_freemuxlet.cpp:297-343.  order[C] = orand (after std::random_shuffle),
+ * jitter[C][K] in visiting order.  Returns the number of changed cells; ccounts[K] as the reference counts them. */
+int32_t oracle_fmxold_vote_refine(int64_t C, int32_t K, const oracle_dropd* dd, const int32_t* order,
+                                  const double* jitter, double bf_thres, int32_t keep_init_missing, int32_t* clust,
+                                  int32_t* ccounts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,10 @@ struct muxgl_handle {
   double* d_cgpq = nullptr;                    // [S][6][4][2] cluster-GP rows re-laid per quad (fmx_quad.hip)
   size_t cgpq_cap = 0;
 
+  // freemuxlet-old (fmx_old.hip)
+  int8_t* d_sgn = nullptr;  // [C][sgn_ld] vote sign of every ordered cell pair: +1 / -1 / 0 against --bf-thres
+  int64_t sgn_ld = 0;       // row stride, a multiple of 16 with at least 16 zero bytes of padding
+
   hipEvent_t ev[2 * MUXGL_T_COUNT] = {};
   bool ev_used[MUXGL_T_COUNT] = {};
   float ms[MUXGL_T_COUNT] = {};

@@ -98,6 +98,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_egls6);
   dev_free(&h->d_cgpq);
   dev_free(&h->d_secnt);
+  dev_free(&h->d_sgn);
   demux_row_free(h);
   demux_wave_free(h);
   if (h->h_dcells) (void)hipHostFree(h->h_dcells);
@@ -179,6 +180,7 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
   }
   h->fmx_prepared = false;
   h->K = 0;
+  dev_free(&h->d_sgn);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -3,6 +3,7 @@
 //
 //   popscle-amd demuxlet   --plp P --vcf V [--field GT|GP|PL] --out O [...]     mirrors cmdCramDemuxlet (cmd_cram_demuxlet.cpp)
 //   popscle-amd freemuxlet --plp P --nsample K --out O [...]                   mirrors cmdCramFreemux2 (cmd_cram_freemux2.cpp)
+//   popscle-amd freemuxlet-old --plp P --nsample K --out O [...]               mirrors cmdCramFreemuxlet (cmd_cram_freemuxlet.cpp)
 //   popscle-amd dump-plp   --plp P [--vcf V --field F] --out FILE              loader only: packed pileup to a binary file
 //
 // Everything here is host plumbing: flag surface, loaders (plp.hpp, vcf.hpp), the sequential control flow of
@@ -42,6 +43,25 @@ void upload(muxgl_handle* h, const Pileup& p) {
                             p.entry_rptr.data(), p.reads.data()),
         "muxgl_set_pileup");
 }
+
+// The reference draws from the C library's rand().  Other code in this process (the HIP runtime) draws from and
+// reseeds that shared generator, so the commands keep their own copy of it: glibc's rand() is random() on the default
+// 128-byte additive-feedback state, which initstate_r / random_r reproduce value for value (srand(s) == seed s; a
+// program that never calls srand() runs on seed 1).
+struct RefRand {
+  random_data rd;
+  char state[128];
+  explicit RefRand(unsigned seed) {
+    memset(&rd, 0, sizeof(rd));
+    memset(state, 0, sizeof(state));
+    initstate_r(seed, state, sizeof(state), &rd);
+  }
+  int next() {
+    int32_t r = 0;
+    random_r(&rd, &r);
+    return (int)r;
+  }
+};
 
 const char* sid(const Pileup& p, int i) { return (i >= 0 && i < p.nv) ? p.sample_ids[(size_t)i].c_str() : "NA"; }
 
@@ -145,9 +165,12 @@ int cmd_demuxlet(int argc, char** argv) {
 }
 
 // ------------------------------------------------------------------------------------------------ freemuxlet
+// old_clust0: the .clust0.vcf.gz of freemuxlet-old (cmd_cram_freemuxlet.cpp:377-431) differs from every other cluster
+// VCF in two expressions: pps = gps * gls / maxGL (:409-411) and gq = (int)(-0.1*log10(..)) (:421)
 void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const std::vector<double>& gls,
-                       const std::vector<int32_t>& cnt, const std::vector<uint8_t>& snps_observed, const tm* ltm) {
-  // cmd_cram_freemux2.cpp:608-658
+                       const std::vector<int32_t>& cnt, const std::vector<uint8_t>& snps_observed, const tm* ltm,
+                       bool old_clust0 = false) {
+  // cmd_cram_freemux2.cpp:608-658 == cmd_cram_freemuxlet.cpp:655-707
   OutFile vc(path, true);
   vc.printf("##fileformat=VCFv4.2\n");
   vc.printf("##fileDate=%04d%02d%02d\n", 1970 + ltm->tm_year, 1 + ltm->tm_mon, ltm->tm_mday);  // sic: 1970+
@@ -186,15 +209,22 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const st
       pls[1] = (int32_t)(-10.0 * log10(g[4] / maxGL));
       pls[2] = (int32_t)(-10.0 * log10(g[8] / maxGL));
       double pps[3];
-      pps[0] = gps[0] * (g[0] / maxGL) + 1e-100;
-      pps[1] = gps[1] * (g[4] / maxGL) + 1e-100;
-      pps[2] = gps[2] * (g[8] / maxGL) + 1e-100;
+      if (old_clust0) {
+        pps[0] = gps[0] * g[0] / maxGL + 1e-100;
+        pps[1] = gps[1] * g[4] / maxGL + 1e-100;
+        pps[2] = gps[2] * g[8] / maxGL + 1e-100;
+      } else {
+        pps[0] = gps[0] * (g[0] / maxGL) + 1e-100;
+        pps[1] = gps[1] * (g[4] / maxGL) + 1e-100;
+        pps[2] = gps[2] * (g[8] / maxGL) + 1e-100;
+      }
       const double sumPP = pps[0] + pps[1] + pps[2];
       pps[0] /= sumPP;
       pps[1] /= sumPP;
       pps[2] /= sumPP;
       const int bestG = (pps[0] > pps[1]) ? (pps[0] > pps[2] ? 0 : 2) : (pps[1] > pps[2] ? 1 : 2);
-      int32_t gq = (int32_t)(-10 * log10(1.0 - pps[bestG] + 1e-100));
+      int32_t gq = old_clust0 ? (int32_t)(-0.1 * log10(1 - pps[bestG] + 1e-100))
+                              : (int32_t)(-10 * log10(1.0 - pps[bestG] + 1e-100));
       if (gq > 255) gq = 255;
       appendf(o, "\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg", bestG == 2 ? 1 : 0, bestG > 0 ? 1 : 0, gq, c[0], c[1],
               c[2], pls[0], pls[1], pls[2], pps[0], pps[1], pps[2]);
@@ -287,11 +317,10 @@ int cmd_freemuxlet(int argc, char** argv) {
                   (llk2[(size_t)i] - llk0[(size_t)i]) / nSNPs[(size_t)i]);
     }
   }
-  if (randomSeed == 0) srand((unsigned)std::time(0));  // :165-168
-  else srand((unsigned)randomSeed);
+  RefRand rng(randomSeed == 0 ? (unsigned)std::time(0) : (unsigned)randomSeed);  // srand(), :165-168
   if (randomizeSingletScore) {  // :171-181
     for (int64_t i = 0; i < C - 1; ++i) {
-      const int64_t j = i + rand() % (C - i);
+      const int64_t j = i + rng.next() % (C - i);
       if (i < j) std::swap(scores[(size_t)i], scores[(size_t)j]);
     }
   }
@@ -362,6 +391,226 @@ int cmd_freemuxlet(int argc, char** argv) {
   }
   wc1.close();
   tmr.lap("freemuxlet: write .clust1.samples.gz");
+  muxgl_destroy(h);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ freemuxlet-old
+// mirrors cmdCramFreemuxlet (cmd_cram_freemuxlet.cpp), registered as "freemuxlet-old" (cramore.cpp:44).  Differences
+// from freemux2 that are reproduced as written:
+//   * the read/cell filter flags are parsed and then never handed to the loader (:55-62 vs :83), so the pileup is loaded
+//     with sc_dropseq_lib_t's own defaults minBQ = 1, capBQ = 60 and no droplet filters (sc_drop_seq.h:181);
+//   * no srand(): rand() runs from the C library's default seed, so the command is deterministic (RefRand(1));
+//   * initial clusters from votes over a pairwise distance matrix (:176-343) instead of the greedy pass;
+//   * ten EM iterations without early stop; --geno-error only enters the last one (:485,500).
+int cmd_freemuxlet_old(int argc, char** argv) {
+  CommonFlags cf;
+  std::string initClusterFile;
+  double doublet_prior = 0.5, geno_error = 0.0, bfThres = 5.41, fracInitClust = 1.0;  // :19-28
+  int32_t nSamples = 0, initIteration = 10, verbose = 0, minUniq = 0;
+  bool auxFiles = false, keepInitMissing = false;
+  Args a;
+  cf.add(a);
+  cf.lo.capBQ = 40;  // the flag's default (:16); see above: it never reaches the loader
+  a.add_int("min-uniq", &minUniq);
+  a.add_string("init-cluster", &initClusterFile);
+  a.add_int("nsample", &nSamples);
+  a.add_bool("aux-files", &auxFiles);
+  a.add_int("verbose", &verbose);
+  a.add_double("doublet-prior", &doublet_prior);
+  a.add_double("geno-error", &geno_error);
+  a.add_double("bf-thres", &bfThres);
+  a.add_double("frac-init-clust", &fracInitClust);
+  a.add_int("iter-init", &initIteration);
+  a.add_bool("keep-init-missing", &keepInitMissing);
+  a.parse(argc, argv);
+  if (cf.plpPrefix.empty() || cf.outPrefix.empty() || nSamples == 0) fatal("Missing required option(s) : --plp, --out, --nsample");
+  if (nSamples > 64) fatal("freemuxlet-old: --nsample %d exceeds the 64 clusters the vote kernel supports", nSamples);
+
+  Pileup p;
+  StageTimer tmr;
+  LoadOptions lo;  // sc_drop_seq.h:181
+  lo.minBQ = 1;
+  lo.capBQ = 60;
+  load_from_plp(cf.plpPrefix, lo, nullptr, p);
+  tmr.lap("freemuxlet-old: load");
+  const int64_t C = p.C(), S = p.S();
+  const int K = nSamples;
+
+  std::map<std::string, int32_t> initCluster;  // :87-99
+  if (!initClusterFile.empty()) {
+    TsvReader t(initClusterFile);
+    while (t.read_line() > 0) {
+      if (t.nfields != 2) fatal("ERROR: Initial clustering file %s has to have 2 columnes", initClusterFile.c_str());
+      const int32_t ic = t.int_field_at(1);
+      if (ic >= 0) {
+        if (ic >= K)
+          fatal("ERROR: --nsample %d parameter was set. The cluster ID must be between 0 to %d, or use negative values "
+                "to not assign initial cluster (not implemented yet)", K, K - 1);
+        initCluster[t.str_field_at(0)] = ic;
+      }
+    }
+  }
+
+  muxgl_config cfg{cf.device, 0};
+  muxgl_handle* h = nullptr;
+  if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
+  upload(h, p);
+  std::vector<double> af((size_t)S), llk0((size_t)C), llk2((size_t)C);
+  std::vector<int32_t> nSNPs((size_t)C), nReads((size_t)C);
+  for (int64_t s = 0; s < S; ++s) af[(size_t)s] = p.snps[(size_t)s].af;
+  check(h, muxgl_fmx_prepare(h, af.data(), llk0.data(), llk2.data(), nSNPs.data(), nReads.data()), "muxgl_fmx_prepare");
+  tmr.lap("freemuxlet-old: hand-over + muxgl_fmx_prepare");
+
+  std::vector<double> scores((size_t)C);
+  {  // .lmix, :110-165
+    OutFile wmix(cf.outPrefix + ".lmix", false);
+    wmix.printf("INT_ID\tBARCODE\tNSNPs\tNREADs\tDBL.LLK\tSNG.LLK\tLOG.BF\tBFpSNP\n");
+    for (int64_t i = 0; i < C; ++i) {
+      scores[(size_t)i] = llk2[(size_t)i] - llk0[(size_t)i];
+      wmix.printf("%d\t%s\t%d\t%d\t%.2lf\t%.2lf\t%.2lf\t%.4lf\n", (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i],
+                  nReads[(size_t)i], llk0[(size_t)i], llk2[(size_t)i], llk0[(size_t)i] - llk2[(size_t)i],
+                  (llk0[(size_t)i] - llk2[(size_t)i]) / nSNPs[(size_t)i]);
+    }
+  }
+  std::vector<int32_t> drops_srted((size_t)C);  // :167-173, comparator sc_drop_seq.h:190-198
+  for (int64_t i = 0; i < C; ++i) drops_srted[(size_t)i] = (int32_t)i;
+  std::sort(drops_srted.begin(), drops_srted.end(), [&](int32_t lhs, int32_t rhs) {
+    const double cmp = scores[(size_t)lhs] - scores[(size_t)rhs];
+    if (cmp != 0) return cmp > 0;
+    return lhs > rhs;
+  });
+
+  notice("Calculate pairwise genetic distance matrix..");
+  const bool wantDist = auxFiles && initClusterFile.empty();  // .ldist.gz rows are printed by the voting loop only (:262-265)
+  std::vector<muxgl_dropd> dropDs(wantDist ? (size_t)(C * (C - 1) / 2) : 0);
+  check(h, muxgl_fmxold_pair_dist(h, bfThres, wantDist ? dropDs.data() : nullptr), "muxgl_fmxold_pair_dist");
+  tmr.lap("freemuxlet-old: pairwise distance matrix");
+
+  std::vector<int32_t> clusts((size_t)C, -1), ccounts((size_t)K, 0);
+  std::vector<double> jitter;
+  RefRand rng(1);
+  auto draw_jitter = [&](int64_t rows) {  // `votes[j] = rand()/(RAND_MAX+1.)/1000.` per visited cell (:257-259,304-306)
+    jitter.resize((size_t)rows * K);
+    for (size_t x = 0; x < jitter.size(); ++x) jitter[x] = rng.next() / (RAND_MAX + 1.) / 1000.;
+  };
+  auto counts_str = [&]() {
+    std::string buf;
+    for (int j = 0; j < K; ++j) buf += " " + std::to_string(ccounts[(size_t)j]);
+    return buf;
+  };
+  {
+    OutFile* wdist = nullptr;
+    if (auxFiles) {  // :178-182
+      wdist = new OutFile(cf.outPrefix + ".ldist.gz", true);
+      wdist->printf("ID1\tID2\tNSNP\tREAD1\tREAD2\tREADMIN\tLLK0\tLLK2\tLDIFF\tDIFF.SNP\n");
+    }
+    if (!initClusterFile.empty()) {  // :227-243
+      int32_t nmiss = 0;
+      for (int64_t i = 0; i < C; ++i) {
+        auto it = initCluster.find(p.bcs[(size_t)i]);
+        if (it == initCluster.end()) ++nmiss;
+        else {
+          clusts[(size_t)i] = it->second;
+          ++ccounts[(size_t)it->second];
+        }
+      }
+      if (nmiss > 0) notice("WARNING: %d of %d droplets do not have initial cluster assignment", nmiss, (int)C);
+    } else {  // :245-291
+      int64_t nvis = 0;
+      for (int64_t i = 0; i < C; ++i)
+        if (!((double)i > (double)C * fracInitClust)) ++nvis;
+      draw_jitter(nvis);
+      check(h, muxgl_fmxold_vote_init(h, K, drops_srted.data(), jitter.data(), fracInitClust, clusts.data(), ccounts.data()),
+            "muxgl_fmxold_vote_init");
+      if (wdist) {  // :262-265
+        for (int64_t i = 0; i < nvis; ++i) {
+          const int32_t si = drops_srted[(size_t)i];
+          for (int64_t j = 0; j < i; ++j) {
+            const int32_t sj = drops_srted[(size_t)j];
+            const int64_t hi = si > sj ? si : sj, lo2 = si > sj ? sj : si;
+            const muxgl_dropd& dd = dropDs[(size_t)(hi * (hi - 1) / 2 + lo2)];
+            wdist->printf("%d\t%d\t%d\t%d\t%d\t%d\t%.2lf\t%.2lf\t%.2lf\t%.4lf\n", si, sj, dd.nsnps, dd.nread1, dd.nread2,
+                          dd.nread1 > dd.nread2 ? dd.nread2 : dd.nread1, dd.llk0, dd.llk2, dd.llk2 - dd.llk0,
+                          (dd.llk2 - dd.llk0) / (dd.nsnps + 1e-6));
+          }
+        }
+      }
+    }
+    if (wdist) {
+      wdist->close();
+      delete wdist;
+    }
+  }
+  notice("Finished calculating pairwise distance between the droplets..");
+  tmr.lap("freemuxlet-old: first voting pass");
+
+  if (initIteration > 0) {  // :295-351: ten passes whatever the value
+    std::vector<int32_t> orand((size_t)C);
+    for (int32_t iter = 0; iter < 10; ++iter) {
+      for (int64_t i = 0; i < C; ++i) orand[(size_t)i] = (int32_t)i;
+      // std::random_shuffle(orand.begin(), orand.end()) as libstdc++ implements it (bits/stl_algo.h): the reference
+      // binary's behaviour; spelled out because the function is gone from C++17
+      for (int64_t i = 1; i < C; ++i) {
+        const int64_t j = rng.next() % (i + 1);
+        if (i != j) std::swap(orand[(size_t)i], orand[(size_t)j]);
+      }
+      draw_jitter(C);
+      int32_t changed = 0;
+      check(h, muxgl_fmxold_vote_refine(h, K, orand.data(), jitter.data(), keepInitMissing ? 1 : 0, clusts.data(), &changed,
+                                        ccounts.data()),
+            "muxgl_fmxold_vote_refine");
+      notice("Iteration %d, # changed = %d, cluster counts:%s", iter, changed, counts_str().c_str());
+    }
+  }
+  tmr.lap("freemuxlet-old: refinement passes");
+
+  if (auxFiles) {  // :353-363
+    OutFile wc0(cf.outPrefix + ".clust0.samples.gz", true);
+    wc0.printf("INT_ID\tBARCODE\tCLUST0\n");
+    for (int64_t i = 0; i < C; ++i) wc0.printf("%d\t%s\t%d\n", (int)i, p.bcs[(size_t)i].c_str(), clusts[(size_t)i]);
+  }
+  std::vector<uint8_t> snps_observed((size_t)S, 0);  // :367-376
+  for (int64_t e = 0; e < p.nnz(); ++e) snps_observed[(size_t)p.entry_snp[(size_t)e]] = 1;
+  check(h, muxgl_fmx_set_clusters(h, K, clusts.data()), "muxgl_fmx_set_clusters");
+  time_t now = std::time(nullptr);
+  tm* ltm = localtime(&now);
+  std::vector<double> cgls((size_t)K * S * 9);
+  std::vector<int32_t> ccnt((size_t)K * S * 3);
+  if (auxFiles) {
+    check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
+    write_cluster_vcf(cf.outPrefix + ".clust0.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm, true);
+  }
+
+  std::vector<muxgl_fmx_cell> cells((size_t)C);
+  const int32_t max_iter = 10;  // :457
+  for (int32_t iter = 0; iter < max_iter; ++iter) {
+    notice("Inferring doublets and refining clusters.., iter = %d", iter + 1);
+    muxgl_fmx_params fp{doublet_prior, (geno_error > 0 && iter + 1 == max_iter) ? geno_error : 0.0};  // :485,500
+    int32_t nsingle = 0, namb = 0, nchanged = 0;
+    check(h, muxgl_fmx_iterate(h, &fp, cells.data(), &nsingle, &namb, &nchanged, nullptr), "muxgl_fmx_iterate");
+    notice("Refining per-cluster genotype likelihoods.... %d singlets, %d doublets, and %d ambiguous", nsingle,
+           (int)C - nsingle - namb, namb);
+  }
+  tmr.lap("freemuxlet-old: EM iterations");
+  check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
+  write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+
+  OutFile wc1(cf.outPrefix + ".clust1.samples.gz", true);  // :709-714
+  wc1.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"
+             "DIFF.LLK.BEST.NEXT\tBEST.POSTERIOR\tSNG.POSTERIOR\tSNG.BEST.GUESS\tSNG.BEST.LLK\tSNG.NEXT.GUESS\t"
+             "SNG.NEXT.LLK\tSNG.ONLY.POSTERIOR\tDBL.BEST.GUESS\tDBL.BEST.LLK\tDIFF.LLK.SNG.DBL\n");
+  for (int64_t i = 0; i < C; ++i) {
+    const muxgl_fmx_cell& c = cells[(size_t)i];
+    wc1.printf("%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
+               "%.2lf\t%.2lf\n",
+               (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i], nReads[(size_t)i],
+               (c.type == 2) ? "AMB" : ((c.type == 0) ? "SNG" : "DBL"), c.jBest, c.kBest, c.bestLLK, c.jNext, c.kNext,
+               c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, c.sBest, c.sngBestLLK, c.sNext, c.sngNextLLK,
+               c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
+  }
+  wc1.close();
+  tmr.lap("freemuxlet-old: writers");
   muxgl_destroy(h);
   return 0;
 }
@@ -443,13 +692,14 @@ int cmd_bgzf(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: popscle-amd <demuxlet|freemuxlet|dump-plp> [options]\n");
+    fprintf(stderr, "usage: popscle-amd <demuxlet|freemuxlet|freemuxlet-old|dump-plp> [options]\n");
     return 1;
   }
   try {
     const std::string cmd = argv[1];
     if (cmd == "demuxlet") return cmd_demuxlet(argc - 2, argv + 2);
     if (cmd == "freemuxlet") return cmd_freemuxlet(argc - 2, argv + 2);
+    if (cmd == "freemuxlet-old") return cmd_freemuxlet_old(argc - 2, argv + 2);
     if (cmd == "dump-plp") return cmd_dump_plp(argc - 2, argv + 2);
     if (cmd == "bgzf") return cmd_bgzf(argc - 2, argv + 2);
     fprintf(stderr, "Cannot recognize the command %s\n", argv[1]);

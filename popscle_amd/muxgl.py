@@ -25,6 +25,7 @@ FLAG_FORCE_TILE_SWEEP = 1
 FLAG_FORCE_ROW_KERNEL = 2
 FLAG_FORCE_WAVE_KERNEL = 4
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
+T_FMXOLD_PAIR, T_FMXOLD_VOTE = 9, 10
 T_COUNT = 16
 BUF_CGP, BUF_CLUST, BUF_CELLS, BUF_STAT = 0, 1, 2, 3
 
@@ -42,6 +43,9 @@ FMX_CELL = np.dtype(
                                  "bestPP", "sngPP", "sngOnlyPP", "sumLLK")],
     align=True,
 )
+DROPD = np.dtype([("nsnps", np.int32), ("nread1", np.int32), ("nread2", np.int32), ("_pad", np.int32),
+                  ("llk0", np.float64), ("llk2", np.float64)], align=True)
+assert DROPD.itemsize == 32
 assert DEMUX_CELL.itemsize == 18 * 4 + 11 * 8
 assert FMX_CELL.itemsize == 12 * 4 + 10 * 8
 
@@ -77,6 +81,10 @@ SYMBOLS = {
     "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_fmxold_pair_dist": (C.c_int, [_VP, C.c_double, _VP]),
+    "muxgl_fmxold_get_signs": (C.c_int, [_VP, _VP]),
+    "muxgl_fmxold_vote_init": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_double, _VP, _VP]),
+    "muxgl_fmxold_vote_refine": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, _VP, _VP, _VP]),
     "muxgl_fmx_set_shard": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "muxgl_fmx_iter_gp": (C.c_int, [_VP, C.POINTER(_FmxParams)]),
     "muxgl_fmx_iter_estep": (C.c_int, [_VP, C.POINTER(_FmxParams)]),
@@ -255,6 +263,36 @@ class Engine:
         if want_full_ll:
             return out, stats, full
         return out, stats
+
+    # ---- freemuxlet-old: pairwise distance matrix and voting passes (cmd_cram_freemuxlet.cpp:176-343)
+    def fmxold_pair_dist(self, bf_thres=5.41, want_full=False):
+        full = np.zeros(self.C * (self.C - 1) // 2, dtype=DROPD) if want_full else None
+        self._check(self.lib.muxgl_fmxold_pair_dist(self.h, float(bf_thres), _ptr(full)))
+        return full
+
+    def fmxold_signs(self):
+        out = np.zeros((self.C, self.C), dtype=np.int8)
+        self._check(self.lib.muxgl_fmxold_get_signs(self.h, _ptr(out)))
+        return out
+
+    def fmxold_vote_init(self, K, order, jitter, frac_init_clust=1.0):
+        order = _arr(order, np.int32, "order")
+        jitter = _arr(jitter, np.float64, "jitter")
+        clust = np.zeros(self.C, dtype=np.int32)
+        cc = np.zeros(int(K), dtype=np.int32)
+        self._check(self.lib.muxgl_fmxold_vote_init(self.h, int(K), _ptr(order), _ptr(jitter), float(frac_init_clust),
+                                                     _ptr(clust), _ptr(cc)))
+        return clust, cc
+
+    def fmxold_vote_refine(self, K, order, jitter, clust, keep_init_missing=False):
+        order = _arr(order, np.int32, "order")
+        jitter = _arr(jitter, np.float64, "jitter")
+        clust = np.array(clust, dtype=np.int32)
+        cc = np.zeros(int(K), dtype=np.int32)
+        ch = C.c_int32()
+        self._check(self.lib.muxgl_fmxold_vote_refine(self.h, int(K), _ptr(order), _ptr(jitter),
+                                                       int(bool(keep_init_missing)), _ptr(clust), C.byref(ch), _ptr(cc)))
+        return clust, ch.value, cc
 
     # ---- sharded EM phases (multi-GPU); the collectives between them belong to the caller (popscle_amd/freemuxlet.py)
     def fmx_set_shard(self, c0, c1, s0, s1):

@@ -165,3 +165,39 @@ def fmx_iterate(plp, eplp, K, cplp, cells, doublet_prior=0.5, geno_error=0.1, fu
     if full_ll:
         return ns.value, na.value, nch, full
     return ns.value, na.value, nch
+
+
+# ---- freemuxlet-old (cmd_cram_freemuxlet.cpp:176-343)
+DROPD = np.dtype([("nsnps", np.int32), ("nread1", np.int32), ("nread2", np.int32), ("_pad", np.int32),
+                  ("llk0", np.float64), ("llk2", np.float64)], align=True)
+assert DROPD.itemsize == 32
+
+
+def fmxold_pair_dist(plp, eplp):
+    out = np.zeros(plp.C * (plp.C - 1) // 2, dtype=DROPD)
+    af = np.ascontiguousarray(plp.af, dtype=np.float64)
+    lib().oracle_fmxold_pair_dist(C.c_int64(plp.C), C.c_int64(plp.S), _p(plp.cell_ptr), _p(plp.entry_snp), _p(eplp),
+                                  _p(af), _p(out))
+    return out
+
+
+def fmxold_vote_init(ncells, K, dd, order, jitter, bf_thres=5.41, frac_init_clust=1.0):
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    jitter = np.ascontiguousarray(jitter, dtype=np.float64)
+    clust = np.zeros(ncells, dtype=np.int32)
+    cc = np.zeros(K, dtype=np.int32)
+    lib().oracle_fmxold_vote_init(C.c_int64(ncells), C.c_int32(K), _p(dd), _p(order), _p(jitter), C.c_double(bf_thres),
+                                  C.c_double(frac_init_clust), _p(clust), _p(cc))
+    return clust, cc
+
+
+def fmxold_vote_refine(ncells, K, dd, order, jitter, clust, bf_thres=5.41, keep_init_missing=False):
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    jitter = np.ascontiguousarray(jitter, dtype=np.float64)
+    clust = np.array(clust, dtype=np.int32)
+    cc = np.zeros(K, dtype=np.int32)
+    f = lib().oracle_fmxold_vote_refine
+    f.restype = C.c_int32
+    changed = f(C.c_int64(ncells), C.c_int32(K), _p(dd), _p(order), _p(jitter), C.c_double(bf_thres),
+                C.c_int32(int(bool(keep_init_missing))), _p(clust), _p(cc))
+    return clust, changed, cc
