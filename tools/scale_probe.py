@@ -3,6 +3,7 @@
 
     python tools/scale_probe.py demux 2 0.1      # configs[2] (100k x 64 x 200k, 6 alphas) at 10 % of the cells
     python tools/scale_probe.py fmx 3 0.2 5      # configs[3] (50k cells, K=16, 100k SNPs) at 20 %, 5 EM iterations
+    python tools/scale_probe.py fmxold 1 1.0     # freemuxlet-old's pair matrix + votes on the cells/SNPs of configs[1]
 """
 import json
 import os
@@ -21,7 +22,8 @@ def main():
     cfg = synth.CONFIGS[idx]
     C = int(cfg["C"] * scale)
     t0 = time.time()
-    p = synth.make_pileup(C, cfg["S"], cfg["V"], seed=synth.BASE_SEED + idx, with_gp=(kind == "demux"))
+    p = synth.make_pileup(C, cfg["S"], cfg["V"], seed=synth.BASE_SEED + idx, with_gp=(kind == "demux"),
+                          **({"cap_bq": 60} if kind == "fmxold" else {}))
     out = {"kind": kind, "config": idx, "cells": C, "V": cfg["V"], "S": cfg["S"], "entries": p.nnz, "reads": p.R,
            "gen_s": round(time.time() - t0, 1)}
     eng = muxgl.Engine(0)
@@ -44,6 +46,39 @@ def main():
                    call_ms=float(ms[muxgl.T_DEMUX_CALL]), lls_per_s=C * (V + V * (V - 1) * (A - 1)) / min(ts),
                    entries_per_s=p.nnz / min(ts), types=np.bincount(cells["type"], minlength=3).tolist(),
                    singlet_acc=float((cells["sBest"][~p.truth["is_doublet"]] == p.truth["s1"][~p.truth["is_doublet"]]).mean()))
+    elif kind == "fmxold":
+        K = cfg["V"]
+        llk0, llk2, _, _ = eng.fmx_prepare(p.af)
+        snp_n = np.bincount(p.entry_snp, minlength=p.S).astype(np.int64)
+        out["pair_terms"] = int((snp_n * (snp_n - 1) // 2).sum())
+        t0 = time.time()
+        eng.fmxold_pair_dist(5.41)
+        out["pair_dist_s"] = round(time.time() - t0, 3)
+        out["pair_kernel_ms"] = float(eng.timing()[muxgl.T_FMXOLD_PAIR])
+        t0 = time.time()
+        eng.fmxold_pair_dist(5.41)
+        out["pair_dist_s_2nd"] = round(time.time() - t0, 3)
+        out["pair_kernel_ms_2nd"] = float(eng.timing()[muxgl.T_FMXOLD_PAIR])
+        out["pair_terms_per_s"] = out["pair_terms"] / (out["pair_kernel_ms_2nd"] * 1e-3)
+        rng = np.random.default_rng(1)
+        order = np.argsort(-(llk2 - llk0), kind="stable").astype(np.int32)
+        jit = rng.integers(0, 2**31, (C, K)) / 2.0**31 / 1000.0
+        t0 = time.time()
+        clust, cc = eng.fmxold_vote_init(K, order, jit)
+        out["vote_init_s"] = round(time.time() - t0, 3)
+        out["vote_init_kernel_ms"] = float(eng.timing()[muxgl.T_FMXOLD_VOTE])
+        passes = []
+        for it in range(3):
+            orand = rng.permutation(C).astype(np.int32)
+            t0 = time.time()
+            clust, ch, cc = eng.fmxold_vote_refine(K, orand, jit, clust)
+            passes.append(dict(wall_s=round(time.time() - t0, 3), kernel_ms=float(eng.timing()[muxgl.T_FMXOLD_VOTE]),
+                               changed=int(ch)))
+        out["refine_passes"] = passes
+        out["cluster_sizes"] = cc.tolist()
+        sng = ~p.truth["is_doublet"]
+        agree = sum(int(np.bincount(p.truth["s1"][sng & (clust == k)], minlength=K).max()) for k in range(K))
+        out["singlets_with_cluster_majority"] = agree / int(sng.sum())
     else:
         K = cfg["V"]
         iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
