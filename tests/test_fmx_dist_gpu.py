@@ -1,0 +1,48 @@
+"""The N-process freemuxlet path on a 1-GPU box: two real processes (torch.distributed.run), each with its own muxgl
+handle on device 0, exchange the cluster-GP rows and the assignments through torch.distributed (gloo stages the device
+tensors; on a multi-GPU node the same code runs over RCCL) and must reproduce the single-process run bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROBE = os.path.join(ROOT, "tools", "bench_fmx.py")
+SHAPE = ["--cells", "400", "--snps", "3000", "--clusters", "5", "--mean-entries", "200", "--iters", "4", "--warmup", "0"]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_processes_match_one(tmp_path, world):
+    one = str(tmp_path / "one.npz")
+    many = str(tmp_path / "many.npz")
+    j1 = run([sys.executable, PROBE, "--gpus", "1", "--dump", one] + SHAPE)
+    jn = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+              "127.0.0.1", "--master-port", str(free_port()), PROBE, "--gpus", str(world), "--dist-backend", "gloo",
+              "--single-device", "--dump", many] + SHAPE)
+    assert j1["n_gpus"] == 1 and jn["n_gpus"] == world and jn["scaling"] == "strong"
+    a, b = np.load(one), np.load(many)
+    assert np.array_equal(a["hist"], b["hist"])
+    assert a["cells"].tobytes() == b["cells"].tobytes()
+    assert (a["cells"]["type"] == 0).sum() > 200
