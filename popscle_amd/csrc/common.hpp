@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <string>
 
 #include "../../include/muxgl.h"
@@ -125,6 +126,24 @@ struct muxgl_handle {
 
 extern thread_local std::string g_muxgl_create_error;
 
+// MUXGL_TIMING=1: host-side stage times of the hand-over calls on stderr
+struct host_timer {
+  bool on;
+  double t0;
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+  }
+  host_timer() : on(getenv("MUXGL_TIMING") != nullptr), t0(now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const double t = now();
+    fprintf(stderr, "[muxgl] %-44s %8.1f ms\n", what, (t - t0) * 1e3);
+    t0 = t;
+  }
+};
+
 #define MUXGL_FAIL(h, ...)                                  \
   do {                                                      \
     char _buf[512];                                         \
@@ -216,11 +235,10 @@ __device__ __forceinline__ double dev_logadd(double la, double lb) {
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg);
-int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp);
+int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);
-int demux_row_build(muxgl_handle* h, muxgl_row_state** st, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t c0,
-                    int64_t c1, int ch);
+int demux_row_build(muxgl_handle* h, muxgl_row_state** st, int64_t c0, int64_t c1, int ch);
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
@@ -232,3 +250,6 @@ int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p);  // standard 
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);
 void demux_row_release(muxgl_row_state** st);
+int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
+int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)
+int plan_build_snp_major(muxgl_handle* h);  // d_entry_cell, d_snp_ptr, d_snp_entry, d_snp_cell (plan_kernels.hip)

@@ -358,70 +358,16 @@ void demux_row_free(muxgl_handle* h) {
 }
 
 // builds the chunk tables of every cell from the host copy of the CSR arrays (called by muxgl_set_pileup)
-int demux_row_plan(muxgl_handle* h, const int64_t* cell_ptr, const int32_t* entry_snp) {
-  if (demux_row_build(h, &h->row, cell_ptr, entry_snp, 0, h->C, MUXGL_ROW_CH)) return 1;
-  return demux_row_build(h, &h->qrow, cell_ptr, entry_snp, 0, h->C, MUXGL_QUAD_CH);
+int demux_row_plan(muxgl_handle* h) {
+  if (demux_row_build(h, &h->row, 0, h->C, MUXGL_ROW_CH)) return 1;
+  return demux_row_build(h, &h->qrow, 0, h->C, MUXGL_QUAD_CH);
 }
 
-// chunk tables of the cells [cb, ce): cells outside the range own no chunk
-int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, const int64_t* cell_ptr, const int32_t* entry_snp, int64_t cb,
-                    int64_t ce, int ch) {
+// chunk tables of the cells [cb, ce): built on the device (plan_kernels.hip) from the device copy of the CSR arrays
+int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, int64_t cb, int64_t ce, int ch) {
   if (!*pst) *pst = new muxgl_row_state();
   muxgl_row_state* st = *pst;
-  const int64_t C = h->C;
-  std::vector<row_chunk> chunks;
-  const int ROW_CH = ch;
-  chunks.reserve((size_t)((cell_ptr[ce] - cell_ptr[cb]) / ROW_CH + (ce - cb) + 1));
-  // a cell is cut into the fewest chunks of <= ROW_CH entries, of (nearly) equal length rounded up to the kernels'
-  // batch of four entries: the slots of a wave then finish together instead of waiting for the full-length ones
-  for (int64_t c = cb; c < ce; ++c) {
-    const int64_t n = cell_ptr[c + 1] - cell_ptr[c];
-    if (n == 0) continue;
-    const int64_t nch = (n + ROW_CH - 1) / ROW_CH;
-    const int64_t step = std::min<int64_t>(ROW_CH, ((n + nch - 1) / nch + 3) / 4 * 4);
-    for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; e += step) {
-      const int64_t len = std::min<int64_t>(step, cell_ptr[c + 1] - e);
-      chunks.push_back(row_chunk{e, (int32_t)len, (int32_t)c});
-    }
-  }
-  // Launch order: ascending first SNP id.  Entries are SNP-sorted inside a cell, so consecutive chunks of the launch
-  // list gather GP rows from neighbouring windows of the [S][V][3] tensor; xcd_swizzle() hands each XCD one contiguous
-  // eighth of the list, whose sliding window fits that XCD's 4 MiB L2 (the whole tensor, 19 MB at config 1, does not).
-  // Chunk lengths are then mixed inside a wave (the tails are ~6 % of the chunks): a wave runs for its longest chunk.
-  if (entry_snp) {
-    std::vector<int32_t> first((size_t)chunks.size());
-    for (size_t i = 0; i < chunks.size(); ++i) first[i] = entry_snp[chunks[i].e0];
-    std::vector<size_t> ord(chunks.size());
-    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
-      return first[a] < first[b];
-    });
-    std::vector<row_chunk> sorted(chunks.size());
-    for (size_t i = 0; i < ord.size(); ++i) sorted[i] = chunks[ord[i]];
-    chunks.swap(sorted);
-  } else {
-    std::stable_sort(chunks.begin(), chunks.end(), [](const row_chunk& a, const row_chunk& b) { return a.len > b.len; });
-  }
-  const int64_t n = (int64_t)chunks.size();
-  std::vector<int64_t> ccp((size_t)C + 1, 0);
-  for (const row_chunk& ch : chunks) ccp[(size_t)ch.cell + 1]++;
-  for (int64_t c = 0; c < C; ++c) ccp[(size_t)c + 1] += ccp[(size_t)c];
-  // chunk ids of each cell in ENTRY order (deterministic summation order of the partial logs)
-  std::vector<int32_t> ids((size_t)n);
-  {
-    std::vector<int32_t> order((size_t)n);
-    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t a, int32_t b) { return chunks[(size_t)a].e0 < chunks[(size_t)b].e0; });
-    for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = order[(size_t)i];  // sorted by e0 == grouped by cell, in order
-  }
-  st->n_chunks = n;
-  if (dev_alloc(h, &st->d_chunks, (size_t)n)) return 1;
-  if (dev_alloc(h, &st->d_cell_chunk_ptr, (size_t)C + 1)) return 1;
-  if (dev_alloc(h, &st->d_cell_chunks, (size_t)n)) return 1;
-  if (n) HIPCHK(h, hipMemcpy(st->d_chunks, chunks.data(), sizeof(row_chunk) * n, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(st->d_cell_chunk_ptr, ccp.data(), sizeof(int64_t) * (C + 1), hipMemcpyHostToDevice));
-  if (n) HIPCHK(h, hipMemcpy(st->d_cell_chunks, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (plan_build_chunks(h, st, cb, ce, ch)) return 1;
   if (!st->d_kmap) {
     if (dev_alloc(h, &st->d_kmap, 256)) return 1;
     hipLaunchKernelGGL(row_kmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_kmap);

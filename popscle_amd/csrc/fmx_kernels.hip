@@ -684,6 +684,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   if (!h->d_cell_ptr) MUXGL_FAIL(h, "muxgl_fmx_prepare: no pileup set (muxgl_set_pileup)");
   if (!af) MUXGL_FAIL(h, "muxgl_fmx_prepare: af is NULL");
   clear_timing(h);
+  host_timer tm;
   const int64_t C = h->C, S = h->S, nnz = h->nnz;
   if (dev_alloc(h, &h->d_af, (size_t)S)) return 1;
   if (S) HIPCHK(h, hipMemcpyAsync(h->d_af, af, sizeof(double) * S, hipMemcpyHostToDevice, h->stream));
@@ -725,35 +726,12 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   cleanup();
   if (e != hipSuccess) MUXGL_FAIL(h, "muxgl_fmx_prepare: %s", hipGetErrorString(e));
   collect_timing(h);
+  tm.lap("fmx_prepare: entry kernels + scores D2H");
 
-  // SNP-major view of the entries (cells ascending inside each SNP) for the ordered M-step: stable counting sort of the
-  // CSR entries by SNP id.  Built once per pileup on the host from the device copy of the CSR arrays.
+  // SNP-major view of the entries (cells ascending inside each SNP) for the ordered M-step, built on the device
   {
-    std::vector<int64_t> cp((size_t)C + 1);
-    std::vector<int32_t> es((size_t)nnz);
-    HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (C + 1), hipMemcpyDeviceToHost));
-    if (nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
-    std::vector<int64_t> sp((size_t)S + 1, 0);
-    for (int64_t e2 = 0; e2 < nnz; ++e2) sp[(size_t)es[(size_t)e2] + 1]++;
-    for (int64_t s = 0; s < S; ++s) sp[(size_t)s + 1] += sp[(size_t)s];
-    std::vector<int64_t> fill(sp.begin(), sp.end() - 1);
-    std::vector<int64_t> se((size_t)nnz);
-    std::vector<int32_t> ec((size_t)nnz), sc((size_t)nnz);
-    for (int64_t c = 0; c < C; ++c)
-      for (int64_t e2 = cp[(size_t)c]; e2 < cp[(size_t)c + 1]; ++e2) {
-        const int64_t pos = fill[(size_t)es[(size_t)e2]]++;
-        se[(size_t)pos] = e2;
-        sc[(size_t)pos] = (int32_t)c;
-        ec[(size_t)e2] = (int32_t)c;
-      }
-    if (dev_alloc(h, &h->d_snp_ptr, (size_t)S + 1)) return 1;
-    if (dev_alloc(h, &h->d_snp_entry, (size_t)nnz)) return 1;
-    if (dev_alloc(h, &h->d_entry_cell, (size_t)nnz)) return 1;
-    if (dev_alloc(h, &h->d_snp_cell, (size_t)nnz)) return 1;
-    HIPCHK(h, hipMemcpy(h->d_snp_ptr, sp.data(), sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice));
-    if (nnz) HIPCHK(h, hipMemcpy(h->d_snp_entry, se.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice));
-    if (nnz) HIPCHK(h, hipMemcpy(h->d_entry_cell, ec.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
-    if (nnz) HIPCHK(h, hipMemcpy(h->d_snp_cell, sc.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    if (plan_build_snp_major(h)) return 1;
+    tm.lap("fmx_prepare: SNP-major view (device sort)");
     if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
     if (dev_alloc(h, &h->d_secnt, (size_t)nnz * 3)) return 1;
     if (nnz) {
@@ -765,6 +743,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
       HIPCHK(h, hipStreamSynchronize(h->stream));
     }
   }
+  tm.lap("fmx_prepare: SNP-major gather of likelihoods");
   h->fmx_prepared = true;
   h->K = 0;
   h->fc0 = 0;
@@ -898,7 +877,8 @@ static int fmx_phase_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingl
   const int64_t C = h->C;
   const int npairs = h->K * (h->K + 1) / 2;
   int32_t stat[4] = {0, 0, 0, 0};
-  if (C) HIPCHK(h, hipMemcpyAsync(h->h_fcells, h->d_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyDeviceToHost, h->stream));
+  // the per-cell records travel only when asked for: an EM loop needs the three counters per iteration and the records once
+  if (C && out) HIPCHK(h, hipMemcpyAsync(h->h_fcells, h->d_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(stat, h->d_fstat, sizeof(stat), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (out && C) memcpy(out, h->h_fcells, sizeof(muxgl_fmx_cell) * C);
@@ -937,13 +917,9 @@ int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int
   h->fs1 = s1;
   demux_row_release(&h->frow);
   demux_row_release(&h->fqrow);
-  if (c0 != 0 || c1 != h->C) {  // chunk tables of the cell shard for the row E-step
-    std::vector<int64_t> cp((size_t)h->C + 1);
-    std::vector<int32_t> es((size_t)h->nnz);
-    HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (h->C + 1), hipMemcpyDeviceToHost));
-    if (h->nnz) HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
-    if (demux_row_build(h, &h->frow, cp.data(), es.data(), c0, c1, MUXGL_ROW_CH)) return 1;
-    if (demux_row_build(h, &h->fqrow, cp.data(), es.data(), c0, c1, MUXGL_QUAD_CH)) return 1;
+  if (c0 != 0 || c1 != h->C) {  // chunk tables of the cell shard for the row / quad E-step
+    if (demux_row_build(h, &h->frow, c0, c1, MUXGL_ROW_CH)) return 1;
+    if (demux_row_build(h, &h->fqrow, c0, c1, MUXGL_QUAD_CH)) return 1;
   }
   return 0;
 }

@@ -117,6 +117,7 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
   if (!cell_ptr || !entry_rptr || (nnz > 0 && !entry_snp) || (R > 0 && !reads))
     MUXGL_FAIL(h, "muxgl_set_pileup: NULL array");
   if (S > INT32_MAX) MUXGL_FAIL(h, "muxgl_set_pileup: S exceeds int32");
+  host_timer tm;
   // structural validation (the reference's containers make these states unrepresentable)
   if (cell_ptr[0] != 0 || cell_ptr[C] != nnz) MUXGL_FAIL(h, "muxgl_set_pileup: cell_ptr must span [0,nnz]");
   if (entry_rptr[0] != 0 || entry_rptr[nnz] != R) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr must span [0,R]");
@@ -136,6 +137,7 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
   for (int64_t e = 0; e < nnz; ++e)
     if (entry_rptr[e + 1] < entry_rptr[e]) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr not monotone at %lld", (long long)e);
 
+  tm.lap("set_pileup: validation");
   h->C = C;
   h->S = S;
   h->nnz = nnz;
@@ -164,24 +166,18 @@ int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t
     h->dcells_cap = C;
   }
   h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
-  if (demux_row_plan(h, cell_ptr, entry_snp)) return 1;
+  tm.lap("set_pileup: alloc + H2D enqueue");
+  if (demux_row_plan(h)) return 1;
+  tm.lap("set_pileup: chunk plans (row, quad)");
   if (demux_wave_plan(h, cell_ptr)) return 1;
-  dev_free(&h->d_qent);
-  if (R < ((int64_t)1 << 32) && nnz > 0) {  // packed per-entry records of the quad kernel
-    std::vector<quad_entry> qe((size_t)nnz);
-    for (int64_t e = 0; e < nnz; ++e) {
-      const int64_t r0 = entry_rptr[e], n = entry_rptr[e + 1] - r0;
-      uint32_t f4 = 0;
-      for (int64_t k = 0; k < n && k < 4; ++k) f4 |= (uint32_t)reads[r0 + k] << (8 * k);
-      qe[(size_t)e] = quad_entry{entry_snp[e], (uint32_t)(n > 0xffffffffLL ? 0xffffffffLL : n), f4, (uint32_t)r0};
-    }
-    if (dev_alloc(h, &h->d_qent, (size_t)nnz)) return 1;
-    HIPCHK(h, hipMemcpy(h->d_qent, qe.data(), sizeof(quad_entry) * (size_t)nnz, hipMemcpyHostToDevice));
-  }
+  tm.lap("set_pileup: wave plan");
+  if (plan_build_qent(h)) return 1;  // packed per-entry records of the quad kernel
+  tm.lap("set_pileup: quad entry records");
   h->fmx_prepared = false;
   h->K = 0;
   dev_free(&h->d_sgn);
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  tm.lap("set_pileup: final sync");
   return 0;
 }
 

@@ -79,13 +79,17 @@ def engine_exchange_tensor(eng, which, device_index=0):
 
 
 def run_em(eng, K, clust0, cell_ptr, entry_snp, doublet_prior=0.5, geno_error=0.1, max_iter=10, early_stop=True,
-           exchange=None, exchange_tensor=engine_exchange_tensor, log=None):
+           exchange=None, exchange_tensor=engine_exchange_tensor, log=None, ranges=None, timings=None, sync=None):
     """EM loop of cmd_cram_freemux2.cpp:373-605 after muxgl_fmx_prepare.  Returns (cells[C] (complete on every rank),
     per-iteration stats).  `eng` needs the fmx_* phase methods of muxgl.Engine; `exchange` a TorchExchange/NoExchange."""
+    import time
+
     ex = exchange or NoExchange()
     C, S = eng.C, eng.S
-    c_ranges = shard.cell_shards(cell_ptr, ex.world)
-    s_ranges = shard.snp_shards(entry_snp, S, ex.world)
+    t_start = time.perf_counter()
+    # ranges = (cell ranges, SNP ranges) planned earlier (shard.cell_shards / snp_shards walk all entries)
+    c_ranges, s_ranges = ranges if ranges is not None else (shard.cell_shards(cell_ptr, ex.world),
+                                                            shard.snp_shards(entry_snp, S, ex.world))
     c0, c1 = c_ranges[ex.rank]
     s0, s1 = s_ranges[ex.rank]
     eng.fmx_set_shard(c0, c1, s0, s1)
@@ -93,12 +97,15 @@ def run_em(eng, K, clust0, cell_ptr, entry_snp, doublet_prior=0.5, geno_error=0.
     t_cgp = exchange_tensor(eng, UNIT_CGP) if ex.world > 1 else None
     t_clust = exchange_tensor(eng, UNIT_CLUST) if ex.world > 1 else None
     history = []
+    if sync:
+        sync()
+    t_loop = time.perf_counter()
     for it in range(max_iter):
         eng.fmx_iter_gp(doublet_prior, geno_error)
         if ex.world > 1:
             ex.allgather_rows(t_cgp, s_ranges)
         eng.fmx_iter_estep(doublet_prior, geno_error)
-        cells, stats = eng.fmx_iter_fetch()
+        _, stats = eng.fmx_iter_fetch(want_cells=False)  # three counters; the records are fetched once, below
         if ex.world > 1:
             ex.allgather_rows(t_clust, c_ranges)
             import torch
@@ -113,6 +120,12 @@ def run_em(eng, K, clust0, cell_ptr, entry_snp, doublet_prior=0.5, geno_error=0.
                 f"{stats[2]} changed")
         if stats[2] == 0 and early_stop:  # :601-604
             break
+    if sync:
+        sync()
+    t_end = time.perf_counter()
+    if timings is not None:  # `sync` (a barrier) makes these comparable across ranks
+        timings.update(setup_s=t_loop - t_start, loop_s=t_end - t_loop, iterations=len(history))
+    cells, _ = eng.fmx_iter_fetch()
     parts = ex.gather_objects((c0, c1, cells[c0:c1].tobytes()))
     out = np.zeros(C, dtype=cells.dtype)
     for b, e, raw in parts:

@@ -309,8 +309,8 @@ class Engine:
     def fmx_iter_mstep(self):
         self._check(self.lib.muxgl_fmx_iter_mstep(self.h))
 
-    def fmx_iter_fetch(self, want_full_ll=False):
-        out = np.zeros(self.C, dtype=FMX_CELL)
+    def fmx_iter_fetch(self, want_full_ll=False, want_cells=True):
+        out = np.empty(self.C, dtype=FMX_CELL) if want_cells else None
         full = np.zeros((self.C, self.K * (self.K + 1) // 2)) if want_full_ll else None
         ns, na, nc = C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self.lib.muxgl_fmx_iter_fetch(self.h, _ptr(out), C.byref(ns), C.byref(na), C.byref(nc), _ptr(full)))

@@ -94,8 +94,8 @@ class FakeFmxEngine:
         self.clust[self.c0:self.c1] = cs["clust"]
         self.stats = (ns, na, nch)
 
-    def fmx_iter_fetch(self):
-        return self.cells.copy(), self.stats
+    def fmx_iter_fetch(self, want_cells=True):
+        return (self.cells.copy() if want_cells else None), self.stats
 
     def fmx_iter_mstep(self):
         assert (self.clust > -1000).all(), "an assignment slice was not exchanged"
