@@ -24,6 +24,7 @@ T_DEMUX_REDUCE, T_DEMUX_SWEEP, T_DEMUX_CALL, T_DEMUX_D2H = 0, 1, 2, 3
 FLAG_FORCE_TILE_SWEEP = 1
 FLAG_FORCE_ROW_KERNEL = 2
 FLAG_FORCE_WAVE_KERNEL = 4
+FLAG_FORCE_BATCHED_GREEDY = 8
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
 T_FMXOLD_PAIR, T_FMXOLD_VOTE = 9, 10
 T_COUNT = 16

@@ -27,6 +27,16 @@ def eng(request):
     e.close()
 
 
+@pytest.fixture(scope="module", params=["auto", "batched", "serial"])
+def geng(request):
+    """greedy initial clustering: 'auto' = serial kernel up to K = 24 and batched kernels above, 'batched' / 'serial' =
+    one of them for every K (the batched kernels cover K <= 64)"""
+    flags = {"auto": 0, "batched": muxgl.FLAG_FORCE_BATCHED_GREEDY, "serial": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
+    e = muxgl.Engine(0, flags)
+    yield e
+    e.close()
+
+
 def oracle_init(p, K, clust=None):
     e = ob.fmx_entry_pileup(p)
     llk0, llk2, ns, nr = ob.fmx_cell_scores(p, e)
@@ -113,7 +123,8 @@ def test_em_trajectory_vs_oracle(eng, K, C, S, ment, iters):
     (64, 200, 1.0, -1e300),    # one stripe per wave
     (100, 260, 1.0, -1e300),   # clusters spread over two waves
 ])
-def test_greedy_init_vs_oracle(eng, K, C, frac, thres):
+def test_greedy_init_vs_oracle(geng, K, C, frac, thres):
+    eng = geng
     """b3+b4 of the product (muxgl_fmx_greedy_init: host sort + the persistent-workgroup kernel of fmx_greedy.hip) vs
     the oracle's restatement of cmd_cram_freemux2.cpp:217-261"""
     p = synth.make_pileup(C, 1500, min(K, 16), seed=900 + K, mean_entries=200, min_entries=30, with_gp=False)
@@ -128,7 +139,24 @@ def test_greedy_init_vs_oracle(eng, K, C, frac, thres):
     assert np.max(np.abs((llk2 - llk0) - scores)) < 1e-8
 
 
-def test_greedy_init_deep_cells(eng):
+@pytest.mark.parametrize("K,C,S,me", [(8, 1500, 3000, 300), (48, 700, 1200, 200), (3, 400, 150, 100)])
+def test_greedy_init_many_batches(geng, K, C, S, me):
+    eng = geng
+    """many batches of the batched kernel (32 cells each), dense SNP sharing between the cells of a batch (every cell
+    of the third case covers two thirds of the markers, so most of its terms are corrected)"""
+    p = synth.make_pileup(C, S, min(K, 12), seed=31 + K, mean_entries=me, min_entries=20, with_gp=False)
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    eng.fmx_prepare(p.af)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    got = eng.fmx_greedy_init(K, scores)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+
+
+def test_greedy_init_deep_cells(geng):
+    eng = geng
     """cells with more entries than one staging pass of the kernel (1024), next to empty and tiny ones"""
     K = 5
     p = synth.make_pileup(60, 6000, K, seed=77, mean_entries=1500, min_entries=0, with_gp=False)
