@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--snps", type=int, default=50000)
     ap.add_argument("--samples", type=int, default=16)
     ap.add_argument("--freemuxlet", type=int, default=0, help="also run freemuxlet with this many clusters")
+    ap.add_argument("--freemuxlet-old", type=int, default=0, help="also run freemuxlet-old with this many clusters")
     ap.add_argument("--dir", default="/tmp/e2e")
     ap.add_argument("--bgzf", action="store_true", help="store the PLP table as BGZF, as dsc-pileup does")
     a = ap.parse_args()
@@ -68,6 +69,10 @@ def main():
     if a.freemuxlet:
         print(f"freemuxlet --nsample {a.freemuxlet}:")
         run([BIN, "freemuxlet", "--plp", prefix, "--nsample", str(a.freemuxlet), "--out", os.path.join(a.dir, "fmx")])
+    if a.freemuxlet_old:
+        print(f"freemuxlet-old --nsample {a.freemuxlet_old}:")
+        run([BIN, "freemuxlet-old", "--plp", prefix, "--nsample", str(a.freemuxlet_old), "--out",
+             os.path.join(a.dir, "fmxold")])
 
 
 if __name__ == "__main__":
