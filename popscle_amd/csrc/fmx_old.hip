@@ -12,8 +12,11 @@
 // wave owns PD_SUB columns and walks ALL entries of cell a in ascending SNP order -- so every pair receives its terms
 // in the reference's order (SNPs ascending, :187) and no two waves ever touch the same accumulator.  For an entry the
 // wave needs the cells of that SNP that fall into its column range: the SNP-major view (cells ascending inside a SNP)
-// makes that a contiguous run, found by two binary searches done 64 entries at a time (lane = entry).  Lanes then map
-// to the cells of the run: one gather of the partner's diagonal likelihoods, two log's, one LDS read-modify-write.
+// makes that a contiguous run, found by two binary searches done 64 entries at a time (lane = entry).  The runs are
+// short (a SNP's ~200 cells spread over 10 k columns), so the terms of the 64 entries are flattened: a prefix sum of
+// the run lengths, then lane = term, 64 terms per step whatever entries they belong to -- one gather of the partner's
+// diagonal likelihoods and two log's on full waves.  Only the LDS read-modify-write goes entry by entry (the same
+// column can occur under two entries of a step, and the order of the additions is the reference's).
 //
 // vote kernel: ONE persistent 1024-thread workgroup.  A step counts, for every cluster k, the +1/-1 votes of the
 // already labelled cells in a row of the sign matrix.  The reference adds them one by one to a double that starts at a
@@ -30,12 +33,20 @@
 namespace {
 
 constexpr int PD_T = 1024;  // 16 waves
-// columns per workgroup: 8192 x 16 B = 128 KB of LDS accumulators; 4096 x 28 B when the counters are wanted too
+// columns per workgroup: 6144 x 16 B = 96 KB of LDS accumulators (3072 x 28 B when the counters are wanted too), plus
+// 3 KB of staging per wave for the entries of a batch
+struct pd_stage {  // per wave and batch of 64 entries
+  double4 ent[64];   // {gl[0,0], gl[1,1], gl[2,2], allele frequency} of the entry
+  int64_t lo[64];    // start of the entry's run in the SNP-major arrays
+  int32_t pre[64];   // exclusive prefix sum of the run lengths
+  int32_t nr[64];    // reads of the entry (counters only)
+};
 template <bool FULL>
 struct pd_geom {
-  static constexpr int NB = FULL ? 4096 : 8192;
+  static constexpr int NB = FULL ? 3072 : 6144;
   static constexpr int SUB = NB / (PD_T / 64);
-  static constexpr size_t LDS = (size_t)NB * (FULL ? 28 : 16);
+  static constexpr size_t ACC = (size_t)NB * (FULL ? 28 : 16);
+  static constexpr size_t LDS = ACC + sizeof(pd_stage) * (PD_T / 64);
 };
 
 __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t lo, int64_t hi, int32_t x) {
@@ -56,7 +67,7 @@ __global__ void __launch_bounds__(PD_T)
                        int8_t* __restrict__ sgn, muxgl_dropd* __restrict__ full) {
   constexpr int PD_NB = pd_geom<FULL>::NB, PD_SUB = pd_geom<FULL>::SUB;
   extern __shared__ double2 s_acc[];  // [PD_NB] {llk0, llk2}; FULL: followed by int32 [PD_NB][3]
-  int32_t* s_cnt = reinterpret_cast<int32_t*>(s_acc + PD_NB);
+  int32_t* s_cnt = reinterpret_cast<int32_t*>(s_acc + PD_NB);  // FULL only
   const int a = (int)blockIdx.x;
   const int base = (int)blockIdx.y * PD_NB;
   if (base >= a) return;
@@ -70,33 +81,58 @@ __global__ void __launch_bounds__(PD_T)
   const int w = tid >> 6, lane = tid & 63;
   const int c_lo = base + w * PD_SUB;
   const int c_hi = min(c_lo + PD_SUB, a);
+  pd_stage* st = reinterpret_cast<pd_stage*>(reinterpret_cast<char*>(s_acc) + pd_geom<FULL>::ACC) + w;
   if (c_lo < c_hi) {
     const int64_t e0 = cell_ptr[a], e1 = cell_ptr[a + 1];
     for (int64_t eb = e0; eb < e1; eb += 64) {
+      // lane = entry: its run of partner cells inside this wave's column range, and what a term needs from the entry
       const int64_t e = eb + lane;
       int64_t lo = 0;
       int n = 0;
+      double4 ent = make_double4(0, 0, 0, 0);
+      int32_t nri = 0;
       if (e < e1) {
         const int32_t v = entry_snp[e];
         const int64_t p0 = snp_ptr[v], p1 = snp_ptr[v + 1];
         lo = lower_bound_i32(snp_cell, p0, p1, c_lo);
         n = (int)(lower_bound_i32(snp_cell, lo, p1, c_hi) - lo);
+        if (n > 0) {
+          ent = make_double4(egls[e * 9], egls[e * 9 + 4], egls[e * 9 + 8], af[v]);
+          if (FULL) nri = ecnt[e * 3];
+        }
       }
-      uint64_t m = __ballot(n > 0);
-      while (m) {
-        const int k = __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        const int64_t lo_k = __shfl(lo, k, 64);
-        const int n_k = __shfl(n, k, 64);
-        const int64_t ek = eb + k;
-        const double gi0 = egls[ek * 9], gi1 = egls[ek * 9 + 4], gi2 = egls[ek * 9 + 8];
-        const double f = af[entry_snp[ek]];
-        const int32_t nri = FULL ? ecnt[ek * 3] : 0;
-        const double gp0 = (1.0 - f) * (1.0 - f), gp1 = 2.0 * f * (1.0 - f), gp2 = f * f;  // :199-201
-        for (int t = lane; t < n_k; t += 64) {
-          const int64_t p = lo_k + t;
-          const int col = snp_cell[p] - base;
+      int pre = n;  // inclusive scan over the lanes
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(pre, off, 64);
+        if (lane >= off) pre += o;
+      }
+      const int total = __shfl(pre, 63, 64);
+      st->ent[lane] = ent;
+      st->lo[lane] = lo;
+      st->pre[lane] = pre - n;
+      if (FULL) st->nr[lane] = nri;
+      // lane = term: 64 terms at a time, whatever entries they belong to (the wave's LDS traffic needs no barrier)
+      for (int g0 = 0; g0 < total; g0 += 64) {
+        const int term = g0 + lane;
+        const bool valid = term < total;
+        int k = 0;  // largest k with pre[k] <= term and a non-empty run
+        if (valid) {
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1)
+            if (st->pre[k + step] <= term) k += step;  // empty runs share their successor's prefix: the last one wins
+        }
+        double l0 = 0, l2 = 0;
+        int col = 0;
+        int32_t nrj = 0;
+        if (valid) {
+          const int64_t p = st->lo[k] + (term - st->pre[k]);
+          col = snp_cell[p] - base;
           const double gj0 = segls[p * 9], gj1 = segls[p * 9 + 4], gj2 = segls[p * 9 + 8];
+          if (FULL) nrj = secnt[p * 3];
+          const double4 en = st->ent[k];
+          const double gi0 = en.x, gi1 = en.y, gi2 = en.z, f = en.w;
+          const double gp0 = (1.0 - f) * (1.0 - f), gp1 = 2.0 * f * (1.0 - f), gp2 = f * f;  // :199-201
           // :203-208, the reference's association: ((gl_a * gl_b) * hwe_g) * hwe_h, summed g-major
           double lk2 = (gi0 * gj0) * gp0;
           lk2 += (gi1 * gj1) * gp1;
@@ -110,15 +146,28 @@ __global__ void __launch_bounds__(PD_T)
           lk0 += ((gi2 * gj0) * gp2) * gp0;
           lk0 += ((gi2 * gj1) * gp2) * gp1;
           lk0 += ((gi2 * gj2) * gp2) * gp2;
-          double2 acc = s_acc[col];
-          acc.x += log(lk0);
-          acc.y += log(lk2);
-          s_acc[col] = acc;
-          if (FULL) {
-            s_cnt[3 * col] += 1;
-            s_cnt[3 * col + 1] += nri;
-            s_cnt[3 * col + 2] += secnt[p * 3];
+          l0 = log(lk0);
+          l2 = log(lk2);
+        }
+        // accumulate entry by entry, in ascending SNP order (:187): the cells of one entry's run are distinct, the same
+        // cell may appear again under a later entry of the group
+        uint64_t pend = __ballot(valid);
+        while (pend) {
+          const int f = __ffsll((unsigned long long)pend) - 1;
+          const int kf = __shfl(k, f, 64);
+          const uint64_t sel = __ballot(valid && k == kf) & pend;
+          if ((sel >> lane) & 1) {
+            double2 acc = s_acc[col];
+            acc.x += l0;
+            acc.y += l2;
+            s_acc[col] = acc;
+            if (FULL) {
+              s_cnt[3 * col] += 1;
+              s_cnt[3 * col + 1] += st->nr[k];
+              s_cnt[3 * col + 2] += nrj;
+            }
           }
+          pend &= ~sel;
         }
       }
     }
