@@ -53,8 +53,38 @@ def fmx_case(name, C, S, K, seed, n_iter, **kw):
     print(name, "cells", p.C, "entries", p.nnz, "stats", stats)
 
 
+def fmxold_case(name, C, S, K, seed, **kw):
+    """freemuxlet-old's initial clustering (cmd_cram_freemuxlet.cpp:176-343): pair records, first pass, three refinement
+    passes; jitters and orders are part of the fixture (the RNG belongs to the caller)"""
+    p = synth.make_pileup(C, S, K, seed=seed, with_gp=False, cap_bq=60, min_bq=2, **kw)
+    e = ob.fmx_entry_pileup(p)
+    llk0, llk2, _, _ = ob.fmx_cell_scores(p, e)
+    order = ob.fmx_sort(llk2 - llk0)
+    dd = ob.fmxold_pair_dist(p, e)
+    rng = np.random.default_rng(seed)
+    thres, frac = 2.0, 0.8
+    nvis = sum(1 for i in range(C) if not i > C * frac)
+    jit0 = rng.integers(0, 2**31, (nvis, K)) / 2.0**31 / 1000.0
+    clust0, cc0 = ob.fmxold_vote_init(C, K, dd, order, jit0, thres, frac)
+    orands, jits, clusts, changed = [], [], [], []
+    cl = clust0
+    for it in range(3):
+        orand = rng.permutation(C).astype(np.int32)
+        jit = rng.integers(0, 2**31, (C, K)) / 2.0**31 / 1000.0
+        cl, ch, _ = ob.fmxold_vote_refine(C, K, dd, orand, jit, cl, thres, keep_init_missing=(it == 0))
+        orands.append(orand), jits.append(jit), clusts.append(cl), changed.append(ch)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), C=p.C, S=p.S, K=K, cell_ptr=p.cell_ptr,
+                        entry_snp=p.entry_snp, entry_rptr=p.entry_rptr, reads=p.reads, af=p.af, bf_thres=thres,
+                        frac_init_clust=frac, order=order, dropd=dd, jitter0=jit0, clust0=clust0, ccounts0=cc0,
+                        orands=np.array(orands), jitters=np.array(jits), clusts=np.array(clusts),
+                        changed=np.array(changed))
+    print(name, "cells", p.C, "pairs", dd.size, "first pass", np.bincount(clust0[clust0 >= 0], minlength=K), "changed",
+          changed)
+
+
 if __name__ == "__main__":
     demux_case("demux_v4_a2", 60, 1500, 4, (0.0, 0.5), seed=101, mean_entries=200, missing_gp_frac=0.05)
     demux_case("demux_v4_a6", 40, 1500, 4, (0.0, 0.1, 0.2, 0.3, 0.4, 0.5), seed=102, mean_entries=200)
     demux_case("demux_v16_a2", 40, 3000, 16, (0.0, 0.5), seed=103, mean_entries=300)
     fmx_case("fmx_k4", 120, 1500, 4, seed=104, n_iter=4, mean_entries=200)
+    fmxold_case("fmxold_k4", 90, 600, 4, seed=105, mean_entries=150, min_entries=30)

@@ -184,3 +184,20 @@ def test_private_random_r_state_equals_rand():
         for _ in range(2000):
             libc.random_r(rd, ctypes.byref(r))
             assert r.value == libc.rand()
+
+
+def test_oracle_reproduces_golden_fmxold():
+    """tests/golden/fmxold_k4.npz (regression vectors of the restatement, tests/golden/make_golden.py)"""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fmxold_k4.npz"))
+    p = synth.Pileup(int(g["C"]), int(g["S"]), g["cell_ptr"], g["entry_snp"], g["entry_rptr"], g["reads"], g["af"])
+    e = ob.fmx_entry_pileup(p)
+    dd = ob.fmxold_pair_dist(p, e)
+    assert dd.tobytes() == g["dropd"].tobytes()
+    K, thres, frac = int(g["K"]), float(g["bf_thres"]), float(g["frac_init_clust"])
+    cl, cc = ob.fmxold_vote_init(p.C, K, dd, g["order"], g["jitter0"], thres, frac)
+    assert np.array_equal(cl, g["clust0"]) and np.array_equal(cc, g["ccounts0"])
+    for it in range(3):
+        cl, ch, _ = ob.fmxold_vote_refine(p.C, K, dd, g["orands"][it], g["jitters"][it], cl, thres, it == 0)
+        assert np.array_equal(cl, g["clusts"][it]) and ch == g["changed"][it]

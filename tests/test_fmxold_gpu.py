@@ -77,6 +77,24 @@ def test_pair_dist_wide_columns(eng):
     assert np.abs(got["llk2"] - want["llk2"]).max() < 1e-9 and np.abs(got["llk0"] - want["llk0"]).max() < 1e-9
 
 
+def test_golden(eng):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fmxold_k4.npz"))
+    p = synth.Pileup(int(g["C"]), int(g["S"]), g["cell_ptr"], g["entry_snp"], g["entry_rptr"], g["reads"], g["af"])
+    K, thres, frac = int(g["K"]), float(g["bf_thres"]), float(g["frac_init_clust"])
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    eng.fmx_prepare(p.af)
+    got = eng.fmxold_pair_dist(thres, want_full=True)
+    want = g["dropd"]
+    for f in ("nsnps", "nread1", "nread2"):
+        assert np.array_equal(got[f], want[f])
+    assert np.abs(got["llk0"] - want["llk0"]).max() < 1e-9 and np.abs(got["llk2"] - want["llk2"]).max() < 1e-9
+    cl, cc = eng.fmxold_vote_init(K, g["order"], g["jitter0"], frac)
+    assert np.array_equal(cl, g["clust0"]) and np.array_equal(cc, g["ccounts0"])
+    for it in range(3):
+        cl, ch, _ = eng.fmxold_vote_refine(K, g["orands"][it], g["jitters"][it], cl, it == 0)
+        assert np.array_equal(cl, g["clusts"][it]) and ch == g["changed"][it]
+
+
 def jitters(rng, n, K, mode):
     if mode == "rand":  # what the reference draws
         return rng.integers(0, 2**31, (n, K)) / (2.0**31) / 1000.0
