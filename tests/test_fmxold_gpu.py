@@ -138,6 +138,54 @@ def test_votes_vs_oracle(eng, K, mode):
             clust = w
 
 
+def test_votes_edge_cases(eng):
+    """empty droplets among the cells, a threshold nobody passes (every election is decided by the jitters alone), a
+    threshold of zero (almost every pair votes), a single cell"""
+    C, K = 120, 6
+    p = synth.make_pileup(C, 400, 4, seed=9, mean_entries=60, min_entries=0, with_gp=False)
+    p = p.subset_cells(np.arange(C))
+    keep = np.ones(C, dtype=bool)
+    keep[[3, 50, 119]] = False  # three droplets without any entry
+    lens = np.where(keep, np.diff(p.cell_ptr), 0)
+    q = p.subset_cells(np.flatnonzero(keep))
+    cp = np.zeros(C + 1, dtype=np.int64)
+    np.cumsum(lens, out=cp[1:])
+    p = synth.Pileup(C, p.S, cp, q.entry_snp, q.entry_rptr, q.reads, p.af)
+    assert (np.diff(p.cell_ptr) == 0).sum() == 3
+    e = prepared(eng, p)
+    dd = ob.fmxold_pair_dist(p, e)
+    rng = np.random.default_rng(17)
+    order = rng.permutation(C).astype(np.int32)
+    for thres in (1e9, 0.0):
+        got_full = eng.fmxold_pair_dist(thres, want_full=True)
+        assert np.array_equal(got_full["nsnps"], dd["nsnps"])
+        jit = jitters(rng, C, K, "rand")
+        w, wcc = ob.fmxold_vote_init(C, K, dd, order, jit, thres, 1.0)
+        g, gcc = eng.fmxold_vote_init(K, order, jit, 1.0)
+        assert np.array_equal(g, w) and np.array_equal(gcc, wcc)
+        if thres > 1:
+            assert np.array_equal(g[order], np.argmax(jit, axis=1))  # no votes at all: the largest jitter wins
+        jit = jitters(rng, C, K, "rand")
+        orand = rng.permutation(C).astype(np.int32)
+        w2, wch, _ = ob.fmxold_vote_refine(C, K, dd, orand, jit, w, thres, False)
+        g2, gch, _ = eng.fmxold_vote_refine(K, orand, jit, w, False)
+        assert np.array_equal(g2, w2) and gch == wch
+    # frac_init_clust = 0: only the first cell of the order is visited (i > C * 0 is false for i = 0 only)
+    jit = jitters(rng, 1, K, "rand")
+    w, _ = ob.fmxold_vote_init(C, K, dd, order, jit, 2.0, 0.0)
+    g, _ = eng.fmxold_vote_init(K, order, jit, 0.0)
+    assert np.array_equal(g, w) and (g >= 0).sum() == 1
+    # one cell
+    q = synth.make_pileup(1, 50, 2, seed=3, mean_entries=20, with_gp=False)
+    prepared(eng, q)
+    eng.fmxold_pair_dist(5.41)
+    jit = jitters(rng, 1, 3, "rand")
+    g, cc = eng.fmxold_vote_init(3, np.zeros(1, dtype=np.int32), jit, 1.0)
+    assert g[0] == int(np.argmax(jit[0])) and cc.sum() == 1
+    g2, ch, _ = eng.fmxold_vote_refine(3, np.zeros(1, dtype=np.int32), jit, g, False)
+    assert g2[0] == g[0] and ch == 0
+
+
 def test_votes_rounding_sensitive(eng):
     """a hand-made sign matrix is not available through the ABI, so build pileups whose pair matrix is dense in +-1 and
     give the clusters jitters 2^-62 apart: the elected cluster then depends on which binades each cluster's running vote
