@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256)
   }
   const int V3 = V * 3;
   const int PG = nAlpha * 9;
+  int since = 0;  // factors multiplied into the accumulators since the last renormalisation
   __syncthreads();
 
   for (int64_t eb = e0; eb < e1; eb += EC) {
@@ -189,7 +190,8 @@ __global__ void __launch_bounds__(256)
             }
           }
         }
-        if ((r & 15) == 15) {
+        if (++since == 16) {  // every factor is >= ~1e-11: sixteen of them cannot underflow.  Counted across chunks:
+          since = 0;           // for V > 96 a chunk holds fewer than 16 entries
 #pragma unroll
           for (int n = 0; n < NA; ++n) prodacc_renorm(acc[n], ex[n]);
         }

@@ -58,6 +58,10 @@ def test_golden(eng, name):
     (7, (0.0, 0.3), 60, 1500, 200),               # no symmetric alpha at all
     (33, (0.0, 0.5), 30, 4000, 400),              # more pairs than one 256-thread tile
     (64, GRID6, 12, 6000, 500),                   # config-3 shape, few cells
+    (65, (0.0, 0.5), 10, 6000, 1500),             # first V of the general tile sweep + one-lane-per-cell call
+    (100, (0.0, 0.25, 0.5), 8, 8000, 2500),       # V > 96: a staging chunk holds fewer than 16 entries; deep cells
+    (130, (0.0, 0.5), 6, 8000, 2500),             # (their products leave the double range without renormalisation)
+    (200, (0.0, 0.5), 4, 6000, 1200),
 ])
 def test_random_vs_oracle(eng, V, alphas, C, S, ment):
     p = synth.make_pileup(C, S, V, seed=1000 + V * 7 + len(alphas), mean_entries=ment, min_entries=20,
