@@ -75,6 +75,34 @@ def test_random_vs_oracle(eng, V, alphas, C, S, ment):
     assert np.all(gfull[:, ~parity.needed_ll_mask(V, alphas)] == 0.0)
 
 
+@pytest.mark.parametrize("V,nalpha,C,S,ment", [(6, 9, 40, 1500, 300), (12, 16, 24, 2000, 300), (40, 13, 10, 3000, 400)])
+def test_long_alpha_grids(eng, V, nalpha, C, S, ment):
+    """more alphas than the row / wave kernels take (<= 5 non-symmetric ones): the general sweep, up to MUXGL_MAX_ALPHA"""
+    alphas = (0.0,) + tuple(np.round(np.linspace(0.04, 0.96, nalpha - 2), 3)) + (0.5,)
+    assert len(alphas) == nalpha
+    p = synth.make_pileup(C, S, V, seed=2000 + V, mean_entries=ment, min_entries=20)
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
+    got, gfull = run_gpu(eng, p, alphas, full=True)
+    rep = parity.compare_demux(got, want, alphas, want_full=wfull)
+    assert rep["max_abs_ll_diff"] < 1e-7 and parity.compare_full_ll(gfull, wfull, V, alphas) < 1e-7
+
+
+@pytest.mark.parametrize("V", [4, 16, 40])
+def test_deep_pileups_per_entry(eng, V):
+    """entries with tens to hundreds of reads (bulk-like coverage): the per-read update with its lazy renormalisation,
+    reads beyond the four a packed entry record carries, base qualities over the whole 7-bit range"""
+    p = synth.make_pileup(30, 600, V, seed=3000 + V, mean_entries=80, min_entries=10, reads_lambda=60.0, min_bq=2,
+                          max_bq=93, cap_bq=127, other=0.03)
+    assert np.diff(p.entry_rptr).max() > 80
+    alphas = (0.0, 0.3, 0.5)
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
+    got, gfull = run_gpu(eng, p, alphas, full=True)
+    rep = parity.compare_demux(got, want, alphas, want_full=wfull)
+    assert rep["max_abs_ll_diff"] < 1e-7 and parity.compare_full_ll(gfull, wfull, V, alphas) < 1e-7
+    got2 = run_gpu(eng, p, (0.0, 0.5))
+    parity.compare_demux(got2, ob.demux(p, alphas=(0.0, 0.5), nthreads=4), (0.0, 0.5))
+
+
 def test_entry_pg_vs_oracle(eng):
     p = synth.make_pileup(30, 800, 4, seed=77, mean_entries=100, min_entries=10, reads_lambda=2.5, other=0.05)
     for alphas in [(0.0, 0.5), GRID6]:

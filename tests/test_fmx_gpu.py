@@ -109,6 +109,8 @@ def test_golden(eng):
     (5, 120, 1000, 200, 3),
     (20, 100, 2500, 400, 2),   # K > 16: pair kernel on both engines
     (64, 40, 4000, 500, 2),    # config-5 shape, few cells
+    (70, 24, 5000, 1200, 2),   # K > 64: the general pair E-step and the (SNP, cluster)-parallel M-step; deep cells
+    (100, 16, 5000, 1500, 2),
 ])
 def test_em_trajectory_vs_oracle(eng, K, C, S, ment, iters):
     p = synth.make_pileup(C, S, K, seed=500 + K, mean_entries=ment, min_entries=30, with_gp=False)
