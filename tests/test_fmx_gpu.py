@@ -118,6 +118,17 @@ def test_em_trajectory_vs_oracle(eng, K, C, S, ment, iters):
     assert worst < 1e-7
 
 
+@pytest.mark.parametrize("K,C,S,ment,lam", [(4, 60, 5000, 2500, 0.3), (16, 40, 6000, 3000, 0.3), (40, 24, 6000, 2500, 0.3),
+                                          (5, 60, 800, 150, 50.0)])
+def test_em_trajectory_deep(eng, K, C, S, ment, lam):
+    """cells of several thousand entries (several chunks / staging passes of every E-step kernel) and entries of tens to
+    hundreds of reads over the whole base-quality range (calculate_snp_droplet_pileup with its per-read normalisation)"""
+    p = synth.make_pileup(C, S, min(K, 8), seed=700 + K, mean_entries=ment, min_entries=200 if lam < 1 else 30,
+                          with_gp=False, reads_lambda=lam, min_bq=2, max_bq=93, cap_bq=127, other=0.02)
+    worst = run_em(eng, p, K, 2)
+    assert worst < 1e-7
+
+
 @pytest.mark.parametrize("K,C,frac,thres", [
     (4, 150, 1.0, -1e300), (6, 100, 0.5, -1e300), (3, 100, 1.0, 5.0),
     (1, 40, 1.0, -1e300),      # a single cluster
