@@ -29,9 +29,11 @@ def local_allgather(engs, which, ranges, row_bytes):
             other.memcpy_dev(dst + b * row_bytes, src + b * row_bytes, (e - b) * row_bytes)
 
 
-@pytest.mark.parametrize("K,world", [(4, 2), (16, 3), (20, 2)])
-def test_virtual_ranks_match_single_handle(K, world):
-    p = synth.make_pileup(240, 2000, K, seed=60 + K, mean_entries=250, min_entries=30, with_gp=False)
+@pytest.mark.parametrize("K,world,C", [(4, 2, 240), (16, 3, 240), (20, 2, 240), (64, 2, 60),
+                                       (3, 5, 3)])  # more ranks than cells: empty cell shards
+def test_virtual_ranks_match_single_handle(K, world, C):
+    p = synth.make_pileup(C, 2000 if C > 3 else 40, min(K, 8), seed=60 + K, mean_entries=250 if C > 3 else 12,
+                          min_entries=30 if C > 3 else 5, with_gp=False)
     oe = ob.fmx_entry_pileup(p)
     o0, o2, _, _ = ob.fmx_cell_scores(p, oe)
     clust0 = ob.fmx_greedy_init(p, oe, K, o2 - o0, ob.fmx_sort(o2 - o0))
