@@ -86,12 +86,14 @@ __device__ __forceinline__ void top2_insert(top2& t, double v, int32_t pos) {
   }
 }
 
-// Second half of the call: merges the per-lane row results (top-2 lists, the row's largest evidence term rowmax, its
-// evidence sum racc relative to rowmax, the singlet term sterm) over the G lanes of the cell and makes the decision.
+// Second half of the call: merges the per-lane row results (top-2 lists, the largest evidence term rowmax of the lane's
+// rows, their evidence sum racc relative to rowmax, the largest singlet term sterm and the singlet sum sacc relative to
+// it -- 1 for a lane with one row) over the G lanes of the cell and makes the decision.
 template <int G>
 __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
                                                   const double* gridAlpha, double doublet_prior, top2 sng, top2 dbl,
-                                                  double sterm, double rowmax, double racc, muxgl_demux_cell* out) {
+                                                  double sterm, double rowmax, double racc, muxgl_demux_cell* out,
+                                                  double sacc = 1.0) {
   const int j = lane & (G - 1);
   const double NEG_INF = -__builtin_huge_val();
   const double log_single_prior = log((1.0 - doublet_prior) / nv);
@@ -107,7 +109,7 @@ __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_
     Ms = fmax(Ms, __shfl_xor(Ms, m, 64));
   }
   double S = (racc > 0.0) ? racc * exp(rowmax - M) : 0.0;
-  double Ss = (sterm > NEG_INF) ? exp(sterm - Ms) : 0.0;
+  double Ss = (sterm > NEG_INF) ? sacc * exp(sterm - Ms) : 0.0;
 #pragma unroll
   for (int m = 1; m < G; m <<= 1) {
     S += __shfl_xor(S, m, 64);
@@ -227,43 +229,54 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
 
   top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
   const double NEG_INF = -__builtin_huge_val();
-  double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0;
+  double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0, sacc = 0.0;
   if (live) {
-    const double* row = ll_cell + (size_t)j * nv * nAlpha;
-    const double s = row[0];  // llksAB[j][0][0]
-    top2_push(sng, s, j);
-    sterm = s + log_single_prior;
-    rowmax = sterm;
-    // pass 1: scans, and the largest evidence term of the row
-    for (int k = 0; k < nv; ++k) {
-      if (k == j) continue;
-      for (int n = 1; n < nAlpha; ++n) {
-        const double v = row[k * nAlpha + n];
-        if (gridAlpha[n] == 0.5) {
-          if (k < j) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
-        } else {
-          rowmax = fmax(rowmax, v + log_doublet_prior1);
-        }
-        top2_push(dbl, v, (j * nv + k) * nAlpha + n);
-      }
-    }
-    // pass 2: the row's evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
-    if (rowmax > NEG_INF) {
-      racc = exp(sterm - rowmax);
+    // a lane takes the rows j, j + G, ..: ascending rows are ascending scan positions, so the reference's update rule
+    // (top2_push) applies across them as it does inside a row
+    // pass 1: scans, and the largest evidence term of the lane's rows
+    for (int jr = j; jr < nv; jr += G) {
+      const double* row = ll_cell + (size_t)jr * nv * nAlpha;
+      const double s = row[0];  // llksAB[j][0][0]
+      top2_push(sng, s, jr);
+      const double st = s + log_single_prior;
+      sterm = fmax(sterm, st);
+      rowmax = fmax(rowmax, st);
       for (int k = 0; k < nv; ++k) {
-        if (k == j) continue;
+        if (k == jr) continue;
         for (int n = 1; n < nAlpha; ++n) {
           const double v = row[k * nAlpha + n];
           if (gridAlpha[n] == 0.5) {
-            if (k < j) racc += exp(v + log_doublet_prior2 - rowmax);
+            if (k < jr) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
           } else {
-            racc += exp(v + log_doublet_prior1 - rowmax);
+            rowmax = fmax(rowmax, v + log_doublet_prior1);
+          }
+          top2_push(dbl, v, (jr * nv + k) * nAlpha + n);
+        }
+      }
+    }
+    // pass 2: the evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
+    if (rowmax > NEG_INF) {
+      for (int jr = j; jr < nv; jr += G) {
+        const double* row = ll_cell + (size_t)jr * nv * nAlpha;
+        const double st = row[0] + log_single_prior;
+        racc += exp(st - rowmax);
+        sacc += exp(st - sterm);
+        for (int k = 0; k < nv; ++k) {
+          if (k == jr) continue;
+          for (int n = 1; n < nAlpha; ++n) {
+            const double v = row[k * nAlpha + n];
+            if (gridAlpha[n] == 0.5) {
+              if (k < jr) racc += exp(v + log_doublet_prior2 - rowmax);
+            } else {
+              racc += exp(v + log_doublet_prior1 - rowmax);
+            }
           }
         }
       }
     }
   }
-  demux_call_finish<G>(lane, cell_ok, nsnps, nv, nAlpha, gridAlpha, doublet_prior, sng, dbl, sterm, rowmax, racc, out);
+  demux_call_finish<G>(lane, cell_ok, nsnps, nv, nAlpha, gridAlpha, doublet_prior, sng, dbl, sterm, rowmax, racc, out,
+                       sacc);
 }
 
 }  // namespace muxgl_call

@@ -485,7 +485,7 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the quad path's finish kernel
     if (rc < 0) rc = demux_row_launch(h, p);    // other grids: row kernel
   }
-  if (rc < 0) rc = demux_wave_launch(h, p);  // V <= 64: one wave per cell, one lane per sample (own LL layout)
+  if (rc < 0) rc = demux_wave_launch(h, p);  // one wave per cell and 64 x 64 block of the pair matrix, lane = sample
   if (rc > 0) return rc;
   if (rc < 0) {                     // general tile sweep
     if (demux_ensure_ll(h, p)) return 1;
@@ -504,8 +504,8 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   tic(h, MUXGL_T_DEMUX_CALL);
   if (h->ll_wave) {
     if (demux_call_wave_launch(h, p)) return 1;
-  } else if (h->V <= 64 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
-    if (demux_call16_launch(h, p)) return 1;  // 16 or 64 lanes per cell
+  } else if (!(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
+    if (demux_call16_launch(h, p)) return 1;  // 16 or 64 lanes per cell (a lane takes every 64th row beyond 64 samples)
   } else {
     const unsigned blocks = (unsigned)((h->C + 63) / 64);
     hipLaunchKernelGGL(demux_call_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,

@@ -30,21 +30,32 @@ __device__ __forceinline__ double dpp_wror1(double x) {
   return __hiloint2double(hi, lo);
 }
 
-// NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise.  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
-template <int NSHIFT, bool WITH_SINGLET>
+// More than 64 samples: the V x V pair matrix is cut into 64 x 64 blocks (X, Y).  A diagonal block is the kernel as
+// described above on the samples 64X .. 64X+63 (jbase).  An off-diagonal block (CROSS) keeps sample 64X + j in lane j and
+// rotates the triples of the samples 64Y + k (kbase) past it: all 64 rotations are pairs, including the unrotated one,
+// which is reached by starting one lane ahead.  One result slab llw[c][block][alpha][step][lane] per block.
+struct wave_blk {
+  int32_t jbase, kbase;  // first sample of the lane's block / of the rotating block
+  int32_t blk, nblk2;    // slab of this launch, slabs per cell
+};
+
+// NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise (64 with CROSS).  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
+template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false>
 __global__ void __launch_bounds__(64, 2)
     demux_wave_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
                       const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                       const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel,
-                      double* __restrict__ ll) {
+                      wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_cells) return;
   const int64_t c = order[blockIdx.x];
   const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
   if (e0 == e1) return;
   const int j = threadIdx.x;
-  const bool live = j < V;
+  const bool live = wb.jbase + j < V;
+  const bool live2 = wb.kbase + j < V;
   const int V3 = V * 3;
   const int PG = nAlpha * 9;
+  const int jo = (wb.jbase + j) * 3, ko = (wb.kbase + j) * 3;
 
   double acc[NSHIFT], accS = 1.0;
   int32_t ex[NSHIFT], exS = 0;
@@ -58,21 +69,34 @@ __global__ void __launch_bounds__(64, 2)
   int64_t e = e0;
   while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+  double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
   if (e < e1 && live) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+    const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
     ng0 = row[0], ng1 = row[1], ng2 = row[2];
+  }
+  if (CROSS && e < e1 && live2) {
+    const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
+    np0 = row[0], np1 = row[1], np2 = row[2];
   }
   int cnt = 0;
   while (e < e1) {
     const int64_t ecur = e;
     const int32_t scur = entry_snp[ecur];
     const double g0 = ng0, g1 = ng1, g2 = ng2;
+    const double p0 = np0, p1 = np1, p2 = np2;
     ++e;
     while (e < e1 && !has_gp[entry_snp[e]]) ++e;
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
     if (e < e1 && live) {
-      const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+      const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
       ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    }
+    if (CROSS) {
+      np0 = 1.0, np1 = 0.0, np2 = 0.0;
+      if (e < e1 && live2) {
+        const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
+        np0 = row[0], np1 = row[1], np2 = row[2];
+      }
     }
     // wave-uniform operands: the nine likelihoods of the selected alpha (and of alpha[0] for the singlet slot)
     const double* q = pg + (size_t)ecur * PG + (size_t)n_sel * 9;
@@ -89,6 +113,11 @@ __global__ void __launch_bounds__(64, 2)
     const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
     const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
     double r0 = g0, r1 = g1, r2 = g2;
+    if (CROSS) {  // one lane ahead: the first rotation then brings sample kbase + j itself
+      r0 = __shfl(p0, (j + 1) & 63, 64);
+      r1 = __shfl(p1, (j + 1) & 63, 64);
+      r2 = __shfl(p2, (j + 1) & 63, 64);
+    }
 #pragma unroll
     for (int t = 0; t < NSHIFT; ++t) {
       r0 = dpp_wror1(r0);
@@ -107,14 +136,14 @@ __global__ void __launch_bounds__(64, 2)
   // Results go to the wave layout llw[c][n][step t][lane j] (coalesced; the partner of (t, j) is re-derived by the
   // readers with the same rotation): lane j, step t holds the hypothesis (j, k = j - t - 1 mod 64).  Alpha = 0.5 fills
   // the mirrored half too: the pair met at step t by lane j is met at step 62 - t by lane k.
-  double* out = ll + (size_t)c * nAlpha * 4096;
+  double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;
   int kk = j;
 #pragma unroll
   for (int t = 0; t < NSHIFT; ++t) {
     kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
     const double v = prodacc_log(acc[t], ex[t]);
     if (n_sel > 0) {
-      if (NSHIFT == 63) {
+      if (NSHIFT >= 63) {
         out[((size_t)n_sel * 64 + t) * 64 + j] = v;
       } else if (t < 31 || j > kk) {  // step 32 of 64 lanes meets every unordered pair twice: one writer
         out[((size_t)n_sel * 64 + t) * 64 + j] = v;
@@ -132,21 +161,23 @@ __global__ void __launch_bounds__(64, 2)
 struct wave_sel {
   int32_t n[4];
 };
-template <int NA, int NS, bool WITH_SINGLET>
+template <int NA, int NS, bool WITH_SINGLET, bool CROSS = false>
 __global__ void __launch_bounds__(64, 2)
     demux_wave_multi_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
                             const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                             const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
-                            wave_sel sel, int s0, double* __restrict__ ll) {
+                            wave_sel sel, int s0, wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_cells) return;
   const int64_t c = order[blockIdx.x];
   const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
   if (e0 == e1) return;
   const int j = threadIdx.x;
-  const bool live = j < V;
+  const bool live = wb.jbase + j < V;
+  const bool live2 = wb.kbase + j < V;
   const int V3 = V * 3;
   const int PG = nAlpha * 9;
-  const int src = (j - s0) & 63;  // lane whose triple this lane starts from
+  const int jo = (wb.jbase + j) * 3, ko = (wb.kbase + j) * 3;
+  const int src = (j - s0 + (CROSS ? 1 : 0)) & 63;  // lane whose triple this lane starts from
 
   // 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
   __shared__ int32_t exs[NA * NS][64];
@@ -161,21 +192,34 @@ __global__ void __launch_bounds__(64, 2)
   int64_t e = e0;
   while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+  double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
   if (e < e1 && live) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+    const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
     ng0 = row[0], ng1 = row[1], ng2 = row[2];
+  }
+  if (CROSS && e < e1 && live2) {
+    const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
+    np0 = row[0], np1 = row[1], np2 = row[2];
   }
   int cnt = 0;
   while (e < e1) {
     const int64_t ecur = e;
     const int32_t scur = entry_snp[ecur];
     const double g0 = ng0, g1 = ng1, g2 = ng2;
+    const double p0 = np0, p1 = np1, p2 = np2;
     ++e;
     while (e < e1 && !has_gp[entry_snp[e]]) ++e;
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
     if (e < e1 && live) {
-      const double* row = gp + (size_t)entry_snp[e] * V3 + j * 3;
+      const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
       ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    }
+    if (CROSS) {
+      np0 = 1.0, np1 = 0.0, np2 = 0.0;
+      if (e < e1 && live2) {
+        const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
+        np0 = row[0], np1 = row[1], np2 = row[2];
+      }
     }
     if (WITH_SINGLET) {
       const double* s = pg + (size_t)ecur * PG;
@@ -193,8 +237,8 @@ __global__ void __launch_bounds__(64, 2)
       u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
       u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
     }
-    double r0 = g0, r1 = g1, r2 = g2;
-    if (s0) {
+    double r0 = CROSS ? p0 : g0, r1 = CROSS ? p1 : g1, r2 = CROSS ? p2 : g2;
+    if (s0 || CROSS) {
       r0 = __shfl(r0, src, 64);
       r1 = __shfl(r1, src, 64);
       r2 = __shfl(r2, src, 64);
@@ -219,10 +263,10 @@ __global__ void __launch_bounds__(64, 2)
     }
   }
 
-  double* out = ll + (size_t)c * nAlpha * 4096;  // wave layout, see demux_wave_kernel
+  double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;  // wave layout, see demux_wave_kernel
 #pragma unroll
   for (int t = 0; t < NS; ++t)
-    if (s0 + t < 63) {
+    if (s0 + t < (CROSS ? 64 : 63)) {
 #pragma unroll
       for (int a = 0; a < NA; ++a)
         out[((size_t)sel.n[a] * 64 + s0 + t) * 64 + j] = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
@@ -230,21 +274,36 @@ __global__ void __launch_bounds__(64, 2)
   if (WITH_SINGLET) out[j] = prodacc_log(accS, exS);
 }
 
-// wave layout -> the ABI's [C][V][V][A] tensor (only when the caller asks for it)
+// wave layout -> the ABI's [C][V][V][A] tensor (when the caller asks for it, and for V > 64, where the call kernel reads
+// the tensor).  grid = (C, blocks per cell); block (X, Y) of a symmetric alpha exists for X >= Y only and is mirrored.
 __global__ void __launch_bounds__(64)
     demux_wave_to_full_kernel(const double* __restrict__ llw, const int64_t* __restrict__ cell_ptr, int V, int nAlpha,
-                              double* __restrict__ ll) {
+                              int nblk, uint32_t symmask, double* __restrict__ ll) {
   const int64_t c = blockIdx.x;
+  const int X = (int)blockIdx.y / nblk, Y = (int)blockIdx.y % nblk;
   const int j = threadIdx.x;
-  if (j >= V || cell_ptr[c] == cell_ptr[c + 1]) return;  // the sweep leaves nothing behind for an empty cell
-  const double* in = llw + (size_t)c * nAlpha * 4096;
+  const int sj = 64 * X + j;
+  if (sj >= V || cell_ptr[c] == cell_ptr[c + 1]) return;  // the sweep leaves nothing behind for an empty cell
+  const double* in = llw + ((size_t)c * nblk * nblk + blockIdx.y) * nAlpha * 4096;
   double* out = ll + (size_t)c * V * V * nAlpha;
-  out[(size_t)j * V * nAlpha] = in[j];
-  for (int n = 1; n < nAlpha; ++n)
-    for (int t = 0; t < 63; ++t) {
-      const int k = (j - t - 1) & 63;  // wave_ror:1 brings lane j the value of lane j - 1
-      if (k < V) out[((size_t)j * V + k) * nAlpha + n] = in[((size_t)n * 64 + t) * 64 + j];
+  if (Y == 0 && X == Y) out[(size_t)sj * V * nAlpha] = in[j];
+  if (Y == 0 && X != Y) {  // singlet slot (sj, 0, 0) of the samples beyond the first block: kept by the diagonal block
+    const double* dg = llw + ((size_t)c * nblk * nblk + (size_t)X * nblk + X) * nAlpha * 4096;
+    out[(size_t)sj * V * nAlpha] = dg[j];
+  }
+  const bool cross = X != Y;
+  for (int n = 1; n < nAlpha; ++n) {
+    const bool sym = (symmask >> n) & 1u;
+    if (sym && X < Y) continue;  // filled by the mirror of (Y, X)
+    for (int t = 0; t < (cross ? 64 : 63); ++t) {
+      const int k = cross ? ((j - t) & 63) : ((j - t - 1) & 63);  // wave_ror:1 brings lane j the value of lane j - 1
+      const int sk = 64 * Y + k;
+      if (sk >= V) continue;
+      const double v = in[((size_t)n * 64 + t) * 64 + j];
+      out[((size_t)sj * V + sk) * nAlpha + n] = v;
+      if (sym && cross) out[((size_t)sk * V + sj) * nAlpha + n] = v;
     }
+  }
 }
 
 }  // namespace
@@ -281,18 +340,23 @@ int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr) {
 
 // returns -1 when the wave path does not apply, 0 ok, 1 error
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
-  if (h->V > 64 || !h->wave || h->C == 0 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
+  if (!h->wave || h->C == 0 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
   if (p->n_alpha < 2) return -1;  // singlets only: left to the general path
+  // a handful of samples beyond a block boundary fill the extra blocks so thinly that the tile sweep is faster
+  // (measured: V = 65 tile 195 ms vs 249 ms, V = 96 tile 497 ms vs 253 ms, per 2000 cells)
+  if (h->V > 64 && h->V % 64 != 0 && h->V % 64 <= 8 && h->V < 128) return -1;
   if (h->V <= 16 && !(h->flags & MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;  // the row/quad kernels are better there
   muxgl_wave_state* st = h->wave;
-  const int A = p->n_alpha;
+  const int A = p->n_alpha, V = h->V;
+  const int nblk = (V + 63) / 64, nblk2 = nblk * nblk;  // 64 x 64 blocks of the pair matrix
   const size_t need = (size_t)h->nnz * A * 9;
-  if ((double)need * 8.0 > 96e9) return -1;  // pG table would not fit comfortably: tile sweep
+  const size_t llw_need = (size_t)h->C * nblk2 * A * 4096;
+  // pG table, result slabs and (V > 64) the tensor the call kernel reads must fit comfortably: else the tile sweep
+  if (((double)need + (double)llw_need + (nblk > 1 ? (double)h->C * V * V * A : 0.0)) * 8.0 > 150e9) return -1;
   if (need > st->pg_cap) {
     if (dev_alloc(h, &st->d_pg, need)) return 1;
     st->pg_cap = need;
   }
-  const size_t llw_need = (size_t)h->C * A * 4096;
   if (llw_need > h->llw_cap) {
     if (dev_alloc(h, &h->d_llw, llw_need)) return 1;
     h->llw_cap = llw_need;
@@ -300,55 +364,96 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   tic(h, MUXGL_T_DEMUX_SWEEP);
   if (demux_entry_pg_launch(h, p, st->d_pg)) return 1;
   const unsigned blocks = (unsigned)h->C;
-  bool first = true;
-  // non-symmetric alphas four (or two) at a time, see demux_wave_multi_kernel; the rest one per launch
-  std::vector<int> plain;
-  for (int n = 1; n < A; ++n)
-    if (p->alpha[n] != 0.5) plain.push_back(n);
-#define MULTI_LAUNCH(NA, NS, WS, S0)                                                                                  \
-  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,   \
-                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, sel, S0, h->d_llw)
-  size_t done = 0;
-  while (plain.size() - done >= 4) {
-    wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
-    if (first) MULTI_LAUNCH(4, 16, true, 0);
-    else MULTI_LAUNCH(4, 16, false, 0);
-    MULTI_LAUNCH(4, 16, false, 16);
-    MULTI_LAUNCH(4, 16, false, 32);
-    MULTI_LAUNCH(4, 16, false, 48);
-    HIPCHK(h, hipGetLastError());
-    first = false;
-    done += 4;
-  }
-  while (plain.size() - done >= 2) {
-    wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
-    if (first) MULTI_LAUNCH(2, 32, true, 0);
-    else MULTI_LAUNCH(2, 32, false, 0);
-    MULTI_LAUNCH(2, 32, false, 32);
-    HIPCHK(h, hipGetLastError());
-    first = false;
-    done += 2;
-  }
-#undef MULTI_LAUNCH
+  std::vector<int> plain;  // non-symmetric alphas
+  uint32_t symmask = 0;
   for (int n = 1; n < A; ++n) {
-    const bool sym = (p->alpha[n] == 0.5);
-    if (!sym && !(done < plain.size() && plain[done] == n)) continue;  // already covered by a multi-alpha launch
-#define WAVE_LAUNCH(NS, WS)                                                                                          \
-  hipLaunchKernelGGL((demux_wave_kernel<NS, WS>), dim3(blocks), dim3(64), 0, h->stream, st->d_order, h->C,             \
-                     h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, h->V, A, n, h->d_llw)
-    if (sym && first) WAVE_LAUNCH(32, true);
-    else if (sym) WAVE_LAUNCH(32, false);
-    else if (first) WAVE_LAUNCH(63, true);
-    else WAVE_LAUNCH(63, false);
-#undef WAVE_LAUNCH
-    HIPCHK(h, hipGetLastError());
-    first = false;
-    if (!sym) ++done;
+    if (p->alpha[n] != 0.5) plain.push_back(n);
+    else symmask |= 1u << n;
   }
-  h->ll_wave = true;
-  if (h->want_full_ll) {
+#define KARGS st->d_order, h->C, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, V, A
+#define MULTI_LAUNCH(NA, NS, WS, CR, S0)                                                                          \
+  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, S0, \
+                     wb, h->d_llw)
+#define WAVE_LAUNCH(NS, WS, CR) \
+  hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
+  for (int X = 0; X < nblk; ++X) {
+    // ---- diagonal block: samples 64X.. against themselves.  Non-symmetric alphas four (or two) at a time, see
+    //      demux_wave_multi_kernel; the rest one per launch; the singlet slot rides along with the first launch
+    {
+      const wave_blk wb = {64 * X, 64 * X, X * nblk + X, nblk2};
+      bool first = true;
+      size_t done = 0;
+      while (plain.size() - done >= 4) {
+        wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
+        if (first) MULTI_LAUNCH(4, 16, true, false, 0);
+        else MULTI_LAUNCH(4, 16, false, false, 0);
+        MULTI_LAUNCH(4, 16, false, false, 16);
+        MULTI_LAUNCH(4, 16, false, false, 32);
+        MULTI_LAUNCH(4, 16, false, false, 48);
+        HIPCHK(h, hipGetLastError());
+        first = false;
+        done += 4;
+      }
+      while (plain.size() - done >= 2) {
+        wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
+        if (first) MULTI_LAUNCH(2, 32, true, false, 0);
+        else MULTI_LAUNCH(2, 32, false, false, 0);
+        MULTI_LAUNCH(2, 32, false, false, 32);
+        HIPCHK(h, hipGetLastError());
+        first = false;
+        done += 2;
+      }
+      for (int n = 1; n < A; ++n) {
+        const bool sym = (p->alpha[n] == 0.5);
+        if (!sym && !(done < plain.size() && plain[done] == n)) continue;  // already covered by a multi-alpha launch
+        if (sym && first) WAVE_LAUNCH(32, true, false);
+        else if (sym) WAVE_LAUNCH(32, false, false);
+        else if (first) WAVE_LAUNCH(63, true, false);
+        else WAVE_LAUNCH(63, false, false);
+        HIPCHK(h, hipGetLastError());
+        first = false;
+        if (!sym) ++done;
+      }
+    }
+    // ---- off-diagonal blocks: every rotation is a pair.  Symmetric alphas only for Y < X (mirrored by the converter)
+    for (int Y = 0; Y < nblk; ++Y) {
+      if (Y == X) continue;
+      const wave_blk wb = {64 * X, 64 * Y, X * nblk + Y, nblk2};
+      size_t done = 0;
+      while (plain.size() - done >= 4) {
+        wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
+        MULTI_LAUNCH(4, 16, false, true, 0);
+        MULTI_LAUNCH(4, 16, false, true, 16);
+        MULTI_LAUNCH(4, 16, false, true, 32);
+        MULTI_LAUNCH(4, 16, false, true, 48);
+        HIPCHK(h, hipGetLastError());
+        done += 4;
+      }
+      while (plain.size() - done >= 2) {
+        wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
+        MULTI_LAUNCH(2, 32, false, true, 0);
+        MULTI_LAUNCH(2, 32, false, true, 32);
+        HIPCHK(h, hipGetLastError());
+        done += 2;
+      }
+      for (int n = 1; n < A; ++n) {
+        const bool sym = (p->alpha[n] == 0.5);
+        if (sym && Y > X) continue;
+        if (!sym && !(done < plain.size() && plain[done] == n)) continue;
+        WAVE_LAUNCH(64, false, true);
+        HIPCHK(h, hipGetLastError());
+        if (!sym) ++done;
+      }
+    }
+  }
+#undef WAVE_LAUNCH
+#undef MULTI_LAUNCH
+#undef KARGS
+  h->ll_wave = nblk == 1;  // the 64-lane call kernel reads the slab directly; beyond 64 samples it reads the tensor
+  if (h->want_full_ll || nblk > 1) {
     if (demux_ensure_ll(h, p)) return 1;
-    hipLaunchKernelGGL(demux_wave_to_full_kernel, dim3(blocks), dim3(64), 0, h->stream, h->d_llw, h->d_cell_ptr, h->V, A, h->d_ll);
+    hipLaunchKernelGGL(demux_wave_to_full_kernel, dim3(blocks, (unsigned)nblk2), dim3(64), 0, h->stream, h->d_llw,
+                       h->d_cell_ptr, V, A, nblk, symmask, h->d_ll);
     HIPCHK(h, hipGetLastError());
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);
