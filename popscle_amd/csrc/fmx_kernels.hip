@@ -657,9 +657,11 @@ __global__ void __launch_bounds__(64)
 static int fmx_mstep_launch(muxgl_handle* h) {
   const int64_t n = (h->fs1 - h->fs0) * h->K;
   if (n <= 0) return 0;
-  const int P = h->K <= 16 ? 1 : (h->K <= 32 ? 2 : 4), KL = (h->K + P - 1) / P;
+  int P = 1;  // lanes per SNP, each holding at most 16 of its cluster states
+  while (P * 16 < h->K) P *= 2;
+  const int KL = (h->K + P - 1) / P;
   const size_t lds = (size_t)64 * (KL * 9 + 1) * sizeof(double);
-  if (h->K <= 64 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // lane(s) per SNP, cluster states in LDS
+  if (P <= 16 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // lane(s) per SNP, cluster states in LDS
     const int64_t ns = h->fs1 - h->fs0;
     const int per = 64 / P;
     HIPCHK(h, hipFuncSetAttribute((const void*)fmx_mstep_snp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
