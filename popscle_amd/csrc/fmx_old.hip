@@ -265,11 +265,20 @@ __global__ void __launch_bounds__(VT)
   const int nseg = VT / K;
   const int k = tid % K, seg = tid / K;
   const uint32_t kk = (uint32_t)k * 0x01010101u;
+  int touch = 0;  // keeps the prefetch loads alive
   for (int t = 0; t < nsteps; ++t) {
     const int target = mode == 0 ? t : order[t];
     const int len = mode == 0 ? t : C;
     const int8_t* row = mat + (int64_t)target * ld;
     const int nchunks = (len + 15) >> 4;
+    // the next step's row is known (the visiting order is input): one load per 128-byte line pulls it into L2 while
+    // this step runs, so that the scan below does not start with a round trip to HBM
+    int pf = 0;
+    if (t + 1 < nsteps) {
+      const int8_t* nrow = mat + (int64_t)(mode == 0 ? t + 1 : order[t + 1]) * ld;
+      const int64_t off = (int64_t)tid * 128;
+      if (off < (mode == 0 ? t + 1 : C)) pf = *reinterpret_cast<const int*>(nrow + off);
+    }
     {  // integer votes of cluster k from this thread's row segment
       const int cps = (nchunks + nseg - 1) / nseg;
       const int c0 = seg * cps, c1 = min(c0 + cps, nchunks);
@@ -382,8 +391,10 @@ __global__ void __launch_bounds__(VT)
       }
     }
     if (tid < 64) s_n[tid] = 0;
+    touch ^= pf;
     __syncthreads();
   }
+  if (touch == 0x5a5a5a5a && nsteps < 0) stats[0] = touch;  // never true: the sign bytes are -1, 0, 1
   if (tid == 0) stats[0] = s_ctl[3];
   if (tid < K) stats[1 + tid] = s_cc[tid];
 }
