@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROBE = os.path.join(ROOT, "tools", "bench_fmx.py")
-SHAPE = ["--cells", "400", "--snps", "3000", "--clusters", "5", "--mean-entries", "200", "--iters", "4", "--warmup", "0"]
+SHAPE = ["--no-cpu-baseline", "--cells", "400", "--snps", "3000", "--clusters", "5", "--mean-entries", "200", "--iters", "4", "--warmup", "0"]
 
 
 def free_port():

@@ -27,6 +27,33 @@ sys.path.insert(0, ROOT)
 from popscle_amd import freemuxlet, muxgl, synth  # noqa: E402
 
 
+def cpu_baseline(p, K, clust0, budget_s=10.0):
+    """One EM iteration of the CPU oracle (restatement of cmd_cram_freemux2.cpp:375-597, kind "port") on a bounded
+    sample of the cells, single-threaded like the reference.  The oracle is only timed here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    def run(n):
+        cells = np.sort(np.random.default_rng(1).choice(p.C, n, replace=False))
+        sub = p.subset_cells(cells)
+        e = ob.fmx_entry_pileup(sub)
+        c0 = np.ascontiguousarray(clust0[cells])
+        cplp = ob.fmx_build_cluster_pileup(sub, e, K, c0)
+        st = ob.fmx_init_cells(c0)
+        t0 = time.perf_counter()
+        ob.fmx_iterate(sub, e, K, cplp, st, 0.5, 0.1, nthreads=1)
+        return time.perf_counter() - t0, sub.nnz
+
+    n = min(p.C, 50)
+    dt, _ = run(n)
+    n = int(min(p.C, max(n, budget_s / max(dt, 1e-6) * n)))
+    dt, nnz = run(n)
+    npairs = K * (K + 1) // 2
+    return {"value": n * npairs / dt, "unit": "LLs/s", "cores": 1, "kind": "port",
+            "sample": f"one EM iteration over {n} of {p.C} cells ({nnz} entries), oracle/muxgl_oracle.c on one core "
+                      f"(the reference is single-threaded), {dt:.1f} s", "entries_per_s": nnz / dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +68,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--single-device", action="store_true")
     ap.add_argument("--dump", default="")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +145,8 @@ def main():
             "setup_ms": setup_s * 1e3,  # shard tables + initial cluster pileups (muxgl_fmx_set_shard / set_clusters)
             "last_iteration": {"nsingle": hist[-1][0], "namb": hist[-1][1], "nchanged": hist[-1][2]},
         }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p, K, clust0)
         print(json.dumps(out), flush=True)
         if args.dump:
             np.savez(args.dump, cells=cells, hist=np.array(hist, dtype=np.int64))
