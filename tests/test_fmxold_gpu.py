@@ -77,6 +77,26 @@ def test_pair_dist_wide_columns(eng):
     assert np.abs(got["llk2"] - want["llk2"]).max() < 1e-9 and np.abs(got["llk0"] - want["llk0"]).max() < 1e-9
 
 
+def test_pair_dist_sign_only_several_column_blocks(eng):
+    """more cells than one column block of the sign-only kernel (6144): signs against the oracle's records"""
+    C = 6300
+    p = synth.make_pileup(C, 300, 3, seed=78, mean_entries=8, min_entries=2, with_gp=False)
+    e = prepared(eng, p)
+    want = ob.fmxold_pair_dist(p, e)
+    eng.fmxold_pair_dist(1.0, want_full=False)
+    gs = eng.fmxold_signs()
+    bf = want["llk2"] - want["llk0"]
+    del want
+    a, b = np.tril_indices(C, -1)
+    gv = gs[a, b]
+    assert np.array_equal(gs, gs.T) and not gs.diagonal().any()
+    del gs
+    wv = np.where(-bf > 1.0, -1, np.where(bf > 1.0, 1, 0)).astype(np.int8)
+    sure = np.abs(np.abs(bf) - 1.0) > 1e-8
+    assert np.array_equal(gv[sure], wv[sure])
+    assert (wv != 0).mean() > 0.001
+
+
 def test_golden(eng):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fmxold_k4.npz"))
     p = synth.Pileup(int(g["C"]), int(g["S"]), g["cell_ptr"], g["entry_snp"], g["entry_rptr"], g["reads"], g["af"])
