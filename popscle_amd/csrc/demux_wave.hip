@@ -274,6 +274,125 @@ __global__ void __launch_bounds__(64, 2)
   if (WITH_SINGLET) out[j] = prodacc_log(accS, exS);
 }
 
+// 16 < V <= 32: a ring of 32.  Both 32-lane halves of the wave hold the same 32 sample triples (lane j and lane j + 32:
+// sample j & 31), so the 64-lane rotation wave_ror:1 IS the rotation of the ring of 32 in each half, and 31 steps meet
+// every ordered pair -- against 63 steps of which more than half face idle lanes when the wave is treated as a ring of
+// 64.  The halves share the rotating triples and differ in the alphas they accumulate: NA alphas per half, 2*NA per
+// launch (the entry's likelihoods are then two address streams instead of wave-uniform scalars).  An alpha of 0.5 is
+// just one of them here (both orders of a pair are computed; the one with the larger sample in the lane is stored twice).  Results go to the slab positions the 64-lane layout
+// assigns to (sample, partner), so the call kernel needs no second code path.
+struct wave32_sel {
+  int32_t n[2][2];  // alpha index [half][slot]; 0 = unused slot (alpha 0 is the singlet slot, never a doublet alpha)
+};
+template <int NA, bool WITH_SINGLET>
+__global__ void __launch_bounds__(64, 2)
+    demux_wave32_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
+                        const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                        const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
+                        wave32_sel sel, uint32_t symmask, double* __restrict__ ll) {
+  constexpr int NS = 31;
+  if ((int64_t)blockIdx.x >= n_cells) return;
+  const int64_t c = order[blockIdx.x];
+  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if (e0 == e1) return;
+  const int j = threadIdx.x;
+  const int half = j >> 5, sj = j & 31;
+  const bool live = sj < V;
+  const int V3 = V * 3;
+  const int PG = nAlpha * 9;
+  int na[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) na[a] = half ? sel.n[1][a] : sel.n[0][a];
+
+  __shared__ int32_t exs[NA * NS][64];
+  double acc[NA * NS], accS = 1.0;
+  int32_t exS = 0;
+#pragma unroll
+  for (int t = 0; t < NA * NS; ++t) {
+    acc[t] = 1.0;
+    exs[t][j] = 0;
+  }
+
+  int64_t e = e0;
+  while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
+  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+  if (e < e1 && live) {
+    const double* row = gp + (size_t)entry_snp[e] * V3 + sj * 3;
+    ng0 = row[0], ng1 = row[1], ng2 = row[2];
+  }
+  int cnt = 0;
+  while (e < e1) {
+    const int64_t ecur = e;
+    const int32_t scur = entry_snp[ecur];
+    const double g0 = ng0, g1 = ng1, g2 = ng2;
+    ++e;
+    while (e < e1 && !has_gp[entry_snp[e]]) ++e;
+    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
+    if (e < e1 && live) {
+      const double* row = gp + (size_t)entry_snp[e] * V3 + sj * 3;
+      ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    }
+    if (WITH_SINGLET) {
+      const double* s = pg + (size_t)ecur * PG;
+      const double* h = gp + (size_t)scur * V3;  // sample 0's triple multiplies every singlet (:806,828)
+      const double v0 = fma(g2, s[6], fma(g1, s[3], g0 * s[0]));
+      const double v1 = fma(g2, s[7], fma(g1, s[4], g0 * s[1]));
+      const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
+      accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
+    }
+    double u[NA][3];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {  // the half's own alpha: one address per half
+      const double* q = pg + (size_t)ecur * PG + (size_t)na[a] * 9;
+      u[a][0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
+      u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
+      u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
+    }
+    double r0 = g0, r1 = g1, r2 = g2;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      r0 = dpp_wror1(r0);
+      r1 = dpp_wror1(r1);
+      r2 = dpp_wror1(r2);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, u[a][2], fma(r1, u[a][1], r0 * u[a][0]));  // :738-746
+    }
+    if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
+      cnt = 0;
+#pragma unroll
+      for (int t = 0; t < NA * NS; ++t) {
+        int ee;
+        acc[t] = frexp(acc[t], &ee);
+        exs[t][j] += ee;
+      }
+      if (WITH_SINGLET) prodacc_renorm(accS, exS);
+    }
+  }
+
+  double* out = ll + (size_t)c * nAlpha * 4096;  // wave layout, see demux_wave_kernel
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const int k = (sj - t - 1) & 31;         // wave_ror:1 brings lane j the value of lane j - 1: here inside the ring of 32
+    const int tt = (sj - k - 1) & 63;        // the step at which the 64-lane layout has sample sj facing sample k
+    if (live && k < V) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        if (na[a] <= 0) continue;
+        const double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
+        if ((symmask >> na[a]) & 1u) {  // alpha 0.5: one writer per unordered pair, mirrored (as on the other paths)
+          if (sj > k) {
+            out[((size_t)na[a] * 64 + tt) * 64 + sj] = v;
+            out[((size_t)na[a] * 64 + ((k - sj - 1) & 63)) * 64 + k] = v;
+          }
+        } else {
+          out[((size_t)na[a] * 64 + tt) * 64 + sj] = v;
+        }
+      }
+    }
+  }
+  if (WITH_SINGLET && half == 0) out[sj] = prodacc_log(accS, exS);  // llw[c][0][0][j]
+}
+
 // wave layout -> the ABI's [C][V][V][A] tensor (when the caller asks for it, and for V > 64, where the call kernel reads
 // the tensor).  grid = (C, blocks per cell); block (X, Y) of a symmetric alpha exists for X >= Y only and is mirrored.
 __global__ void __launch_bounds__(64)
@@ -376,7 +495,37 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
                      wb, h->d_llw)
 #define WAVE_LAUNCH(NS, WS, CR) \
   hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
-  for (int X = 0; X < nblk; ++X) {
+  if (V <= 32) {  // ring of 32: 31 rotation steps, four alphas per launch (two per half), see demux_wave32_kernel
+    std::vector<int> all;
+    for (int n = 1; n < A; ++n) all.push_back(n);
+    bool first = true;
+    for (size_t done = 0; done < all.size();) {
+      const size_t left = all.size() - done;
+      wave32_sel sel = {{{0, 0}, {0, 0}}};
+      if (left > 2) {  // two alphas per half (the fourth slot may stay empty)
+        sel.n[0][0] = all[done];
+        sel.n[0][1] = all[done + 1];
+        sel.n[1][0] = all[done + 2];
+        sel.n[1][1] = left > 3 ? all[done + 3] : 0;
+        if (first)
+          hipLaunchKernelGGL((demux_wave32_kernel<2, true>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
+        else
+          hipLaunchKernelGGL((demux_wave32_kernel<2, false>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
+        done += left > 3 ? 4 : 3;
+      } else {  // one alpha per half
+        sel.n[0][0] = all[done];
+        sel.n[1][0] = left > 1 ? all[done + 1] : 0;
+        if (first)
+          hipLaunchKernelGGL((demux_wave32_kernel<1, true>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
+        else
+          hipLaunchKernelGGL((demux_wave32_kernel<1, false>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
+        done += left > 1 ? 2 : 1;
+      }
+      HIPCHK(h, hipGetLastError());
+      first = false;
+    }
+  }
+  for (int X = 0; X < (V <= 32 ? 0 : nblk); ++X) {
     // ---- diagonal block: samples 64X.. against themselves.  Non-symmetric alphas four (or two) at a time, see
     //      demux_wave_multi_kernel; the rest one per launch; the singlet slot rides along with the first launch
     {

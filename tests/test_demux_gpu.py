@@ -56,6 +56,10 @@ def test_golden(eng, name):
     (1, (0.0, 0.5), 20, 500, 100),                # nv-1 == 0: infinite doublet prior, no doublet hypotheses
     (5, (0.0,), 40, 800, 150),                    # nAlpha == 1 (reference quirk: division by nAlpha-1 == 0)
     (7, (0.0, 0.3), 60, 1500, 200),               # no symmetric alpha at all
+    (17, (0.0, 0.5), 30, 3000, 400),              # ring-of-32 wave kernel: one alpha in one half
+    (24, GRID6, 24, 4000, 500),                   #   five doublet alphas: a launch of 2 + 2 and one of 1 + 0
+    (32, (0.0, 0.2, 0.5, 0.7), 20, 4000, 500),    #   three: 2 + 1
+    (29, (0.0, 0.3, 0.6), 20, 3000, 400),         #   two: 1 + 1
     (33, (0.0, 0.5), 30, 4000, 400),              # more pairs than one 256-thread tile
     (64, GRID6, 12, 6000, 500),                   # config-3 shape, few cells
     (65, (0.0, 0.5), 10, 6000, 1500),             # first V of the general tile sweep + one-lane-per-cell call
