@@ -249,6 +249,7 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc);  // 16 < K <
 int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p);  // standard LL tensor allocated and zeroed
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);
+int demux_gp_neutral_rows(muxgl_handle* h, int V);  // d_gp rows of markers without genotypes := (1,0,0) (demux_wave.hip)
 void demux_row_release(muxgl_row_state** st);
 int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
 int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)

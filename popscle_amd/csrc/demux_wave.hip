@@ -23,6 +23,18 @@
 
 namespace {
 
+// Markers without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) are skipped by the reference.  The wave kernels do
+// not test for them -- a test per entry is a chain of two dependent scalar loads in front of every sweep -- but make
+// them neutral instead: their row of the device copy of the GP tensor is (1, 0, 0) for every sample (demux_set_gp) and
+// their likelihoods in the pG table are all ones, so every factor they contribute is exactly 1.
+__global__ void __launch_bounds__(256)
+    wave_neutral_pg_kernel(int64_t nnz, int width, const int32_t* __restrict__ entry_snp,
+                           const uint8_t* __restrict__ has_gp, double* __restrict__ pg) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz || has_gp[entry_snp[e]]) return;
+  for (int i = 0; i < width; ++i) pg[(size_t)e * width + i] = 1.0;
+}
+
 __device__ __forceinline__ double dpp_wror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1 : lane j <- lane (j-1) mod 64
@@ -67,7 +79,6 @@ __global__ void __launch_bounds__(64, 2)
 
   // software pipeline: triples of the next marker with genotypes are loaded while the current one is swept
   int64_t e = e0;
-  while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
   double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
   if (e < e1 && live) {
@@ -85,7 +96,6 @@ __global__ void __launch_bounds__(64, 2)
     const double g0 = ng0, g1 = ng1, g2 = ng2;
     const double p0 = np0, p1 = np1, p2 = np2;
     ++e;
-    while (e < e1 && !has_gp[entry_snp[e]]) ++e;
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
     if (e < e1 && live) {
       const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
@@ -190,7 +200,6 @@ __global__ void __launch_bounds__(64, 2)
   }
 
   int64_t e = e0;
-  while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
   double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
   if (e < e1 && live) {
@@ -208,7 +217,6 @@ __global__ void __launch_bounds__(64, 2)
     const double g0 = ng0, g1 = ng1, g2 = ng2;
     const double p0 = np0, p1 = np1, p2 = np2;
     ++e;
-    while (e < e1 && !has_gp[entry_snp[e]]) ++e;
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
     if (e < e1 && live) {
       const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
@@ -275,34 +283,30 @@ __global__ void __launch_bounds__(64, 2)
 }
 
 // 16 < V <= 32: a ring of 32.  Both 32-lane halves of the wave hold the same 32 sample triples (lane j and lane j + 32:
-// sample j & 31), so the 64-lane rotation wave_ror:1 IS the rotation of the ring of 32 in each half, and 31 steps meet
-// every ordered pair -- against 63 steps of which more than half face idle lanes when the wave is treated as a ring of
-// 64.  The halves share the rotating triples and differ in the alphas they accumulate: NA alphas per half, 2*NA per
-// launch (the entry's likelihoods are then two address streams instead of wave-uniform scalars).  An alpha of 0.5 is
-// just one of them here (both orders of a pair are computed; the one with the larger sample in the lane is stored twice).  Results go to the slab positions the 64-lane layout
-// assigns to (sample, partner), so the call kernel needs no second code path.
-struct wave32_sel {
-  int32_t n[2][2];  // alpha index [half][slot]; 0 = unused slot (alpha 0 is the singlet slot, never a doublet alpha)
-};
+// sample j & 31), so the 64-lane rotation wave_ror:1 IS the rotation of the ring of 32 in each half.  The stationary
+// side differs: lane j of the upper half works for sample (j + 16) & 31, i.e. it sees the ring 16 positions further
+// on, so 16 steps meet all 31 partners of every sample (lower half: offsets 1..16, upper half: 17..32, the last one
+// being the sample itself) -- against 63 steps of which more than half face idle lanes when the wave is a ring of 64.
+// NA alphas per launch share the rotation as in demux_wave_multi_kernel; an alpha of 0.5 is just one of them (both
+// orders of a pair are computed, the one with the larger sample on the stationary side is stored twice).  Results go
+// to the slab positions the 64-lane layout assigns to (sample, partner): the call kernel needs no second code path.
 template <int NA, bool WITH_SINGLET>
 __global__ void __launch_bounds__(64, 2)
     demux_wave32_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                         const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
-                        wave32_sel sel, uint32_t symmask, double* __restrict__ ll) {
-  constexpr int NS = 31;
+                        wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
+  constexpr int NS = 16;
   if ((int64_t)blockIdx.x >= n_cells) return;
   const int64_t c = order[blockIdx.x];
   const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
   if (e0 == e1) return;
   const int j = threadIdx.x;
-  const int half = j >> 5, sj = j & 31;
-  const bool live = sj < V;
+  const int half = j >> 5, sj = j & 31;  // ring position
+  const int so = (sj + 16 * half) & 31;  // the sample this lane works for
+  const bool live = so < V, rlive = sj < V;
   const int V3 = V * 3;
   const int PG = nAlpha * 9;
-  int na[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) na[a] = half ? sel.n[1][a] : sel.n[0][a];
 
   __shared__ int32_t exs[NA * NS][64];
   double acc[NA * NS], accS = 1.0;
@@ -314,23 +318,26 @@ __global__ void __launch_bounds__(64, 2)
   }
 
   int64_t e = e0;
-  while (e < e1 && !has_gp[entry_snp[e]]) ++e;  // :733
-  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-  if (e < e1 && live) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + sj * 3;
-    ng0 = row[0], ng1 = row[1], ng2 = row[2];
+  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;  // own triple (sample so)
+  double nr0 = 1.0, nr1 = 0.0, nr2 = 0.0;  // ring triple (sample sj)
+  if (e < e1) {
+    const double* row = gp + (size_t)entry_snp[e] * V3;
+    if (live) ng0 = row[so * 3], ng1 = row[so * 3 + 1], ng2 = row[so * 3 + 2];
+    if (rlive) nr0 = row[sj * 3], nr1 = row[sj * 3 + 1], nr2 = row[sj * 3 + 2];
   }
   int cnt = 0;
   while (e < e1) {
     const int64_t ecur = e;
     const int32_t scur = entry_snp[ecur];
     const double g0 = ng0, g1 = ng1, g2 = ng2;
+    double r0 = nr0, r1 = nr1, r2 = nr2;
     ++e;
-    while (e < e1 && !has_gp[entry_snp[e]]) ++e;
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    if (e < e1 && live) {
-      const double* row = gp + (size_t)entry_snp[e] * V3 + sj * 3;
-      ng0 = row[0], ng1 = row[1], ng2 = row[2];
+    nr0 = 1.0, nr1 = 0.0, nr2 = 0.0;
+    if (e < e1) {
+      const double* row = gp + (size_t)entry_snp[e] * V3;
+      if (live) ng0 = row[so * 3], ng1 = row[so * 3 + 1], ng2 = row[so * 3 + 2];
+      if (rlive) nr0 = row[sj * 3], nr1 = row[sj * 3 + 1], nr2 = row[sj * 3 + 2];
     }
     if (WITH_SINGLET) {
       const double* s = pg + (size_t)ecur * PG;
@@ -342,13 +349,12 @@ __global__ void __launch_bounds__(64, 2)
     }
     double u[NA][3];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {  // the half's own alpha: one address per half
-      const double* q = pg + (size_t)ecur * PG + (size_t)na[a] * 9;
+    for (int a = 0; a < NA; ++a) {  // wave-uniform likelihoods through the scalar cache
+      const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
       u[a][0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
       u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
       u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
     }
-    double r0 = g0, r1 = g1, r2 = g2;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       r0 = dpp_wror1(r0);
@@ -372,25 +378,25 @@ __global__ void __launch_bounds__(64, 2)
   double* out = ll + (size_t)c * nAlpha * 4096;  // wave layout, see demux_wave_kernel
 #pragma unroll
   for (int t = 0; t < NS; ++t) {
-    const int k = (sj - t - 1) & 31;         // wave_ror:1 brings lane j the value of lane j - 1: here inside the ring of 32
-    const int tt = (sj - k - 1) & 63;        // the step at which the 64-lane layout has sample sj facing sample k
-    if (live && k < V) {
+    const int k = (sj - t - 1) & 31;   // wave_ror:1 brings lane j the value of lane j - 1: here inside the ring of 32
+    const int tt = (so - k - 1) & 63;  // the step at which the 64-lane layout has sample so facing sample k
+    if (live && k < V && k != so) {
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
-        if (na[a] <= 0) continue;
+        const int n = sel.n[a];
         const double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
-        if ((symmask >> na[a]) & 1u) {  // alpha 0.5: one writer per unordered pair, mirrored (as on the other paths)
-          if (sj > k) {
-            out[((size_t)na[a] * 64 + tt) * 64 + sj] = v;
-            out[((size_t)na[a] * 64 + ((k - sj - 1) & 63)) * 64 + k] = v;
+        if ((symmask >> n) & 1u) {  // alpha 0.5: one writer per unordered pair, mirrored (as on the other paths)
+          if (so > k) {
+            out[((size_t)n * 64 + tt) * 64 + so] = v;
+            out[((size_t)n * 64 + ((k - so - 1) & 63)) * 64 + k] = v;
           }
         } else {
-          out[((size_t)na[a] * 64 + tt) * 64 + sj] = v;
+          out[((size_t)n * 64 + tt) * 64 + so] = v;
         }
       }
     }
   }
-  if (WITH_SINGLET && half == 0) out[sj] = prodacc_log(accS, exS);  // llw[c][0][0][j]
+  if (WITH_SINGLET && half == 0 && live) out[so] = prodacc_log(accS, exS);  // llw[c][0][0][j]
 }
 
 // wave layout -> the ABI's [C][V][V][A] tensor (when the caller asks for it, and for V > 64, where the call kernel reads
@@ -432,6 +438,29 @@ struct muxgl_wave_state {
   double* d_pg = nullptr;      // [nnz][A][9]
   size_t pg_cap = 0;
 };
+
+namespace {
+__global__ void __launch_bounds__(256)
+    gp_neutral_rows_kernel(int64_t S, int V, const uint8_t* __restrict__ has_gp, double* __restrict__ gp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (marker, sample)
+  if (i >= S * V) return;
+  const int64_t s = i / V;
+  if (has_gp[s]) return;
+  gp[i * 3] = 1.0;
+  gp[i * 3 + 1] = 0.0;
+  gp[i * 3 + 2] = 0.0;
+}
+}  // namespace
+
+// every kernel that reads d_gp either tests has_gp first or (wave kernels) relies on these neutral rows
+int demux_gp_neutral_rows(muxgl_handle* h, int V) {
+  const int64_t n = h->S * V;
+  if (n > 0)
+    hipLaunchKernelGGL(gp_neutral_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, V,
+                       h->d_has_gp, h->d_gp);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
 
 const int32_t* demux_wave_order(const muxgl_handle* h) { return h->wave ? h->wave->d_order : nullptr; }
 
@@ -482,6 +511,9 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   tic(h, MUXGL_T_DEMUX_SWEEP);
   if (demux_entry_pg_launch(h, p, st->d_pg)) return 1;
+  if (h->nnz)
+    hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
+                       A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
   const unsigned blocks = (unsigned)h->C;
   std::vector<int> plain;  // non-symmetric alphas
   uint32_t symmask = 0;
@@ -495,35 +527,32 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
                      wb, h->d_llw)
 #define WAVE_LAUNCH(NS, WS, CR) \
   hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
-  if (V <= 32) {  // ring of 32: 31 rotation steps, four alphas per launch (two per half), see demux_wave32_kernel
+  if (V <= 32) {  // ring of 32: 16 rotation steps, up to four alphas per launch, see demux_wave32_kernel
     std::vector<int> all;
     for (int n = 1; n < A; ++n) all.push_back(n);
     bool first = true;
+#define W32_LAUNCH(NA, WS) \
+  hipLaunchKernelGGL((demux_wave32_kernel<NA, WS>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw)
     for (size_t done = 0; done < all.size();) {
       const size_t left = all.size() - done;
-      wave32_sel sel = {{{0, 0}, {0, 0}}};
-      if (left > 2) {  // two alphas per half (the fourth slot may stay empty)
-        sel.n[0][0] = all[done];
-        sel.n[0][1] = all[done + 1];
-        sel.n[1][0] = all[done + 2];
-        sel.n[1][1] = left > 3 ? all[done + 3] : 0;
-        if (first)
-          hipLaunchKernelGGL((demux_wave32_kernel<2, true>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
-        else
-          hipLaunchKernelGGL((demux_wave32_kernel<2, false>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
-        done += left > 3 ? 4 : 3;
-      } else {  // one alpha per half
-        sel.n[0][0] = all[done];
-        sel.n[1][0] = left > 1 ? all[done + 1] : 0;
-        if (first)
-          hipLaunchKernelGGL((demux_wave32_kernel<1, true>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
-        else
-          hipLaunchKernelGGL((demux_wave32_kernel<1, false>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, symmask, h->d_llw);
-        done += left > 1 ? 2 : 1;
+      const int na = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+      wave_sel sel = {{0, 0, 0, 0}};
+      for (int a = 0; a < na; ++a) sel.n[a] = all[done + a];
+      if (na == 4) {
+        if (first) W32_LAUNCH(4, true);
+        else W32_LAUNCH(4, false);
+      } else if (na == 2) {
+        if (first) W32_LAUNCH(2, true);
+        else W32_LAUNCH(2, false);
+      } else {
+        if (first) W32_LAUNCH(1, true);
+        else W32_LAUNCH(1, false);
       }
       HIPCHK(h, hipGetLastError());
       first = false;
+      done += na;
     }
+#undef W32_LAUNCH
   }
   for (int X = 0; X < (V <= 32 ? 0 : nblk); ++X) {
     // ---- diagonal block: samples 64X.. against themselves.  Non-symmetric alphas four (or two) at a time, see

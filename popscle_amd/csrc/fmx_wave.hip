@@ -61,33 +61,45 @@ __global__ void __launch_bounds__(64, 2)
     const double* row = cgp + (size_t)entry_snp[e0] * K3 + (kbase + j) * 3;
     np0 = row[0], np1 = row[1], np2 = row[2];
   }
+  // Software pipeline over the entries: the posterior triples AND the entry's nine (wave-uniform, scalar-loaded)
+  // likelihoods of entry e + 1 are requested before entry e is swept, and the per-entry factors that do not depend on
+  // the rotation (u, the singlet term) are formed for e + 1 right after the sweep of e: the scalar loads then have a
+  // whole sweep to land instead of stalling the wave at the top of every entry.
+  double u0 = 0, u1 = 0, u2 = 0, sing = 1.0;
+  double c0r = ng0, c1r = ng1, c2r = ng2;  // ring start of the current entry (own triple, or the partner's with CROSS)
+  if (e0 < e1) {
+    const double* q = egls + (size_t)e0 * 9;
+    sing = fma(ng2, q[8], fma(ng1, q[4], ng0 * q[0]));
+    u0 = fma(ng2, q[6], fma(ng1, q[3], ng0 * q[0]));
+    u1 = fma(ng2, q[7], fma(ng1, q[4], ng0 * q[1]));
+    u2 = fma(ng2, q[8], fma(ng1, q[5], ng0 * q[2]));
+    if (CROSS) c0r = np0, c1r = np1, c2r = np2;
+  }
   int cnt = 0;
   for (int64_t e = e0; e < e1; ++e) {
-    const double g0 = ng0, g1 = ng1, g2 = ng2;
-    const double p0 = np0, p1 = np1, p2 = np2;
+    const bool more = e + 1 < e1;
+    // requests for entry e + 1
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    if (e + 1 < e1 && live) {
+    if (more && live) {
       const double* row = cgp + (size_t)entry_snp[e + 1] * K3 + sj * 3;
       ng0 = row[0], ng1 = row[1], ng2 = row[2];
     }
     if (CROSS) {
       np0 = 1.0, np1 = 0.0, np2 = 0.0;
-      if (e + 1 < e1 && live2) {
+      if (more && live2) {
         const double* row = cgp + (size_t)entry_snp[e + 1] * K3 + (kbase + j) * 3;
         np0 = row[0], np1 = row[1], np2 = row[2];
       }
     }
-    const double* q = egls + (size_t)e * 9;  // wave-uniform: glis[g1*3+g2]
+    const double* q = egls + (size_t)(more ? e + 1 : e) * 9;  // wave-uniform: glis[g1*3+g2] of the next entry
     const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
-    if (!CROSS) accS *= fma(g2, q8, fma(g1, q4, g0 * q0));  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
-    const double u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
-    const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
-    const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
-    double r0 = g0, r1 = g1, r2 = g2;
+    // sweep of entry e
+    if (!CROSS) accS *= sing;  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
+    double r0 = c0r, r1 = c1r, r2 = c2r;
     if (CROSS) {  // one lane ahead: the first rotation then brings cluster kbase + j itself
-      r0 = __shfl(p0, (j + 1) & 63, 64);
-      r1 = __shfl(p1, (j + 1) & 63, 64);
-      r2 = __shfl(p2, (j + 1) & 63, 64);
+      r0 = __shfl(r0, (j + 1) & 63, 64);
+      r1 = __shfl(r1, (j + 1) & 63, 64);
+      r2 = __shfl(r2, (j + 1) & 63, 64);
     }
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
@@ -96,6 +108,12 @@ __global__ void __launch_bounds__(64, 2)
       r2 = fw_wror1(r2);
       acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :440-446 as a product
     }
+    // factors of entry e + 1
+    sing = fma(ng2, q8, fma(ng1, q4, ng0 * q0));
+    u0 = fma(ng2, q6, fma(ng1, q3, ng0 * q0));
+    u1 = fma(ng2, q7, fma(ng1, q4, ng0 * q1));
+    u2 = fma(ng2, q8, fma(ng1, q5, ng0 * q2));
+    c0r = CROSS ? np0 : ng0, c1r = CROSS ? np1 : ng1, c2r = CROSS ? np2 : ng2;
     if (++cnt == 16) {  // a factor is >= ~1e-13 (clamped likelihoods, mixed posteriors): sixteen cannot underflow
       cnt = 0;
 #pragma unroll

@@ -224,6 +224,7 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
     HIPCHK(h, hipMemcpy(h->d_gpq, q.data(), sizeof(double) * q.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_gp0s, g0.data(), sizeof(double) * g0.size(), hipMemcpyHostToDevice));
   }
+  if (demux_gp_neutral_rows(h, V)) return 1;  // rows of markers without genotypes: (1,0,0) in the device copy
   h->V = V;
   h->have_dp = false;
   h->pairs_valid = false;
