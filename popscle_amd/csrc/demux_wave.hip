@@ -500,7 +500,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const size_t need = (size_t)h->nnz * A * 9;
   const size_t llw_need = (size_t)h->C * nblk2 * A * 4096;
   // pG table, result slabs and (V > 64) the tensor the call kernel reads must fit comfortably: else the tile sweep
-  if (((double)need + (double)llw_need + (nblk > 1 ? (double)h->C * V * V * A : 0.0)) * 8.0 > 150e9) return -1;
+  if (((double)need + (double)llw_need + (nblk > 1 ? (double)h->C * V * V * A : 0.0)) * 8.0 > 230e9) return -1;
   if (need > st->pg_cap) {
     if (dev_alloc(h, &st->d_pg, need)) return 1;
     st->pg_cap = need;
