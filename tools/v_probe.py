@@ -14,7 +14,7 @@ from popscle_amd import muxgl, synth  # noqa: E402
 
 V, C = int(sys.argv[1]), int(sys.argv[2])
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 200000
-alphas = (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)
+alphas = (0.0, 0.5) if os.environ.get("VPROBE_DEFAULT_GRID") else (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)
 p = synth.make_pileup(C, S, V, seed=5)
 eng = muxgl.Engine(0)
 eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
@@ -28,4 +28,4 @@ cells = eng.demux_results_view()
 sng = ~p.truth["is_doublet"]
 print(json.dumps({"V": V, "cells": C, "entries": p.nnz, "pass_s": dt, "sweep_ms": float(ms[muxgl.T_DEMUX_SWEEP]),
                   "call_ms": float(ms[muxgl.T_DEMUX_CALL]), "ns_per_entry_hypothesis":
-                  dt * 1e9 / (p.nnz * (V + V * (V - 1) * 5)), "singlet_acc": float((cells["sBest"][sng] == p.truth["s1"][sng]).mean())}))
+                  dt * 1e9 / (p.nnz * (V + V * (V - 1) * (len(alphas) - 1))), "singlet_acc": float((cells["sBest"][sng] == p.truth["s1"][sng]).mean())}))
