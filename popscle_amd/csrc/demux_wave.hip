@@ -51,16 +51,29 @@ struct wave_blk {
   int32_t blk, nblk2;    // slab of this launch, slabs per cell
 };
 
+// Work unit of the wave kernels: a run of entries of one cell.  A cell is walked by one wave, so a launch cannot end
+// before its longest cell has been walked; with few cells that walk IS the launch (10 k cells: 10 ms for any shape),
+// with many it hides behind throughput-bound work.  Cells longer than WAVE_ITEM entries are therefore cut into equal
+// parts, each with a result slab of its own (part 0: the cell's slab, the others: overflow slabs behind the C cell
+// slabs), and the parts' log-likelihoods are added up afterwards (wave_combine_kernel).  The cut depends on the cell
+// alone, so a cell's result does not depend on which other cells share the handle (shards reproduce the whole run bit
+// for bit).
+struct wave_item {
+  int64_t e0, e1;  // entries
+  int64_t slab;    // result slab (in units of one cell's slabs)
+};
+
 // NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise (64 with CROSS).  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
 template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false>
 __global__ void __launch_bounds__(64, 2)
-    demux_wave_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
+    demux_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                       const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                       const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel,
                       wave_blk wb, double* __restrict__ ll) {
-  if ((int64_t)blockIdx.x >= n_cells) return;
-  const int64_t c = order[blockIdx.x];
-  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if ((int64_t)blockIdx.x >= n_items) return;
+  const wave_item it = items[blockIdx.x];
+  const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
+  const int64_t e0 = it.e0, e1 = it.e1;
   if (e0 == e1) return;
   const int j = threadIdx.x;
   const bool live = wb.jbase + j < V;
@@ -173,13 +186,14 @@ struct wave_sel {
 };
 template <int NA, int NS, bool WITH_SINGLET, bool CROSS = false>
 __global__ void __launch_bounds__(64, 2)
-    demux_wave_multi_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
+    demux_wave_multi_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                             const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                             const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                             wave_sel sel, int s0, wave_blk wb, double* __restrict__ ll) {
-  if ((int64_t)blockIdx.x >= n_cells) return;
-  const int64_t c = order[blockIdx.x];
-  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if ((int64_t)blockIdx.x >= n_items) return;
+  const wave_item it = items[blockIdx.x];
+  const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
+  const int64_t e0 = it.e0, e1 = it.e1;
   if (e0 == e1) return;
   const int j = threadIdx.x;
   const bool live = wb.jbase + j < V;
@@ -292,14 +306,15 @@ __global__ void __launch_bounds__(64, 2)
 // to the slab positions the 64-lane layout assigns to (sample, partner): the call kernel needs no second code path.
 template <int NA, bool WITH_SINGLET>
 __global__ void __launch_bounds__(64, 2)
-    demux_wave32_kernel(const int32_t* __restrict__ order, int64_t n_cells, const int64_t* __restrict__ cell_ptr,
+    demux_wave32_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                         const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
   constexpr int NS = 16;
-  if ((int64_t)blockIdx.x >= n_cells) return;
-  const int64_t c = order[blockIdx.x];
-  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if ((int64_t)blockIdx.x >= n_items) return;
+  const wave_item it = items[blockIdx.x];
+  const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
+  const int64_t e0 = it.e0, e1 = it.e1;
   if (e0 == e1) return;
   const int j = threadIdx.x;
   const int half = j >> 5, sj = j & 31;  // ring position
@@ -399,6 +414,21 @@ __global__ void __launch_bounds__(64, 2)
   if (WITH_SINGLET && half == 0 && live) out[so] = prodacc_log(accS, exS);  // llw[c][0][0][j]
 }
 
+// adds the overflow slabs of a cut cell, in entry order, into the cell's slab.  grid = (cut cells, slab pieces)
+struct wave_cut {
+  int64_t cell, first, count;  // overflow slabs [first, first + count)
+};
+__global__ void __launch_bounds__(256)
+    wave_combine_kernel(const wave_cut* __restrict__ cuts, int64_t slab_doubles, double* __restrict__ llw) {
+  const wave_cut cu = cuts[blockIdx.x];
+  double* dst = llw + (size_t)cu.cell * slab_doubles;
+  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < slab_doubles; i += (int64_t)gridDim.y * blockDim.x) {
+    double v = dst[i];
+    for (int64_t q = 0; q < cu.count; ++q) v += llw[(size_t)(cu.first + q) * slab_doubles + i];
+    dst[i] = v;  // positions no launch writes hold whatever they held: nobody reads them
+  }
+}
+
 // wave layout -> the ABI's [C][V][V][A] tensor (when the caller asks for it, and for V > 64, where the call kernel reads
 // the tensor).  grid = (C, blocks per cell); block (X, Y) of a symmetric alpha exists for X >= Y only and is mirrored.
 __global__ void __launch_bounds__(64)
@@ -435,6 +465,9 @@ __global__ void __launch_bounds__(64)
 
 struct muxgl_wave_state {
   int32_t* d_order = nullptr;  // cells, longest first
+  wave_item* d_items = nullptr;  // work units of the demuxlet wave kernels, longest first
+  wave_cut* d_cuts = nullptr;    // cells cut into several units
+  int64_t n_items = 0, n_cuts = 0, n_over = 0;
   double* d_pg = nullptr;      // [nnz][A][9]
   size_t pg_cap = 0;
 };
@@ -468,6 +501,8 @@ void demux_wave_free(muxgl_handle* h) {
   muxgl_wave_state* st = h->wave;
   if (!st) return;
   dev_free(&st->d_order);
+  dev_free(&st->d_items);
+  dev_free(&st->d_cuts);
   dev_free(&st->d_pg);
   delete st;
   h->wave = nullptr;
@@ -483,6 +518,30 @@ int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr) {
   });
   if (dev_alloc(h, &st->d_order, (size_t)h->C)) return 1;
   if (h->C) HIPCHK(h, hipMemcpy(st->d_order, order.data(), sizeof(int32_t) * h->C, hipMemcpyHostToDevice));
+  // work units: long cells in equal parts (see wave_item); longest unit first
+  constexpr int64_t WAVE_ITEM = 2048;
+  std::vector<wave_item> items;
+  std::vector<wave_cut> cuts;
+  items.reserve((size_t)h->C);
+  int64_t n_over = 0;
+  for (int64_t i = 0; i < h->C; ++i) {
+    const int64_t c = order[(size_t)i], b = cell_ptr[c], n = cell_ptr[c + 1] - b;
+    const int64_t parts = n > WAVE_ITEM ? (n + WAVE_ITEM - 1) / WAVE_ITEM : 1;
+    if (parts > 1) cuts.push_back(wave_cut{c, h->C + n_over, parts - 1});
+    for (int64_t q = 0; q < parts; ++q)
+      items.push_back(wave_item{b + n * q / parts, b + n * (q + 1) / parts, q == 0 ? c : h->C + n_over + q - 1});
+    n_over += parts - 1;
+  }
+  std::stable_sort(items.begin(), items.end(),
+                   [](const wave_item& a, const wave_item& b) { return a.e1 - a.e0 > b.e1 - b.e0; });
+  st->n_items = (int64_t)items.size();
+  st->n_cuts = (int64_t)cuts.size();
+  st->n_over = n_over;
+  if (dev_alloc(h, &st->d_items, items.size()) || dev_alloc(h, &st->d_cuts, cuts.size())) return 1;
+  if (!items.empty())
+    HIPCHK(h, hipMemcpy(st->d_items, items.data(), sizeof(wave_item) * items.size(), hipMemcpyHostToDevice));
+  if (!cuts.empty())
+    HIPCHK(h, hipMemcpy(st->d_cuts, cuts.data(), sizeof(wave_cut) * cuts.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -498,7 +557,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const int A = p->n_alpha, V = h->V;
   const int nblk = (V + 63) / 64, nblk2 = nblk * nblk;  // 64 x 64 blocks of the pair matrix
   const size_t need = (size_t)h->nnz * A * 9;
-  const size_t llw_need = (size_t)h->C * nblk2 * A * 4096;
+  const size_t llw_need = (size_t)(h->C + st->n_over) * nblk2 * A * 4096;
   // pG table, result slabs and (V > 64) the tensor the call kernel reads must fit comfortably: else the tile sweep
   if (((double)need + (double)llw_need + (nblk > 1 ? (double)h->C * V * V * A : 0.0)) * 8.0 > 230e9) return -1;
   if (need > st->pg_cap) {
@@ -514,14 +573,14 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (h->nnz)
     hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
                        A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
-  const unsigned blocks = (unsigned)h->C;
+  const unsigned blocks = (unsigned)st->n_items;
   std::vector<int> plain;  // non-symmetric alphas
   uint32_t symmask = 0;
   for (int n = 1; n < A; ++n) {
     if (p->alpha[n] != 0.5) plain.push_back(n);
     else symmask |= 1u << n;
   }
-#define KARGS st->d_order, h->C, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, V, A
+#define KARGS st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, V, A
 #define MULTI_LAUNCH(NA, NS, WS, CR, S0)                                                                          \
   hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, S0, \
                      wb, h->d_llw)
@@ -627,10 +686,15 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 #undef WAVE_LAUNCH
 #undef MULTI_LAUNCH
 #undef KARGS
+  if (st->n_cuts) {  // cells walked in several parts: add the parts' log-likelihoods up
+    hipLaunchKernelGGL(wave_combine_kernel, dim3((unsigned)st->n_cuts, 8), dim3(256), 0, h->stream, st->d_cuts,
+                       (int64_t)nblk2 * A * 4096, h->d_llw);
+    HIPCHK(h, hipGetLastError());
+  }
   h->ll_wave = nblk == 1;  // the 64-lane call kernel reads the slab directly; beyond 64 samples it reads the tensor
   if (h->want_full_ll || nblk > 1) {
     if (demux_ensure_ll(h, p)) return 1;
-    hipLaunchKernelGGL(demux_wave_to_full_kernel, dim3(blocks, (unsigned)nblk2), dim3(64), 0, h->stream, h->d_llw,
+    hipLaunchKernelGGL(demux_wave_to_full_kernel, dim3((unsigned)h->C, (unsigned)nblk2), dim3(64), 0, h->stream, h->d_llw,
                        h->d_cell_ptr, V, A, nblk, symmask, h->d_ll);
     HIPCHK(h, hipGetLastError());
   }
