@@ -32,13 +32,24 @@ class TorchExchange:
         self.world = world
 
     def allgather_rows(self, tensor, ranges):
-        """tensor: [n_units, row]; ranges[r] = (b, e) unit range owned by rank r.  One broadcast per owner."""
+        """tensor: [n_units, row]; ranges[r] = (b, e) unit range owned by rank r.  One broadcast per owner.
+        Returns when the data has landed: the engine launches its kernels on a stream of its own, which does not
+        wait for torch's streams (a collective that has merely been enqueued would be raced by the next phase)."""
         for r, (b, e) in enumerate(ranges):
             if e > b:
                 self.dist.broadcast(tensor[b:e], src=r)
+        self._landed(tensor)
 
     def allreduce_sum(self, tensor):
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+        self._landed(tensor)
+
+    @staticmethod
+    def _landed(tensor):
+        if getattr(tensor, "is_cuda", False):
+            import torch
+
+            torch.cuda.current_stream(tensor.device).synchronize()
 
     def gather_objects(self, obj):
         out = [None] * self.world
