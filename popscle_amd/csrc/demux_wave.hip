@@ -1,4 +1,7 @@
-// demux_wave.hip -- the demuxlet pair sweep for 16 < V <= 64 samples: one wave per cell, one lane per sample.
+// demux_wave.hip -- the demuxlet pair sweep for more than 16 samples: one wave per cell, one lane per sample.
+//   16 < V <= 32   demux_wave32_kernel: the wave as a ring of 32 (both halves hold the same triples)
+//   32 < V <= 64   demux_wave_kernel / demux_wave_multi_kernel, described below
+//   64 < V <= 255  the same kernels on 64 x 64 blocks of the pair matrix (wave_blk)
 //
 // Reference being replaced: cmd_cram_demuxlet.cpp:733-747 (pair sweep); the per-entry likelihoods pG (:655-725) come
 // from demux_entry_pg_kernel (demux_kernels.hip), written once per run for all alphas ([nnz][A][9] doubles).
@@ -15,7 +18,8 @@
 //     (demux_wave_multi_kernel: the rotation is paid once for all of them); the singlet slot (j,0,n=0) rides along
 //     with the first launch;
 //   * products are kept as mantissa * 2^exponent and turned into one log per (cell, hypothesis).
-// Work unit = cell (100 k waves at BASELINE configs[2]); cells are launched longest first.
+// Work unit = cell, or a part of a cell longer than 2048 entries (wave_item; 100 k waves at BASELINE configs[2]); the
+// units are launched longest first.  Markers without genotypes are neutral by construction (wave_neutral_pg_kernel).
 #include <algorithm>
 #include <vector>
 
