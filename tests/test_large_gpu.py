@@ -70,3 +70,35 @@ def test_config3_shape_freemuxlet():
         assert np.allclose(g, cplp["gls"], rtol=1e-10, atol=1e-300)
     ok = (gcells["type"] == 0) & ~p.truth["is_doublet"]
     assert ok.sum() > 0.5 * (~p.truth["is_doublet"]).sum()  # sanity only: parity with the oracle is the test above
+
+
+def test_config1_shape_freemuxlet_old_pair_matrix():
+    """freemuxlet-old's pair matrix at the cell and SNP counts of configs[1] (909 M pair terms): size-independent
+    properties.  A pair's record depends on its two cells only and its terms are accumulated in SNP order, so the signs
+    among a subset of the cells must be reproduced bit for bit by a run on that subset alone; the oracle checks a
+    sample of the pairs."""
+    cfg = synth.CONFIGS[1]
+    p = synth.make_pileup(cfg["C"], cfg["S"], cfg["V"], seed=synth.BASE_SEED + 1, with_gp=False, cap_bq=60)
+    pick = np.sort(np.random.default_rng(2).choice(p.C, 400, replace=False))
+    sub = p.subset_cells(pick)
+    with muxgl.Engine(0) as eng:
+        eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        eng.fmx_prepare(p.af)
+        eng.fmxold_pair_dist(5.41)
+        s = eng.fmxold_signs()
+        assert np.array_equal(s, s.T) and not s.diagonal().any()
+        assert 0.05 < (s != 0).mean() < 1.0
+        eng.set_pileup(sub.S, sub.cell_ptr, sub.entry_snp, sub.entry_rptr, sub.reads)
+        eng.fmx_prepare(sub.af)
+        got = eng.fmxold_pair_dist(5.41, want_full=True)
+        ssub = eng.fmxold_signs()
+    assert np.array_equal(ssub, s[np.ix_(pick, pick)])
+    want = ob.fmxold_pair_dist(sub, ob.fmx_entry_pileup(sub))
+    assert np.array_equal(got["nsnps"], want["nsnps"]) and np.array_equal(got["nread1"], want["nread1"])
+    assert np.abs(got["llk0"] - want["llk0"]).max() < 1e-8 and np.abs(got["llk2"] - want["llk2"]).max() < 1e-8
+    # same-donor singlet pairs look alike (+1), different donors differ (-1), wherever the evidence passes the threshold
+    t = p.truth
+    sng = ~t["is_doublet"][pick]
+    same = t["s1"][pick][:, None] == t["s1"][pick][None, :]
+    m = sng[:, None] & sng[None, :] & ~np.eye(len(pick), dtype=bool)
+    assert (ssub[m & same] >= 0).mean() > 0.99 and (ssub[m & ~same] <= 0).mean() > 0.99
