@@ -232,6 +232,22 @@ __device__ __forceinline__ double dev_logadd(double la, double lb) {
   return lb + log(1.0 + exp(la - lb));
 }
 
+// Work unit of the wave kernels (demux_wave.hip, fmx_wave.hip): a run of entries of one cell.  A cell is walked by one
+// wave, so a launch cannot end before its longest cell has been walked; with few cells that walk IS the launch (10 k
+// cells: 10 ms for any shape), with many it hides behind throughput-bound work.  Cells longer than 2048 entries are
+// therefore cut into equal parts, each with a result slab of its own (part 0: the cell's slab, the others: overflow
+// slabs behind the C cell slabs), and the parts' log-likelihoods are added up afterwards.  The cut depends on the cell
+// alone, so a cell's result does not depend on which other cells share the handle (shards reproduce the whole run bit
+// for bit).
+struct wave_item {
+  int64_t e0, e1;  // entries
+  int64_t slab;    // result slab (in units of one cell's slabs)
+  int64_t cell;
+};
+struct wave_cut {
+  int64_t cell, first, count;  // overflow slabs [first, first + count)
+};
+
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg);
@@ -245,7 +261,10 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 const int32_t* demux_wave_order(const muxgl_handle* h);  // cells, longest first (device)
-int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc);  // 16 < K <= 64; -1: not applicable
+int demux_wave_items(const muxgl_handle* h, const wave_item** items, int64_t* n_items, const wave_cut** cuts,
+                     int64_t* n_cuts, int64_t* n_over);  // work units of the wave kernels (device)
+int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc);  // 16 < K <= 255; -1: not applicable
+int64_t fmx_wave_fll_rows(const muxgl_handle* h);  // rows of d_fll: C + extra parts of long cells
 int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p);  // standard LL tensor allocated and zeroed
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);

@@ -55,18 +55,6 @@ struct wave_blk {
   int32_t blk, nblk2;    // slab of this launch, slabs per cell
 };
 
-// Work unit of the wave kernels: a run of entries of one cell.  A cell is walked by one wave, so a launch cannot end
-// before its longest cell has been walked; with few cells that walk IS the launch (10 k cells: 10 ms for any shape),
-// with many it hides behind throughput-bound work.  Cells longer than WAVE_ITEM entries are therefore cut into equal
-// parts, each with a result slab of its own (part 0: the cell's slab, the others: overflow slabs behind the C cell
-// slabs), and the parts' log-likelihoods are added up afterwards (wave_combine_kernel).  The cut depends on the cell
-// alone, so a cell's result does not depend on which other cells share the handle (shards reproduce the whole run bit
-// for bit).
-struct wave_item {
-  int64_t e0, e1;  // entries
-  int64_t slab;    // result slab (in units of one cell's slabs)
-};
-
 // NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise (64 with CROSS).  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
 template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false>
 __global__ void __launch_bounds__(64, 2)
@@ -419,9 +407,6 @@ __global__ void __launch_bounds__(64, 2)
 }
 
 // adds the overflow slabs of a cut cell, in entry order, into the cell's slab.  grid = (cut cells, slab pieces)
-struct wave_cut {
-  int64_t cell, first, count;  // overflow slabs [first, first + count)
-};
 __global__ void __launch_bounds__(256)
     wave_combine_kernel(const wave_cut* __restrict__ cuts, int64_t slab_doubles, double* __restrict__ llw) {
   const wave_cut cu = cuts[blockIdx.x];
@@ -501,6 +486,17 @@ int demux_gp_neutral_rows(muxgl_handle* h, int V) {
 
 const int32_t* demux_wave_order(const muxgl_handle* h) { return h->wave ? h->wave->d_order : nullptr; }
 
+int demux_wave_items(const muxgl_handle* h, const wave_item** items, int64_t* n_items, const wave_cut** cuts,
+                     int64_t* n_cuts, int64_t* n_over) {
+  if (!h->wave) return 1;
+  *items = h->wave->d_items;
+  *n_items = h->wave->n_items;
+  *cuts = h->wave->d_cuts;
+  *n_cuts = h->wave->n_cuts;
+  *n_over = h->wave->n_over;
+  return 0;
+}
+
 void demux_wave_free(muxgl_handle* h) {
   muxgl_wave_state* st = h->wave;
   if (!st) return;
@@ -533,7 +529,7 @@ int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr) {
     const int64_t parts = n > WAVE_ITEM ? (n + WAVE_ITEM - 1) / WAVE_ITEM : 1;
     if (parts > 1) cuts.push_back(wave_cut{c, h->C + n_over, parts - 1});
     for (int64_t q = 0; q < parts; ++q)
-      items.push_back(wave_item{b + n * q / parts, b + n * (q + 1) / parts, q == 0 ? c : h->C + n_over + q - 1});
+      items.push_back(wave_item{b + n * q / parts, b + n * (q + 1) / parts, q == 0 ? c : h->C + n_over + q - 1, c});
     n_over += parts - 1;
   }
   std::stable_sort(items.begin(), items.end(),

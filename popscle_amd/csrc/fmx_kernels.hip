@@ -779,7 +779,7 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   if (dev_alloc(h, &h->d_cgls, (size_t)K * S * 9)) return 1;
   if (dev_alloc(h, &h->d_ccnt, (size_t)K * S * 3)) return 1;
   if (dev_alloc(h, &h->d_cgp, (size_t)S * K * 3)) return 1;
-  if (dev_alloc(h, &h->d_fll, (size_t)C * K * (K + 1) / 2)) return 1;
+  if (dev_alloc(h, &h->d_fll, (size_t)fmx_wave_fll_rows(h) * K * (K + 1) / 2)) return 1;
   // state before the first iteration: cmd_cram_freemux2.cpp:191-194,213,244 and :345-367
   std::vector<int32_t> cl((size_t)C);
   for (int64_t i = 0; i < C; ++i) {

@@ -26,15 +26,16 @@ __device__ __forceinline__ double fw_wror1(double x) {
 
 template <bool CROSS>
 __global__ void __launch_bounds__(64, 2)
-    fmx_estep_wave_kernel(const int32_t* __restrict__ order, int64_t n_cells, int64_t c0, int64_t c1,
+    fmx_estep_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, int64_t c0, int64_t c1,
                           const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ entry_snp,
                           const double* __restrict__ egls, const double* __restrict__ cgp, int K, int jbase, int kbase,
                           double* __restrict__ fll) {
   constexpr int NS = CROSS ? 64 : 32;
-  if ((int64_t)blockIdx.x >= n_cells) return;
-  const int64_t c = order[blockIdx.x];
-  if (c < c0 || c >= c1) return;  // not in this rank's cell shard
-  const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
+  if ((int64_t)blockIdx.x >= n_items) return;
+  const wave_item it = items[blockIdx.x];  // a cell, or a part of a long one (common.hpp)
+  if (it.cell < c0 || it.cell >= c1) return;  // not in this rank's cell shard
+  const int64_t c = it.slab;  // row of fll: the cell, or an overflow row behind the C cell rows
+  const int64_t e0 = it.e0, e1 = it.e1;
   const int j = threadIdx.x;
   const int sj = jbase + j;
   const bool live = sj < K, live2 = kbase + j < K;
@@ -146,21 +147,48 @@ __global__ void __launch_bounds__(64, 2)
   if (!CROSS && live) out[sj * (sj + 1) / 2 + sj] = prodacc_log(accS, exS);
 }
 
+// rows of the parts of a cut cell added, in entry order, into the cell's row of fll
+__global__ void __launch_bounds__(256)
+    fmx_wave_combine_kernel(const wave_cut* __restrict__ cuts, int64_t c0, int64_t c1, int npairs, double* __restrict__ fll) {
+  const wave_cut cu = cuts[blockIdx.x];
+  if (cu.cell < c0 || cu.cell >= c1) return;
+  double* dst = fll + (size_t)cu.cell * npairs;
+  for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+    double v = dst[i];
+    for (int64_t q = 0; q < cu.count; ++q) v += fll[(size_t)(cu.first + q) * npairs + i];
+    dst[i] = v;
+  }
+}
+
 }  // namespace
+
+// rows of d_fll the wave E-step needs: one per cell plus one per extra part of a long cell
+int64_t fmx_wave_fll_rows(const muxgl_handle* h) {
+  const wave_item* items;
+  const wave_cut* cuts;
+  int64_t n_items, n_cuts, n_over = 0;
+  if (demux_wave_items(h, &items, &n_items, &cuts, &n_cuts, &n_over)) return h->C;
+  return h->C + n_over;
+}
 
 // returns -1 when this path does not apply, 0 ok, 1 error
 int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
   if (h->K <= 16 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
-  const int32_t* order = demux_wave_order(h);
-  if (!order) return -1;
+  const wave_item* items;
+  const wave_cut* cuts;
+  int64_t n_items, n_cuts, n_over;
+  if (demux_wave_items(h, &items, &n_items, &cuts, &n_cuts, &n_over) || n_items == 0) return -1;
   const int nblk = (h->K + 63) / 64;
   for (int X = 0; X < nblk; ++X) {
-    hipLaunchKernelGGL(fmx_estep_wave_kernel<false>, dim3((unsigned)h->C), dim3(64), 0, h->stream, order, h->C, c0, c0 + nc,
-                       h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, 64 * X, 64 * X, h->d_fll);
+    hipLaunchKernelGGL(fmx_estep_wave_kernel<false>, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
+                       c0 + nc, h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, 64 * X, 64 * X, h->d_fll);
     for (int Y = 0; Y < X; ++Y)
-      hipLaunchKernelGGL(fmx_estep_wave_kernel<true>, dim3((unsigned)h->C), dim3(64), 0, h->stream, order, h->C, c0, c0 + nc,
-                         h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, 64 * X, 64 * Y, h->d_fll);
+      hipLaunchKernelGGL(fmx_estep_wave_kernel<true>, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
+                         c0 + nc, h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, 64 * X, 64 * Y, h->d_fll);
   }
+  if (n_cuts)
+    hipLaunchKernelGGL(fmx_wave_combine_kernel, dim3((unsigned)n_cuts), dim3(256), 0, h->stream, cuts, c0, c0 + nc,
+                       h->K * (h->K + 1) / 2, h->d_fll);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
