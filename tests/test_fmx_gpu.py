@@ -107,7 +107,9 @@ def test_golden(eng):
     (4, 200, 2000, 250, 4),
     (16, 300, 3000, 400, 3),
     (5, 120, 1000, 200, 3),
-    (20, 100, 2500, 400, 2),   # K > 16: pair kernel on both engines
+    (17, 60, 2000, 300, 2),    # 16 < K <= 32: ring-of-32 wave E-step (pair kernel on the 'pair' engine)
+    (20, 100, 2500, 400, 2),
+    (32, 50, 3000, 2600, 2),   #   full ring, cells in several parts
     (64, 40, 4000, 500, 2),    # config-5 shape, few cells
     (70, 24, 5000, 1200, 2),   # K > 64: the general pair E-step and the (SNP, cluster)-parallel M-step; deep cells
     (100, 16, 5000, 1500, 2),
