@@ -296,13 +296,16 @@ __global__ void __launch_bounds__(64, 2)
 // NA alphas per launch share the rotation as in demux_wave_multi_kernel; an alpha of 0.5 is just one of them (both
 // orders of a pair are computed, the one with the larger sample on the stationary side is stored twice).  Results go
 // to the slab positions the 64-lane layout assigns to (sample, partner): the call kernel needs no second code path.
-template <int NA, bool WITH_SINGLET>
+// ALLSYM: every alpha of the launch is 0.5 (the reference's default grid has just that one): the ring offsets 1..16 are
+// all the unordered pairs, so the halves sit eight positions apart and eight steps do (offset 16 meets a pair from
+// both ends: one writer).
+template <int NA, bool WITH_SINGLET, bool ALLSYM = false>
 __global__ void __launch_bounds__(64, 2)
     demux_wave32_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                         const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
-  constexpr int NS = 16;
+  constexpr int NS = ALLSYM ? 8 : 16;
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
   const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
@@ -310,7 +313,7 @@ __global__ void __launch_bounds__(64, 2)
   if (e0 == e1) return;
   const int j = threadIdx.x;
   const int half = j >> 5, sj = j & 31;  // ring position
-  const int so = (sj + 16 * half) & 31;  // the sample this lane works for
+  const int so = (sj + NS * half) & 31;  // the sample this lane works for
   const bool live = so < V, rlive = sj < V;
   const int V3 = V * 3;
   const int PG = nAlpha * 9;
@@ -393,7 +396,8 @@ __global__ void __launch_bounds__(64, 2)
         const int n = sel.n[a];
         const double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
         if ((symmask >> n) & 1u) {  // alpha 0.5: one writer per unordered pair, mirrored (as on the other paths)
-          if (so > k) {
+          // (ALLSYM: a pair is met once, except at ring offset 16, the last step of the upper half)
+          if (ALLSYM ? !(half == 1 && t == NS - 1 && so < k) : so > k) {
             out[((size_t)n * 64 + tt) * 64 + so] = v;
             out[((size_t)n * 64 + ((k - so - 1) & 63)) * 64 + k] = v;
           }
@@ -603,6 +607,13 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       } else if (na == 2) {
         if (first) W32_LAUNCH(2, true);
         else W32_LAUNCH(2, false);
+      } else if ((symmask >> sel.n[0]) & 1u) {  // a lone alpha of 0.5: eight steps
+        if (first)
+          hipLaunchKernelGGL((demux_wave32_kernel<1, true, true>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel,
+                             symmask, h->d_llw);
+        else
+          hipLaunchKernelGGL((demux_wave32_kernel<1, false, true>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel,
+                             symmask, h->d_llw);
       } else {
         if (first) W32_LAUNCH(1, true);
         else W32_LAUNCH(1, false);
