@@ -84,17 +84,29 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const 
                                                               const double* __restrict__ lut_g, int nAlpha,
                                                               alpha_args al, double* __restrict__ pg) {
   __shared__ double lut[256];
+  __shared__ double stage[4][64 * 9 + 1];  // one alpha of a wave's 64 entries at a time (+1: odd stride, no bank conflicts)
   lut[threadIdx.x] = lut_g[threadIdx.x];
   __syncthreads();
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int W = nAlpha * 9;  // doubles per entry in the table
+  // lane <-> entry for the arithmetic; the table rows of a wave's 64 entries are contiguous, so they are written by
+  // consecutive lanes through LDS instead of 64 streams W doubles apart
+  for (int64_t eb = ((int64_t)blockIdx.x * 4 + w) * 64; eb < nnz; eb += (int64_t)gridDim.x * 256) {
+    const int64_t e = eb + lane;
     double pG[NA * 9];
-    entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], nAlpha, al.a, lut, pG);
+    if (e < nnz) entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], nAlpha, al.a, lut, pG);
+    const int ne = (int)((nnz - eb < 64) ? (nnz - eb) : 64);
 #pragma unroll
-    for (int n = 0; n < NA; ++n)
-      if (n < nAlpha) {
+    for (int n = 0; n < NA; ++n) {
+      if (n >= nAlpha) break;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) pg[(size_t)e * nAlpha * 9 + n * 9 + i] = pG[n * 9 + i];
+      for (int i = 0; i < 9; ++i) stage[w][lane * 9 + i] = pG[n * 9 + i];
+      // (a wave's LDS traffic is in order: no barrier between the phases)
+      for (int x = lane; x < ne * 9; x += 64) {
+        const int le = x / 9, i = x - le * 9;
+        pg[(size_t)(eb + le) * W + n * 9 + i] = stage[w][x];
       }
+    }
   }
 }
 
