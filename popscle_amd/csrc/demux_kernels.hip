@@ -13,6 +13,7 @@
 //   * only hypotheses the reference ever reads are computed: (j,0,0) singlets and (j,k!=j,n>=1) doublets; for
 //     alpha==0.5 the likelihood is symmetric in (j,k), so k<j is computed once and mirrored.
 #include "common.hpp"
+#include "demux_entry.hpp"
 
 namespace {
 
@@ -83,9 +84,9 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const 
                                                               const uint8_t* __restrict__ reads,
                                                               const double* __restrict__ lut_g, int nAlpha,
                                                               alpha_args al, double* __restrict__ pg) {
-  __shared__ double lut[256];
+  __shared__ double lut[384];
   __shared__ double stage[4][64 * 9 + 1];  // one alpha of a wave's 64 entries at a time (+1: odd stride, no bank conflicts)
-  lut[threadIdx.x] = lut_g[threadIdx.x];
+  for (int i = threadIdx.x; i < 384; i += 256) lut[i] = lut_g[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int W = nAlpha * 9;  // doubles per entry in the table
@@ -94,7 +95,12 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const 
   for (int64_t eb = ((int64_t)blockIdx.x * 4 + w) * 64; eb < nnz; eb += (int64_t)gridDim.x * 256) {
     const int64_t e = eb + lane;
     double pG[NA * 9];
-    if (e < nnz) entry_pg<NA>(reads, entry_rptr[e], entry_rptr[e + 1], nAlpha, al.a, lut, pG);
+    if (e < nnz) {  // the row kernel's formulation (demux_entry.hpp); slots beyond nAlpha repeat alpha[0]
+      const int64_t r0 = entry_rptr[e], r1 = entry_rptr[e + 1];
+      uint32_t first4 = 0;
+      for (int64_t k = 0; k < 4 && r0 + k < r1; ++k) first4 |= (uint32_t)reads[r0 + k] << (8 * (int)k);
+      row_entry_pg<NA>(reads, r0, r1, first4, al.a, lut, pG);
+    }
     const int ne = (int)((nnz - eb < 64) ? (nnz - eb) : 64);
 #pragma unroll
     for (int n = 0; n < NA; ++n) {
@@ -531,7 +537,7 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg) {
   const int A = p->n_alpha;
   alpha_args al;
-  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : 0.0;
+  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : p->alpha[0];
 #define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg)
   DISPATCH_NA(A, CALL_PG);
 #undef CALL_PG
