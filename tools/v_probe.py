@@ -20,12 +20,14 @@ eng = muxgl.Engine(0)
 eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
 eng.demux_set_gp(p.gp, p.has_gp)
 eng.demux_run(alphas, 0.5, want_cells=False)
-t0 = time.time()
-eng.demux_run(alphas, 0.5, want_cells=False)
-dt = time.time() - t0
+dt = 1e9
+for _ in range(5):  # best of five passes (the first ones still allocate)
+    t0 = time.time()
+    eng.demux_run(alphas, 0.5, want_cells=False)
+    dt = min(dt, time.time() - t0)
 ms = eng.timing()
 cells = eng.demux_results_view()
 sng = ~p.truth["is_doublet"]
-print(json.dumps({"V": V, "cells": C, "entries": p.nnz, "pass_s": dt, "sweep_ms": float(ms[muxgl.T_DEMUX_SWEEP]),
+print(json.dumps({"V": V, "cells": C, "entries": p.nnz, "pass_s": dt, "sweep_ms": float(ms[muxgl.T_DEMUX_SWEEP]), "reduce_ms": float(ms[muxgl.T_DEMUX_REDUCE]),
                   "call_ms": float(ms[muxgl.T_DEMUX_CALL]), "ns_per_entry_hypothesis":
                   dt * 1e9 / (p.nnz * (V + V * (V - 1) * (len(alphas) - 1))), "singlet_acc": float((cells["sBest"][sng] == p.truth["s1"][sng]).mean())}))
