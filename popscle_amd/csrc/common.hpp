@@ -259,6 +259,7 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not
 int demux_row2_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable (demux_row2.hip)
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
+int fmx_row2_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 const int32_t* demux_wave_order(const muxgl_handle* h);  // cells, longest first (device)

@@ -17,11 +17,13 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(scope="module", params=["default", "row", "pair"])
+@pytest.fixture(scope="module", params=["default", "row", "wave", "pair"])
 def eng(request):
-    """'default' = normal dispatch (quad E-step for K <= 16), 'row' = quad disabled (row E-step), 'pair' = the general
-    pair kernel and the (SNP, cluster)-parallel M-step forced for every K"""
-    flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "pair": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
+    """'default' = normal dispatch (quad E-step for K <= 16, two clusters per lane up to 32, wave kernels above), 'row' =
+    quad disabled (row E-step), 'wave' = the ring-of-32 wave E-step for 16 < K <= 32, 'pair' = the general pair kernel
+    and the (SNP, cluster)-parallel M-step forced for every K"""
+    flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "wave": muxgl.FLAG_FORCE_WAVE_KERNEL,
+             "pair": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
     e = muxgl.Engine(0, flags)
     yield e
     e.close()
@@ -107,7 +109,7 @@ def test_golden(eng):
     (4, 200, 2000, 250, 4),
     (16, 300, 3000, 400, 3),
     (5, 120, 1000, 200, 3),
-    (17, 60, 2000, 300, 2),    # 16 < K <= 32: ring-of-32 wave E-step (pair kernel on the 'pair' engine)
+    (17, 60, 2000, 300, 2),    # 16 < K <= 32: two clusters per lane ('wave': ring of 32, 'pair': pair kernel)
     (20, 100, 2500, 400, 2),
     (32, 50, 3000, 2600, 2),   #   full ring, cells in several parts
     (64, 40, 4000, 500, 2),    # config-5 shape, few cells
