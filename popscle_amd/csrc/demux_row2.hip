@@ -13,15 +13,18 @@
 //     3 moves per hypothesis instead of 6; alpha = 0.5 is symmetric, so 8 rotations cover the 496 unordered pairs
 //     (the eighth visits every pair twice: one writer, see the reduce kernel) and the pair (j, j+16) is formed in the lane;
 //   * 35 product accumulators per lane (mantissa * 2^exponent, prodacc), one log per chunk, chunk partials added per
-//     cell in chunk order by demux_row2_reduce_kernel into the [C][V][V][A] tensor the call kernel reads;
+//     cell in chunk order: by demux_row2_finish_kernel into a tile in LDS where the call is made at once, or by
+//     demux_row2_reduce_kernel into the [C][V][V][A] tensor when the caller asks for it;
 //   * phase 1 of every 16-entry batch is lane <-> entry (a4, a5), exactly the row kernel's.
 //
 // 75 VALU instructions per entry (258 per four entries in the inner loop, 96 of them DPP moves) and no table pass.
-// Measured at 10 k cells x 50 k SNPs: sweep 1.9-2.0 ms, pass 2.2 ms at V = 17 and 2.4 ms at V = 32, against 4.0 ms for
+// Measured at 10 k cells x 50 k SNPs: sweep 1.8-1.9 ms, pass 2.05 ms at V = 17 and 2.14 ms at V = 32, against 4.0 ms for
 // the ring of 32 (3.25 ms sweep + 0.54 ms table pass).  246 VGPRs, two waves per SIMD; three waves (168 VGPRs, the
 // epilogue spilling) measured slower (2.4 ms).
 #include "common.hpp"
+#include "demux_call_body.hpp"
 #include "demux_entry.hpp"
+#include "row2.hpp"
 
 namespace {
 
@@ -29,31 +32,7 @@ struct row2_alpha {
   double a[2];  // [0] = the singlet slot's alpha, [1] = 0.5
 };
 
-// the value lane (j + T) mod 16 of the same 16-lane row holds (DPP row_ror:T): every rotation reads the original
-// triple, so the eight steps do not form a chain
-template <int T>
-__device__ __forceinline__ int r2_ror_i32(int x) {
-  return __builtin_amdgcn_mov_dpp(x, 0x120 + T, 0xF, 0xF, false);
-}
-template <int T>
-__device__ __forceinline__ double r2_ror(double x) {
-  return __hiloint2double(r2_ror_i32<T>(__double2hiint(x)), r2_ror_i32<T>(__double2loint(x)));
-}
-
-// which lane's samples lane j sees after row_ror:t (measured with the same instruction, so the kernels never assume a
-// rotation direction): kmap[t][j], t = 0..8
-__global__ void row2_kmap_kernel(int32_t* kmap) {
-  const int lane = threadIdx.x, v = lane & 15;
-  int r[9] = {v, r2_ror_i32<1>(v), r2_ror_i32<2>(v), r2_ror_i32<3>(v), r2_ror_i32<4>(v), r2_ror_i32<5>(v),
-              r2_ror_i32<6>(v), r2_ror_i32<7>(v), r2_ror_i32<8>(v)};
-  if (lane < 16)
-    for (int t = 0; t < 9; ++t) kmap[t * 16 + lane] = r[t];
-}
-
-// accumulators of lane j (a = sample j, b = sample j + 16; after t rotations the partner lane's samples are
-// ka = kmap[t][j], kb = ka + 16):
-//   0 singlet a, 1 singlet b, 2 pair (a,b), 3 + 4 (t-1) + {0 (a,ka), 1 (a,kb), 2 (b,ka), 3 (b,kb)} for t = 1..8
-constexpr int R2_NACC = 35;
+constexpr int R2_NACC = ROW2_NACC;  // accumulator layout: row2.hpp
 constexpr int R2_PGS = 18;                    // doubles per entry in LDS (two alphas x 9)
 constexpr int R2_SLOT_STRIDE = 16 * R2_PGS + 4;  // +4 doubles: the 4 slots' broadcast reads fall on distinct banks
 
@@ -197,8 +176,8 @@ __global__ void __launch_bounds__(64, 2)
       acc[2] *= fma(b2, ua2, fma(b1, ua1, b0 * ua0));  // the lane's own two samples (:738-746)
 #define R2_STEP(T)                                                                                       \
   {                                                                                                      \
-    const double ra0 = r2_ror<T>(a0), ra1 = r2_ror<T>(a1), ra2 = r2_ror<T>(a2);                          \
-    const double rb0 = r2_ror<T>(b0), rb1 = r2_ror<T>(b1), rb2 = r2_ror<T>(b2);                          \
+    const double ra0 = row2_ror<T>(a0), ra1 = row2_ror<T>(a1), ra2 = row2_ror<T>(a2);                          \
+    const double rb0 = row2_ror<T>(b0), rb1 = row2_ror<T>(b1), rb2 = row2_ror<T>(b2);                          \
     acc[3 + 4 * (T - 1) + 0] *= fma(ra2, ua2, fma(ra1, ua1, ra0 * ua0)); /* :738-746 as a product */     \
     acc[3 + 4 * (T - 1) + 1] *= fma(rb2, ua2, fma(rb1, ua1, rb0 * ua0));                                 \
     acc[3 + 4 * (T - 1) + 2] *= fma(ra2, ub2, fma(ra1, ub1, ra0 * ub0));                                 \
@@ -231,17 +210,9 @@ __global__ void __launch_bounds__(192)
   for (int idx = threadIdx.x; idx < R2_NACC * 16; idx += blockDim.x) {
     const int a = idx >> 4, j = idx & 15;
     int x, y;
-    bool singlet = false;
-    if (a < 2) {
-      x = j + 16 * a, y = 0, singlet = true;
-    } else if (a == 2) {
-      x = j, y = j + 16;
-    } else {
-      const int t = 1 + ((a - 3) >> 2), combo = (a - 3) & 3;
-      const int ka = kmap[t * 16 + j];
-      if (t == 8 && j < ka) continue;  // rotation 8 visits every unordered pair of lanes twice: one writer
-      x = j + 16 * (combo >> 1), y = ka + 16 * (combo & 1);
-    }
+    if (!row2_pair_of(a, j, kmap, x, y)) continue;
+    const bool singlet = a < 2;
+    if (singlet) y = 0;  // llksAB[x][0][0]
     if (x >= V || y >= V) continue;
     double s = 0.0;
     for (int64_t ci = c0; ci < c1; ++ci) s += part[(size_t)cell_chunks[ci] * R2_NACC * 16 + idx];
@@ -254,6 +225,46 @@ __global__ void __launch_bounds__(192)
   }
 }
 
+// reduce + call fused (the LL tensor is not requested): the cell's [V][V][2] tile is put together in LDS from the chunk
+// partials, one wave makes the call on it (demux_call_body.hpp, 64 lanes per cell) and the record goes straight to the
+// caller's pinned host buffer -- no round trip of the 164 MB tensor (10 k cells, V = 32) through HBM
+__global__ void __launch_bounds__(256)
+    demux_row2_finish_kernel(const int64_t* __restrict__ cell_ptr, const int64_t* __restrict__ cell_chunk_ptr,
+                             const int32_t* __restrict__ cell_chunks, const double* __restrict__ part,
+                             const int32_t* __restrict__ kmap, int V, muxgl_call::call_alpha al, double doublet_prior,
+                             muxgl_demux_cell* __restrict__ out) {
+  __shared__ double llt[32 * 32 * 2];
+  __shared__ __align__(16) muxgl_demux_cell rec;
+  static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
+  const int64_t c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  for (int t = tid; t < V * V * 2; t += 256) llt[t] = 0.0;
+  __syncthreads();
+  for (int idx = tid; idx < R2_NACC * 16 && c0 != c1; idx += 256) {
+    const int a = idx >> 4, j = idx & 15;
+    int x, y;
+    if (!row2_pair_of(a, j, kmap, x, y)) continue;
+    if (a < 2) y = 0;  // llksAB[x][0][0]
+    if (x >= V || y >= V) continue;
+    double s = 0.0;
+    for (int64_t ci = c0; ci < c1; ++ci) s += part[(size_t)cell_chunks[ci] * R2_NACC * 16 + idx];
+    if (a < 2) {
+      llt[(x * V) * 2] = s;
+    } else {
+      llt[(x * V + y) * 2 + 1] = s;
+      llt[(y * V + x) * 2 + 1] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < 64)
+    muxgl_call::demux_call_group<64>(tid, true, (int32_t)(cell_ptr[c + 1] - cell_ptr[c]), V, 2, al.a, doublet_prior, llt,
+                                     &rec);
+  __syncthreads();
+  constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
+  if (tid < NQ) reinterpret_cast<uint4*>(out + c)[tid] = reinterpret_cast<const uint4*>(&rec)[tid];
+}
+
 }  // namespace
 
 // returns -1 when the two-samples-per-lane row path does not apply, 0 ok, 1 error
@@ -263,6 +274,7 @@ int demux_row2_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (p->n_alpha != 2 || p->alpha[1] != 0.5 || p->alpha[0] == 0.5) return -1;
   muxgl_row_state* st = h->row;
   const size_t need = (size_t)st->n_chunks * R2_NACC * 16;
+  if ((double)need * 8.0 > ROW2_PART_LIMIT) return -1;
   if (need > st->part_cap) {
     if (dev_alloc(h, &st->d_part, need)) return 1;
     st->part_cap = need;
@@ -283,8 +295,17 @@ int demux_row2_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);
   tic(h, MUXGL_T_DEMUX_REDUCE);
-  hipLaunchKernelGGL(demux_row2_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
-                     st->d_cell_chunks, st->d_part, st->d_tmap, h->V, p->n_alpha, h->d_ll);
+  if (h->want_full_ll) {
+    hipLaunchKernelGGL(demux_row2_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                       st->d_cell_chunks, st->d_part, st->d_tmap, h->V, p->n_alpha, h->d_ll);
+  } else {  // reduce + call fused, records written to the pinned host buffer
+    muxgl_call::call_alpha ca;
+    for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) ca.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+    hipLaunchKernelGGL(demux_row2_finish_kernel, dim3((unsigned)h->C), dim3(256), 0, h->stream, h->d_cell_ptr,
+                       st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_tmap, h->V, ca, p->doublet_prior,
+                       h->h_dcells);
+    h->records_on_host = true;
+  }
   HIPCHK(h, hipGetLastError());
   toc(h, MUXGL_T_DEMUX_REDUCE);
   return 0;

@@ -11,30 +11,11 @@
 // one log per chunk (:454-455), chunk partials added per cell in chunk order.  The ring-of-32 wave kernel it replaces
 // (fmx_wave.hip) walks one entry per wave and pays 6 moves per pair.
 #include "common.hpp"
+#include "row2.hpp"
 
 namespace {
 
-template <int T>
-__device__ __forceinline__ int f2_ror_i32(int x) {
-  return __builtin_amdgcn_mov_dpp(x, 0x120 + T, 0xF, 0xF, false);  // row_ror:T
-}
-template <int T>
-__device__ __forceinline__ double f2_ror(double x) {
-  return __hiloint2double(f2_ror_i32<T>(__double2hiint(x)), f2_ror_i32<T>(__double2loint(x)));
-}
-
-// which lane's clusters lane j sees after row_ror:t (measured with the same instruction): kmap[t][j], t = 0..8
-__global__ void f2_kmap_kernel(int32_t* kmap) {
-  const int lane = threadIdx.x, v = lane & 15;
-  int r[9] = {v, f2_ror_i32<1>(v), f2_ror_i32<2>(v), f2_ror_i32<3>(v), f2_ror_i32<4>(v), f2_ror_i32<5>(v),
-              f2_ror_i32<6>(v), f2_ror_i32<7>(v), f2_ror_i32<8>(v)};
-  if (lane < 16)
-    for (int t = 0; t < 9; ++t) kmap[t * 16 + lane] = r[t];
-}
-
-// accumulators of lane j (a = cluster j, b = cluster j + 16; ka = kmap[t][j], kb = ka + 16):
-//   0 singlet a, 1 singlet b, 2 pair (a,b), 3 + 4 (t-1) + {0 (a,ka), 1 (a,kb), 2 (b,ka), 3 (b,kb)} for t = 1..8
-constexpr int F2_NACC = 35;
+constexpr int F2_NACC = ROW2_NACC;  // accumulator layout: row2.hpp
 constexpr int F2_PGS = 10;  // 9 likelihoods + 1 pad (16-byte aligned rows)
 constexpr int F2_SLOT_STRIDE = 16 * F2_PGS + 4;
 
@@ -112,8 +93,8 @@ __global__ void __launch_bounds__(64, 2)
       acc[2] *= fma(b2, ua2, fma(b1, ua1, b0 * ua0));
 #define F2_STEP(T)                                                                  \
   {                                                                                 \
-    const double ra0 = f2_ror<T>(a0), ra1 = f2_ror<T>(a1), ra2 = f2_ror<T>(a2);     \
-    const double rb0 = f2_ror<T>(b0), rb1 = f2_ror<T>(b1), rb2 = f2_ror<T>(b2);     \
+    const double ra0 = row2_ror<T>(a0), ra1 = row2_ror<T>(a1), ra2 = row2_ror<T>(a2);     \
+    const double rb0 = row2_ror<T>(b0), rb1 = row2_ror<T>(b1), rb2 = row2_ror<T>(b2);     \
     acc[3 + 4 * (T - 1) + 0] *= fma(ra2, ua2, fma(ra1, ua1, ra0 * ua0));            \
     acc[3 + 4 * (T - 1) + 1] *= fma(rb2, ua2, fma(rb1, ua1, rb0 * ua0));            \
     acc[3 + 4 * (T - 1) + 2] *= fma(ra2, ub2, fma(ra1, ub1, ra0 * ub0));            \
@@ -144,16 +125,7 @@ __global__ void __launch_bounds__(192)
   for (int idx = threadIdx.x; idx < F2_NACC * 16; idx += blockDim.x) {
     const int a = idx >> 4, j = idx & 15;
     int x, y;
-    if (a < 2) {
-      x = y = j + 16 * a;
-    } else if (a == 2) {
-      x = j, y = j + 16;
-    } else {
-      const int t = 1 + ((a - 3) >> 2), combo = (a - 3) & 3;
-      const int ka = kmap[t * 16 + j];
-      if (t == 8 && j < ka) continue;  // rotation 8 visits every unordered pair of lanes twice: one writer
-      x = j + 16 * (combo >> 1), y = ka + 16 * (combo & 1);
-    }
+    if (!row2_pair_of(a, j, kmap, x, y)) continue;
     if (x >= K || y >= K) continue;
     double s = 0.0;
     for (int64_t ci = c0; ci < c1; ++ci) s += part[(size_t)cell_chunks[ci] * F2_NACC * 16 + idx];
@@ -170,10 +142,11 @@ int fmx_row2_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
   if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;
   if (!st->d_tmap) {  // (the quad tile-map slot of this table set is unused beyond 16 clusters) lane map of the rotations
     if (dev_alloc(h, &st->d_tmap, 9 * 16)) return 1;
-    hipLaunchKernelGGL(f2_kmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
+    hipLaunchKernelGGL(row2_kmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
     HIPCHK(h, hipGetLastError());
   }
   const size_t need = (size_t)st->n_chunks * F2_NACC * 16;
+  if ((double)need * 8.0 > ROW2_PART_LIMIT) return -1;
   if (need > st->part_cap) {
     if (dev_alloc(h, &st->d_part, need)) return 1;
     st->part_cap = need;

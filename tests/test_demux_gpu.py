@@ -109,6 +109,18 @@ def test_deep_pileups_per_entry(eng, V):
     parity.compare_demux(got2, ob.demux(p, alphas=(0.0, 0.5), nthreads=4), (0.0, 0.5))
 
 
+@pytest.mark.parametrize("V", [8, 16, 17, 27, 32, 48])
+def test_records_do_not_depend_on_the_tensor_request(eng, V):
+    """the quad and two-per-lane row paths make the call in LDS when the LL tensor is not asked for: same records,
+    bit for bit, as the reduce + call kernels behind the tensor"""
+    p = synth.make_pileup(70, 3000, V, seed=4000 + V, mean_entries=500, min_entries=5, missing_gp_frac=0.05)
+    alphas = (0.0, 0.5)
+    with_tensor, _ = run_gpu(eng, p, alphas, full=True)
+    without = run_gpu(eng, p, alphas)
+    assert without.tobytes() == with_tensor.tobytes()
+    parity.compare_demux(without, ob.demux(p, alphas=alphas, nthreads=4), alphas)
+
+
 def test_entry_pg_vs_oracle(eng):
     p = synth.make_pileup(30, 800, 4, seed=77, mean_entries=100, min_entries=10, reads_lambda=2.5, other=0.05)
     for alphas in [(0.0, 0.5), GRID6]:
@@ -119,11 +131,12 @@ def test_entry_pg_vs_oracle(eng):
             assert np.allclose(pg[e], want, rtol=1e-13, atol=1e-24)
 
 
-def test_ragged_and_edge_inputs(eng):
+@pytest.mark.parametrize("V", [5, 20])
+def test_ragged_and_edge_inputs(eng, V):
     """empty cells, entries without reads, entries with only 'other' alleles, SNPs without GP, one very deep entry,
     one cell longer than several chunks"""
     rng = np.random.default_rng(5)
-    S, V = 600, 5
+    S = 600
     base = synth.make_pileup(6, S, V, seed=31, mean_entries=120, min_entries=40)
     lens = [0, 1, 3, 500, 0, 70, 0]
     cell_ptr = np.zeros(len(lens) + 1, dtype=np.int64)
@@ -148,6 +161,7 @@ def test_ragged_and_edge_inputs(eng):
         parity.compare_demux(got, want, alphas, want_full=wfull)
         parity.compare_full_ll(gfull, wfull, V, alphas)
         assert got["valid"].tolist() == [0, 1, 1, 1, 0, 1, 0]
+        assert run_gpu(eng, p, alphas).tobytes() == got.tobytes()  # the call made in LDS (no tensor requested)
 
 
 def test_zero_cells_and_reuse_of_handle(eng):
