@@ -53,9 +53,8 @@ def as_pileup(d):
                         d["gp"] if d["nv"] else None, d["has_gp"] if d["nv"] else None)
 
 
-@pytest.mark.parametrize("alphas", [None, (0.0, 0.1, 0.3, 0.5)])
-def test_demuxlet_cli(tmp_path, alphas):
-    V = 6
+@pytest.mark.parametrize("V,alphas", [(6, None), (6, (0.0, 0.1, 0.3, 0.5)), (20, None)])
+def test_demuxlet_cli(tmp_path, V, alphas):
     p = synth.make_pileup(60, 800, V, seed=5, mean_entries=150, min_entries=20)
     prefix = str(tmp_path / "plp")
     plpio.write_plp(prefix, p, seed=5, extra_cells=1)
