@@ -49,6 +49,8 @@ def sweep_kernel_name(V, alphas):
         return "demux_quad_kernel"
     if V <= 16 and sum(1 for a in alphas[1:] if a != 0.5) <= 5 and sum(1 for a in alphas[1:] if a == 0.5) <= 1:
         return "demux_row_kernel"
+    if V <= 24 and tuple(alphas) == (0.0, 0.5):
+        return "demux_rowx_kernel"
     if V <= 32 and len(alphas) == 2 and alphas[1] == 0.5 and alphas[0] != 0.5:
         return "demux_row2_kernel"
     if V <= 32:

@@ -56,7 +56,11 @@ def test_golden(eng, name):
     (1, (0.0, 0.5), 20, 500, 100),                # nv-1 == 0: infinite doublet prior, no doublet hypotheses
     (5, (0.0,), 40, 800, 150),                    # nAlpha == 1 (reference quirk: division by nAlpha-1 == 0)
     (7, (0.0, 0.3), 60, 1500, 200),               # no symmetric alpha at all
-    (17, (0.0, 0.5), 30, 3000, 400),              # two samples per lane (demux_row2.hip); 'wave': ring of 32, one alpha
+    (17, (0.0, 0.5), 30, 3000, 400),              # row kernel + one broadcast sample (demux_rowx.hip); 'row': two samples
+                                                  # per lane (demux_row2.hip); 'wave': ring of 32, one alpha
+    (18, (0.0, 0.5), 24, 3000, 400),              #   two broadcast samples: the even ring's half-way offset
+    (21, (0.0, 0.5), 24, 3000, 700),              #   five (odd ring), several chunks per cell
+    (24, (0.0, 0.5), 24, 3000, 400),              #   eight: the last shape of demux_rowx.hip
     (32, (0.0, 0.5), 24, 4000, 700),              #   every lane with two live samples, several chunks per cell
     (25, (0.2, 0.5), 24, 3000, 300),              #   singlet slot at a non-zero alpha
     (24, GRID6, 24, 4000, 500),                   #   five doublet alphas: a launch of 2 + 2 and one of 1 + 0
@@ -109,7 +113,7 @@ def test_deep_pileups_per_entry(eng, V):
     parity.compare_demux(got2, ob.demux(p, alphas=(0.0, 0.5), nthreads=4), (0.0, 0.5))
 
 
-@pytest.mark.parametrize("V", [8, 16, 17, 27, 32, 48])
+@pytest.mark.parametrize("V", [8, 16, 17, 19, 22, 24, 27, 32, 48])
 def test_records_do_not_depend_on_the_tensor_request(eng, V):
     """the quad and two-per-lane row paths make the call in LDS when the LL tensor is not asked for: same records,
     bit for bit, as the reduce + call kernels behind the tensor"""
