@@ -20,7 +20,9 @@ GRID6 = (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)
 @pytest.fixture(scope="module", params=["default", "row", "wave", "tile"])
 def eng(request):
     """all sweep implementations: 'default' = normal dispatch (quad kernel for V <= 16 with the grid {0,0.5}, row kernel
-    for other grids at V <= 16, tile sweep above), 'row' = quad kernel disabled, 'tile' = the general tile sweep forced"""
+    for other grids at V <= 16; default grid beyond: row kernel + broadcast extras up to 24 samples, two samples per
+    lane up to 32; wave kernels otherwise), 'row' = quad and broadcast-extras kernels disabled, 'wave' = the wave
+    kernels for every shape they take, 'tile' = the general tile sweep forced"""
     flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "wave": muxgl.FLAG_FORCE_WAVE_KERNEL,
              "tile": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
     e = muxgl.Engine(0, flags)
