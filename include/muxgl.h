@@ -42,7 +42,8 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 
 /* muxgl_config.flags */
 #define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row/quad kernels (lets tests cover the general tile sweep) */
-#define MUXGL_FLAG_FORCE_ROW_KERNEL 2  /* never take the default-grid quad kernel (lets tests cover the row kernel) */
+#define MUXGL_FLAG_FORCE_ROW_KERNEL 2  /* never take the default-grid quad kernel nor, at 17..24 samples / clusters, the
+                                          broadcast-extras kernels (lets tests cover the row kernels behind them) */
 #define MUXGL_FLAG_FORCE_WAVE_KERNEL 4 /* take the wave kernels for V <= 16 too, and the rings of 32 instead of the
                                           two-per-lane row kernels at 17..32 samples / clusters (test coverage) */
 #define MUXGL_FLAG_FORCE_BATCHED_GREEDY 8 /* batched greedy-init kernels for every K <= 64, not only K > 24 (test coverage) */

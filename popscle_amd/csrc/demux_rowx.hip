@@ -29,38 +29,9 @@ struct rowx_alpha {
   double a[2];  // {0, 0.5}
 };
 
-constexpr int RX_MAX_NB = 8;
+constexpr int RX_MAX_NB = ROWX_MAX_NB;  // accumulator layout: row2.hpp
 constexpr int RX_PGS = 8;                        // doubles per entry in LDS: q0[l] (alpha 0), q1[l+m] (alpha 0.5)
 constexpr int RX_SLOT_STRIDE = 16 * RX_PGS + 4;  // +4 doubles: the 4 slots' broadcast reads fall on distinct banks
-
-// accumulators of lane j: 0 singlet j; t = 1..8: (j, kmap[t][j]); 9 + m: (j, 16 + m), m < NB; and for lanes j < NB:
-// 9 + NB: singlet 16 + j; 9 + NB + d: (16 + j, 16 + (j + d) mod NB), d = 1 .. NB/2
-__host__ __device__ constexpr int rowx_nacc(int NB) { return 10 + NB + NB / 2; }
-
-// the hypothesis (x, y) accumulator `a` of lane j stands for (singlets: y = -1); false where nobody or another lane
-// is the writer
-__device__ __forceinline__ bool rowx_pair_of(int a, int j, int NB, const int32_t* __restrict__ kmap, int& x, int& y) {
-  if (a == 0) {
-    x = j, y = -1;
-  } else if (a <= 8) {
-    const int ka = kmap[a * 16 + j];
-    if (a == 8 && j < ka) return false;  // rotation 8 visits every unordered pair of lanes twice
-    x = j, y = ka;
-  } else if (a < 9 + NB) {
-    x = j, y = 16 + (a - 9);
-  } else {
-    if (j >= NB) return false;
-    const int d = a - (9 + NB);
-    if (d == 0) {
-      x = 16 + j, y = -1;
-    } else {
-      const int pm = (j + d) % NB;
-      if (2 * d == NB && j > pm) return false;  // the half-way offset of an even ring: visited from both ends
-      x = 16 + j, y = 16 + pm;
-    }
-  }
-  return true;
-}
 
 template <int NB>
 __global__ void __launch_bounds__(64, 2)

@@ -833,6 +833,7 @@ static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   muxgl_row_state* st = h->frow ? h->frow : h->row;
   int qrc = -1;
   if (nc > 0) qrc = fmx_quad_estep_launch(h, h->fqrow ? h->fqrow : h->qrow, c0, nc);  // K <= 16: quad tiling
+  if (nc > 0 && qrc < 0) qrc = fmx_rowx_estep_launch(h, st, c0, nc);  // 16 < K <= 24: row kernel + broadcast extras
   if (nc > 0 && qrc < 0) qrc = fmx_row2_estep_launch(h, st, c0, nc);  // 16 < K <= 32: two clusters per lane
   if (nc > 0 && qrc < 0) qrc = fmx_wave_estep_launch(h, c0, nc);  // 32 < K: one wave per cell (part) and block
   if (qrc > 0) return 1;

@@ -148,7 +148,11 @@ FMX_INT_FIELDS = ("type", "clust", "jBest", "kBest", "jNext", "kNext", "sBest", 
                   "dNext2")
 
 
-def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7):
+def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7, want_full=None):
+    """want_full: the oracle's packed LL triangle [C][K(K+1)/2] (optional).  With it, a different runner-up doublet is
+    accepted where the pair the GPU names is tied with the oracle's runner-up IN THE ORACLE'S OWN NUMBERS (clusters
+    without cells have identical posteriors, so their pairs tie exactly in the reference, which then keeps the first
+    in scan order; the kernels evaluate the two tied pairs in different associations)."""
     assert got.shape == want.shape
     worst = 0.0
     for f in FMX_LL_FIELDS:
@@ -161,7 +165,15 @@ def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7):
         assert ok.all(), f"{f}: {int((~ok).sum())} cells beyond {tol}"
     tie = (np.abs(want["sngBestLLK"] - want["sngNextLLK"]) < tie_eps) | \
           (np.abs(want["dblBestLLK"] - want["dblNextLLK"]) < tie_eps)
+    next_tie = np.zeros(got.shape, dtype=bool)
+    if want_full is not None:
+        hi = np.maximum(got["dNext1"], got["dNext2"]).astype(np.int64)
+        lo = np.minimum(got["dNext1"], got["dNext2"]).astype(np.int64)
+        ok_idx = (lo >= 0) & (hi * (hi + 1) // 2 + lo < want_full.shape[1])
+        named = want_full[np.arange(got.size), np.where(ok_idx, hi * (hi + 1) // 2 + lo, 0)]
+        next_tie = ok_idx & (np.abs(named - want["dblNextLLK"]) < tie_eps)
     for f in FMX_INT_FIELDS:
-        bad = (got[f] != want[f]) & ~tie
+        excused = tie | (next_tie if f in ("dNext1", "dNext2") else False)
+        bad = (got[f] != want[f]) & ~excused
         assert not bad.any(), f"{f} differs in {int(bad.sum())} cells"
     return {"cells": int(got.size), "max_abs_ll_diff": worst, "ties": int(tie.sum())}

@@ -19,9 +19,10 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.fixture(scope="module", params=["default", "row", "wave", "pair"])
 def eng(request):
-    """'default' = normal dispatch (quad E-step for K <= 16, two clusters per lane up to 32, wave kernels above), 'row' =
-    quad disabled (row E-step), 'wave' = the ring-of-32 wave E-step for 16 < K <= 32, 'pair' = the general pair kernel
-    and the (SNP, cluster)-parallel M-step forced for every K"""
+    """'default' = normal dispatch (quad E-step for K <= 16, row E-step + broadcast clusters up to 24, two clusters per
+    lane up to 32, wave kernels above), 'row' = quad and broadcast kernels disabled (row E-step, two clusters per lane),
+    'wave' = the ring-of-32 wave E-step for 16 < K <= 32, 'pair' = the general pair kernel and the (SNP, cluster)-
+    parallel M-step forced for every K"""
     flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "wave": muxgl.FLAG_FORCE_WAVE_KERNEL,
              "pair": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
     e = muxgl.Engine(0, flags)
@@ -72,7 +73,7 @@ def run_em(eng, p, K, n_iter, clust=None, doublet_prior=0.5, geno_error=0.1):
         gcells, gstats, gfull = eng.fmx_iterate(doublet_prior, geno_error, want_full_ll=True)
         d = np.abs(gfull - ostats[3])
         assert np.max(d[np.isfinite(d)], initial=0.0) < 1e-7, f"iteration {it}: E-step LL tensor off by {d.max()}"
-        rep = parity.compare_fmx(gcells, cells)
+        rep = parity.compare_fmx(gcells, cells, want_full=ostats[3])
         worst = max(worst, rep["max_abs_ll_diff"])
         assert tuple(gstats) == tuple(ostats[:3]), f"iteration {it}: (nsingle, namb, nchanged) {gstats} vs {ostats[:3]}"
         g, c = eng.fmx_cluster_pileup()
@@ -109,8 +110,12 @@ def test_golden(eng):
     (4, 200, 2000, 250, 4),
     (16, 300, 3000, 400, 3),
     (5, 120, 1000, 200, 3),
-    (17, 60, 2000, 300, 2),    # 16 < K <= 32: two clusters per lane ('wave': ring of 32, 'pair': pair kernel)
+    (17, 60, 2000, 300, 2),    # 16 < K <= 24: row E-step + broadcast clusters ('row': two clusters per lane, 'wave':
+    (18, 40, 2000, 300, 2),    #   ring of 32, 'pair': pair kernel); even / odd rings among the extra clusters
     (20, 100, 2500, 400, 2),
+    (21, 40, 2500, 700, 2),
+    (24, 40, 2500, 400, 2),    #   the last shape of fmx_rowx.hip
+    (27, 40, 2500, 400, 2),    # 24 < K <= 32: two clusters per lane
     (32, 50, 3000, 2600, 2),   #   full ring, cells in several parts
     (64, 40, 4000, 500, 2),    # config-5 shape, few cells
     (70, 24, 5000, 1200, 2),   # K > 64: the general pair E-step and the (SNP, cluster)-parallel M-step; deep cells
