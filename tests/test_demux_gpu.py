@@ -99,7 +99,7 @@ def test_long_alpha_grids(eng, V, nalpha, C, S, ment):
     assert rep["max_abs_ll_diff"] < 1e-7 and parity.compare_full_ll(gfull, wfull, V, alphas) < 1e-7
 
 
-@pytest.mark.parametrize("V", [4, 16, 40])
+@pytest.mark.parametrize("V", [4, 16, 20, 28, 40])
 def test_deep_pileups_per_entry(eng, V):
     """entries with tens to hundreds of reads (bulk-like coverage): the per-read update with its lazy renormalisation,
     reads beyond the four a packed entry record carries, base qualities over the whole 7-bit range"""
