@@ -1,23 +1,43 @@
 #!/usr/bin/env python
-"""Benchmark of the demuxlet hot path on MI355X -- BASELINE.json's metric on BASELINE.json's configs[1].
+"""Benchmark of the demuxlet / freemuxlet hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 1 --steps 2000 --warmup 200              # BASELINE.json's metric on configs[1] (headline)
+    python bench.py --config 2 --steps 3 --warmup 1                 # demuxlet 100k x 64 x 200k, six alphas
+    python bench.py --config 3 --steps 20 --warmup 2                # freemuxlet K=16, 50k x 100k, 20 EM iterations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config I]
 
-A "step" is one full pass of the hot path (entry likelihoods + sample-pair sweep + evidence/scan/call + per-cell records
-to the host) over one batch: the whole synthetic pileup of the workload, already resident in HBM.  One process per
-GPU; every rank owns its own 10k-cell shard (weak scaling; demuxlet's cells are independent, so there is no data-path
-collective -- torch.distributed/RCCL only provides the barrier and the max-over-ranks of the elapsed time).
+One process per GPU.
+  * demuxlet (configs 1, 2): a "step" is one full pass of the hot path (entry likelihoods + sample-pair sweep +
+    evidence/scan/call + per-cell records to the host) over the whole synthetic pileup of the workload, resident in HBM.
+    Every rank owns its own config-sized shard of cells (WEAK scaling; demuxlet's cells are independent, so there is no
+    data-path collective -- torch.distributed/RCCL only provides the barrier and the max-over-ranks of the elapsed time).
+  * freemuxlet (configs 3, 4): a "step" is one EM iteration (cluster posteriors, E-step, scans, re-assignment, ordered
+    M-step and the two all-gathers + one all-reduce between them) of the fixed job (STRONG scaling): the E-step is
+    sharded by cells, the ordered M-step by SNPs, each rank holding 2/N of the pileup (popscle_amd/freemuxlet.py).
+  * The default run (config 1) also times the freemuxlet EM of configs[3] on the same ranks and reports it as
+    "freemuxlet_em" inside the same JSON line, so that a scaling run of the default command exercises the one path
+    that has a collective (--no-fmx-leg skips it).
 
-Prints ONE JSON line (rank 0).  LL = one hypothesis log-likelihood feeding a call: per cell V singlets +
-V(V-1)(A-1) ordered doublets.
+Prints ONE JSON line (rank 0).  LL = one hypothesis log-likelihood feeding a call: demuxlet V singlets +
+V(V-1)(A-1) ordered doublets per cell, freemuxlet K(K+1)/2 per cell and iteration.
+
+Roofline ("the binding fraction is the max of the two"): two roofs are priced for the dominant kernel,
+    hbm   bytes that actually crossed the L2<->fabric boundary (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, own passes,
+          profiles/traffic.json, quoted only when it was measured on these very sources) / time / 8.0 TB/s -- next to
+          the ALGORITHMIC bytes of SURVEY 8d (a gather of cache-resident GP rows: an equivalent rate, not a bandwidth);
+    fp64  FP64 operations actually ISSUED (PMC: 64 x (2 FMA + MUL + ADD) wave instructions; a model of the same when no
+          fresh counters exist) / time / 78.6 TFLOP/s -- next to the reference's operation count (which the kernels
+          undercut by evaluating only the hypotheses the reference reads, mirrored alpha = 0.5 pairs once);
+and "bound" names the larger fraction.
 """
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
+import signal
 import sys
 import time
 
@@ -26,24 +46,49 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from popscle_amd import muxgl, synth  # noqa: E402
+from popscle_amd import freemuxlet, muxgl, shard, synth  # noqa: E402
+from popscle_amd.build import source_hash  # noqa: E402
 
 METRIC = "cell-sample-pair LLs/sec (singlet+doublet), demuxlet 10k cells×16 samples"
+FMX_METRIC = "freemuxlet EM cell-cluster-pair LLs/sec"
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # vector FP64 = half the 157.3 TF FP32 vector rate (same guide); FP64 MFMA runs at the same rate
+SIMDS, PEAK_CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 4.0  # 256 CUs x 4 SIMDs; one wave64 VALU instruction = 4 issue cycles
 
 
-def algorithmic_bytes_per_entry(V: int, reads_per_entry: float) -> float:
-    """12 B (SNP id + read offset) + reads + 24*V (GP row gather)"""
-    return 12.0 + reads_per_entry + 24.0 * V
+# ---- per-entry work, SURVEY.md 8d -------------------------------------------------------------------------------------
+def demux_bytes_per_entry(V, rpe):
+    return 12.0 + rpe + 24.0 * V  # SNP id + read offset, reads, GP row gather
 
 
-def algorithmic_flops_per_entry(V: int, A: int, reads_per_entry: float) -> float:
-    """A*(18V + 7V^2) + reads*A*27"""
-    return A * (18.0 * V + 7.0 * V * V) + reads_per_entry * A * 27.0
+def demux_flops_per_entry(V, A, rpe):
+    return A * (18.0 * V + 7.0 * V * V) + rpe * A * 27.0  # the reference's own operation count
 
 
-def sweep_kernel_name(V, alphas):
+def demux_issued_flops_model(V, alphas, rpe):
+    """FP64 operations the kernels issue per entry (model, used when no fresh PMC pass exists): a hypothesis costs a
+    3-term dot product (MUL + 2 FMA = 5) and one multiply into its product accumulator; the u-factors 3 dots per sample
+    and alpha; singlets a dot, the sample-0 factor and the accumulate; alpha = 0.5 pairs are evaluated once (k < j)."""
+    nsym = sum(1 for a in alphas[1:] if a == 0.5)
+    nns = len(alphas) - 1 - nsym
+    pairs = V * (V - 1)
+    hyp = nsym * pairs / 2 + nns * pairs
+    return hyp * 6.0 + (nsym + nns) * V * 15.0 + V * 7.0 + rpe * len(alphas) * 27.0
+
+
+def fmx_bytes_per_entry(K):
+    return 76.0 + 24.0 * K  # SNP id + 9 entry likelihoods, cluster-GP row gather
+
+
+def fmx_flops_per_entry(K):
+    return 33.0 * K + 3.5 * K * (K + 1)
+
+
+def fmx_issued_flops_model(K):
+    return K * (K + 1) / 2 * 6.0 + K * 15.0
+
+
+def demux_sweep_kernel(V, alphas):
     """the kernel libmuxgl dispatches for this shape (popscle_amd/csrc/demux_kernels.hip: demux_launch)"""
     if V <= 16 and tuple(alphas) == (0.0, 0.5):
         return "demux_quad_kernel"
@@ -60,165 +105,402 @@ def sweep_kernel_name(V, alphas):
     return "demux_sweep_kernel"
 
 
-def cpu_baseline(p, alphas, gpu_cells, budget_s=15.0):
-    """The CPU oracle (the restatement of the reference's loop, kind "port") timed on this host's cores on a bounded
-    sample of the same workload.  Also used as a last parity check of the GPU records for the sampled cells."""
+def fmx_estep_kernel(K):
+    if K <= 16:
+        return "fmx_estep_quad_kernel"
+    if K <= 24:
+        return "fmx_estep_rowx_kernel"
+    if K <= 32:
+        return "fmx_estep_row2_kernel"
+    return "fmx_estep_wave_kernel"
+
+
+def pmc_record(config):
+    """counters of the dominant kernel for this config from profiles/traffic.json -- only if they were measured on the
+    sources this run is built from (the file carries their fingerprint)"""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        d = json.load(open(tfile))
+    except Exception:
+        return None, "no profiles/traffic.json"
+    if d.get("source_hash") != source_hash():
+        return None, f"profiles/traffic.json is stale (measured on sources {d.get('source_hash')}, git {d.get('git_head')})"
+    return d.get(f"config{config}"), d.get("measured_with", "")
+
+
+def roofline(kernel, kern_s, abytes, ref_flops, issued_model_flops, config, scale=1.0):
+    """the two roofs of the dominant kernel; `scale` = this run's units / the units of the PMC pass (a reduced run)"""
+    rec, note = pmc_record(config)
+    if rec and rec.get("units") and scale:
+        k = scale / rec["units"]  # counters are per launch over rec["units"] entries
+    else:
+        k = None
+    traffic = rec["hbm_bytes_per_launch"] * k if rec and k and rec.get("hbm_bytes_per_launch") else None
+    issued, src = issued_model_flops, "model (popscle_amd per-hypothesis instruction count)"
+    valu = None
+    if rec and k and rec.get("fma_f64") is not None:
+        issued = 64.0 * (2.0 * rec["fma_f64"] + rec.get("mul_f64", 0.0) + rec.get("add_f64", 0.0)) * k
+        src = "pmc (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64, " + str(note) + ")"
+        valu = rec.get("valu", 0.0) * k or None
+    t = max(kern_s, 1e-12)
+    hbm = {"algorithmic_bytes": abytes, "algorithmic_equiv_GBps": abytes / t / 1e9,
+           "traffic_bytes": traffic, "traffic_over_algorithmic": (traffic / abytes) if traffic else None,
+           "achieved": (traffic / t / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": (traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "note": "traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch" if traffic else f"no counter traffic: {note}"}
+    fp = {"issued_flops": issued, "source": src, "achieved": issued / t / 1e12, "peak": FP64_PEAK_TFLOPS,
+          "unit": "TFLOP/s", "frac": issued / t / 1e12 / FP64_PEAK_TFLOPS, "reference_flops": ref_flops,
+          "reference_equiv_TFLOPs": ref_flops / t / 1e12, "issued_over_reference": issued / ref_flops if ref_flops else None,
+          "valu_issue_frac": (valu * VALU_CYCLES / (SIMDS * PEAK_CLOCK_HZ * t)) if valu else None}
+    bound = "hbm" if (hbm["frac"] or 0.0) > fp["frac"] else "fp64_valu"
+    top = hbm if bound == "hbm" else fp
+    return {"bound": bound, "kernel": kernel, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+            "frac": top["frac"], "traffic": traffic, "kernel_ms": kern_s * 1e3, "hbm": hbm, "fp64": fp}
+
+
+# ---- CPU baselines: the oracle (restatement of the reference's loops, kind "port") on this host's cores ---------------
+def _demux_shard_job(job):
+    p, alphas = job
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    t0 = time.perf_counter()
+    ob.demux(p, alphas=alphas, nthreads=1)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_demux(p, alphas, gpu_cells, budget_s=9.0):
+    """(i) ONE thread -- the reference's execution model (it has no threads) -- and (ii) N independent
+    single-threaded processes over N cell shards, the reference's documented way to use more cores (--group-list,
+    README.md:168), N = physical cores.  Bounded samples of the same workload; the sampled cells double as a last parity
+    check of the GPU records."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multiprocessing as mp
+
     import oracle_binding as ob
     import parity
 
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    V = p.gp.shape[1]
+    V, A = p.gp.shape[1], len(alphas)
+    lls_per_cell = V + V * (V - 1) * (A - 1)
     rng = np.random.default_rng(0)
-    probe = np.sort(rng.choice(p.C, min(p.C, 2 * threads), replace=False))
-    sub = p.subset_cells(probe)
+    probe = p.subset_cells(np.sort(rng.choice(p.C, min(p.C, 8), replace=False)))
     t0 = time.perf_counter()
-    ob.demux(sub, alphas=alphas, nthreads=threads)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(p.C, max(len(probe), budget_s / dt * len(probe))))
-    pick = np.sort(rng.choice(p.C, n, replace=False))
+    ob.demux(probe, alphas=alphas, nthreads=1)
+    per_cell = max(time.perf_counter() - t0, 1e-6) / probe.C
+    # (i) one thread
+    n1 = int(min(p.C, max(8, budget_s / per_cell)))
+    pick = np.sort(rng.choice(p.C, n1, replace=False))
     sub = p.subset_cells(pick)
     t0 = time.perf_counter()
-    want = ob.demux(sub, alphas=alphas, nthreads=threads)
-    dt = time.perf_counter() - t0
-    lls = n * (V + V * (V - 1) * (len(alphas) - 1))
+    want = ob.demux(sub, alphas=alphas, nthreads=1)
+    dt1 = time.perf_counter() - t0
     rep = parity.compare_demux(gpu_cells[pick], want, alphas)
+    single = {"value": n1 * lls_per_cell / dt1, "unit": "LLs/s", "cores": 1, "entries_per_s": sub.nnz / dt1,
+              "sample": f"{n1} of {p.C} cells ({int(sub.nnz)} entries), one thread, {dt1:.1f} s"}
+    # (ii) N processes, one cell shard each
+    try:
+        import psutil
+
+        ncores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        ncores = os.cpu_count() or 1
+    ncores = int(min(ncores, 256))
+    nn = int(min(p.C, max(ncores, ncores * budget_s / per_cell)))
+    pickn = np.sort(rng.choice(p.C, nn, replace=False))
+    shards = [p.subset_cells(pickn[i::ncores]) for i in range(ncores) if len(pickn[i::ncores])]
+    ents = int(sum(s.nnz for s in shards))
+    with mp.get_context("fork").Pool(len(shards)) as pool:
+        t0 = time.perf_counter()
+        pool.map(_demux_shard_job, [(s, alphas) for s in shards])
+        dtn = time.perf_counter() - t0
     return {
-        "value": lls / dt, "unit": "LLs/s", "cores": threads, "kind": "port",
-        "sample": f"{n} of {p.C} cells of the same workload ({int(sub.nnz)} entries), oracle/muxgl_oracle.c with "
-                  f"{threads} OpenMP threads over cells, {dt:.1f} s",
-        "entries_per_s": sub.nnz / dt,
+        "value": nn * lls_per_cell / dtn, "unit": "LLs/s", "cores": len(shards), "kind": "port",
+        "sample": f"{nn} of {p.C} cells of the same workload ({ents} entries) as {len(shards)} independent single-threaded "
+                  f"processes over cell shards (oracle/muxgl_oracle.c; the reference's --group-list parallelisation), "
+                  f"{dtn:.1f} s",
+        "entries_per_s": ents / dtn, "single_thread": single,
+        "note": "LLs/s per core depends on entries per cell (LLs per cell are fixed, work is per entry): this workload "
+                "has ~950 entries per cell, BASELINE.md's reference timing (36.6 k LLs/s, 71 k entries/s per core) had 500",
         "parity_checked_cells": rep["cells"], "parity_max_abs_ll_diff": rep["max_abs_ll_diff"],
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--ramp-seconds", type=float, default=1.0,
-                    help="untimed passes before the W warmup steps, until the engine clock has ramped up (a 0.6 ms step "
-                         "repeated 20 times runs ~10 %% below the sustained clock)")
-    ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs (1 or 2)")
-    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the config's cells (debug only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="functional test of the N>1 path on a 1-GPU box: every rank uses device 0 (use with gloo)")
-    args = ap.parse_args()
+def cpu_baseline_fmx(p, K, clust0, budget_s=10.0):
+    """One EM iteration of the CPU oracle (restatement of cmd_cram_freemux2.cpp:375-597, kind "port") on a bounded sample of
+    the cells, single-threaded: the reference's freemuxlet has no process-level parallelism either (global EM state)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
 
-    import torch
-    import torch.distributed as dist
+    def run(n):
+        cells = np.sort(np.random.default_rng(1).choice(p.C, n, replace=False))
+        sub = p.subset_cells(cells)
+        e = ob.fmx_entry_pileup(sub)
+        c0 = np.ascontiguousarray(clust0[cells])
+        cplp = ob.fmx_build_cluster_pileup(sub, e, K, c0)
+        st = ob.fmx_init_cells(c0)
+        t0 = time.perf_counter()
+        ob.fmx_iterate(sub, e, K, cplp, st, 0.5, 0.1, nthreads=1)
+        return time.perf_counter() - t0, sub.nnz
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+    n = min(p.C, 50)
+    dt, _ = run(n)
+    n = int(min(p.C, max(n, budget_s / max(dt, 1e-6) * n)))
+    dt, nnz = run(n)
+    npairs = K * (K + 1) // 2
+    return {"value": n * npairs / dt, "unit": "LLs/s", "cores": 1, "kind": "port",
+            "sample": f"one EM iteration over {n} of {p.C} cells ({nnz} entries), oracle/muxgl_oracle.c on one core "
+                      f"(the reference is single-threaded), {dt:.1f} s", "entries_per_s": nnz / dt}
+
+
+# ---- distributed context --------------------------------------------------------------------------------------------
+class Ctx:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dev = 0 if args.single_device else local_rank
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(args.dist_backend)
-    tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        self.dev = 0 if args.single_device else local_rank
+        torch.cuda.set_device(self.dev)
+        self.backend = args.dist_backend
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            to = datetime.timedelta(seconds=600)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev), timeout=to)
+            else:
+                dist.init_process_group(self.backend, timeout=to)
+        self.tdev = "cuda" if self.backend == "nccl" else "cpu"
 
-    cfg = synth.CONFIGS[args.config]
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, xs):
+        if self.world == 1:
+            return [float(x) for x in xs]
+        t = self.torch.tensor([float(x) for x in xs], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+
+# ---- demuxlet leg (configs 1, 2): weak scaling -----------------------------------------------------------------------
+def demux_leg(args, ctx, config):
+    cfg = synth.CONFIGS[config]
     alphas = tuple(cfg["alphas"])
     V, A = cfg["V"], len(alphas)
     # weak scaling: every rank owns a full config-sized shard of cells (its own seed), GP tensor replicated
     C = max(1, int(round(cfg["C"] * args.scale)))
-    p = synth.make_pileup(C, cfg["S"], V, seed=synth.BASE_SEED + args.config + 1000 * rank,
-                          donor_seed=synth.BASE_SEED + args.config)
-
-    eng = muxgl.Engine(dev)
+    p = synth.make_pileup(C, cfg["S"], V, seed=synth.BASE_SEED + config + 1000 * ctx.rank,
+                          donor_seed=synth.BASE_SEED + config)
+    eng = muxgl.Engine(ctx.dev)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.demux_set_gp(p.gp, p.has_gp)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < args.ramp_seconds:
         eng.demux_run(alphas, 0.5, want_cells=False)
     for _ in range(args.warmup):
         eng.demux_run(alphas, 0.5, want_cells=False)
-    barrier()
+    ctx.barrier()
     kern_ms = np.zeros(muxgl.T_COUNT)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.demux_run(alphas, 0.5, want_cells=False)
         kern_ms += eng.timing()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(p.C), float(p.nnz)], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_cells, total_entries = float(tot[0].item()), float(tot[1].item())
-    else:
-        total_cells, total_entries = float(p.C), float(p.nnz)
-
-    if rank == 0:
+    ctx.barrier()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    total_cells, total_entries = ctx.sum_over_ranks([p.C, p.nnz])
+    out = None
+    if ctx.rank == 0:
         lls_per_cell = V + V * (V - 1) * (A - 1)
         step_s = elapsed / args.steps
-        value = total_cells * lls_per_cell / step_s
         kern_ms /= args.steps
         rpe = p.R / max(p.nnz, 1)
         sweep_s = kern_ms[muxgl.T_DEMUX_SWEEP] * 1e-3
-        abytes = algorithmic_bytes_per_entry(V, rpe) * p.nnz
-        aflops = algorithmic_flops_per_entry(V, A, rpe) * p.nnz
-        achieved = abytes / sweep_s / 1e9 if sweep_s > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(f"config{args.config}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
-            "metric": METRIC, "value": value, "unit": "LLs/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC if config == 1 else f"cell-sample-pair LLs/sec (singlet+doublet), demuxlet BASELINE.json configs[{config}]",
+            "value": total_cells * lls_per_cell / step_s, "unit": "LLs/s", "n_gpus": ctx.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"demuxlet synthetic PLP (BASELINE.json configs[{args.config}]): {C} cells x {V} samples x "
+                "workload": f"demuxlet synthetic PLP (BASELINE.json configs[{config}]): {C} cells x {V} samples x "
                             f"{cfg['S']} SNPs per GPU, alpha grid {list(alphas)}, {p.nnz} entries, {p.R} reads",
                 "cells_per_gpu": C, "samples": V, "snps": cfg["S"], "alphas": list(alphas),
-                "entries_per_gpu": int(p.nnz), "lls_per_cell": lls_per_cell, "parallelism": f"cells sharded x{world}",
+                "entries_per_gpu": int(p.nnz), "lls_per_cell": lls_per_cell, "parallelism": f"cells sharded x{ctx.world}",
             },
-            "entries_per_s": total_entries / step_s,
-            "cells_per_s": total_cells / step_s,
+            "entries_per_s": total_entries / step_s, "cells_per_s": total_cells / step_s,
             # quad path: "reduce" is the fused finish kernel (chunk reduction + call + records written to pinned host
             # memory), "call" and "d2h" are then 0; other paths run them as separate launches
             "kernel_ms": {"sweep": float(kern_ms[muxgl.T_DEMUX_SWEEP]), "reduce": float(kern_ms[muxgl.T_DEMUX_REDUCE]),
-                          "call": float(kern_ms[muxgl.T_DEMUX_CALL]),
-                          "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},
-            "roofline": {
-                "bound": "hbm", "kernel": sweep_kernel_name(V, alphas), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": abytes,
-                "fp64_valu": {"achieved": aflops / sweep_s / 1e12 if sweep_s > 0 else 0.0, "peak": FP64_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": (aflops / sweep_s / 1e12 / FP64_PEAK_TFLOPS) if sweep_s > 0 else 0.0},
-            },
+                          "call": float(kern_ms[muxgl.T_DEMUX_CALL]), "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},
+            "roofline": roofline(demux_sweep_kernel(V, alphas), sweep_s, demux_bytes_per_entry(V, rpe) * p.nnz,
+                                 demux_flops_per_entry(V, A, rpe) * p.nnz,
+                                 demux_issued_flops_model(V, alphas, rpe) * p.nnz, config, scale=float(p.nnz)),
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(p, alphas, eng.demux_results_view().copy())
-        elif world > 1:
+        if not args.no_cpu_baseline and ctx.world == 1:
+            out["cpu_baseline"] = cpu_baseline_demux(p, alphas, eng.demux_results_view().copy())
+        else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
+
+
+# ---- freemuxlet leg (configs 3, 4): strong scaling -------------------------------------------------------------------
+def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
+    torch, dist = ctx.torch, ctx.dist
+    cfg = synth.CONFIGS[config]
+    C = args.cells or max(1, int(round(cfg["C"] * args.scale)))
+    S = args.snps or cfg["S"]
+    K = args.clusters or cfg["V"]
+    # the same job on every rank (same seed): strong scaling
+    p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + config, with_gp=False, mean_entries=args.mean_entries,
+                          min_entries=min(50, max(1, int(args.mean_entries // 4))))
+    ordered = ctx.world > 1 and ctx.backend == "nccl"
+    eng = muxgl.Engine(ctx.dev, muxgl.FLAG_ASYNC_PHASES if ordered else 0)
+    (c_ranges, per_c), (s_ranges, per_s) = freemuxlet.plan_ranges(C, S, ctx.world)
+    t0 = time.perf_counter()
+    if ctx.world > 1:
+        freemuxlet.load_rank(eng, p, c_ranges[ctx.rank], s_ranges[ctx.rank])
+    else:
+        eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        eng.fmx_prepare(p.af)
+    handover_s = time.perf_counter() - t0
+    # a seeded start (--init-cluster style): 90 % of the cells start in their source sample's cluster
+    clust0 = np.where(np.random.default_rng(0).random(C) < 0.9, p.truth["s1"], -1).astype(np.int32)
+    ex = freemuxlet.TorchExchange(dist, ctx.rank, ctx.world, device_ordered=ordered) if ctx.world > 1 else None
+    stream_ctx = None
+    if ordered:
+        ext = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", ctx.dev))
+        stream_ctx = lambda: torch.cuda.stream(ext)  # noqa: E731
+
+    def run(n, timings=None):
+        return freemuxlet.run_em(eng, K, clust0, max_iter=n, early_stop=False, exchange=ex,
+                                 exchange_tensor=lambda e, w: freemuxlet.engine_exchange_tensor(e, w, ctx.dev),
+                                 per=(per_c, per_s), timings=timings, sync=ctx.barrier, stream_ctx=stream_ctx)
+
+    if warmup:
+        run(warmup)
+    tm = {}
+    cells, hist = run(steps, tm)  # exactly `steps` EM iterations, bracketed by barrier + device synchronize on both sides
+    kern = eng.timing()           # kernels of the last iteration on this rank
+    elapsed = ctx.max_over_ranks(tm["loop_s"])
+    out = None
+    if ctx.rank == 0:
+        npairs = K * (K + 1) // 2
+        est_s = float(kern[muxgl.T_FMX_ESTEP]) * 1e-3
+        my_entries = float(p.cell_ptr[c_ranges[0][1]] - p.cell_ptr[c_ranges[0][0]])
+        out = {
+            "metric": FMX_METRIC, "value": C * npairs * steps / elapsed, "unit": "LLs/s", "n_gpus": ctx.world,
+            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"freemuxlet EM (BASELINE.json configs[{config}]): {C} cells x {S} SNPs, K = {K}, "
+                                   f"{p.nnz} entries, {steps} EM iterations (cluster posteriors, E-step, scans, "
+                                   f"re-assignment, ordered M-step, exchanges)",
+                       "cells": C, "snps": S, "clusters": K, "entries": int(p.nnz),
+                       "parallelism": f"E-step by cells x{ctx.world}, ordered M-step by SNPs x{ctx.world}, "
+                                      f"2 all-gathers + 1 all-reduce per iteration" if ctx.world > 1 else "one GPU",
+                       "backend": ctx.backend if ctx.world > 1 else None},
+            "entries_per_s": p.nnz * steps / elapsed,
+            "handover_ms": handover_s * 1e3,  # H2D of this rank's slabs + derived tables + entry likelihoods
+            "setup_ms": tm["setup_s"] * 1e3,  # initial cluster pileups (muxgl_fmx_set_clusters)
+            "kernel_ms_rank0_last_iteration": {"gp": float(kern[muxgl.T_FMX_GP]), "estep": float(kern[muxgl.T_FMX_ESTEP]),
+                                               "call": float(kern[muxgl.T_FMX_CALL]), "mstep": float(kern[muxgl.T_FMX_MSTEP])},
+            "last_iteration": {"nsingle": hist[-1][0], "namb": hist[-1][1], "nchanged": hist[-1][2]},
+            "roofline": roofline(fmx_estep_kernel(K), est_s, fmx_bytes_per_entry(K) * my_entries,
+                                 fmx_flops_per_entry(K) * my_entries, fmx_issued_flops_model(K) * my_entries, config,
+                                 scale=my_entries),
+        }
+        if cpu_baseline and ctx.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_fmx(p, K, clust0)
+        else:
+            out["cpu_baseline"] = None
+        if args.dump:
+            np.savez(args.dump, cells=cells, hist=np.array(hist, dtype=np.int64))
+    eng.close()
+    return out
+
+
+def guarded_fmx_leg(args, ctx, headline):
+    """The secondary freemuxlet leg of the default run must never cost the headline line: a watchdog prints the line
+    without it (rank 0) and ends every rank cleanly if the leg hangs (a collective waiting for a rank that failed)."""
+    def give_up(signum=None, frame=None, why="timeout"):
+        if ctx.rank == 0:
+            headline["freemuxlet_em"] = {"error": f"freemuxlet leg did not finish: {why}"}
+            print(json.dumps(headline), flush=True)
+        os._exit(0)
+
+    signal.signal(signal.SIGALRM, give_up)
+    signal.alarm(int(args.fmx_leg_timeout))
+    try:
+        leg = fmx_leg(args, ctx, 3, args.fmx_leg_steps, 2, cpu_baseline=False)
+        signal.alarm(0)
+        return leg
+    except BaseException as ex:  # noqa: BLE001 -- includes a failed collective on this rank
+        sys.stderr.write(f"[bench rank {ctx.rank}] freemuxlet leg failed: {ex!r}\n")
+        if ctx.world == 1:
+            signal.alarm(0)
+            return {"error": repr(ex)}
+        while True:  # the other ranks may be waiting for us in a collective: leave together, when the alarm fires
+            time.sleep(1.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default: 2000 / 3 / 20 / 5 for configs 1 / 2 / 3 / 4")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 200 / 1 / 2 / 1")
+    ap.add_argument("--ramp-seconds", type=float, default=1.0,
+                    help="untimed passes before the W warmup steps, until the engine clock has ramped up (a 0.6 ms step "
+                         "repeated 20 times runs ~10 %% below the sustained clock)")
+    ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs: 1, 2 demuxlet; 3, 4 freemuxlet")
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the config's cells (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fmx-leg", action="store_true", help="default run: skip the secondary freemuxlet EM leg")
+    ap.add_argument("--fmx-leg-steps", type=int, default=20, help="EM iterations of the secondary leg (configs[3]: 20)")
+    ap.add_argument("--fmx-leg-timeout", type=float, default=420.0)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="functional test of the N>1 path on a 1-GPU box: every rank uses device 0 (use with gloo)")
+    ap.add_argument("--cells", type=int, default=0, help="freemuxlet: override the cell count (tests)")
+    ap.add_argument("--snps", type=int, default=0, help="freemuxlet: override the SNP count (tests)")
+    ap.add_argument("--clusters", type=int, default=0, help="freemuxlet: override K (tests)")
+    ap.add_argument("--mean-entries", type=float, default=800.0)
+    ap.add_argument("--dump", default="", help="freemuxlet: write rank 0's final records (tests)")
+    args = ap.parse_args()
+    if args.config not in synth.CONFIGS:
+        raise SystemExit("--config must be 1, 2 (demuxlet) or 3, 4 (freemuxlet)")
+    if args.steps is None:
+        args.steps = {1: 2000, 2: 3, 3: 20, 4: 5}[args.config]
+    if args.warmup is None:
+        args.warmup = {1: 200, 2: 1, 3: 2, 4: 1}[args.config]
+
+    ctx = Ctx(args)
+    if args.config in (1, 2):
+        out = demux_leg(args, ctx, args.config)
+        if args.config == 1 and not args.no_fmx_leg and args.scale == 1.0:
+            leg = guarded_fmx_leg(args, ctx, out)
+            if ctx.rank == 0:
+                out["freemuxlet_em"] = leg
+    else:
+        out = fmx_leg(args, ctx, args.config, args.steps, args.warmup)
+    if ctx.rank == 0:
+        print(json.dumps(out), flush=True)
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

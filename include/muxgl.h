@@ -14,8 +14,9 @@
  *     replaces the reference's error() -> throw pexception -> abort (Error.cpp:29-43).
  *   - the library needs a HIP device; there is NO CPU fallback.  muxgl_create fails if no gfx950 device is usable.
  *   - all pointer arguments are HOST pointers borrowed for the duration of the call unless the name ends in _dev.
- *   - every call is synchronous: results are complete when it returns.  One handle = one device; the reference is
- *     single-threaded and so is each handle (use one handle per thread/process/GPU).
+ *   - every call is synchronous: results are complete when it returns (the EM phases of a handle created with
+ *     MUXGL_FLAG_ASYNC_PHASES excepted).  The reference is single-threaded and so is each handle: use one handle per
+ *     thread / process, on one device or on a device group (muxgl_config).
  *
  * Packed pileup (what sc_dropseq_lib_t holds after load_from_plp, sc_drop_seq.h:130-184, flattened):
  *   cell_ptr   int64[C+1]   entries of cell c = [cell_ptr[c], cell_ptr[c+1])   <- cell_umis[c] (std::map order =
@@ -34,9 +35,10 @@
 extern "C" {
 #endif
 
-#define MUXGL_VERSION 1
+#define MUXGL_VERSION 2
 #define MUXGL_READ_OTHER 0xFF
 #define MUXGL_MAX_ALPHA 16
+#define MUXGL_MAX_DEVICES 16
 
 enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 
@@ -47,12 +49,25 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 #define MUXGL_FLAG_FORCE_WAVE_KERNEL 4 /* take the wave kernels for V <= 16 too, and the rings of 32 instead of the
                                           two-per-lane row kernels at 17..32 samples / clusters (test coverage) */
 #define MUXGL_FLAG_FORCE_BATCHED_GREEDY 8 /* batched greedy-init kernels for every K <= 64, not only K > 24 (test coverage) */
+#define MUXGL_FLAG_DEMUX_ONLY 16   /* device group: the caller will only run demuxlet, so muxgl_set_pileup need not cut
+                                      the SNP-major column slabs freemuxlet's ordered M-step works on */
+#define MUXGL_FLAG_ASYNC_PHASES 32 /* muxgl_fmx_iter_gp / _estep / _mstep return once their kernels are enqueued on the
+                                      handle's stream (muxgl_stream); muxgl_fmx_iter_fetch and every other call still
+                                      return with the stream drained.  For callers that order their own collectives
+                                      against that stream (popscle_amd/freemuxlet.py) */
 
 typedef struct muxgl_handle muxgl_handle;
 
+/* One handle drives one device (n_devices <= 1) or a device group (n_devices > 1): the same entry points, with the
+ * cells of the pileup cut into n_devices contiguous ranges (demuxlet: no exchange; freemuxlet: E-step by cells, ordered
+ * M-step by SNPs, two all-gathers per EM iteration as peer-to-peer copies over xGMI).  The reference's own way to use
+ * several workers is the same cut at file level (--group-list, README.md:168; sc_drop_seq.cpp:93-101,164-170).  A
+ * device may be named more than once (virtual ranks on one GPU: tests). */
 typedef struct {
-  int32_t device_id; /* HIP device ordinal this handle runs on */
+  int32_t device_id; /* HIP device ordinal this handle runs on (n_devices == 0) */
   int32_t flags;     /* MUXGL_FLAG_* bits, normally 0 */
+  int32_t n_devices; /* 0: device_id; >= 1: device_ids[0 .. n_devices) */
+  int32_t device_ids[MUXGL_MAX_DEVICES];
 } muxgl_config;
 
 /* demuxlet parameters: --alpha grid and --doublet-prior (cmd_cram_demuxlet.cpp:32,62-63,85-89) */
@@ -206,22 +221,45 @@ int muxgl_fmxold_vote_init(muxgl_handle* h, int32_t K, const int32_t* order, con
 int muxgl_fmxold_vote_refine(muxgl_handle* h, int32_t K, const int32_t* order, const double* jitter,
                              int32_t keep_init_missing, int32_t* clust_inout, int32_t* changed, int32_t* ccounts);
 
-/* ---- sharded EM (multi-GPU).  Every rank holds the whole pileup (muxgl_set_pileup + muxgl_fmx_prepare) and owns a
- *      cell range [c0,c1) for the E-step/scans/re-assignment and a SNP range [s0,s1) for the cluster GP rows and the
- *      ordered M-step.  One iteration = iter_gp -> all-gather MUXGL_BUF_CGP slices [s0*K*3, s1*K*3) -> iter_estep ->
- *      all-gather MUXGL_BUF_CLUST slices [c0,c1) (+ all-reduce of the three counters) -> iter_mstep.  The collectives
- *      are the caller's (RCCL over xGMI via torch.distributed in this repo); muxgl_fmx_buffer exposes the device
- *      buffers they run on.  With the full ranges the phases reproduce muxgl_fmx_iterate bit for bit. ---------------- */
-enum { MUXGL_BUF_CGP = 0 /* f64[S][K][3] */, MUXGL_BUF_CLUST = 1 /* i32[C] */, MUXGL_BUF_CELLS = 2 /* muxgl_fmx_cell[C] */,
+/* ---- sharded EM: one handle per rank (one process per GPU, popscle_amd/freemuxlet.py; a device group does the same
+ *      inside one process, see muxgl_config).  Rank r owns a cell range [c0,c1) for the E-step / scans / re-assignment
+ *      and a SNP range [s0,s1) for the cluster GP rows and the ordered M-step (a chain per (cluster, SNP) in ascending
+ *      cell id with a clamp after every merge, sc_drop_seq.h:77-101: not an associative reduction, so exactly one rank
+ *      evaluates it).  One iteration =
+ *          iter_gp -> all-gather MUXGL_BUF_CGP slices [s0*K*3, s1*K*3) -> iter_estep -> all-gather MUXGL_BUF_CLUST
+ *          slices [c0,c1) (+ sum of the three counters) -> iter_mstep.
+ *      The collectives are the caller's (RCCL over xGMI via torch.distributed in this repo); muxgl_fmx_buffer exposes
+ *      the device buffers they run on, muxgl_stream the stream the phases are enqueued on.  Both buffers have
+ *      MUXGL_XCHG_PAD units of slack behind them, so equal slices of ceil(n / ranks) units can be gathered in place.
+ *      With the full ranges the phases reproduce muxgl_fmx_iterate bit for bit.
+ *
+ *      What a rank holds, two ways:
+ *        a) slabs -- muxgl_set_pileup(row slab: the rank's cells [c0,c1) with every SNP, cells renumbered from 0) then
+ *           muxgl_fmx_set_column_slab(column slab: all C_total cells, only the entries with s0 <= SNP < s1, SNP ids
+ *           unchanged), then muxgl_fmx_prepare / muxgl_fmx_set_clusters(clust[C_total]) / the phases.  Device memory
+ *           and H2D traffic are 2/ranks of the pileup.  Per-cell outputs (prepare's scores, iter_fetch's records) cover
+ *           the rank's own cells [C = c1-c0]; MUXGL_BUF_CLUST is job-wide [C_total], MUXGL_BUF_CGP is [S][K][3];
+ *           muxgl_fmx_get_cluster_pileup returns the rows of [s0,s1) and zeros elsewhere.
+ *        b) the whole pileup on every rank + muxgl_fmx_set_shard(c0,c1,s0,s1) after muxgl_fmx_prepare (simple, but every
+ *           rank uploads and keeps everything; kept for callers that hold the whole pileup anyway). ------------------- */
+enum { MUXGL_BUF_CGP = 0 /* f64[S][K][3] */, MUXGL_BUF_CLUST = 1 /* i32[C_total] */, MUXGL_BUF_CELLS = 2 /* muxgl_fmx_cell[C] */,
        MUXGL_BUF_STAT = 3 /* i32[4]: nsingle, namb, nchanged of the local cell range */ };
+#define MUXGL_XCHG_PAD 64
+int muxgl_fmx_set_column_slab(muxgl_handle* h, int64_t C_total, int64_t c0, int64_t s0, int64_t s1, int64_t nnz_s,
+                              int64_t R_s, const int64_t* cell_ptr_s /*[C_total+1]*/, const int32_t* entry_snp_s,
+                              const int64_t* entry_rptr_s, const uint8_t* reads_s);
 int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int64_t s1);
 int muxgl_fmx_iter_gp(muxgl_handle* h, const muxgl_fmx_params* p);
 int muxgl_fmx_iter_estep(muxgl_handle* h, const muxgl_fmx_params* p);
 int muxgl_fmx_iter_mstep(muxgl_handle* h);
+/* counters of the last E-step and, when out / full_ll are given, the records / E-step tensor of the own cells.  With
+ * out == NULL and full_ll == NULL it waits for the counters only (work enqueued behind the E-step keeps running). */
 int muxgl_fmx_iter_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb, int32_t* nchanged,
                          double* full_ll);
 int muxgl_fmx_buffer(muxgl_handle* h, int32_t which, void** dev_ptr, int64_t* n_elems);
 int muxgl_memcpy_dev(muxgl_handle* h, void* dst_dev, const void* src_dev, int64_t bytes);
+/* the hipStream_t every kernel of this handle is enqueued on (NULL for a device group) */
+void* muxgl_stream(const muxgl_handle* h);
 
 /* ---- measurement --------------------------------------------------------------------------------------------- */
 /* ms[MUXGL_T_COUNT]: hipEvent durations of the kernels of the most recent run/iterate call (0 where not run) */

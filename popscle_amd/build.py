@@ -21,3 +21,18 @@ def build_lib(force: bool = False, jobs: int = 3) -> str:
 
 if __name__ == "__main__":
     print(build_lib())
+
+
+def source_hash() -> str:
+    """fingerprint of the kernel sources (csrc/*.hip, *.hpp, include/muxgl.h): stamps measurements that are only valid
+    for the code they were taken on (profiles/traffic.json); works on the GPU box, where there is no .git"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "muxgl.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

@@ -42,10 +42,24 @@ struct muxgl_row_state {
   int64_t n_chunks = 0;
 };
 
+// what a handle's pileup is (muxgl_fmx_set_column_slab / device groups): the whole pileup, the cell-major row slab of a
+// rank (its cells, every SNP: E-step, scans, re-assignment), or the column slab (every cell, its SNPs: ordered M-step)
+enum { MUXGL_ROLE_FULL = 0, MUXGL_ROLE_ROWS = 1, MUXGL_ROLE_COLS = 2 };
+
+struct muxgl_group;
+
 struct muxgl_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;
   std::string err;
+  int role = MUXGL_ROLE_FULL;
+  muxgl_handle* col = nullptr;         // column slab of a slabbed handle (owned; same device, same stream)
+  int64_t C_total = 0, cell_base = 0;  // slabbed handle: cells of the whole job, global id of local cell 0
+  int64_t slab_s0 = 0, slab_s1 = 0;    // column slab: its SNP range
+  muxgl_group* group = nullptr;        // device group behind this handle (muxgl_group.hip); the fields below are unused then
+  int32_t* h_fstat = nullptr;          // pinned: counters of the last E-step (asynchronous phases)
+  hipEvent_t ev_stat = nullptr;
 
   // packed pileup (device)
   int64_t C = 0, S = 0, nnz = 0, R = 0;
@@ -277,3 +291,37 @@ void demux_row_release(muxgl_row_state** st);
 int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
 int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)
 int plan_build_snp_major(muxgl_handle* h);  // d_entry_cell, d_snp_ptr, d_snp_entry, d_snp_cell (plan_kernels.hip)
+
+// handle plumbing shared by muxgl_api.hip and muxgl_group.hip
+int muxgl_handle_create(int device, int32_t flags, hipStream_t shared_stream, muxgl_handle** out, std::string* err);
+int muxgl_validate_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                          const int32_t* entry_snp, const int64_t* entry_rptr, int64_t* maxlen_out);
+int muxgl_set_pileup_role(muxgl_handle* h, int role, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                          const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads, bool trusted = false);
+int fmx_attach_column_slab(muxgl_handle* h, int64_t C_total, int64_t c0, int64_t s0, int64_t s1, int64_t nnz_s, int64_t R_s,
+                           const int64_t* cell_ptr_s, const int32_t* entry_snp_s, const int64_t* entry_rptr_s,
+                           const uint8_t* reads_s, bool trusted);
+int fmx_cluster_counts_device(muxgl_handle* m);  // m->d_ccnt := read counts of the cluster pileups (stream-ordered)
+int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p);
+int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p);
+int fmx_phase_mstep(muxgl_handle* h);
+
+// device groups (muxgl_group.hip): every entry point of the C-ABI forwards here when h->group is set
+int group_create(const muxgl_config* cfg, muxgl_handle** out, std::string* err);
+void group_destroy(muxgl_handle* h);
+int group_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                     const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads);
+int group_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8_t* has_gp);
+int group_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_cell* out, double* full_ll);
+const muxgl_demux_cell* group_demux_results(const muxgl_handle* h);
+int group_demux_get_entry_pg(muxgl_handle* h, double* pg);
+int group_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
+                      int32_t* cell_nreads);
+int group_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
+int group_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust);
+int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
+                      int32_t* nchanged, double* full_ll);
+int group_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
+int group_get_timing(const muxgl_handle* h, float* ms);
+#define MUXGL_NOT_FOR_GROUPS(h, who) \
+  if ((h)->group) MUXGL_FAIL(h, who ": not available on a device group (use a one-device handle)")

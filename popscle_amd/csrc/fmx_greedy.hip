@@ -639,6 +639,10 @@ __global__ void __launch_bounds__(BT)
 extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,
                                      double singlet_score_thres, int32_t* clust_out) {
   if (!h) return 1;
+  // the procedure is sequential over ALL cells (cmd_cram_freemux2.cpp:217-261): it runs on one device holding the
+  // whole pileup; a multi-device run makes the initial clustering on a one-device handle first (popscle-amd does)
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_greedy_init");
+  if (h->col) MUXGL_FAIL(h, "muxgl_fmx_greedy_init: needs the whole pileup on one handle (this one holds slabs)");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_greedy_init: call muxgl_fmx_prepare first");
   if (K < 1 || K > 255) MUXGL_FAIL(h, "muxgl_fmx_greedy_init: K=%d outside [1,255]", K);

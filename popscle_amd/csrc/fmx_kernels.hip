@@ -84,15 +84,18 @@ __global__ void __launch_bounds__(256)
       egls[(size_t)e * 9 + i] = gls[i];
     }
     // the matrix is symmetric (fraction 1-(g1+g2)/4 depends on g1+g2 only): six distinct values for the quad E-step
-    egls6[(size_t)e * 6 + 0] = gls[0];
-    egls6[(size_t)e * 6 + 1] = gls[4];
-    egls6[(size_t)e * 6 + 2] = gls[8];
-    egls6[(size_t)e * 6 + 3] = gls[1];
-    egls6[(size_t)e * 6 + 4] = gls[2];
-    egls6[(size_t)e * 6 + 5] = gls[5];
+    if (egls6) {  // (a column slab has no E-step: no six-value copy, no scores)
+      egls6[(size_t)e * 6 + 0] = gls[0];
+      egls6[(size_t)e * 6 + 1] = gls[4];
+      egls6[(size_t)e * 6 + 2] = gls[8];
+      egls6[(size_t)e * 6 + 3] = gls[1];
+      egls6[(size_t)e * 6 + 4] = gls[2];
+      egls6[(size_t)e * 6 + 5] = gls[5];
+    }
     ecnt[(size_t)e * 3 + 0] = nreads;
     ecnt[(size_t)e * 3 + 1] = nref;
     ecnt[(size_t)e * 3 + 2] = nalt;
+    if (!l0) continue;
     // cmd_cram_freemux2.cpp:138-149
     const double a = af[entry_snp[e]];
     const double gps[3] = {(1.0 - a) * (1.0 - a), 2.0 * a * (1.0 - a), a * a};
@@ -677,11 +680,61 @@ static int fmx_mstep_launch(muxgl_handle* h) {
   return 0;
 }
 
+// SNP-major view of the entries (cells ascending inside each SNP) and SNP-major copies of the entry likelihoods for the
+// ordered M-step, built on the device
+static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm) {
+  const int64_t nnz = h->nnz;
+  if (plan_build_snp_major(h)) return 1;
+  tm.lap("fmx_prepare: SNP-major view (device sort)");
+  if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
+  if (dev_alloc(h, &h->d_secnt, (size_t)nnz * 3)) return 1;
+  if (nnz) {
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
+                       h->d_egls, h->d_ecnt, h->d_segls, h->d_secnt);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  tm.lap("fmx_prepare: SNP-major gather of likelihoods");
+  return 0;
+}
+
+// b1 for a column slab: entry likelihoods of its entries, straight into the SNP-major order the M-step streams; the
+// cell-major copy is dropped again (nothing reads it: the E-step works on the row slab)
+static int fmx_prepare_cols(muxgl_handle* h, const double* af) {
+  HIPCHK(h, hipSetDevice(h->device));
+  host_timer tm;
+  const int64_t S = h->S, nnz = h->nnz;
+  if (dev_alloc(h, &h->d_af, (size_t)S)) return 1;
+  if (S) HIPCHK(h, hipMemcpyAsync(h->d_af, af, sizeof(double) * S, hipMemcpyHostToDevice, h->stream));
+  if (dev_alloc(h, &h->d_egls, (size_t)nnz * 9)) return 1;
+  if (dev_alloc(h, &h->d_ecnt, (size_t)nnz * 3)) return 1;
+  if (nnz) {
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fmx_entry_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_entry_rptr,
+                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, (double*)nullptr, h->d_ecnt,
+                       (double*)nullptr, (double*)nullptr);
+    HIPCHK(h, hipGetLastError());
+  }
+  if (fmx_build_snp_major(h, tm)) return 1;
+  if (!(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) dev_free(&h->d_egls);  // the plain M-step kernel gathers from it
+  h->fmx_prepared = true;
+  h->K = 0;
+  h->fc0 = 0;
+  h->fc1 = h->C;
+  h->fs0 = h->slab_s0;
+  h->fs1 = h->slab_s1;
+  return 0;
+}
+
 extern "C" {
 
 int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
                       int32_t* cell_nreads) {
   if (!h) return 1;
+  if (h->group) return group_fmx_prepare(h, af, cell_llk0, cell_llk2, cell_nsnps, cell_nreads);
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->d_cell_ptr) MUXGL_FAIL(h, "muxgl_fmx_prepare: no pileup set (muxgl_set_pileup)");
   if (!af) MUXGL_FAIL(h, "muxgl_fmx_prepare: af is NULL");
@@ -730,28 +783,22 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   collect_timing(h);
   tm.lap("fmx_prepare: entry kernels + scores D2H");
 
-  // SNP-major view of the entries (cells ascending inside each SNP) for the ordered M-step, built on the device
-  {
-    if (plan_build_snp_major(h)) return 1;
-    tm.lap("fmx_prepare: SNP-major view (device sort)");
-    if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
-    if (dev_alloc(h, &h->d_secnt, (size_t)nnz * 3)) return 1;
-    if (nnz) {
-      int64_t blocks = (nnz + 255) / 256;
-      if (blocks > 16384) blocks = 16384;
-      hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
-                         h->d_egls, h->d_ecnt, h->d_segls, h->d_secnt);
-      HIPCHK(h, hipGetLastError());
-      HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->col) {  // slabbed: the SNP-major side lives in the column slab
+    if (fmx_prepare_cols(h->col, af)) {
+      h->err = h->col->err;
+      return 1;
     }
+    dev_free(&h->d_segls);
+    dev_free(&h->d_secnt);
+  } else if (fmx_build_snp_major(h, tm)) {
+    return 1;
   }
-  tm.lap("fmx_prepare: SNP-major gather of likelihoods");
   h->fmx_prepared = true;
   h->K = 0;
   h->fc0 = 0;
   h->fc1 = C;
-  h->fs0 = 0;
-  h->fs1 = S;
+  h->fs0 = h->col ? h->col->slab_s0 : 0;
+  h->fs1 = h->col ? h->col->slab_s1 : S;
   demux_row_release(&h->frow);
   demux_row_release(&h->fqrow);
   return 0;
@@ -759,6 +806,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
 
 int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
   if (!h) return 1;
+  if (h->group) return group_fmx_get_entry_gls(h, gls, counts);
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_get_entry_gls: call muxgl_fmx_prepare first");
   if (gls && h->nnz) HIPCHK(h, hipMemcpy(gls, h->d_egls, sizeof(double) * 9 * h->nnz, hipMemcpyDeviceToHost));
@@ -766,28 +814,100 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
   return 0;
 }
 
+// Attaches the column slab of a rank to a handle whose pileup (muxgl_set_pileup) is the rank's row slab.
+int muxgl_fmx_set_column_slab(muxgl_handle* h, int64_t C_total, int64_t c0, int64_t s0, int64_t s1, int64_t nnz_s,
+                              int64_t R_s, const int64_t* cell_ptr_s, const int32_t* entry_snp_s,
+                              const int64_t* entry_rptr_s, const uint8_t* reads_s) {
+  if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_set_column_slab");
+  return fmx_attach_column_slab(h, C_total, c0, s0, s1, nnz_s, R_s, cell_ptr_s, entry_snp_s, entry_rptr_s, reads_s, false);
+}
+
+}  // extern "C"
+
+int fmx_attach_column_slab(muxgl_handle* h, int64_t C_total, int64_t c0, int64_t s0, int64_t s1, int64_t nnz_s, int64_t R_s,
+                           const int64_t* cell_ptr_s, const int32_t* entry_snp_s, const int64_t* entry_rptr_s,
+                           const uint8_t* reads_s, bool trusted) {
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_cell_ptr || h->role == MUXGL_ROLE_COLS)
+    MUXGL_FAIL(h, "muxgl_fmx_set_column_slab: hand the row slab over first (muxgl_set_pileup)");
+  if (c0 < 0 || C_total < 0 || c0 + h->C > C_total)
+    MUXGL_FAIL(h, "muxgl_fmx_set_column_slab: cells [%lld, %lld) do not fit %lld cells", (long long)c0,
+               (long long)(c0 + h->C), (long long)C_total);
+  if (s0 < 0 || s1 < s0 || s1 > h->S) MUXGL_FAIL(h, "muxgl_fmx_set_column_slab: bad SNP range");
+  if (nnz_s < 0 || !cell_ptr_s || !entry_rptr_s || (nnz_s > 0 && !entry_snp_s))
+    MUXGL_FAIL(h, "muxgl_fmx_set_column_slab: bad arrays");
+  for (int64_t e = 0; e < nnz_s && !trusted; ++e)
+    if (entry_snp_s[e] < s0 || entry_snp_s[e] >= s1)
+      MUXGL_FAIL(h, "muxgl_fmx_set_column_slab: entry %lld has SNP id %d outside the slab's range [%lld, %lld)",
+                 (long long)e, entry_snp_s[e], (long long)s0, (long long)s1);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->col) muxgl_destroy(h->col);
+  h->col = nullptr;
+  muxgl_handle* col = nullptr;
+  if (muxgl_handle_create(h->device, h->flags, h->stream, &col, &h->err)) return 1;
+  col->slab_s0 = s0;
+  col->slab_s1 = s1;
+  if (muxgl_set_pileup_role(col, MUXGL_ROLE_COLS, C_total, h->S, nnz_s, R_s, cell_ptr_s, entry_snp_s, entry_rptr_s,
+                            reads_s, trusted)) {
+    h->err = col->err;
+    muxgl_destroy(col);
+    return 1;
+  }
+  h->col = col;
+  h->role = MUXGL_ROLE_ROWS;
+  h->C_total = C_total;
+  h->cell_base = c0;
+  h->fmx_prepared = false;
+  h->K = 0;
+  return 0;
+}
+
+int fmx_cluster_counts_device(muxgl_handle* m) {
+  const size_t n = (size_t)m->K * m->S;
+  HIPCHK(m, hipMemsetAsync(m->d_ccnt, 0, sizeof(int32_t) * 3 * n, m->stream));
+  if (m->nnz) {
+    int64_t blocks = (m->nnz + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fmx_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, m->stream, m->nnz, m->S, m->d_entry_snp,
+                       m->d_entry_cell, m->d_clust, m->d_ecnt, m->d_ccnt);
+    HIPCHK(m, hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" {
+
 int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   if (!h) return 1;
+  if (h->group) return group_fmx_set_clusters(h, K, clust);
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: call muxgl_fmx_prepare first");
   if (K < 1 || K > 255) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: K=%d outside [1,255]", K);
-  if (!clust && h->C) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: clust is NULL");
   const int64_t C = h->C, S = h->S;
-  for (int64_t i = 0; i < C; ++i)
+  const int64_t CT = h->col ? h->C_total : C, cb = h->col ? h->cell_base : 0;  // clust[] spans the whole job
+  if (!clust && CT) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: clust is NULL");
+  for (int64_t i = 0; i < CT; ++i)
     if (clust[i] >= K) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: cell %lld has cluster %d >= K", (long long)i, clust[i]);
   h->K = K;
-  if (dev_alloc(h, &h->d_cgls, (size_t)K * S * 9)) return 1;
-  if (dev_alloc(h, &h->d_ccnt, (size_t)K * S * 3)) return 1;
-  if (dev_alloc(h, &h->d_cgp, (size_t)S * K * 3)) return 1;
+  muxgl_handle* m = h->col ? h->col : h;  // who holds the cluster pileups and runs the ordered merge
+  m->K = K;
+  if (dev_alloc(h, &m->d_cgls, (size_t)K * S * 9)) return 1;
+  if (dev_alloc(h, &m->d_ccnt, (size_t)K * S * 3)) return 1;
+  if (dev_alloc(h, &h->d_cgp, (size_t)(S + MUXGL_XCHG_PAD) * K * 3)) return 1;
   if (dev_alloc(h, &h->d_fll, (size_t)fmx_wave_fll_rows(h) * K * (K + 1) / 2)) return 1;
+  if (h->col) {  // rows of SNPs outside the own range stay zero until a caller gathers them
+    HIPCHK(h, hipMemsetAsync(m->d_cgls, 0, sizeof(double) * (size_t)K * S * 9, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_cgp, 0, sizeof(double) * (size_t)(S + MUXGL_XCHG_PAD) * K * 3, h->stream));
+  }
   // state before the first iteration: cmd_cram_freemux2.cpp:191-194,213,244 and :345-367
-  std::vector<int32_t> cl((size_t)C);
+  std::vector<int32_t> cl((size_t)CT);
+  for (int64_t i = 0; i < CT; ++i) cl[(size_t)i] = clust[i] >= 0 ? clust[i] : -1;
   for (int64_t i = 0; i < C; ++i) {
     muxgl_fmx_cell& c = h->h_fcells[i];
     memset(&c, 0, sizeof(c));
-    cl[(size_t)i] = clust[i] >= 0 ? clust[i] : -1;
-    c.type = (clust[i] >= 0) ? 0 : -1;
-    c.clust = cl[(size_t)i];
+    c.type = (cl[(size_t)(cb + i)] >= 0) ? 0 : -1;
+    c.clust = cl[(size_t)(cb + i)];
     c.jBest = c.kBest = c.jNext = c.kNext = -1;
     c.sBest = c.sNext = c.dBest1 = c.dBest2 = c.dNext1 = c.dNext2 = -1;
     c.bestLLK = c.nextLLK = c.sngBestLLK = c.sngNextLLK = c.dblBestLLK = c.dblNextLLK = -1e300;
@@ -795,11 +915,16 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   }
   if (C) {
     HIPCHK(h, hipMemcpyAsync(h->d_fcells, h->h_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_clust, cl.data(), sizeof(int32_t) * C, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_clust, cl.data() + cb, sizeof(int32_t) * C, hipMemcpyHostToDevice, h->stream));
   }
+  if (h->col && CT)
+    HIPCHK(h, hipMemcpyAsync(m->d_clust, cl.data(), sizeof(int32_t) * CT, hipMemcpyHostToDevice, h->stream));
   clear_timing(h);
   tic(h, MUXGL_T_FMX_MSTEP);
-  if (fmx_mstep_launch(h)) return 1;  // :277-288: every assigned cell, ascending cell id
+  if (fmx_mstep_launch(m)) {  // :277-288: every assigned cell, ascending cell id
+    if (m != h) h->err = m->err;
+    return 1;
+  }
   toc(h, MUXGL_T_FMX_MSTEP);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
@@ -812,20 +937,23 @@ static int fmx_check_iter(muxgl_handle* h, const muxgl_fmx_params* p, const char
   return 0;
 }
 
+}  // extern "C"
+
 // cluster genotype posteriors of the SNP shard [fs0,fs1) from the cluster pileups (cmd_cram_freemux2.cpp:402-415)
-static int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p) {
+int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p) {
   tic(h, MUXGL_T_FMX_GP);
-  const int64_t n = (h->fs1 - h->fs0) * h->K;
+  const muxgl_handle* m = h->col ? h->col : h;
+  const int64_t n = (m->fs1 - m->fs0) * h->K;
   if (n > 0)
-    hipLaunchKernelGGL(fmx_cgp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->fs0, h->fs1,
-                       h->K, h->d_af, h->d_cgls, p->geno_error, h->d_cgp);
+    hipLaunchKernelGGL(fmx_cgp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, m->fs0, m->fs1,
+                       h->K, h->d_af, m->d_cgls, p->geno_error, h->d_cgp);
   toc(h, MUXGL_T_FMX_GP);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
 // E-step, scans and re-assignment of the cell shard [fc0,fc1) (:383-584); needs the whole cgp tensor
-static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
+int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   const int64_t c0 = h->fc0, c1 = h->fc1, nc = c1 - c0;
   const int K = h->K;
   const int npairs = K * (K + 1) / 2;
@@ -865,30 +993,45 @@ static int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
                        p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
   toc(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipGetLastError());
+  if (h->col && h->C)  // the new assignments of the own cells, at their place in the job-wide array the M-step reads
+    HIPCHK(h, hipMemcpyAsync(h->col->d_clust + h->cell_base, h->d_clust, sizeof(int32_t) * (size_t)h->C,
+                             hipMemcpyDeviceToDevice, h->stream));
+  // the three counters, on their way to the host while the caller enqueues the next phase
+  HIPCHK(h, hipMemcpyAsync(h->h_fstat, h->d_fstat, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_stat, h->stream));
   return 0;
 }
 
 // ordered clamped merge for the SNP shard [fs0,fs1) (:516-517 clear + :590-596); needs every cell's assignment
-static int fmx_phase_mstep(muxgl_handle* h) {
+int fmx_phase_mstep(muxgl_handle* h) {
   tic(h, MUXGL_T_FMX_MSTEP);
-  if (fmx_mstep_launch(h)) return 1;
+  muxgl_handle* m = h->col ? h->col : h;
+  if (fmx_mstep_launch(m)) {
+    if (m != h) h->err = m->err;
+    return 1;
+  }
   toc(h, MUXGL_T_FMX_MSTEP);
   return 0;
 }
+
+extern "C" {
 
 static int fmx_phase_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb, int32_t* nchanged,
                            double* full_ll) {
   const int64_t C = h->C;
   const int npairs = h->K * (h->K + 1) / 2;
-  int32_t stat[4] = {0, 0, 0, 0};
   // the per-cell records travel only when asked for: an EM loop needs the three counters per iteration and the records once
-  if (C && out) HIPCHK(h, hipMemcpyAsync(h->h_fcells, h->d_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(stat, h->d_fstat, sizeof(stat), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!out && !full_ll) {
+    HIPCHK(h, hipEventSynchronize(h->ev_stat));  // counters only: whatever was enqueued behind the E-step keeps running
+  } else {
+    if (C && out)
+      HIPCHK(h, hipMemcpyAsync(h->h_fcells, h->d_fcells, sizeof(muxgl_fmx_cell) * C, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   if (out && C) memcpy(out, h->h_fcells, sizeof(muxgl_fmx_cell) * C);
-  if (nsingle) *nsingle = stat[0];
-  if (namb) *namb = stat[1];
-  if (nchanged) *nchanged = stat[2];
+  if (nsingle) *nsingle = h->h_fstat[0];
+  if (namb) *namb = h->h_fstat[1];
+  if (nchanged) *nchanged = h->h_fstat[2];
   if (full_ll && C) HIPCHK(h, hipMemcpy(full_ll, h->d_fll, sizeof(double) * (size_t)C * npairs, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -896,12 +1039,15 @@ static int fmx_phase_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingl
 int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
                       int32_t* nchanged, double* full_ll) {
   if (!h) return 1;
+  if (h->group) return group_fmx_iterate(h, p, out, nsingle, namb, nchanged, full_ll);
   HIPCHK(h, hipSetDevice(h->device));
   if (fmx_check_iter(h, p, "muxgl_fmx_iterate")) return 1;
-  if (h->fc0 != 0 || h->fc1 != h->C || h->fs0 != 0 || h->fs1 != h->S)
-    MUXGL_FAIL(h, "muxgl_fmx_iterate: handle is sharded (muxgl_fmx_set_shard); use the muxgl_fmx_iter_* phases");
+  if (h->col || h->fc0 != 0 || h->fc1 != h->C || h->fs0 != 0 || h->fs1 != h->S)
+    MUXGL_FAIL(h, "muxgl_fmx_iterate: handle is sharded (muxgl_fmx_set_shard / muxgl_fmx_set_column_slab); use the "
+                  "muxgl_fmx_iter_* phases");
   clear_timing(h);
   if (fmx_phase_gp(h, p) || fmx_phase_estep(h, p) || fmx_phase_mstep(h)) return 1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   if (fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll)) return 1;
   collect_timing(h);
   return 0;
@@ -912,8 +1058,10 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
 
 int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int64_t s1) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_set_shard");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared) MUXGL_FAIL(h, "muxgl_fmx_set_shard: call muxgl_fmx_prepare first");
+  if (h->col) MUXGL_FAIL(h, "muxgl_fmx_set_shard: the handle holds slabs (muxgl_fmx_set_column_slab), which fix its ranges");
   if (c0 < 0 || c1 < c0 || c1 > h->C || s0 < 0 || s1 < s0 || s1 > h->S) MUXGL_FAIL(h, "muxgl_fmx_set_shard: bad range");
   h->fc0 = c0;
   h->fc1 = c1;
@@ -928,49 +1076,59 @@ int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int
   return 0;
 }
 
+// end of a phase call: drained stream and timings, or (MUXGL_FLAG_ASYNC_PHASES) nothing -- the kernels are enqueued on
+// muxgl_stream(h) and the caller orders its collectives against that stream
+static int fmx_phase_done(muxgl_handle* h) {
+  if (h->flags & MUXGL_FLAG_ASYNC_PHASES) return 0;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  return 0;
+}
+
 int muxgl_fmx_iter_gp(muxgl_handle* h, const muxgl_fmx_params* p) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_iter_gp");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmx_check_iter(h, p, "muxgl_fmx_iter_gp")) return 1;
   clear_timing(h);
   if (fmx_phase_gp(h, p)) return 1;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  collect_timing(h);
-  return 0;
+  return fmx_phase_done(h);
 }
 
 int muxgl_fmx_iter_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_iter_estep");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmx_check_iter(h, p, "muxgl_fmx_iter_estep")) return 1;
-  clear_timing(h);
+  if (!(h->flags & MUXGL_FLAG_ASYNC_PHASES)) clear_timing(h);
   if (fmx_phase_estep(h, p)) return 1;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  collect_timing(h);
-  return 0;
+  return fmx_phase_done(h);
 }
 
 int muxgl_fmx_iter_mstep(muxgl_handle* h) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_iter_mstep");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iter_mstep: no clusters set");
-  clear_timing(h);
+  if (!(h->flags & MUXGL_FLAG_ASYNC_PHASES)) clear_timing(h);
   if (fmx_phase_mstep(h)) return 1;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  collect_timing(h);
-  return 0;
+  return fmx_phase_done(h);
 }
 
 int muxgl_fmx_iter_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb, int32_t* nchanged,
                          double* full_ll) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_iter_fetch");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iter_fetch: no clusters set");
-  return fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll);
+  if (fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll)) return 1;
+  if ((h->flags & MUXGL_FLAG_ASYNC_PHASES) && (out || full_ll)) collect_timing(h);  // the stream is drained here
+  return 0;
 }
 
 int muxgl_fmx_buffer(muxgl_handle* h, int32_t which, void** dev_ptr, int64_t* n_elems) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_buffer");
   if (!dev_ptr || !n_elems) MUXGL_FAIL(h, "muxgl_fmx_buffer: NULL output");
   if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_buffer: no clusters set");
   switch (which) {
@@ -978,9 +1136,9 @@ int muxgl_fmx_buffer(muxgl_handle* h, int32_t which, void** dev_ptr, int64_t* n_
       *dev_ptr = h->d_cgp;
       *n_elems = h->S * h->K * 3;
       return 0;
-    case MUXGL_BUF_CLUST:
-      *dev_ptr = h->d_clust;
-      *n_elems = h->C;
+    case MUXGL_BUF_CLUST:  // job-wide: a slabbed handle keeps it with the column slab, whose merge reads it
+      *dev_ptr = h->col ? h->col->d_clust : h->d_clust;
+      *n_elems = h->col ? h->C_total : h->C;
       return 0;
     case MUXGL_BUF_CELLS:
       *dev_ptr = h->d_fcells;
@@ -997,28 +1155,29 @@ int muxgl_fmx_buffer(muxgl_handle* h, int32_t which, void** dev_ptr, int64_t* n_
 
 int muxgl_memcpy_dev(muxgl_handle* h, void* dst_dev, const void* src_dev, int64_t bytes) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_memcpy_dev");
   HIPCHK(h, hipSetDevice(h->device));
-  if (bytes > 0) HIPCHK(h, hipMemcpy(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice));
+  if (bytes > 0) HIPCHK(h, hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, h->stream));
+  if (!(h->flags & MUXGL_FLAG_ASYNC_PHASES)) HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 
 int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts) {
   if (!h) return 1;
+  if (h->group) return group_fmx_get_cluster_pileup(h, gls, counts);
   HIPCHK(h, hipSetDevice(h->device));
   if (h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_get_cluster_pileup: no clusters set");
+  muxgl_handle* m = h->col ? h->col : h;  // a slabbed handle: rows of its SNP range, zeros elsewhere
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   const size_t n = (size_t)h->K * h->S;
-  if (gls && n) HIPCHK(h, hipMemcpy(gls, h->d_cgls, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+  if (gls && n) HIPCHK(h, hipMemcpy(gls, m->d_cgls, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
   if (counts && n) {
-    HIPCHK(h, hipMemsetAsync(h->d_ccnt, 0, sizeof(int32_t) * 3 * n, h->stream));
-    if (h->nnz) {
-      int64_t blocks = (h->nnz + 255) / 256;
-      if (blocks > 16384) blocks = 16384;
-      hipLaunchKernelGGL(fmx_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->nnz, h->S, h->d_entry_snp,
-                         h->d_entry_cell, h->d_clust, h->d_ecnt, h->d_ccnt);
-      HIPCHK(h, hipGetLastError());
+    if (fmx_cluster_counts_device(m)) {
+      if (m != h) h->err = m->err;
+      return 1;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(counts, h->d_ccnt, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(counts, m->d_ccnt, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -427,6 +427,8 @@ extern "C" {
 
 int muxgl_fmxold_pair_dist(muxgl_handle* h, double bf_thres, muxgl_dropd* full) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmxold_pair_dist");
+  if (h->col) MUXGL_FAIL(h, "muxgl_fmxold_pair_dist: needs the whole pileup on one handle (this one holds slabs)");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmxold_check(h, "muxgl_fmxold_pair_dist", 0)) return 1;
   const int64_t C = h->C;
@@ -474,6 +476,8 @@ int muxgl_fmxold_pair_dist(muxgl_handle* h, double bf_thres, muxgl_dropd* full) 
 
 int muxgl_fmxold_get_signs(muxgl_handle* h, int8_t* out) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmxold_get_signs");
+  if (h->col) MUXGL_FAIL(h, "muxgl_fmxold_get_signs: needs the whole pileup on one handle (this one holds slabs)");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->d_sgn || !out) MUXGL_FAIL(h, "muxgl_fmxold_get_signs: no sign matrix (muxgl_fmxold_pair_dist) or NULL output");
   if (h->C)
@@ -485,6 +489,8 @@ int muxgl_fmxold_get_signs(muxgl_handle* h, int8_t* out) {
 int muxgl_fmxold_vote_init(muxgl_handle* h, int32_t K, const int32_t* order, const double* jitter,
                            double frac_init_clust, int32_t* clust_out, int32_t* ccounts) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmxold_vote_init");
+  if (h->col) MUXGL_FAIL(h, "muxgl_fmxold_vote_init: needs the whole pileup on one handle (this one holds slabs)");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmxold_check(h, "muxgl_fmxold_vote_init", K)) return 1;
   const int64_t C = h->C;
@@ -535,6 +541,8 @@ int muxgl_fmxold_vote_init(muxgl_handle* h, int32_t K, const int32_t* order, con
 int muxgl_fmxold_vote_refine(muxgl_handle* h, int32_t K, const int32_t* order, const double* jitter,
                              int32_t keep_init_missing, int32_t* clust_inout, int32_t* changed, int32_t* ccounts) {
   if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmxold_vote_refine");
+  if (h->col) MUXGL_FAIL(h, "muxgl_fmxold_vote_refine: needs the whole pileup on one handle (this one holds slabs)");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmxold_check(h, "muxgl_fmxold_vote_refine", K)) return 1;
   const int64_t C = h->C;

@@ -1,50 +1,51 @@
 // muxgl_api.hip -- the C-ABI of include/muxgl.h: handle lifetime, hand-over of the packed pileup and GP tensor to
 // device memory, and the synchronous run/iterate entry points.  No CPU fallback: every compute call needs a HIP device.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
 
 thread_local std::string g_muxgl_create_error;
 
-extern "C" {
-
-int muxgl_version(void) { return MUXGL_VERSION; }
-
-const char* muxgl_last_error(const muxgl_handle* h) { return h ? h->err.c_str() : g_muxgl_create_error.c_str(); }
-
-int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
-  if (!out) {
-    g_muxgl_create_error = "muxgl_create: out is NULL";
-    return 1;
-  }
+// One handle on one device.  shared_stream != nullptr: the handle launches on that stream and does not own it (the
+// column slab of a slabbed handle shares its parent's stream, so the phases of an EM iteration stay in stream order).
+int muxgl_handle_create(int dev, int32_t flags, hipStream_t shared_stream, muxgl_handle** out, std::string* errp) {
+  std::string& err = *errp;
   *out = nullptr;
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
-    g_muxgl_create_error = std::string("muxgl_create: no HIP device available (") +
-                           (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
-                           "); libmuxgl has no CPU fallback";
+    err = std::string("muxgl_create: no HIP device available (") +
+          (e != hipSuccess ? hipGetErrorString(e) : "device count 0") + "); libmuxgl has no CPU fallback";
     return 1;
   }
-  const int dev = cfg ? cfg->device_id : 0;
   if (dev < 0 || dev >= ndev) {
-    g_muxgl_create_error = "muxgl_create: device_id out of range";
+    err = "muxgl_create: device_id out of range";
     return 1;
   }
   muxgl_handle* h = new muxgl_handle();
   h->device = dev;
-  h->flags = cfg ? cfg->flags : 0;
-  auto fail = [&](const char* what, hipError_t err) {
-    g_muxgl_create_error = std::string("muxgl_create: ") + what + ": " + hipGetErrorString(err);
-    delete h;
+  h->flags = flags;
+  auto fail = [&](const char* what, hipError_t er) {
+    err = std::string("muxgl_create: ") + what + ": " + hipGetErrorString(er);
+    muxgl_destroy(h);
     return 1;
   };
   if ((e = hipSetDevice(dev)) != hipSuccess) return fail("hipSetDevice", e);
-  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if (shared_stream) {
+    h->stream = shared_stream;
+    h->owns_stream = false;
+  } else if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+    h->stream = nullptr;
+    return fail("hipStreamCreate", e);
+  }
   for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
     if ((e = hipEventCreate(&h->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreateWithFlags(&h->ev_stat, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipHostMalloc((void**)&h->h_fstat, 4 * sizeof(int32_t))) != hipSuccess) return fail("hipHostMalloc(stat)", e);
 
   // Phred tables, PhredHelper.cpp:24-41: phred2Err[i] = (i > 1) ? pow(0.1, i*0.1) : 0.75; phred2Mat = 1 - Err.
   // The packed read byte carries 7 bits of quality, so 128 entries of each suffice.
@@ -62,10 +63,176 @@ int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
   return 0;
 }
 
+// structural validation of a packed pileup (the reference's containers make these states unrepresentable), cells cut
+// into slices checked by host threads: 480 M entries took 0.32 s in one loop, the largest stage of that hand-over
+int muxgl_validate_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                           const int32_t* entry_snp, const int64_t* entry_rptr, int64_t* maxlen_out) {
+  if (cell_ptr[0] != 0 || cell_ptr[C] != nnz) MUXGL_FAIL(h, "muxgl_set_pileup: cell_ptr must span [0,nnz]");
+  if (entry_rptr[0] != 0 || entry_rptr[nnz] != R) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr must span [0,R]");
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = (int)(hw ? (hw > 16 ? 16 : hw) : 1);
+  if (nnz < (1 << 20)) T = 1;
+  struct result {
+    int64_t maxlen = 0;
+    std::string err;
+  };
+  std::vector<result> res((size_t)T);
+  auto work = [&](int t) {
+    result& r = res[(size_t)t];
+    char buf[256];
+    const int64_t cb = C * t / T, ce = C * (t + 1) / T;
+    for (int64_t c = cb; c < ce; ++c) {
+      const int64_t b = cell_ptr[c], e1 = cell_ptr[c + 1], len = e1 - b;
+      if (len < 0 || b < 0 || e1 > nnz) {
+        snprintf(buf, sizeof(buf), "muxgl_set_pileup: cell_ptr not monotone at cell %lld", (long long)c);
+        r.err = buf;
+        return;
+      }
+      if (len > r.maxlen) r.maxlen = len;
+      for (int64_t e = b; e < e1; ++e) {
+        if (entry_snp[e] < 0 || entry_snp[e] >= S) {
+          snprintf(buf, sizeof(buf), "muxgl_set_pileup: entry %lld has SNP id %d outside [0,%lld)", (long long)e,
+                   entry_snp[e], (long long)S);
+          r.err = buf;
+          return;
+        }
+        if (e > b && entry_snp[e] <= entry_snp[e - 1]) {
+          snprintf(buf, sizeof(buf), "muxgl_set_pileup: SNP ids of cell %lld are not strictly ascending", (long long)c);
+          r.err = buf;
+          return;
+        }
+        if (entry_rptr[e + 1] < entry_rptr[e]) {
+          snprintf(buf, sizeof(buf), "muxgl_set_pileup: entry_rptr not monotone at %lld", (long long)e);
+          r.err = buf;
+          return;
+        }
+      }
+    }
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  int64_t maxlen = 0;
+  for (auto& r : res) {
+    if (!r.err.empty()) {
+      h->err = r.err;
+      return 1;
+    }
+    if (r.maxlen > maxlen) maxlen = r.maxlen;
+  }
+  *maxlen_out = maxlen;
+  return 0;
+}
+
+// Hand-over of a packed pileup in one of three roles: the whole pileup (every derived table), a rank's row slab (the same,
+// its cells only), or a column slab (all cells, the entries of a SNP range; it only ever feeds the SNP-major view of the
+// ordered M-step, so the chunk plans, the wave plan and the packed quad records are skipped).
+int muxgl_set_pileup_role(muxgl_handle* h, int role, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
+                          const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads, bool trusted) {
+  HIPCHK(h, hipSetDevice(h->device));
+  if (C < 0 || S < 0 || nnz < 0 || R < 0) MUXGL_FAIL(h, "muxgl_set_pileup: negative size");
+  if (!cell_ptr || !entry_rptr || (nnz > 0 && !entry_snp) || (R > 0 && !reads))
+    MUXGL_FAIL(h, "muxgl_set_pileup: NULL array");
+  if (S > INT32_MAX) MUXGL_FAIL(h, "muxgl_set_pileup: S exceeds int32");
+  if (C > INT32_MAX) MUXGL_FAIL(h, "muxgl_set_pileup: C exceeds int32");
+  host_timer tm;
+  int64_t maxlen = 0;
+  if (trusted) {  // a slab cut by the library from arrays it has validated: only the longest cell is needed
+    for (int64_t c = 0; c < C; ++c) maxlen = std::max(maxlen, cell_ptr[c + 1] - cell_ptr[c]);
+  } else if (muxgl_validate_pileup(h, C, S, nnz, R, cell_ptr, entry_snp, entry_rptr, &maxlen)) {
+    return 1;
+  }
+  tm.lap("set_pileup: validation");
+  if (h->col) {  // a new pileup: the column slab of the previous one goes
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    muxgl_destroy(h->col);
+    h->col = nullptr;
+  }
+  h->role = role;
+  h->C_total = C;
+  h->cell_base = 0;
+  h->C = C;
+  h->S = S;
+  h->nnz = nnz;
+  h->R = R;
+  h->max_cell_entries = maxlen;
+  if (dev_alloc(h, &h->d_cell_ptr, (size_t)C + 1)) return 1;
+  if (dev_alloc(h, &h->d_entry_snp, (size_t)nnz)) return 1;
+  if (dev_alloc(h, &h->d_entry_rptr, (size_t)nnz + 1)) return 1;
+  if (dev_alloc(h, &h->d_reads, (size_t)R)) return 1;
+  HIPCHK(h, hipMemcpyAsync(h->d_cell_ptr, cell_ptr, sizeof(int64_t) * (C + 1), hipMemcpyHostToDevice, h->stream));
+  if (nnz) HIPCHK(h, hipMemcpyAsync(h->d_entry_snp, entry_snp, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_entry_rptr, entry_rptr, sizeof(int64_t) * (nnz + 1), hipMemcpyHostToDevice, h->stream));
+  if (R) HIPCHK(h, hipMemcpyAsync(h->d_reads, reads, (size_t)R, hipMemcpyHostToDevice, h->stream));
+
+  // per-cell result buffers
+  if (C > h->dcells_cap && role != MUXGL_ROLE_COLS) {
+    if (dev_alloc(h, &h->d_dcells, (size_t)C)) return 1;
+    if (dev_alloc(h, &h->d_fcells, (size_t)C)) return 1;
+    if (dev_alloc(h, &h->d_clust, (size_t)(C + MUXGL_XCHG_PAD))) return 1;
+    if (h->h_dcells) (void)hipHostFree(h->h_dcells);
+    if (h->h_fcells) (void)hipHostFree(h->h_fcells);
+    h->h_dcells = nullptr;
+    h->h_fcells = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_dcells, sizeof(muxgl_demux_cell) * (size_t)(C ? C : 1)));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_fcells, sizeof(muxgl_fmx_cell) * (size_t)(C ? C : 1)));
+    h->dcells_cap = C;
+  }
+  if (role == MUXGL_ROLE_COLS && dev_alloc(h, &h->d_clust, (size_t)(C + MUXGL_XCHG_PAD))) return 1;
+  h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
+  tm.lap("set_pileup: alloc + H2D enqueue");
+  if (role != MUXGL_ROLE_COLS) {
+    if (demux_row_plan(h)) return 1;
+    tm.lap("set_pileup: chunk plans (row, quad)");
+    if (demux_wave_plan(h, cell_ptr)) return 1;
+    tm.lap("set_pileup: wave plan");
+    if (plan_build_qent(h)) return 1;  // packed per-entry records of the quad kernel
+    tm.lap("set_pileup: quad entry records");
+  }
+  h->fmx_prepared = false;
+  h->K = 0;
+  dev_free(&h->d_sgn);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  tm.lap("set_pileup: final sync");
+  return 0;
+}
+
+extern "C" {
+
+int muxgl_version(void) { return MUXGL_VERSION; }
+
+const char* muxgl_last_error(const muxgl_handle* h) { return h ? h->err.c_str() : g_muxgl_create_error.c_str(); }
+
+int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
+  if (!out) {
+    g_muxgl_create_error = "muxgl_create: out is NULL";
+    return 1;
+  }
+  *out = nullptr;
+  if (cfg && (cfg->n_devices < 0 || cfg->n_devices > MUXGL_MAX_DEVICES)) {
+    g_muxgl_create_error = "muxgl_create: n_devices outside [0, MUXGL_MAX_DEVICES]";
+    return 1;
+  }
+  if (cfg && cfg->n_devices > 1) return group_create(cfg, out, &g_muxgl_create_error);
+  const int dev = cfg ? (cfg->n_devices == 1 ? cfg->device_ids[0] : cfg->device_id) : 0;
+  return muxgl_handle_create(dev, cfg ? cfg->flags : 0, nullptr, out, &g_muxgl_create_error);
+}
+
 void muxgl_destroy(muxgl_handle* h) {
   if (!h) return;
+  if (h->group) {
+    group_destroy(h);
+    delete h;
+    return;
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->col) muxgl_destroy(h->col);
+  h->col = nullptr;
   dev_free(&h->d_cell_ptr);
   dev_free(&h->d_entry_snp);
   dev_free(&h->d_entry_rptr);
@@ -103,86 +270,24 @@ void muxgl_destroy(muxgl_handle* h) {
   demux_wave_free(h);
   if (h->h_dcells) (void)hipHostFree(h->h_dcells);
   if (h->h_fcells) (void)hipHostFree(h->h_fcells);
+  if (h->h_fstat) (void)hipHostFree(h->h_fstat);
+  if (h->ev_stat) (void)hipEventDestroy(h->ev_stat);
   for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
                      const int32_t* entry_snp, const int64_t* entry_rptr, const uint8_t* reads) {
   if (!h) return 1;
-  HIPCHK(h, hipSetDevice(h->device));
-  if (C < 0 || S < 0 || nnz < 0 || R < 0) MUXGL_FAIL(h, "muxgl_set_pileup: negative size");
-  if (!cell_ptr || !entry_rptr || (nnz > 0 && !entry_snp) || (R > 0 && !reads))
-    MUXGL_FAIL(h, "muxgl_set_pileup: NULL array");
-  if (S > INT32_MAX) MUXGL_FAIL(h, "muxgl_set_pileup: S exceeds int32");
-  host_timer tm;
-  // structural validation (the reference's containers make these states unrepresentable)
-  if (cell_ptr[0] != 0 || cell_ptr[C] != nnz) MUXGL_FAIL(h, "muxgl_set_pileup: cell_ptr must span [0,nnz]");
-  if (entry_rptr[0] != 0 || entry_rptr[nnz] != R) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr must span [0,R]");
-  int64_t maxlen = 0;
-  for (int64_t c = 0; c < C; ++c) {
-    const int64_t len = cell_ptr[c + 1] - cell_ptr[c];
-    if (len < 0) MUXGL_FAIL(h, "muxgl_set_pileup: cell_ptr not monotone at cell %lld", (long long)c);
-    if (len > maxlen) maxlen = len;
-    for (int64_t e = cell_ptr[c]; e < cell_ptr[c + 1]; ++e) {
-      if (entry_snp[e] < 0 || entry_snp[e] >= S)
-        MUXGL_FAIL(h, "muxgl_set_pileup: entry %lld has SNP id %d outside [0,%lld)", (long long)e, entry_snp[e],
-                   (long long)S);
-      if (e > cell_ptr[c] && entry_snp[e] <= entry_snp[e - 1])
-        MUXGL_FAIL(h, "muxgl_set_pileup: SNP ids of cell %lld are not strictly ascending", (long long)c);
-    }
-  }
-  for (int64_t e = 0; e < nnz; ++e)
-    if (entry_rptr[e + 1] < entry_rptr[e]) MUXGL_FAIL(h, "muxgl_set_pileup: entry_rptr not monotone at %lld", (long long)e);
-
-  tm.lap("set_pileup: validation");
-  h->C = C;
-  h->S = S;
-  h->nnz = nnz;
-  h->R = R;
-  h->max_cell_entries = maxlen;
-  if (dev_alloc(h, &h->d_cell_ptr, (size_t)C + 1)) return 1;
-  if (dev_alloc(h, &h->d_entry_snp, (size_t)nnz)) return 1;
-  if (dev_alloc(h, &h->d_entry_rptr, (size_t)nnz + 1)) return 1;
-  if (dev_alloc(h, &h->d_reads, (size_t)R)) return 1;
-  HIPCHK(h, hipMemcpyAsync(h->d_cell_ptr, cell_ptr, sizeof(int64_t) * (C + 1), hipMemcpyHostToDevice, h->stream));
-  if (nnz) HIPCHK(h, hipMemcpyAsync(h->d_entry_snp, entry_snp, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_entry_rptr, entry_rptr, sizeof(int64_t) * (nnz + 1), hipMemcpyHostToDevice, h->stream));
-  if (R) HIPCHK(h, hipMemcpyAsync(h->d_reads, reads, (size_t)R, hipMemcpyHostToDevice, h->stream));
-
-  // per-cell result buffers
-  if (C > h->dcells_cap) {
-    if (dev_alloc(h, &h->d_dcells, (size_t)C)) return 1;
-    if (dev_alloc(h, &h->d_fcells, (size_t)C)) return 1;
-    if (dev_alloc(h, &h->d_clust, (size_t)C)) return 1;
-    if (h->h_dcells) (void)hipHostFree(h->h_dcells);
-    if (h->h_fcells) (void)hipHostFree(h->h_fcells);
-    h->h_dcells = nullptr;
-    h->h_fcells = nullptr;
-    HIPCHK(h, hipHostMalloc((void**)&h->h_dcells, sizeof(muxgl_demux_cell) * (size_t)(C ? C : 1)));
-    HIPCHK(h, hipHostMalloc((void**)&h->h_fcells, sizeof(muxgl_fmx_cell) * (size_t)(C ? C : 1)));
-    h->dcells_cap = C;
-  }
-  h->ll_zeroed = false;  // the LL tensor must be re-zeroed for the new cell set
-  tm.lap("set_pileup: alloc + H2D enqueue");
-  if (demux_row_plan(h)) return 1;
-  tm.lap("set_pileup: chunk plans (row, quad)");
-  if (demux_wave_plan(h, cell_ptr)) return 1;
-  tm.lap("set_pileup: wave plan");
-  if (plan_build_qent(h)) return 1;  // packed per-entry records of the quad kernel
-  tm.lap("set_pileup: quad entry records");
-  h->fmx_prepared = false;
-  h->K = 0;
-  dev_free(&h->d_sgn);
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  tm.lap("set_pileup: final sync");
-  return 0;
+  if (h->group) return group_set_pileup(h, C, S, nnz, R, cell_ptr, entry_snp, entry_rptr, reads);
+  return muxgl_set_pileup_role(h, MUXGL_ROLE_FULL, C, S, nnz, R, cell_ptr, entry_snp, entry_rptr, reads);
 }
 
 int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8_t* has_gp) {
   if (!h) return 1;
+  if (h->group) return group_demux_set_gp(h, V, gp, has_gp);
   HIPCHK(h, hipSetDevice(h->device));
   if (V < 1 || V > 255) MUXGL_FAIL(h, "muxgl_demux_set_gp: V=%d outside [1,255]", V);
   if (!gp || !has_gp) MUXGL_FAIL(h, "muxgl_demux_set_gp: NULL array");
@@ -244,6 +349,7 @@ static int check_demux_params(muxgl_handle* h, const muxgl_demux_params* p) {
 
 int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_cell* out, double* full_ll) {
   if (!h) return 1;
+  if (h->group) return group_demux_run(h, p, out, full_ll);
   HIPCHK(h, hipSetDevice(h->device));
   if (check_demux_params(h, p)) return 1;
   clear_timing(h);
@@ -266,10 +372,14 @@ int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_ce
   return 0;
 }
 
-const muxgl_demux_cell* muxgl_demux_results(const muxgl_handle* h) { return h ? h->h_dcells : nullptr; }
+const muxgl_demux_cell* muxgl_demux_results(const muxgl_handle* h) {
+  if (h && h->group) return group_demux_results(h);
+  return h ? h->h_dcells : nullptr;
+}
 
 int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg) {
   if (!h) return 1;
+  if (h->group) return group_demux_get_entry_pg(h, pg);
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->have_dp) MUXGL_FAIL(h, "muxgl_demux_get_entry_pg: no previous muxgl_demux_run");
   if (!pg) MUXGL_FAIL(h, "muxgl_demux_get_entry_pg: NULL output");
@@ -289,8 +399,11 @@ int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg) {
   return rc;
 }
 
+void* muxgl_stream(const muxgl_handle* h) { return (h && !h->group) ? (void*)h->stream : nullptr; }
+
 int muxgl_get_timing(const muxgl_handle* h, float* ms) {
   if (!h || !ms) return 1;
+  if (h->group) return group_get_timing(h, ms);
   memcpy(ms, h->ms, sizeof(float) * MUXGL_T_COUNT);
   return 0;
 }

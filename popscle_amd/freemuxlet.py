@@ -1,52 +1,61 @@
 """Host-side driver of the freemuxlet EM loop -- the sequential control flow of cmdCramFreemux2
 (cmd_cram_freemux2.cpp:373-605) around the libmuxgl phases, for one GPU or for one process per GPU.
 
-Multi-GPU scheme (exact): every rank holds the whole packed pileup and entry likelihoods;
-rank r owns the cell range c_ranges[r] (E-step, scans, re-assignment) and the SNP range s_ranges[r] (cluster-GP rows,
-ordered M-step).  Per iteration:
+Multi-GPU scheme (exact).  Rank r holds two slabs of the packed pileup, 2/N of it in all:
+its ROW slab (cells c_ranges[r], every SNP: E-step, scans, re-assignment) and its COLUMN slab (every cell, SNPs
+s_ranges[r]: cluster pileups, cluster-GP rows, ordered M-step).  Per iteration:
 
     iter_gp     -> all-gather of the cluster-GP rows   f64[S][K][3]   (38 MB at config 3, 768 MB at config 4)
     iter_estep  -> all-gather of the assignments       i32[C]         + all-reduce of (nsingle, namb, nchanged)
     iter_mstep
 
-The collectives run over RCCL (torch.distributed backend "nccl") directly on the library's device buffers; xGMI is
-point-to-point, so each rank's slice is sent as one broadcast per owner (N large messages, no small-bucket traffic).
-An all-reduce of sufficient statistics would NOT reproduce the reference: merge() clamps after every cell
-(sc_drop_seq.h:92-100), so the chain per (cluster, SNP) is evaluated by exactly one rank, in ascending cell id.
+Each exchange is ONE collective (all_gather_into_tensor, in place on the library's own device buffer: the ranges are
+equal slices and the buffers carry a little slack).  Over RCCL (backend "nccl") nothing on the host waits between the
+phases: the library enqueues on its own stream (MUXGL_FLAG_ASYNC_PHASES), that stream is torch's current stream while
+the collectives are issued, and ProcessGroupNCCL orders its communication stream against it with events; the host
+blocks once per iteration, on the three reduced counters the reference's early stop reads (:601-604), while the M-step
+is already running.  An all-reduce of sufficient statistics would NOT reproduce the reference: merge() clamps after
+every cell (sc_drop_seq.h:92-100), so the chain per (cluster, SNP) is evaluated by exactly one rank, in ascending cell id.
 """
 from __future__ import annotations
+
+import contextlib
+import time
 
 import numpy as np
 
 from . import shard
 
-UNIT_CGP, UNIT_CLUST = 0, 1
+UNIT_CGP, UNIT_CLUST, UNIT_STAT = 0, 1, 2
 
 
 class TorchExchange:
-    """Collectives over torch.distributed on tensors that alias the engine's exchange buffers."""
+    """Collectives over torch.distributed on tensors that alias the engine's exchange buffers.
 
-    def __init__(self, dist_module, rank: int, world: int):
+    device_ordered=True (RCCL): the collectives are enqueued behind the engine's stream and nothing waits on the host.
+    device_ordered=False (gloo staging, tests on a 1-GPU box or on CPU): every exchange returns when the data has landed."""
+
+    def __init__(self, dist_module, rank: int, world: int, device_ordered: bool = False):
         self.dist = dist_module
         self.rank = rank
         self.world = world
+        self.device_ordered = device_ordered
 
-    def allgather_rows(self, tensor, ranges):
-        """tensor: [n_units, row]; ranges[r] = (b, e) unit range owned by rank r.  One broadcast per owner.
-        Returns when the data has landed: the engine launches its kernels on a stream of its own, which does not
-        wait for torch's streams (a collective that has merely been enqueued would be raced by the next phase)."""
-        for r, (b, e) in enumerate(ranges):
-            if e > b:
-                self.dist.broadcast(tensor[b:e], src=r)
+    def allgather_equal(self, tensor, per: int):
+        """tensor: [>= world*per, row]; rank r owns rows [r*per, (r+1)*per).  One collective, in place."""
+        if per <= 0:
+            return
+        out = tensor[: self.world * per]
+        inp = tensor[self.rank * per:(self.rank + 1) * per]
+        self.dist.all_gather_into_tensor(out, inp)
         self._landed(tensor)
 
     def allreduce_sum(self, tensor):
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
         self._landed(tensor)
 
-    @staticmethod
-    def _landed(tensor):
-        if getattr(tensor, "is_cuda", False):
+    def _landed(self, tensor):
+        if not self.device_ordered and getattr(tensor, "is_cuda", False):
             import torch
 
             torch.cuda.current_stream(tensor.device).synchronize()
@@ -58,9 +67,9 @@ class TorchExchange:
 
 
 class NoExchange:
-    rank, world = 0, 1
+    rank, world, device_ordered = 0, 1, False
 
-    def allgather_rows(self, tensor, ranges):
+    def allgather_equal(self, tensor, per):
         pass
 
     def allreduce_sum(self, tensor):
@@ -71,74 +80,104 @@ class NoExchange:
 
 
 def engine_exchange_tensor(eng, which, device_index=0):
-    """torch tensor aliasing a libmuxgl device buffer (zero-copy, __cuda_array_interface__): CGP -> f64[S, K*3],
-    CLUST -> i32[C, 1]"""
+    """torch tensor aliasing a libmuxgl device buffer (zero-copy, __cuda_array_interface__), slack included:
+    CGP -> f64[S + pad, K*3], CLUST -> i32[C_total + pad, 1], STAT -> i32[4]"""
     import torch
 
     from . import muxgl
 
-    buf = muxgl.BUF_CGP if which == UNIT_CGP else muxgl.BUF_CLUST
+    buf = {UNIT_CGP: muxgl.BUF_CGP, UNIT_CLUST: muxgl.BUF_CLUST, UNIT_STAT: muxgl.BUF_STAT}[which]
     ptr, n = eng.fmx_buffer(buf)
+    row = {UNIT_CGP: eng.K * 3, UNIT_CLUST: 1, UNIT_STAT: 1}[which]
+    n_all = n + (muxgl.XCHG_PAD * row if which != UNIT_STAT else 0)
     typestr, dtype = ("<f8", torch.float64) if which == UNIT_CGP else ("<i4", torch.int32)
 
     class _Wrap:
-        __cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        __cuda_array_interface__ = {"shape": (int(n_all),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
     t = torch.as_tensor(_Wrap(), device=torch.device("cuda", device_index))
     assert t.dtype == dtype and t.data_ptr() == ptr
-    return t.view(eng.S, eng.K * 3) if which == UNIT_CGP else t.view(eng.C, 1)
+    return t if which == UNIT_STAT else t.view(-1, row)
 
 
-def run_em(eng, K, clust0, cell_ptr, entry_snp, doublet_prior=0.5, geno_error=0.1, max_iter=10, early_stop=True,
-           exchange=None, exchange_tensor=engine_exchange_tensor, log=None, ranges=None, timings=None, sync=None):
-    """EM loop of cmd_cram_freemux2.cpp:373-605 after muxgl_fmx_prepare.  Returns (cells[C] (complete on every rank),
-    per-iteration stats).  `eng` needs the fmx_* phase methods of muxgl.Engine; `exchange` a TorchExchange/NoExchange."""
-    import time
+def plan_ranges(C: int, S: int, world: int):
+    """((cell ranges, cells per rank), (SNP ranges, SNPs per rank)): equal slices, see shard.equal_ranges"""
+    return shard.equal_ranges(C, world), shard.equal_ranges(S, world)
 
+
+def load_rank(eng, p, c_range, s_range):
+    """Hand-over of one rank's share of the pileup p: row slab, column slab, entry likelihoods.  Returns the singlet
+    scores (llk0, llk2, nsnps, nreads) of the rank's own cells.  (A loader that never materialises the whole pileup on a
+    rank would cut the same two slabs at file level: .plp.gz rows are sorted by SNP, then droplet.)"""
+    c0, c1 = c_range
+    s0, s1 = s_range
+    sub = shard.take_cells(p, c0, c1)
+    eng.set_pileup(p.S, sub.cell_ptr, sub.entry_snp, sub.entry_rptr, sub.reads)
+    eng.fmx_set_column_slab(p.C, c0, s0, s1, *shard.take_snps(p, s0, s1))
+    return eng.fmx_prepare(p.af)
+
+
+def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early_stop=True, exchange=None,
+           exchange_tensor=engine_exchange_tensor, log=None, per=None, timings=None, sync=None, stream_ctx=None):
+    """EM loop of cmd_cram_freemux2.cpp:373-605 on a prepared engine.  One rank: a plain engine holding the whole
+    pileup.  Several ranks: an engine holding the rank's slabs (load_rank), `exchange` a TorchExchange and
+    per = (cells per rank, SNPs per rank) of the equal-slice plan the slabs were cut by.  clust0 spans the whole job.
+    Returns (records of ALL cells, complete on every rank; per-iteration stats).  stream_ctx: context manager that
+    makes the engine's stream torch's current one (device-ordered exchanges)."""
     ex = exchange or NoExchange()
-    C, S = eng.C, eng.S
     t_start = time.perf_counter()
-    # ranges = (cell ranges, SNP ranges) planned earlier (shard.cell_shards / snp_shards walk all entries)
-    c_ranges, s_ranges = ranges if ranges is not None else (shard.cell_shards(cell_ptr, ex.world),
-                                                            shard.snp_shards(entry_snp, S, ex.world))
-    c0, c1 = c_ranges[ex.rank]
-    s0, s1 = s_ranges[ex.rank]
-    eng.fmx_set_shard(c0, c1, s0, s1)
-    eng.fmx_set_clusters(K, np.ascontiguousarray(clust0, dtype=np.int32))  # :277-288, own SNP shard
-    t_cgp = exchange_tensor(eng, UNIT_CGP) if ex.world > 1 else None
-    t_clust = exchange_tensor(eng, UNIT_CLUST) if ex.world > 1 else None
+    eng.fmx_set_clusters(K, np.ascontiguousarray(clust0, dtype=np.int32))  # :277-288, own SNP range
+    multi = ex.world > 1
+    if multi:
+        per_c, per_s = per
+        t_cgp, t_clust = exchange_tensor(eng, UNIT_CGP), exchange_tensor(eng, UNIT_CLUST)
+        t_stat = exchange_tensor(eng, UNIT_STAT)
+    ordered = multi and ex.device_ordered
+    if ordered:
+        import torch
+
+        stat_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        stat_ready = torch.cuda.Event()
     history = []
     if sync:
         sync()
     t_loop = time.perf_counter()
-    for it in range(max_iter):
-        eng.fmx_iter_gp(doublet_prior, geno_error)
-        if ex.world > 1:
-            ex.allgather_rows(t_cgp, s_ranges)
-        eng.fmx_iter_estep(doublet_prior, geno_error)
-        _, stats = eng.fmx_iter_fetch(want_cells=False)  # three counters; the records are fetched once, below
-        if ex.world > 1:
-            ex.allgather_rows(t_clust, c_ranges)
-            import torch
-
-            st = torch.tensor(list(stats), dtype=torch.int64, device=t_clust.device)
-            ex.allreduce_sum(st)
-            stats = tuple(int(x) for x in st.tolist())
-        eng.fmx_iter_mstep()  # :516-517 + :590-596 for the own SNP shard
-        history.append(stats)
-        if log:
-            log(f"iter {it + 1}: {stats[0]} singlets, {C - stats[0] - stats[1]} doublets, {stats[1]} ambiguous, "
-                f"{stats[2]} changed")
-        if stats[2] == 0 and early_stop:  # :601-604
-            break
+    with (stream_ctx() if stream_ctx else contextlib.nullcontext()):
+        for it in range(max_iter):
+            eng.fmx_iter_gp(doublet_prior, geno_error)
+            if multi:
+                ex.allgather_equal(t_cgp, per_s)
+            eng.fmx_iter_estep(doublet_prior, geno_error)
+            if multi:
+                ex.allgather_equal(t_clust, per_c)
+                ex.allreduce_sum(t_stat)
+            if ordered:  # counters on their way to the host; the M-step is enqueued before anybody waits for them
+                stat_host.copy_(t_stat, non_blocking=True)
+                stat_ready.record()
+                eng.fmx_iter_mstep()
+                stat_ready.synchronize()
+                stats = tuple(int(x) for x in stat_host[:3].tolist())
+            else:
+                if multi:
+                    stats = tuple(int(x) for x in t_stat[:3].tolist())
+                else:
+                    _, stats = eng.fmx_iter_fetch(want_cells=False)  # three counters; the records travel once, below
+                eng.fmx_iter_mstep()  # :516-517 + :590-596 for the own SNP range
+            history.append(stats)
+            if log:
+                log(f"iter {it + 1}: {stats[0]} singlets, {eng.C_total - stats[0] - stats[1]} doublets, "
+                    f"{stats[1]} ambiguous, {stats[2]} changed")
+            if stats[2] == 0 and early_stop:  # :601-604
+                break
     if sync:
         sync()
     t_end = time.perf_counter()
     if timings is not None:  # `sync` (a barrier) makes these comparable across ranks
         timings.update(setup_s=t_loop - t_start, loop_s=t_end - t_loop, iterations=len(history))
-    cells, _ = eng.fmx_iter_fetch()
-    parts = ex.gather_objects((c0, c1, cells[c0:c1].tobytes()))
-    out = np.zeros(C, dtype=cells.dtype)
+    cells, _ = eng.fmx_iter_fetch()  # the rank's own cells
+    c0 = eng.cell_base
+    parts = ex.gather_objects((c0, c0 + len(cells), cells.tobytes()))
+    out = np.zeros(eng.C_total, dtype=cells.dtype)
     for b, e, raw in parts:
         out[b:e] = np.frombuffer(raw, dtype=cells.dtype)
     return out, history

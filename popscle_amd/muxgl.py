@@ -25,6 +25,10 @@ FLAG_FORCE_TILE_SWEEP = 1
 FLAG_FORCE_ROW_KERNEL = 2
 FLAG_FORCE_WAVE_KERNEL = 4
 FLAG_FORCE_BATCHED_GREEDY = 8
+FLAG_DEMUX_ONLY = 16
+FLAG_ASYNC_PHASES = 32
+MAX_DEVICES = 16
+XCHG_PAD = 64
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
 T_FMXOLD_PAIR, T_FMXOLD_VOTE = 9, 10
 T_COUNT = 16
@@ -52,7 +56,8 @@ assert FMX_CELL.itemsize == 12 * 4 + 10 * 8
 
 
 class _Config(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("flags", C.c_int32)]
+    _fields_ = [("device_id", C.c_int32), ("flags", C.c_int32), ("n_devices", C.c_int32),
+                ("device_ids", C.c_int32 * MAX_DEVICES)]
 
 
 class _DemuxParams(C.Structure):
@@ -86,6 +91,8 @@ SYMBOLS = {
     "muxgl_fmxold_get_signs": (C.c_int, [_VP, _VP]),
     "muxgl_fmxold_vote_init": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_double, _VP, _VP]),
     "muxgl_fmxold_vote_refine": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, _VP, _VP, _VP]),
+    "muxgl_fmx_set_column_slab": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP, _VP,
+                                            _VP, _VP]),
     "muxgl_fmx_set_shard": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "muxgl_fmx_iter_gp": (C.c_int, [_VP, C.POINTER(_FmxParams)]),
     "muxgl_fmx_iter_estep": (C.c_int, [_VP, C.POINTER(_FmxParams)]),
@@ -93,6 +100,7 @@ SYMBOLS = {
     "muxgl_fmx_iter_fetch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_buffer": (C.c_int, [_VP, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_int64)]),
     "muxgl_memcpy_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64]),
+    "muxgl_stream": (_VP, [_VP]),
     "muxgl_get_timing": (C.c_int, [_VP, _VP]),
 }
 
@@ -134,15 +142,28 @@ def _arr(a, dtype, name):
 
 
 class Engine:
-    """One muxgl handle = one GPU.  Methods mirror the C-ABI one to one."""
+    """One muxgl handle: one GPU (device_id an int) or a device group (a list of device ordinals; the same ordinal may
+    appear more than once = virtual ranks on one GPU).  Methods mirror the C-ABI one to one."""
 
-    def __init__(self, device_id: int = 0, flags: int = 0):
+    def __init__(self, device_id=0, flags: int = 0):
         self.lib = load_library()
         self.h = _VP()
-        cfg = _Config(device_id, flags)
+        cfg = _Config()
+        cfg.flags = flags
+        if isinstance(device_id, (list, tuple)):
+            if not 1 <= len(device_id) <= MAX_DEVICES:
+                raise ValueError("1..MAX_DEVICES device ordinals")
+            cfg.n_devices = len(device_id)
+            for i, d in enumerate(device_id):
+                cfg.device_ids[i] = int(d)
+            cfg.device_id = int(device_id[0])
+        else:
+            cfg.device_id = int(device_id)
         if self.lib.muxgl_create(C.byref(cfg), C.byref(self.h)) != 0:
             raise MuxglError(self.lib.muxgl_last_error(None).decode())
         self.C = self.S = self.nnz = self.R = 0
+        self.C_total = 0   # slabbed handle: cells of the whole job
+        self.cell_base = 0
         self.V = 0
         self.K = 0
         self.n_alpha = 0
@@ -182,6 +203,24 @@ class Engine:
         self._check(self.lib.muxgl_set_pileup(self.h, C_, int(S), nnz, R, _ptr(cell_ptr), _ptr(entry_snp),
                                                _ptr(entry_rptr), _ptr(reads)))
         self.C, self.S, self.nnz, self.R = C_, int(S), nnz, R
+        self.C_total, self.cell_base = C_, 0
+
+    def fmx_set_column_slab(self, C_total, c0, s0, s1, cell_ptr, entry_snp, entry_rptr, reads):
+        """attach the column slab (all C_total cells, entries with s0 <= SNP < s1) to a handle holding a row slab"""
+        cell_ptr = _arr(cell_ptr, np.int64, "cell_ptr")
+        entry_snp = _arr(entry_snp, np.int32, "entry_snp")
+        entry_rptr = _arr(entry_rptr, np.int64, "entry_rptr")
+        reads = _arr(reads, np.uint8, "reads")
+        if cell_ptr.size != int(C_total) + 1 or entry_rptr.size != entry_snp.size + 1:
+            raise ValueError("column slab: cell_ptr must have C_total+1 and entry_rptr nnz+1 elements")
+        self._check(self.lib.muxgl_fmx_set_column_slab(self.h, int(C_total), int(c0), int(s0), int(s1), entry_snp.size,
+                                                        reads.size, _ptr(cell_ptr), _ptr(entry_snp), _ptr(entry_rptr),
+                                                        _ptr(reads)))
+        self.C_total, self.cell_base = int(C_total), int(c0)
+
+    def stream(self):
+        """the hipStream_t (as an integer) the handle's kernels are enqueued on"""
+        return self.lib.muxgl_stream(self.h)
 
     # ---- demuxlet
     def demux_set_gp(self, gp, has_gp):
@@ -248,8 +287,8 @@ class Engine:
 
     def fmx_set_clusters(self, K, clust):
         clust = _arr(clust, np.int32, "clust")
-        if clust.shape != (self.C,):
-            raise ValueError("clust must be [C]")
+        if clust.shape != (self.C_total,):
+            raise ValueError("clust must be [C] (the whole job's cells for a slabbed handle)")
         self._check(self.lib.muxgl_fmx_set_clusters(self.h, int(K), _ptr(clust)))
         self.K = int(K)
 

@@ -40,6 +40,33 @@ def snp_shards(entry_snp, S: int, n: int):
     return split_by_weight(cov, n)
 
 
+def equal_ranges(n: int, world: int):
+    """world contiguous ranges of ceil(n / world) units (the last ones shorter or empty): slices of equal size can be
+    all-gathered in place, as ONE collective, on a buffer with a little slack behind it (muxgl.XCHG_PAD units).  Cells
+    arrive in barcode order and SNPs in genome order, neither sorted by depth, so equal counts are balanced in entries
+    to within a percent at the sizes where balance matters (relative spread ~ 0.7 / sqrt(units per rank))."""
+    per = -(-n // world) if world > 0 and n > 0 else 0
+    return [(min(r * per, n), min((r + 1) * per, n)) for r in range(world)], per
+
+
 def take_cells(p, c0: int, c1: int):
-    """the pileup of cells [c0, c1) (same SNP axis / GP tensor): what a demuxlet rank uploads"""
+    """the pileup of cells [c0, c1) (same SNP axis / GP tensor): a rank's row slab -- what a demuxlet rank uploads, and
+    what a freemuxlet rank runs its E-step on"""
     return p.subset_cells(np.arange(c0, c1, dtype=np.int64))
+
+
+def take_snps(p, s0: int, s1: int):
+    """(cell_ptr[C+1], entry_snp, entry_rptr, reads) of the entries with s0 <= SNP < s1, all cells, SNP ids unchanged: a
+    rank's column slab (muxgl_fmx_set_column_slab).  A cell's entries ascend by SNP, so the slab is a run per cell."""
+    from .synth import _ranges
+
+    keep = (p.entry_snp >= s0) & (p.entry_snp < s1)
+    cell_of = np.repeat(np.arange(p.C, dtype=np.int64), np.diff(p.cell_ptr))
+    cell_ptr = np.zeros(p.C + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cell_of[keep], minlength=p.C), out=cell_ptr[1:])
+    eidx = np.flatnonzero(keep)
+    rl = p.entry_rptr[eidx + 1] - p.entry_rptr[eidx]
+    entry_rptr = np.zeros(eidx.size + 1, dtype=np.int64)
+    np.cumsum(rl, out=entry_rptr[1:])
+    reads = p.reads[_ranges(p.entry_rptr[eidx], rl)]
+    return cell_ptr, np.ascontiguousarray(p.entry_snp[eidx]), entry_rptr, np.ascontiguousarray(reads)

@@ -39,7 +39,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_version(lib):
-    assert lib.muxgl_version() == 1
+    assert lib.muxgl_version() == 2
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -51,6 +51,7 @@ def test_struct_layouts_match_header(tmp_path):
         'printf("%zu %zu %zu %zu\\n", sizeof(muxgl_demux_cell), sizeof(muxgl_fmx_cell), sizeof(muxgl_demux_params), sizeof(muxgl_fmx_params));\n'
         'printf("%zu %zu %zu\\n", offsetof(muxgl_demux_cell, sngBestLLK), offsetof(muxgl_demux_cell, sngOnlyPP), offsetof(muxgl_fmx_cell, bestLLK));\n'
         'printf("%zu %zu\\n", offsetof(muxgl_demux_params, alpha), offsetof(muxgl_demux_params, doublet_prior));\n'
+        'printf("%zu %zu %zu\\n", sizeof(muxgl_config), offsetof(muxgl_config, n_devices), offsetof(muxgl_config, device_ids));\n'
         "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -65,6 +66,8 @@ def test_struct_layouts_match_header(tmp_path):
     assert vals[6] == muxgl.FMX_CELL.fields["bestLLK"][1]
     assert vals[7] == muxgl._DemuxParams.alpha.offset
     assert vals[8] == muxgl._DemuxParams.doublet_prior.offset
+    assert vals[9] == ctypes.sizeof(muxgl._Config)
+    assert vals[10] == muxgl._Config.n_devices.offset and vals[11] == muxgl._Config.device_ids.offset
 
 
 def test_oracle_and_library_records_share_a_layout():

@@ -31,6 +31,27 @@ def test_split_by_weight_properties():
     assert shard.split_by_weight([5, 5], 4)[-1][1] == 2
 
 
+def test_equal_ranges_and_slabs():
+    for n, w in ((10, 3), (3, 5), (0, 2), (64, 8), (65, 8)):
+        r, per = shard.equal_ranges(n, w)
+        assert len(r) == w and r[0][0] == 0 and r[-1][1] == n and per * w >= n and per * w < n + w
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1)) and all(e - b <= per for b, e in r)
+    p = synth.make_pileup(40, 300, 3, seed=5, mean_entries=50, min_entries=5, with_gp=False)
+    total = 0
+    for s0, s1 in shard.equal_ranges(p.S, 4)[0]:
+        cp, es, er, rd = shard.take_snps(p, s0, s1)
+        assert cp.size == p.C + 1 and cp[-1] == es.size and er[-1] == rd.size
+        assert ((es >= s0) & (es < s1)).all()
+        for c in (0, 7, 39):  # the slab's run of a cell is that cell's entries in the range, reads attached
+            m = (p.entry_snp[p.cell_ptr[c]:p.cell_ptr[c + 1]] >= s0) & (p.entry_snp[p.cell_ptr[c]:p.cell_ptr[c + 1]] < s1)
+            idx = np.arange(p.cell_ptr[c], p.cell_ptr[c + 1])[m]
+            assert np.array_equal(es[cp[c]:cp[c + 1]], p.entry_snp[idx])
+            want = np.concatenate([p.reads[p.entry_rptr[i]:p.entry_rptr[i + 1]] for i in idx]) if len(idx) else np.zeros(0, np.uint8)
+            assert np.array_equal(rd[er[cp[c]]:er[cp[c + 1]]], want)
+        total += es.size
+    assert total == p.nnz
+
+
 def test_cell_and_snp_shards_cover_everything():
     p = synth.make_pileup(50, 400, 3, seed=2, mean_entries=60, min_entries=5, with_gp=False)
     cr = shard.cell_shards(p.cell_ptr, 4)
@@ -54,51 +75,53 @@ class FakeDemuxEngine:
 
 
 class FakeFmxEngine:
-    """oracle-backed stand-in with muxgl.Engine's sharded-EM interface"""
+    """oracle-backed stand-in with the interface of a muxgl.Engine holding a rank's slabs (set_pileup + set_column_slab):
+    E-step on the row slab (own cells, every SNP), ordered merge on the column slab (every cell, own SNPs)"""
 
-    def __init__(self, p):
+    def __init__(self, p, c_range, s_range):
         self.p = p
-        self.C, self.S = p.C, p.S
-        self.e = ob.fmx_entry_pileup(p)
-
-    def fmx_set_shard(self, c0, c1, s0, s1):
-        self.c0, self.c1, self.s0, self.s1 = c0, c1, s0, s1
+        self.C_total, self.S = p.C, p.S
+        self.c0, self.c1 = c_range
+        self.s0, self.s1 = s_range
+        self.cell_base = self.c0
+        self.rows = shard.take_cells(p, self.c0, self.c1)
+        self.e_rows = ob.fmx_entry_pileup(self.rows)
+        cp, es, er, rd = shard.take_snps(p, self.s0, self.s1)
+        self.cols = synth.Pileup(p.C, p.S, cp, es, er, rd, p.af)
+        self.e_cols = ob.fmx_entry_pileup(self.cols)
 
     def _mstep(self):
-        full = ob.fmx_build_cluster_pileup(self.p, self.e, self.K, self.clust)
+        full = ob.fmx_build_cluster_pileup(self.cols, self.e_cols, self.K, self.clust[:self.C_total])
         self.cplp[:, self.s0:self.s1] = full[:, self.s0:self.s1]
 
     def fmx_set_clusters(self, K, clust):
+        assert clust.shape == (self.C_total,)
         self.K = K
-        self.clust = np.ascontiguousarray(clust, dtype=np.int32).copy()
-        self.cells = ob.fmx_init_cells(self.clust)
+        self.clust = np.concatenate([np.ascontiguousarray(clust, dtype=np.int32), np.full(64, -7, np.int32)])  # + slack
+        self.cells = ob.fmx_init_cells(self.clust[self.c0:self.c1].copy())
         self.cplp = np.zeros((K, self.S), dtype=ob.PLP)
-        self.cplp["gls"] = np.nan  # rows of foreign SNP shards must arrive through the exchange
-        self.xg = np.full((self.S, K * 9), np.nan)
+        self.cplp["gls"] = np.nan  # rows of foreign SNP ranges must arrive through the exchange
+        self.xg = np.full((self.S + 64, K * 9), np.nan)
+        self.stat = np.zeros(4, dtype=np.int32)  # the exchange aliases it, as it aliases the library's device buffer
         self._mstep()
 
     def fmx_iter_gp(self, dp, ge):
         self.xg[self.s0:self.s1] = self.cplp["gls"][:, self.s0:self.s1].transpose(1, 0, 2).reshape(-1, self.K * 9)
 
     def fmx_iter_estep(self, dp, ge):
-        assert not np.isnan(self.xg).any(), "a cluster-GP slice was not exchanged"
+        assert not np.isnan(self.xg[:self.S]).any(), "a cluster-GP slice was not exchanged"
         cp = np.zeros((self.K, self.S), dtype=ob.PLP)
-        cp["gls"] = self.xg.reshape(self.S, self.K, 9).transpose(1, 0, 2)
-        cells_r = np.arange(self.c0, self.c1)
-        sub = self.p.subset_cells(cells_r)
-        e_sub = self.e[self.p.cell_ptr[self.c0]:self.p.cell_ptr[self.c1]].copy()
-        cs = self.cells[self.c0:self.c1].copy()
-        ns, na, nch = ob.fmx_iterate(sub, e_sub, self.K, cp, cs, dp, ge)
-        self.cells[self.c0:self.c1] = cs
+        cp["gls"] = self.xg[:self.S].reshape(self.S, self.K, 9).transpose(1, 0, 2)
+        ns, na, nch = ob.fmx_iterate(self.rows, self.e_rows, self.K, cp, self.cells, dp, ge)
         self.clust[:] = -1000  # poison: every slice must come back through the exchange
-        self.clust[self.c0:self.c1] = cs["clust"]
-        self.stats = (ns, na, nch)
+        self.clust[self.c0:self.c1] = self.cells["clust"]
+        self.stat[:] = (ns, na, nch, 0)
 
     def fmx_iter_fetch(self, want_cells=True):
-        return (self.cells.copy() if want_cells else None), self.stats
+        return (self.cells.copy() if want_cells else None), tuple(int(x) for x in self.stat[:3])
 
     def fmx_iter_mstep(self):
-        assert (self.clust > -1000).all(), "an assignment slice was not exchanged"
+        assert (self.clust[:self.C_total] > -1000).all(), "an assignment slice was not exchanged"
         self.cplp["gls"] = np.nan
         self._mstep()
         self.xg[:] = np.nan
@@ -107,6 +130,8 @@ class FakeFmxEngine:
 def fake_exchange_tensor(eng, which):
     if which == freemuxlet.UNIT_CGP:
         return torch.from_numpy(eng.xg)
+    if which == freemuxlet.UNIT_STAT:
+        return torch.from_numpy(eng.stat)
     return torch.from_numpy(eng.clust).view(-1, 1)
 
 
@@ -130,11 +155,13 @@ def _worker(rank, world, port, kind, outdir):
     else:
         K = 3
         p = synth.make_pileup(60, 500, K, seed=44, mean_entries=120, min_entries=20, with_gp=False)
-        eng = FakeFmxEngine(p)
-        llk0, llk2, _, _ = ob.fmx_cell_scores(p, eng.e)
-        clust0 = ob.fmx_greedy_init(p, eng.e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
-        cells, hist = freemuxlet.run_em(eng, K, clust0, p.cell_ptr, p.entry_snp, 0.5, 0.1, max_iter=6, exchange=ex,
-                                        exchange_tensor=fake_exchange_tensor)
+        (c_ranges, per_c), (s_ranges, per_s) = freemuxlet.plan_ranges(p.C, p.S, world)
+        eng = FakeFmxEngine(p, c_ranges[rank], s_ranges[rank])
+        e = ob.fmx_entry_pileup(p)
+        llk0, llk2, _, _ = ob.fmx_cell_scores(p, e)
+        clust0 = ob.fmx_greedy_init(p, e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
+        cells, hist = freemuxlet.run_em(eng, K, clust0, 0.5, 0.1, max_iter=6, exchange=ex,
+                                        exchange_tensor=fake_exchange_tensor, per=(per_c, per_s))
         np.save(os.path.join(outdir, f"fmx_{rank}.npy"), cells)
         np.save(os.path.join(outdir, f"fmxhist_{rank}.npy"), np.array(hist))
     dist.barrier()

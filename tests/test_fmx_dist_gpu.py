@@ -1,6 +1,8 @@
-"""The N-process freemuxlet path on a 1-GPU box: two real processes (torch.distributed.run), each with its own muxgl
-handle on device 0, exchange the cluster-GP rows and the assignments through torch.distributed (gloo stages the device
-tensors; on a multi-GPU node the same code runs over RCCL) and must reproduce the single-process run bit for bit."""
+"""The N-process freemuxlet path of bench.py (--config 3) on a 1-GPU box: two and three real processes
+(torch.distributed.run), each with its own muxgl handle on device 0 holding the rank's row and column slabs, exchange the
+cluster-GP rows and the assignments through torch.distributed -- one in-place all_gather_into_tensor per exchange on the
+library's own device buffers (gloo stages them here; on a multi-GPU node the same calls run over RCCL, ordered against
+the library's stream) -- and must reproduce the single-process, whole-pileup run bit for bit."""
 import json
 import os
 import socket
@@ -13,8 +15,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROBE = os.path.join(ROOT, "tools", "bench_fmx.py")
-SHAPE = ["--no-cpu-baseline", "--cells", "400", "--snps", "3000", "--clusters", "5", "--mean-entries", "200", "--iters", "4", "--warmup", "0"]
+PROBE = os.path.join(ROOT, "bench.py")
+SHAPE = ["--config", "3", "--no-cpu-baseline", "--cells", "400", "--snps", "3000", "--clusters", "5", "--mean-entries", "200",
+         "--steps", "4", "--warmup", "0"]
 
 
 def free_port():

@@ -1,7 +1,9 @@
-"""GPU parity at the shapes of BASELINE.json configs[2] (demuxlet, 64 samples, six alphas, 200 k SNPs) and configs[3]
-(freemuxlet, 16 clusters, 100 k SNPs) with a reduced number of cells, so that the CPU oracle can still check a sample /
-the whole trajectory in seconds.  Cells are independent in demuxlet and enter freemuxlet's E-step independently, so the
-per-cell arithmetic exercised here is the full-size one (same V / K / A / SNP axis / entry density)."""
+"""GPU parity at the shapes of BASELINE.json's configs.  configs[2] (demuxlet, 100 k cells x 64 samples x 200 k SNPs, six
+alphas) and configs[4] (freemuxlet, 500 k cells x 500 k SNPs, K = 64, eight cell-sharded ranks) run at FULL size with
+size-independent properties and oracle samples; configs[2] and configs[3] (freemuxlet, 16 clusters, 100 k SNPs) also run
+with a reduced number of cells, where the CPU oracle checks the whole trajectory (cells are independent in demuxlet and
+enter freemuxlet's E-step independently, so the per-cell arithmetic is the full-size one: same V / K / A / SNP axis /
+entry density)."""
 import os
 
 import numpy as np
@@ -40,6 +42,117 @@ def test_config2_shape_demuxlet():
     t = p.truth
     sng = (cells["type"] == 0) & ~t["is_doublet"]
     assert sng.sum() > 0.9 * (~t["is_doublet"]).sum() and np.all(cells["sBest"][sng] == t["s1"][sng])
+
+
+def test_config2_full_size_demuxlet():
+    """BASELINE configs[2] at FULL size: 100 k cells x 64 samples x 200 k SNPs, six alphas (95 M entries; the 41 GB pG
+    table and the 19.6 GB result slabs of the wave path at size).  Size-independent properties: a sample of the cells run
+    alone gives bit-identical records (cells are independent and the work cut of a cell depends on the cell alone), the
+    alpha = 0.5 slice of their hypothesis tensor is symmetric, the oracle agrees on them, and the calls agree with the
+    simulated truth."""
+    cfg = synth.CONFIGS[2]
+    alphas = cfg["alphas"]
+    p = synth.make_pileup(cfg["C"], cfg["S"], cfg["V"], seed=synth.BASE_SEED + 2)
+    assert p.C == 100_000 and p.nnz > 90_000_000
+    with muxgl.Engine(0) as eng:
+        eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        eng.demux_set_gp(p.gp, p.has_gp)
+        cells = eng.demux_run(alphas, 0.5)
+        assert cells["valid"].all()
+        again = eng.demux_run(alphas, 0.5)
+        assert again.tobytes() == cells.tobytes()  # run to run
+        pick = np.sort(np.random.default_rng(0).choice(p.C, 24, replace=False))
+        longest = np.argsort(np.diff(p.cell_ptr))[-2:]  # and the two longest cells (walked in parts)
+        pick = np.unique(np.concatenate([pick, longest]))
+        sub = p.subset_cells(pick)
+        eng.set_pileup(sub.S, sub.cell_ptr, sub.entry_snp, sub.entry_rptr, sub.reads)
+        got, gfull = eng.demux_run(alphas, 0.5, want_full_ll=True)
+    assert got.tobytes() == cells[pick].tobytes()
+    n5 = alphas.index(0.5)
+    assert np.array_equal(gfull[..., n5], gfull[..., n5].transpose(0, 2, 1))
+    want, wfull = ob.demux(sub, alphas=alphas, full_ll=True, nthreads=NT)
+    rep = parity.compare_demux(cells[pick], want, alphas, want_full=wfull)
+    assert rep["max_abs_ll_diff"] < 1e-6
+    assert parity.compare_full_ll(gfull, wfull, cfg["V"], alphas) < 1e-6
+    t = p.truth
+    sng = (cells["type"] == 0) & ~t["is_doublet"]
+    assert sng.sum() > 0.9 * (~t["is_doublet"]).sum() and np.all(cells["sBest"][sng] == t["s1"][sng])
+    dbl = (cells["type"] == 1) & t["is_doublet"]
+    assert dbl.sum() > 0.9 * t["is_doublet"].sum()
+
+
+def test_config4_full_size_freemuxlet_eight_ranks():
+    """BASELINE configs[4] at FULL size -- freemuxlet --nsample 64, 500 k cells x 500 k SNPs (478 M entries), cell-sharded
+    over 8 ranks -- on one GPU: a device group of eight virtual ranks (device 0 named eight times), each with the slabs,
+    shard shapes and exchanges of the 8-GPU run (62 500 cells x 500 k SNPs row slab, 500 k cells x 62 500 SNPs column slab).
+    From a seeded --init-cluster start, two EM iterations must equal the one-device, whole-pileup run of the same job bit
+    for bit (records of all 500 k cells and counters); the oracle checks a sample: the cluster pileups of sampled SNPs
+    (ordered merge over ALL cells of those SNPs) and the E-step / scans / re-assignment of sampled cells."""
+    cfg = synth.CONFIGS[4]
+    K, S, C = cfg["V"], cfg["S"], cfg["C"]
+    p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + 4, with_gp=False)
+    assert p.C == 500_000 and p.nnz > 450_000_000
+    rng = np.random.default_rng(4)
+    clust0 = np.where(rng.random(C) < 0.9, p.truth["s1"], -1).astype(np.int32)
+    wrong = rng.random(C) < 0.02  # a few cells start in a random cluster
+    clust0[wrong] = rng.integers(0, K, int(wrong.sum()))
+    with muxgl.Engine([0] * 8) as g:
+        g.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        llk0, llk2, ns, nr = g.fmx_prepare(p.af)
+        g.fmx_set_clusters(K, clust0)
+        gls0, cnt0 = g.fmx_cluster_pileup()  # cluster pileups of the start, [K][S][9]
+        its = [g.fmx_iterate(0.5, 0.1) for _ in range(2)]
+    assert np.array_equal(ns, np.diff(p.cell_ptr).astype(np.int32))
+    # oracle, cluster pileups: the ordered clamped merge over all cells, for a sample of the SNPs
+    snps = np.sort(rng.choice(S, 300, replace=False))
+    keep = np.isin(p.entry_snp, snps)
+    cp, es, er, rd = _masked(p, keep)
+    q = synth.Pileup(C, S, cp, es, er, rd, p.af)
+    qe = ob.fmx_entry_pileup(q)
+    oc = ob.fmx_build_cluster_pileup(q, qe, K, clust0)
+    assert np.array_equal(cnt0[:, snps], np.stack([oc["nreads"], oc["nref"], oc["nalt"]], axis=-1)[:, snps])
+    assert np.allclose(gls0[:, snps], oc["gls"][:, snps], rtol=1e-10, atol=1e-300)
+    # oracle, E-step + scans + re-assignment of a sample of the cells against the device's own cluster pileups
+    cells_s = np.sort(rng.choice(C, 40, replace=False))
+    sub = p.subset_cells(cells_s)
+    se = ob.fmx_entry_pileup(sub)
+    o0, o2, _, _ = ob.fmx_cell_scores(sub, se)
+    assert np.max(np.abs(llk0[cells_s] - o0)) < 1e-7 and np.max(np.abs(llk2[cells_s] - o2)) < 1e-7
+    cplp = np.zeros((K, S), dtype=ob.PLP)
+    cplp["gls"] = gls0
+    cplp["nreads"], cplp["nref"], cplp["nalt"] = cnt0[..., 0], cnt0[..., 1], cnt0[..., 2]
+    del gls0, cnt0
+    ocells = ob.fmx_init_cells(np.ascontiguousarray(clust0[cells_s]))
+    ob.fmx_iterate(sub, se, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
+    rep = parity.compare_fmx(its[0][0][cells_s], ocells)
+    assert rep["max_abs_ll_diff"] < 1e-6
+    del cplp
+    # the one-device, whole-pileup run of the same job: bit-identical records and counters
+    with muxgl.Engine(0) as e:
+        e.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        w0, w2, _, _ = e.fmx_prepare(p.af)
+        assert np.array_equal(w0, llk0) and np.array_equal(w2, llk2)
+        e.fmx_set_clusters(K, clust0)
+        for it in range(2):
+            cells, stats = e.fmx_iterate(0.5, 0.1)
+            assert tuple(stats) == tuple(its[it][1]), (it, stats, its[it][1])
+            assert cells.tobytes() == its[it][0].tobytes()
+    ok = (cells["type"] == 0) & ~p.truth["is_doublet"]
+    assert ok.sum() > 0.9 * (~p.truth["is_doublet"]).sum() and (cells["clust"][ok] == p.truth["s1"][ok]).mean() > 0.99
+
+
+def _masked(p, keep):
+    """packed arrays of the entries selected by the boolean mask (all cells)"""
+    from popscle_amd.synth import _ranges
+
+    cell_of = np.repeat(np.arange(p.C, dtype=np.int64), np.diff(p.cell_ptr))
+    cp = np.zeros(p.C + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cell_of[keep], minlength=p.C), out=cp[1:])
+    eidx = np.flatnonzero(keep)
+    rl = p.entry_rptr[eidx + 1] - p.entry_rptr[eidx]
+    er = np.zeros(eidx.size + 1, dtype=np.int64)
+    np.cumsum(rl, out=er[1:])
+    return cp, np.ascontiguousarray(p.entry_snp[eidx]), er, np.ascontiguousarray(p.reads[_ranges(p.entry_rptr[eidx], rl)])
 
 
 def test_config3_shape_freemuxlet():
