@@ -142,7 +142,10 @@ def roofline(kernel, kern_s, abytes, ref_flops, issued_model_flops, config, scal
         issued = 64.0 * (2.0 * rec["fma_f64"] + rec.get("mul_f64", 0.0) + rec.get("add_f64", 0.0)) * k
         src = "pmc (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64, " + str(note) + ")"
         valu = rec.get("valu", 0.0) * k or None
-    t = max(kern_s, 1e-12)
+    if kern_s <= 0:
+        return {"bound": None, "kernel": kernel, "achieved": None, "peak": None, "unit": None, "frac": None,
+                "traffic": traffic, "note": "no kernel time was recorded"}
+    t = kern_s
     hbm = {"algorithmic_bytes": abytes, "algorithmic_equiv_GBps": abytes / t / 1e9,
            "traffic_bytes": traffic, "traffic_over_algorithmic": (traffic / abytes) if traffic else None,
            "achieved": (traffic / t / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -159,6 +162,34 @@ def roofline(kernel, kern_s, abytes, ref_flops, issued_model_flops, config, scal
 
 
 # ---- CPU baselines: the oracle (restatement of the reference's loops, kind "port") on this host's cores ---------------
+def usable_cores():
+    """cores this process may actually use: physical cores, capped by the affinity mask and by the cgroup CPU quota (a
+    container on a 128-core host with a quota of 16 CPUs runs 128 workers no faster than 16)"""
+    try:
+        import psutil
+
+        n = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:  # cgroup v2, then v1
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period)))
+        except Exception:
+            pass
+    return int(max(1, min(n, 256)))
+
+
 def _demux_shard_job(job):
     p, alphas = job
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -198,13 +229,7 @@ def cpu_baseline_demux(p, alphas, gpu_cells, budget_s=9.0):
     single = {"value": n1 * lls_per_cell / dt1, "unit": "LLs/s", "cores": 1, "entries_per_s": sub.nnz / dt1,
               "sample": f"{n1} of {p.C} cells ({int(sub.nnz)} entries), one thread, {dt1:.1f} s"}
     # (ii) N processes, one cell shard each
-    try:
-        import psutil
-
-        ncores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-    except Exception:
-        ncores = os.cpu_count() or 1
-    ncores = int(min(ncores, 256))
+    ncores = usable_cores()
     nn = int(min(p.C, max(ncores, ncores * budget_s / per_cell)))
     pickn = np.sort(rng.choice(p.C, nn, replace=False))
     shards = [p.subset_cells(pickn[i::ncores]) for i in range(ncores) if len(pickn[i::ncores])]
@@ -219,6 +244,8 @@ def cpu_baseline_demux(p, alphas, gpu_cells, budget_s=9.0):
                   f"processes over cell shards (oracle/muxgl_oracle.c; the reference's --group-list parallelisation), "
                   f"{dtn:.1f} s",
         "entries_per_s": ents / dtn, "single_thread": single,
+        # what the host really delivered: a quota or shared cores show up here, whatever the core count says
+        "speedup_over_single_thread": (ents / dtn) / single["entries_per_s"],
         "note": "LLs/s per core depends on entries per cell (LLs per cell are fixed, work is per entry): this workload "
                 "has ~950 entries per cell, BASELINE.md's reference timing (36.6 k LLs/s, 71 k entries/s per core) had 500",
         "parity_checked_cells": rep["cells"], "parity_max_abs_ll_diff": rep["max_abs_ll_diff"],

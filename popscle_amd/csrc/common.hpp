@@ -205,7 +205,7 @@ static inline void collect_timing(muxgl_handle* h) {
   for (int i = 0; i < MUXGL_T_COUNT; ++i) {
     if (h->ev_used[i]) {
       float t = 0.f;
-      if (hipEventElapsedTime(&t, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) h->ms[i] += t;
+      if (hipEventElapsedTime(&t, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) h->ms[i] = t;  // (idempotent)
     }
   }
 }

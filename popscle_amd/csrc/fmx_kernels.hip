@@ -1100,8 +1100,7 @@ int muxgl_fmx_iter_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_iter_estep");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmx_check_iter(h, p, "muxgl_fmx_iter_estep")) return 1;
-  if (!(h->flags & MUXGL_FLAG_ASYNC_PHASES)) clear_timing(h);
-  if (fmx_phase_estep(h, p)) return 1;
+  if (fmx_phase_estep(h, p)) return 1;  // (timings accumulate over the phases of an iteration: iter_gp clears them)
   return fmx_phase_done(h);
 }
 
@@ -1110,7 +1109,6 @@ int muxgl_fmx_iter_mstep(muxgl_handle* h) {
   MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_iter_mstep");
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->fmx_prepared || h->K < 1) MUXGL_FAIL(h, "muxgl_fmx_iter_mstep: no clusters set");
-  if (!(h->flags & MUXGL_FLAG_ASYNC_PHASES)) clear_timing(h);
   if (fmx_phase_mstep(h)) return 1;
   return fmx_phase_done(h);
 }

@@ -274,6 +274,7 @@ int group_demux_get_entry_pg(muxgl_handle* h, double* pg) {
   if (g->n_alpha < 1) MUXGL_FAIL(h, "muxgl_demux_get_entry_pg: no previous muxgl_demux_run");
   if (!pg) MUXGL_FAIL(h, "muxgl_demux_get_entry_pg: NULL output");
   return for_members(h, [&](int r) {
+    if (g->eb[(size_t)r + 1] == g->eb[(size_t)r]) return 0;  // a member without entries has nothing to report
     return muxgl_demux_get_entry_pg(g->m[(size_t)r], pg + (size_t)g->eb[(size_t)r] * g->n_alpha * 9);
   });
 }
