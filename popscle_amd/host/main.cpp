@@ -25,6 +25,8 @@ struct CommonFlags {
   std::string plpPrefix, outPrefix, groupList;
   LoadOptions lo;
   int32_t device = 0;
+  std::string devices;  // --devices 0,1,2,...: a device group (muxgl_config.n_devices), the in-process counterpart of
+                        // running one popscle per --group-list chunk (README.md:168)
   void add(Args& a) {
     a.add_string("plp", &plpPrefix);
     a.add_string("out", &outPrefix);
@@ -35,7 +37,30 @@ struct CommonFlags {
     a.add_int("min-umi", &lo.minUMI);
     a.add_int("min-snp", &lo.minSNP);
     a.add_int("device", &device);
+    a.add_string("devices", &devices);
   }
+  // the handle the command computes on: one device, or the group named by --devices
+  muxgl_config config(int32_t flags) const {
+    muxgl_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.device_id = device;
+    cfg.flags = flags;
+    if (!devices.empty()) {
+      size_t pos = 0;
+      while (pos <= devices.size()) {
+        const size_t comma = std::min(devices.find(',', pos), devices.size());
+        const std::string tok = devices.substr(pos, comma - pos);
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos)
+          fatal("--devices expects a comma-separated list of device ordinals, got '%s'", devices.c_str());
+        if (cfg.n_devices >= MUXGL_MAX_DEVICES) fatal("--devices names more than %d devices", MUXGL_MAX_DEVICES);
+        cfg.device_ids[cfg.n_devices++] = atoi(tok.c_str());
+        pos = comma + 1;
+      }
+      cfg.device_id = cfg.device_ids[0];
+    }
+    return cfg;
+  }
+  bool grouped() const { return devices.find(',') != std::string::npos; }
 };
 
 void upload(muxgl_handle* h, const Pileup& p) {
@@ -115,7 +140,7 @@ int cmd_demuxlet(int argc, char** argv) {
   load_from_plp(cf.plpPrefix, cf.lo, &vr, p);
   tm.lap("demuxlet: load");
 
-  muxgl_config cfg{cf.device, 0};
+  muxgl_config cfg = cf.config(MUXGL_FLAG_DEMUX_ONLY);  // cells are independent: a group needs no column slabs
   muxgl_handle* h = nullptr;
   if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
   tm.lap("demuxlet: device init");
@@ -295,7 +320,7 @@ int cmd_freemuxlet(int argc, char** argv) {
     }
   }
 
-  muxgl_config cfg{cf.device, 0};
+  muxgl_config cfg = cf.config(0);
   muxgl_handle* h = nullptr;
   if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
   upload(h, p);
@@ -334,9 +359,22 @@ int cmd_freemuxlet(int argc, char** argv) {
       else clusts[(size_t)i] = it->second;
     }
     if (nmiss > 0) notice("WARNING: %d of %d droplets do not have initial cluster assignment", nmiss, (int)C);
-  } else {  // greedy clustering, :217-261
+  } else if (!cf.grouped()) {  // greedy clustering, :217-261
     check(h, muxgl_fmx_greedy_init(h, K, scores.data(), fracInitClust, singletScoreThres, clusts.data()),
           "muxgl_fmx_greedy_init");
+  } else {
+    // The greedy procedure is sequential over all cells, each step scoring one cell against the cluster pileups of
+    // all earlier ones: it runs on ONE device holding the whole pileup (the group's first), then the group takes over.
+    muxgl_config one;
+    memset(&one, 0, sizeof(one));
+    one.device_id = cfg.device_ids[0];
+    muxgl_handle* g = nullptr;
+    if (muxgl_create(&one, &g) != 0) fatal("%s", muxgl_last_error(nullptr));
+    upload(g, p);
+    check(g, muxgl_fmx_prepare(g, af.data(), nullptr, nullptr, nullptr, nullptr), "muxgl_fmx_prepare");
+    check(g, muxgl_fmx_greedy_init(g, K, scores.data(), fracInitClust, singletScoreThres, clusts.data()),
+          "muxgl_fmx_greedy_init");
+    muxgl_destroy(g);
   }
   tmr.lap("freemuxlet: .lmix + initial clusters");
   notice("Finished assigning initial identity of the cluster..");
@@ -452,7 +490,8 @@ int cmd_freemuxlet_old(int argc, char** argv) {
     }
   }
 
-  muxgl_config cfg{cf.device, 0};
+  if (cf.grouped()) fatal("freemuxlet-old: --devices is not supported (its pairwise matrix and votes run on one device)");
+  muxgl_config cfg = cf.config(0);
   muxgl_handle* h = nullptr;
   if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
   upload(h, p);

@@ -200,3 +200,41 @@ def test_cli_errors(tmp_path):
     r = subprocess.run([BIN, "demuxlet", "--plp", str(tmp_path / "nowhere"), "--vcf", str(tmp_path / "no.vcf"), "--out",
                         str(tmp_path / "o")], capture_output=True, text=True)
     assert r.returncode != 0 and "FATAL ERROR" in r.stderr
+
+
+def _read(path):
+    if path.endswith(".gz"):
+        with gzip.open(path, "rt") as f:
+            return [ln for ln in f.readlines() if not ln.startswith("##fileDate")]  # wall-clock header line
+    return open(path).readlines()
+
+
+def test_cli_devices_flag_reproduces_the_one_device_outputs(tmp_path):
+    """--devices a,b,... (muxgl_config.n_devices; here the same GPU named several times) must write the same files,
+    byte for byte, as the one-device run: demuxlet's .best, freemuxlet's .lmix / .clust1.samples.gz / .clust1.vcf.gz --
+    with the greedy initial clustering made on the group's first device and the EM on the group."""
+    p = synth.make_pileup(90, 900, 5, seed=21, mean_entries=160, min_entries=20)
+    prefix = str(tmp_path / "plp")
+    plpio.write_plp(prefix, p, seed=21)
+    vcf = str(tmp_path / "g.vcf.gz")
+    plpio.write_vcf(vcf, p, p.truth["G"].astype(np.int64), missing_frac=0.02)
+    outs = {}
+    for tag, extra in (("one", []), ("grp", ["--devices", "0,0,0"])):
+        o = str(tmp_path / f"d_{tag}")
+        r = subprocess.run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", o] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        f = str(tmp_path / f"f_{tag}")
+        r = subprocess.run([BIN, "freemuxlet", "--plp", prefix, "--nsample", "5", "--out", f, "--seed", "1"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = (o, f)
+    assert _read(outs["one"][0] + ".best") == _read(outs["grp"][0] + ".best")
+    for ext in (".lmix", ".clust1.samples.gz", ".clust1.vcf.gz"):
+        assert _read(outs["one"][1] + ext) == _read(outs["grp"][1] + ext), ext
+    r = subprocess.run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--out", str(tmp_path / "x"), "--devices", "0,x"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "--devices" in r.stderr
+    r = subprocess.run([BIN, "freemuxlet-old", "--plp", prefix, "--nsample", "3", "--out", str(tmp_path / "y"), "--devices",
+                        "0,0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--devices" in r.stderr
