@@ -232,7 +232,8 @@ def test_cli_devices_flag_reproduces_the_one_device_outputs(tmp_path):
     assert _read(outs["one"][0] + ".best") == _read(outs["grp"][0] + ".best")
     for ext in (".lmix", ".clust1.samples.gz", ".clust1.vcf.gz"):
         assert _read(outs["one"][1] + ext) == _read(outs["grp"][1] + ext), ext
-    r = subprocess.run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--out", str(tmp_path / "x"), "--devices", "0,x"],
+    r = subprocess.run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", str(tmp_path / "x"), "--devices",
+                        "0,x"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "--devices" in r.stderr
     r = subprocess.run([BIN, "freemuxlet-old", "--plp", prefix, "--nsample", "3", "--out", str(tmp_path / "y"), "--devices",
