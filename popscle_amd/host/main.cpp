@@ -662,6 +662,7 @@ int cmd_dump_plp(int argc, char** argv) {
   CommonFlags cf;
   VcfReader vr;
   std::vector<std::string> smIDs;
+  std::string smList;
   Args a;
   cf.add(a);
   a.add_string("vcf", &vr.path);
@@ -672,11 +673,16 @@ int cmd_dump_plp(int argc, char** argv) {
   a.add_int("min-mac", &vr.vfilt.minMAC);
   a.add_double("min-callrate", &vr.vfilt.minCallRate);
   a.add_multi_string("sm", &smIDs);
+  a.add_string("sm-list", &smList);
   a.parse(argc, argv);
   if (cf.plpPrefix.empty() || cf.outPrefix.empty()) fatal("Missing required option(s) : --plp, --out");
   Pileup p;
   if (!vr.path.empty()) {
     vr.wanted = smIDs;
+    if (!smList.empty()) {
+      TsvReader t(smList);
+      while (t.read_line() > 0) vr.wanted.push_back(t.str_field_at(0));
+    }
     vr.init();
     load_from_plp(cf.plpPrefix, cf.lo, &vr, p);
   } else {

@@ -27,7 +27,7 @@ class VcfReader {
   std::string path;
   VcfFilter vfilt;
   std::vector<std::string> wanted;  // --sm / --sm-list; empty = all
-  std::vector<std::string> sample_ids;  // selected, in VCF column order
+  std::vector<std::string> sample_ids;  // selected: VCF column order, or sorted ID order when a subset was requested
   bool eof = false;
 
   // cursor
@@ -49,11 +49,24 @@ class VcfReader {
         }
       } else if (line.rfind("#CHROM", 0) == 0) {
         std::vector<std::string> f = split_tab(line);
-        std::set<std::string> want(wanted.begin(), wanted.end());
-        for (size_t i = 9; i < f.size(); ++i) {
-          if (want.empty() || want.count(f[i])) {
+        if (wanted.empty()) {
+          for (size_t i = 9; i < f.size(); ++i) {
             sm_cols_.push_back((int)(i - 9));
             sample_ids.push_back(f[i]);
+          }
+        } else {
+          // bcf_filtered_reader.cpp:105-122: the requested IDs are walked as a std::set, i.e. in sorted order, and that
+          // order -- not the VCF's column order -- numbers the samples (it decides ties in the best/next scans and which
+          // sample is "sample 0", whose GP factor every singlet carries, cmd_cram_demuxlet.cpp:806); an ID the header
+          // does not have is an error there (:110-111), not a warning.
+          std::set<std::string> want(wanted.begin(), wanted.end());
+          for (const std::string& id : want) {
+            size_t col = 0;
+            for (size_t i = 9; i < f.size() && !col; ++i)
+              if (f[i] == id) col = i;
+            if (!col) fatal("Cannot find sample ID %s from the BCF file", id.c_str());
+            sm_cols_.push_back((int)(col - 9));
+            sample_ids.push_back(id);
           }
         }
         n_vcf_samples_ = f.size() > 9 ? (int)f.size() - 9 : 0;
@@ -64,9 +77,6 @@ class VcfReader {
       }
     }
     if (!have_hdr) fatal("%s: no #CHROM header line", path.c_str());
-    if (!want_all() && sample_ids.size() != wanted.size())
-      notice("WARNING: only %zu of %zu requested sample IDs were found in %s", sample_ids.size(), wanted.size(),
-             path.c_str());
     if (sample_ids.empty()) fatal("%s: no sample to compare with", path.c_str());
   }
   int nsamples() const { return (int)sample_ids.size(); }

@@ -293,3 +293,83 @@ def test_loader_bgzf_input(exe, tmp_path):
     r = subprocess.run([exe, "dump-plp", "--plp", bprefix, "--out", str(tmp_path / "x.bin")], capture_output=True,
                        text=True)
     assert r.returncode != 0
+
+
+def _write_tiny(tmp_path, header_ids, rows, fmt):
+    """PLP files with three SNPs at 1:1000/1010/1020 and a hand-written VCF with the given sample columns"""
+    p = synth.make_pileup(4, 3, 3, seed=1, mean_entries=3, min_entries=3)
+    prefix = str(tmp_path / "plp")
+    plpio.write_plp(prefix, p, seed=1)
+    vcf = str(tmp_path / "h.vcf")
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=1>\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(header_ids) + "\n")
+        for i, cols in enumerate(rows):
+            f.write(f"1\t{1000 + 10 * i}\t.\tA\tG\t.\tPASS\t.\t{fmt}\t" + "\t".join(cols) + "\n")
+    return prefix, vcf
+
+
+def _mix(gp32, err=0.1):
+    """sc_drop_seq.cpp:287-315 on float GPs: promote, avgGP with the 1e-10 pseudo-count, (1-err) gp + err avg"""
+    gp = gp32.astype(np.float64)
+    avg = np.full(3, 1e-10)
+    for v in range(gp.shape[0]):
+        avg += gp[v]
+    avg /= (avg[0] + avg[1]) + avg[2]
+    return (1 - err) * gp + err * avg
+
+
+def test_vcf_rules_against_hand_derived_rows(exe, tmp_path):
+    """A third check of the VCF -> GP rules, independent of tests/pyplp.py: rows derived by hand from
+    bcf_filtered_reader.cpp:385-408 (GT: one-hot, missing genotype -> HWE from AC/AN with pseudo-counts, all through
+    float) and :412-455 (GP: per-sample normalisation in float; gt_error = 0 as load_from_plp passes it,
+    sc_drop_seq.cpp:285), followed by the mixing of sc_drop_seq.cpp:287-315."""
+    f32 = np.float32
+    # GT: S_a 0/0, S_b 0/1, S_c missing -> acs = (3, 1), an = 4, nalleles = 2:
+    #   (0,0): 1 * (3+.5)/5 * (3+.5)/5   (1,0): 2 * (1+.5)/5 * (3+.5)/5   (1,1): 1 * (1+.5)/5 * (1+.5)/5
+    prefix, vcf = _write_tiny(tmp_path, ["A", "B", "C"], [["0/0", "0/1", "./."], ["1/1", "1|0", "0/0"], ["0/1", "0/1", "1/1"]],
+                              "GT")
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--vcf", vcf, "--field", "GT")
+    miss = np.array([f32(1.0 * (3 + 0.5) / 5.0 * (3 + 0.5) / 5.0), f32(2.0 * (1 + 0.5) / 5.0 * (3 + 0.5) / 5.0),
+                     f32(1.0 * (1 + 0.5) / 5.0 * (1 + 0.5) / 5.0)], dtype=f32)
+    want0 = _mix(np.array([[1, 0, 0], [0, 1, 0], miss], dtype=f32))
+    want1 = _mix(np.array([[0, 0, 1], [0, 1, 0], [1, 0, 0]], dtype=f32))
+    assert got["sample_ids"] == ["A", "B", "C"] and got["has_gp"].tolist() == [1, 1, 1]
+    assert np.array_equal(got["gp"][0], want0) and np.array_equal(got["gp"][1], want1)
+    # GP: float arithmetic, each sample divided by its own float sum
+    prefix, vcf = _write_tiny(tmp_path, ["A", "B", "C"],
+                              [["0/0:0.8,0.15,0.05", "0/1:0.1,0.6,0.3", "0/1:0.2,0.2,0.2"],
+                               ["0/1:0.5,0.5,0", "1/1:0,0.25,0.75", "0/0:1,0,0"],
+                               ["0/1:0.3,0.4,0.3", "0/1:0.3,0.4,0.3", "1/1:0.1,0.1,0.8"]], "GT:GP")
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--vcf", vcf, "--field", "GP")
+
+    def norm(a, b, c):
+        a, b, c = f32(a), f32(b), f32(c)
+        s = f32(f32(f32(0) + a) + b) + c  # sumgp = 0; sumgp += gps[j]
+        return [a / s, b / s, c / s]
+
+    want0 = _mix(np.array([norm(0.8, 0.15, 0.05), norm(0.1, 0.6, 0.3), norm(0.2, 0.2, 0.2)], dtype=f32))
+    assert np.array_equal(got["gp"][0], want0)
+    assert np.allclose(got["gp"][0][2], 0.9 / 3 + 0.1 * want0.mean(axis=0), atol=0.05)  # sanity of the hand row itself
+
+
+def test_vcf_sample_subset_is_numbered_in_sorted_id_order(exe, tmp_path):
+    """--sm / --sm-list: bcf_filtered_reader.cpp:105-122 walks the requested IDs as a std::set, so the samples are
+    numbered in SORTED ID order whatever the order of the VCF's columns or of the flags; an unknown ID is an error."""
+    rows = [["0/0", "0/1", "1/1", "0/1"], ["1/1", "0/0", "0/1", "0/0"], ["0/1", "1/1", "0/0", "1/1"]]
+    prefix, vcf = _write_tiny(tmp_path, ["zeta", "alpha", "mid", "beta"], rows, "GT")
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--vcf", vcf, "--field", "GT", "--sm", "zeta", "--sm", "beta",
+               "--min-mac", "0", "--min-callrate", "0")
+    assert got["sample_ids"] == ["beta", "zeta"] and got["nv"] == 2
+    onehot = {"0/0": [1, 0, 0], "0/1": [0, 1, 0], "1/1": [0, 0, 1]}
+    for s in range(3):
+        want = _mix(np.array([onehot[rows[s][3]], onehot[rows[s][0]]], dtype=np.float32))  # beta = column 3, zeta = column 0
+        assert np.array_equal(got["gp"][s], want), s
+    lst = tmp_path / "ids.txt"
+    lst.write_text("mid\nalpha\n")
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--vcf", vcf, "--field", "GT", "--sm-list", str(lst), "--min-mac", "0",
+               "--min-callrate", "0")
+    assert got["sample_ids"] == ["alpha", "mid"]
+    r = subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", str(tmp_path / "x.bin"), "--vcf", vcf, "--field", "GT",
+                        "--sm", "nobody"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Cannot find sample ID nobody" in r.stderr
