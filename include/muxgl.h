@@ -55,6 +55,9 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
                                       handle's stream (muxgl_stream); muxgl_fmx_iter_fetch and every other call still
                                       return with the stream drained.  For callers that order their own collectives
                                       against that stream (popscle_amd/freemuxlet.py) */
+#define MUXGL_FLAG_NO_LINEAR_ENTRIES 64 /* sweep every entry through the general three-term form, also those whose
+                                          likelihoods are linear in the genotypes (one usable read) and would take the
+                                          two-term form (lets tests compare the two) */
 
 typedef struct muxgl_handle muxgl_handle;
 

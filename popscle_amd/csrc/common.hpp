@@ -69,6 +69,11 @@ struct muxgl_handle {
   uint8_t* d_reads = nullptr;
   int32_t* d_entry_cell = nullptr;  // cell id of each entry (for SNP-major views)
   quad_entry* d_qent = nullptr;     // [nnz] packed records of the quad kernel (built when R < 2^32)
+  // One bit per entry: the entry has at most one usable read, so its likelihoods are LINEAR in the two genotypes
+  // (demuxlet: pG[l][m] = A + Bl*l + Bm*m, cmd_cram_demuxlet.cpp:673-685 for a single factor) and a pair hypothesis is a
+  // two-term form in the samples' moments (sum g, sum l*g) instead of a three-term one -- see demux_wave.hip.
+  uint32_t* d_lin = nullptr;        // [ceil(nnz/32)] demuxlet
+  uint32_t* d_flin = nullptr;       // [ceil(nnz/32)] freemuxlet: additionally, no clamp fired (checked on the values)
   int64_t max_cell_entries = 0;
 
   // Phred LUT: [0..127] = phred2Err, [128..255] = phred2Mat (bq is 7 bits in the packed read byte)
@@ -290,6 +295,7 @@ int demux_gp_neutral_rows(muxgl_handle* h, int V);  // d_gp rows of markers with
 void demux_row_release(muxgl_row_state** st);
 int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
 int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)
+int plan_build_lin(muxgl_handle* h);        // d_lin (plan_kernels.hip)
 int plan_build_snp_major(muxgl_handle* h);  // d_entry_cell, d_snp_ptr, d_snp_entry, d_snp_cell (plan_kernels.hip)
 
 // handle plumbing shared by muxgl_api.hip and muxgl_group.hip

@@ -55,11 +55,41 @@ struct wave_blk {
   int32_t blk, nblk2;    // slab of this launch, slabs per cell
 };
 
+// Entries with at most one usable read (bit set in `lin`, plan_kernels.hip).  A single factor pR*(1-p) + pA*p with
+// p = l/2 + (m-l)*alpha/2 (cmd_cram_demuxlet.cpp:673,685) is LINEAR in the two genotypes, and so is everything the tail
+// (:703-725) makes of it: pG[l][m] = A + Bl*l + Bm*m.  Then
+//     sum_{l,m} g_j[l] g_k[m] pG[l][m] = s_k (A s_j + Bl E_j) + E_k (Bm s_j),     s = sum_l g[l],  E = g[1] + 2 g[2]:
+// the partner's two moments rotate instead of its triple (4 DPP moves instead of 6) and a hypothesis costs a multiply, an
+// FMA and the product update instead of a multiply, two FMAs and the update.  Three quarters of the entries of a typical
+// pileup are such entries.  (A, Bl, Bm are read off the table: pG[0][0], pG[1][0] - pG[0][0], pG[0][1] - pG[0][0].)
+// Two sweep bodies in one kernel do not fit the register file next to 64 accumulators per lane, so the two kinds of
+// entries get a launch each -- EM_LINEAR walks the flagged entries of a cell and writes, EM_GENERAL walks the others and
+// ADDS its log-likelihoods to what is there -- EM_ALL is the single launch without the distinction.  The walk is a
+// scalar scan of the bit set, so an entry of the other kind costs a few scalar instructions and no loads.
+enum { EM_ALL = 0, EM_LINEAR = 1, EM_GENERAL = 2 };
+
+// first entry >= e in [e, e1) of the kind the launch sweeps (wave-uniform: scalar loads and bit scans)
+template <int EM>
+__device__ __forceinline__ int64_t wave_next_entry(const uint32_t* __restrict__ lin, int64_t e, int64_t e1) {
+  if (EM == EM_ALL) return e;
+  while (e < e1) {
+    uint32_t w = lin[e >> 5];
+    if (EM == EM_GENERAL) w = ~w;
+    w >>= (uint32_t)(e & 31);
+    if (w) {
+      e += __builtin_ctz(w);
+      return e < e1 ? e : e1;
+    }
+    e = (e | 31) + 1;
+  }
+  return e1;
+}
+
 // NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise (64 with CROSS).  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
-template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false>
+template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL>
 __global__ void __launch_bounds__(64, 2)
     demux_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
-                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const uint32_t* __restrict__ lin,
                       const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel,
                       wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_items) return;
@@ -83,7 +113,7 @@ __global__ void __launch_bounds__(64, 2)
   }
 
   // software pipeline: triples of the next marker with genotypes are loaded while the current one is swept
-  int64_t e = e0;
+  int64_t e = wave_next_entry<EM>(lin, e0, e1);
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
   double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
   if (e < e1 && live) {
@@ -100,7 +130,7 @@ __global__ void __launch_bounds__(64, 2)
     const int32_t scur = entry_snp[ecur];
     const double g0 = ng0, g1 = ng1, g2 = ng2;
     const double p0 = np0, p1 = np1, p2 = np2;
-    ++e;
+    e = wave_next_entry<EM>(lin, ecur + 1, e1);
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
     if (e < e1 && live) {
       const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
@@ -124,21 +154,33 @@ __global__ void __launch_bounds__(64, 2)
       const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
       accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
     }
-    const double u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
-    const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
-    const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
-    double r0 = g0, r1 = g1, r2 = g2;
-    if (CROSS) {  // one lane ahead: the first rotation then brings sample kbase + j itself
-      r0 = __shfl(p0, (j + 1) & 63, 64);
-      r1 = __shfl(p1, (j + 1) & 63, 64);
-      r2 = __shfl(p2, (j + 1) & 63, 64);
-    }
+    if (EM == EM_LINEAR) {
+      const double sm = (g0 + g1) + g2, Em = fma(2.0, g2, g1);
+      const double u0 = fma(q3 - q0, Em, q0 * sm), u1 = (q1 - q0) * sm;
+      double r0 = sm, r1 = Em;
 #pragma unroll
-    for (int t = 0; t < NSHIFT; ++t) {
-      r0 = dpp_wror1(r0);
-      r1 = dpp_wror1(r1);
-      r2 = dpp_wror1(r2);
-      acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :738-746 as a product
+      for (int t = 0; t < NSHIFT; ++t) {
+        r0 = dpp_wror1(r0);
+        r1 = dpp_wror1(r1);
+        acc[t] *= fma(r0, u0, r1 * u1);
+      }
+    } else {
+      const double u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
+      const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
+      const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
+      double r0 = g0, r1 = g1, r2 = g2;
+      if (CROSS) {  // one lane ahead: the first rotation then brings sample kbase + j itself
+        r0 = __shfl(p0, (j + 1) & 63, 64);
+        r1 = __shfl(p1, (j + 1) & 63, 64);
+        r2 = __shfl(p2, (j + 1) & 63, 64);
+      }
+#pragma unroll
+      for (int t = 0; t < NSHIFT; ++t) {
+        r0 = dpp_wror1(r0);
+        r1 = dpp_wror1(r1);
+        r2 = dpp_wror1(r2);
+        acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :738-746 as a product
+      }
     }
     if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
       cnt = 0;
@@ -156,17 +198,25 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
   for (int t = 0; t < NSHIFT; ++t) {
     kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
-    const double v = prodacc_log(acc[t], ex[t]);
+    double v = prodacc_log(acc[t], ex[t]);
     if (n_sel > 0) {
       if (NSHIFT >= 63) {
-        out[((size_t)n_sel * 64 + t) * 64 + j] = v;
+        double* o = out + ((size_t)n_sel * 64 + t) * 64 + j;
+        if (EM == EM_GENERAL) v += *o;  // on top of the linear entries' launch
+        *o = v;
       } else if (t < 31 || j > kk) {  // step 32 of 64 lanes meets every unordered pair twice: one writer
-        out[((size_t)n_sel * 64 + t) * 64 + j] = v;
+        double* o = out + ((size_t)n_sel * 64 + t) * 64 + j;
+        if (EM == EM_GENERAL) v += *o;
+        *o = v;
         out[((size_t)n_sel * 64 + (62 - t)) * 64 + kk] = v;
       }
     }
   }
-  if (WITH_SINGLET) out[j] = prodacc_log(accS, exS);  // llw[c][0][0][j]
+  if (WITH_SINGLET) {
+    double v = prodacc_log(accS, exS);  // llw[c][0][0][j]
+    if (EM == EM_GENERAL) v += out[j];
+    out[j] = v;
+  }
 }
 
 // Several non-symmetric alphas in one launch.  The partner rotation (six DPP moves per step) does not depend on alpha,
@@ -176,12 +226,13 @@ __global__ void __launch_bounds__(64, 2)
 struct wave_sel {
   int32_t n[4];
 };
-template <int NA, int NS, bool WITH_SINGLET, bool CROSS = false>
+template <int NA, int NS, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL>
 __global__ void __launch_bounds__(64, 2)
     demux_wave_multi_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                             const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
-                            const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
-                            wave_sel sel, int s0, wave_blk wb, double* __restrict__ ll) {
+                            const uint32_t* __restrict__ lin, const double* __restrict__ gp,
+                            const uint8_t* __restrict__ has_gp, int V, int nAlpha, wave_sel sel, int s0, wave_blk wb,
+                            double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
   const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
@@ -205,7 +256,7 @@ __global__ void __launch_bounds__(64, 2)
     exs[t][j] = 0;
   }
 
-  int64_t e = e0;
+  int64_t e = wave_next_entry<EM>(lin, e0, e1);
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
   double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
   if (e < e1 && live) {
@@ -222,7 +273,7 @@ __global__ void __launch_bounds__(64, 2)
     const int32_t scur = entry_snp[ecur];
     const double g0 = ng0, g1 = ng1, g2 = ng2;
     const double p0 = np0, p1 = np1, p2 = np2;
-    ++e;
+    e = wave_next_entry<EM>(lin, ecur + 1, e1);
     ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
     if (e < e1 && live) {
       const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
@@ -243,27 +294,50 @@ __global__ void __launch_bounds__(64, 2)
       const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
       accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
     }
-    double u[NA][3];
+    if (EM == EM_LINEAR) {  // two moments instead of three genotypes, see EM_LINEAR above
+      const double sm = (g0 + g1) + g2, Em = fma(2.0, g2, g1);
+      double u[NA][2];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {  // wave-uniform likelihoods through the scalar cache
-      const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
-      u[a][0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
-      u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
-      u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
-    }
-    double r0 = CROSS ? p0 : g0, r1 = CROSS ? p1 : g1, r2 = CROSS ? p2 : g2;
-    if (s0 || CROSS) {
-      r0 = __shfl(r0, src, 64);
-      r1 = __shfl(r1, src, 64);
-      r2 = __shfl(r2, src, 64);
-    }
+      for (int a = 0; a < NA; ++a) {
+        const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
+        u[a][0] = fma(q[3] - q[0], Em, q[0] * sm);
+        u[a][1] = (q[1] - q[0]) * sm;
+      }
+      double r0 = sm, r1 = Em;
+      if (s0) {
+        r0 = __shfl(r0, src, 64);
+        r1 = __shfl(r1, src, 64);
+      }
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      r0 = dpp_wror1(r0);
-      r1 = dpp_wror1(r1);
-      r2 = dpp_wror1(r2);
+      for (int t = 0; t < NS; ++t) {
+        r0 = dpp_wror1(r0);
+        r1 = dpp_wror1(r1);
 #pragma unroll
-      for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, u[a][2], fma(r1, u[a][1], r0 * u[a][0]));  // :738-746
+        for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r0, u[a][0], r1 * u[a][1]);
+      }
+    } else {
+      double u[NA][3];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {  // wave-uniform likelihoods through the scalar cache
+        const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
+        u[a][0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
+        u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
+        u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
+      }
+      double r0 = CROSS ? p0 : g0, r1 = CROSS ? p1 : g1, r2 = CROSS ? p2 : g2;
+      if (s0 || CROSS) {
+        r0 = __shfl(r0, src, 64);
+        r1 = __shfl(r1, src, 64);
+        r2 = __shfl(r2, src, 64);
+      }
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        r0 = dpp_wror1(r0);
+        r1 = dpp_wror1(r1);
+        r2 = dpp_wror1(r2);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, u[a][2], fma(r1, u[a][1], r0 * u[a][0]));  // :738-746
+      }
     }
     if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
       cnt = 0;
@@ -282,10 +356,18 @@ __global__ void __launch_bounds__(64, 2)
   for (int t = 0; t < NS; ++t)
     if (s0 + t < (CROSS ? 64 : 63)) {
 #pragma unroll
-      for (int a = 0; a < NA; ++a)
-        out[((size_t)sel.n[a] * 64 + s0 + t) * 64 + j] = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
+      for (int a = 0; a < NA; ++a) {
+        double* o = out + ((size_t)sel.n[a] * 64 + s0 + t) * 64 + j;
+        double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
+        if (EM == EM_GENERAL) v += *o;  // on top of the linear entries' launch
+        *o = v;
+      }
     }
-  if (WITH_SINGLET) out[j] = prodacc_log(accS, exS);
+  if (WITH_SINGLET) {
+    double v = prodacc_log(accS, exS);
+    if (EM == EM_GENERAL) v += out[j];
+    out[j] = v;
+  }
 }
 
 // 16 < V <= 32: a ring of 32.  Both 32-lane halves of the wave hold the same 32 sample triples (lane j and lane j + 32:
@@ -303,6 +385,7 @@ template <int NA, bool WITH_SINGLET, bool ALLSYM = false>
 __global__ void __launch_bounds__(64, 2)
     demux_wave32_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                        const uint32_t* __restrict__ /*lin: the rings of 32 keep the single launch*/,
                         const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
   constexpr int NS = ALLSYM ? 8 : 16;
@@ -584,12 +667,32 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (p->alpha[n] != 0.5) plain.push_back(n);
     else symmask |= 1u << n;
   }
-#define KARGS st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_gp, h->d_has_gp, V, A
-#define MULTI_LAUNCH(NA, NS, WS, CR, S0)                                                                          \
-  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, S0, \
-                     wb, h->d_llw)
-#define WAVE_LAUNCH(NS, WS, CR) \
-  hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
+  // linear entries (one usable read) in a launch of their own with the two-term form, the others on top: see EM_LINEAR
+  const bool use_lin = h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+#define KARGS st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_lin, h->d_gp, h->d_has_gp, V, A
+#define MULTI_K(NA, NS, WS, CR, EMODE, S0)                                                                                \
+  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, \
+                     S0, wb, h->d_llw)
+#define MULTI_LAUNCH(NA, NS, WS, CR, S0)         \
+  do {                                           \
+    if (use_lin && !(CR)) {                      \
+      MULTI_K(NA, NS, WS, false, EM_LINEAR, S0); \
+      MULTI_K(NA, NS, WS, false, EM_GENERAL, S0); \
+    } else {                                     \
+      MULTI_K(NA, NS, WS, CR, EM_ALL, S0);       \
+    }                                            \
+  } while (0)
+#define WAVE_K(NS, WS, CR, EMODE) \
+  hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR, EMODE>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
+#define WAVE_LAUNCH(NS, WS, CR)           \
+  do {                                    \
+    if (use_lin && !(CR)) {               \
+      WAVE_K(NS, WS, false, EM_LINEAR);   \
+      WAVE_K(NS, WS, false, EM_GENERAL);  \
+    } else {                              \
+      WAVE_K(NS, WS, CR, EM_ALL);         \
+    }                                     \
+  } while (0)
   if (V <= 32) {  // ring of 32: 16 rotation steps, up to four alphas per launch, see demux_wave32_kernel
     std::vector<int> all;
     for (int n = 1; n < A; ++n) all.push_back(n);
@@ -695,7 +798,9 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     }
   }
 #undef WAVE_LAUNCH
+#undef WAVE_K
 #undef MULTI_LAUNCH
+#undef MULTI_K
 #undef KARGS
   if (st->n_cuts) {  // cells walked in several parts: add the parts' log-likelihoods up
     hipLaunchKernelGGL(wave_combine_kernel, dim3((unsigned)st->n_cuts, 8), dim3(256), 0, h->stream, st->d_cuts,

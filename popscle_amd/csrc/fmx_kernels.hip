@@ -40,11 +40,17 @@ __global__ void __launch_bounds__(256)
     fmx_entry_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
                      const int32_t* __restrict__ entry_snp, const double* __restrict__ af,
                      const double* __restrict__ lut_g, double* __restrict__ egls, double* __restrict__ egls6,
-                     int32_t* __restrict__ ecnt, double* __restrict__ l0, double* __restrict__ l2) {
+                     int32_t* __restrict__ ecnt, double* __restrict__ l0, double* __restrict__ l2,
+                     uint32_t* __restrict__ flin) {
   __shared__ double lut[256];
   lut[threadIdx.x] = lut_g[threadIdx.x];
   __syncthreads();
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+  // (the trip count is wave-uniform: the ballot below needs every lane of the wave, also those beyond the last entry)
+  for (int64_t eb = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); eb < nnz; eb += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = eb + (threadIdx.x & 63);
+    const bool in = e < nnz;
+    bool linear = false;
+    if (in) {
     double gls[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) gls[i] = 1.0;
@@ -95,7 +101,18 @@ __global__ void __launch_bounds__(256)
     ecnt[(size_t)e * 3 + 0] = nreads;
     ecnt[(size_t)e * 3 + 1] = nref;
     ecnt[(size_t)e * 3 + 2] = nalt;
-    if (!l0) continue;
+    // With at most one usable read and no clamp the nine likelihoods are f(g1 + g2) with f LINEAR (one factor
+    // mat * frac + e4 with frac = 1 - (g1+g2)/4, then a common scale): the E-step of such an entry is a two-term form
+    // (fmx_wave.hip).  Checked on the values themselves, so whatever made them non-linear (a clamp at a high quality
+    // cap, a second read) keeps the entry on the general path.
+    {
+      const double c0 = gls[0], c1 = gls[1] - gls[0];
+      const double tol = 1e-14 * fmax(gls[0], gls[8]);  // a few roundings apart at most; 1e-14 per factor is 1e-11 per cell
+      linear = nref + nalt <= 1 && fabs(gls[2] - fma(2.0, c1, c0)) <= tol && fabs(gls[5] - fma(3.0, c1, c0)) <= tol &&
+               fabs(gls[8] - fma(4.0, c1, c0)) <= tol && gls[3] == gls[1] && gls[6] == gls[2] && gls[4] == gls[2] &&
+               gls[7] == gls[5];
+    }
+    if (l0) {
     // cmd_cram_freemux2.cpp:138-149
     const double a = af[entry_snp[e]];
     const double gps[3] = {(1.0 - a) * (1.0 - a), 2.0 * a * (1.0 - a), a * a};
@@ -108,6 +125,13 @@ __global__ void __launch_bounds__(256)
     }
     l0[e] = log(lk0);
     l2[e] = log(lk2);
+    }
+    }
+    if (flin) {
+      const uint64_t m = __ballot(linear);
+      if ((threadIdx.x & 63) == 0) flin[eb >> 5] = (uint32_t)m;
+      if ((threadIdx.x & 63) == 32 && eb + 32 < nnz) flin[(eb >> 5) + 1] = (uint32_t)(m >> 32);
+    }
   }
 }
 
@@ -715,7 +739,7 @@ static int fmx_prepare_cols(muxgl_handle* h, const double* af) {
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(fmx_entry_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_entry_rptr,
                        h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, (double*)nullptr, h->d_ecnt,
-                       (double*)nullptr, (double*)nullptr);
+                       (double*)nullptr, (double*)nullptr, (uint32_t*)nullptr);
     HIPCHK(h, hipGetLastError());
   }
   if (fmx_build_snp_major(h, tm)) return 1;
@@ -746,6 +770,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   if (dev_alloc(h, &h->d_egls, (size_t)nnz * 9)) return 1;
   if (dev_alloc(h, &h->d_ecnt, (size_t)nnz * 3)) return 1;
   if (dev_alloc(h, &h->d_egls6, (size_t)nnz * 6)) return 1;
+  if (dev_alloc(h, &h->d_flin, (size_t)((nnz + 31) / 32))) return 1;
   double *d_l0 = nullptr, *d_l2 = nullptr, *d_c0 = nullptr, *d_c2 = nullptr;
   int32_t *d_ns = nullptr, *d_nr = nullptr;
   auto cleanup = [&]() {
@@ -766,7 +791,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(fmx_entry_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_entry_rptr,
-                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, h->d_egls6, h->d_ecnt, d_l0, d_l2);
+                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, h->d_egls6, h->d_ecnt, d_l0, d_l2, h->d_flin);
   }
   if (C)
     hipLaunchKernelGGL(fmx_cell_score_kernel, dim3((unsigned)C), dim3(64), 0, h->stream, h->d_cell_ptr, d_l0, d_l2,

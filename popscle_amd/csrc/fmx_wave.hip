@@ -24,12 +24,19 @@ __device__ __forceinline__ double fw_wror1(double x) {
   return __hiloint2double(hi, lo);
 }
 
-template <bool CROSS>
-__global__ void __launch_bounds__(64, 2)
+// LIN: entries flagged in `lin` (fmx_entry_kernel: at most one usable read, no clamp) have likelihoods that are linear
+// in g1 + g2, glis[g1][g2] = c0 + c1 (g1 + g2), so that
+//     sum_{l,m} P_j[l] P_k[m] glis[l][m] = s_k (c0 s_j + c1 E_j) + E_k (c1 s_j),   s = sum_l P[l],  E = P[1] + 2 P[2]:
+// two moments of the partner rotate instead of its three posteriors (4 DPP moves instead of 6) and a pair costs a
+// multiply, an FMA and the product update instead of a multiply, two FMAs and the update -- 7 vector instructions per
+// pair instead of 10.  Three quarters of the entries of a typical pileup are such entries.  The branch is wave-uniform
+// (a wave walks one cell, one entry at a time), so the order of a cell's factors is unchanged.
+template <bool CROSS, bool LIN>
+__global__ void __launch_bounds__(64, (LIN && !CROSS) ? 3 : 2)
     fmx_estep_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, int64_t c0, int64_t c1,
                           const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ entry_snp,
-                          const double* __restrict__ egls, const double* __restrict__ cgp, int K, int jbase, int kbase,
-                          double* __restrict__ fll) {
+                          const double* __restrict__ egls, const uint32_t* __restrict__ lin,
+                          const double* __restrict__ cgp, int K, int jbase, int kbase, double* __restrict__ fll) {
   constexpr int NS = CROSS ? 64 : 32;
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];  // a cell, or a part of a long one (common.hpp)
@@ -43,13 +50,14 @@ __global__ void __launch_bounds__(64, 2)
   const int npairs = K * (K + 1) / 2;
 
   // CROSS: 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
-  __shared__ int32_t exs[CROSS ? 64 : 1][64];
+  constexpr bool EXL = CROSS || LIN;  // exponents in LDS: the two sweep bodies of LIN leave no room for them either
+  __shared__ int32_t exs[EXL ? NS : 1][64];
   double acc[NS], accS = 1.0;
-  int32_t ex[CROSS ? 1 : NS], exS = 0;
+  int32_t ex[EXL ? 1 : NS], exS = 0;
 #pragma unroll
   for (int t = 0; t < NS; ++t) {
     acc[t] = 1.0;
-    if (CROSS) exs[t][j] = 0;
+    if (EXL) exs[t][j] = 0;
     else ex[t] = 0;
   }
   double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
@@ -66,15 +74,27 @@ __global__ void __launch_bounds__(64, 2)
   // likelihoods of entry e + 1 are requested before entry e is swept, and the per-entry factors that do not depend on
   // the rotation (u, the singlet term) are formed for e + 1 right after the sweep of e: the scalar loads then have a
   // whole sweep to land instead of stalling the wave at the top of every entry.
+  // u0..u2 of the general form; for a linear entry u0 = c0 s_j + c1 E_j, u1 = c1 s_j and the ring carries (s, E)
   double u0 = 0, u1 = 0, u2 = 0, sing = 1.0;
   double c0r = ng0, c1r = ng1, c2r = ng2;  // ring start of the current entry (own triple, or the partner's with CROSS)
+  bool lin_cur = false;
+  auto is_lin = [&](int64_t e) { return LIN && ((lin[e >> 5] >> (e & 31)) & 1u); };
   if (e0 < e1) {
     const double* q = egls + (size_t)e0 * 9;
     sing = fma(ng2, q[8], fma(ng1, q[4], ng0 * q[0]));
-    u0 = fma(ng2, q[6], fma(ng1, q[3], ng0 * q[0]));
-    u1 = fma(ng2, q[7], fma(ng1, q[4], ng0 * q[1]));
-    u2 = fma(ng2, q[8], fma(ng1, q[5], ng0 * q[2]));
-    if (CROSS) c0r = np0, c1r = np1, c2r = np2;
+    lin_cur = is_lin(e0);
+    if (lin_cur) {
+      const double s = (ng0 + ng1) + ng2, E = fma(2.0, ng2, ng1), cc1 = q[1] - q[0];
+      u0 = fma(cc1, E, q[0] * s);
+      u1 = cc1 * s;
+      c0r = CROSS ? (np0 + np1) + np2 : s;
+      c1r = CROSS ? fma(2.0, np2, np1) : E;
+    } else {
+      u0 = fma(ng2, q[6], fma(ng1, q[3], ng0 * q[0]));
+      u1 = fma(ng2, q[7], fma(ng1, q[4], ng0 * q[1]));
+      u2 = fma(ng2, q[8], fma(ng1, q[5], ng0 * q[2]));
+      if (CROSS) c0r = np0, c1r = np1, c2r = np2;
+    }
   }
   int cnt = 0;
   for (int64_t e = e0; e < e1; ++e) {
@@ -92,34 +112,61 @@ __global__ void __launch_bounds__(64, 2)
         np0 = row[0], np1 = row[1], np2 = row[2];
       }
     }
-    const double* q = egls + (size_t)(more ? e + 1 : e) * 9;  // wave-uniform: glis[g1*3+g2] of the next entry
+    const int64_t en = more ? e + 1 : e;
+    const double* q = egls + (size_t)en * 9;  // wave-uniform: glis[g1*3+g2] of the next entry
+    const bool lin_nx = is_lin(en);
     const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
     // sweep of entry e
     if (!CROSS) accS *= sing;  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
-    double r0 = c0r, r1 = c1r, r2 = c2r;
-    if (CROSS) {  // one lane ahead: the first rotation then brings cluster kbase + j itself
-      r0 = __shfl(r0, (j + 1) & 63, 64);
-      r1 = __shfl(r1, (j + 1) & 63, 64);
-      r2 = __shfl(r2, (j + 1) & 63, 64);
-    }
+    if (lin_cur) {
+      double r0 = c0r, r1 = c1r;  // the partner's (s, E)
+      if (CROSS) {
+        r0 = __shfl(r0, (j + 1) & 63, 64);
+        r1 = __shfl(r1, (j + 1) & 63, 64);
+      }
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      r0 = fw_wror1(r0);
-      r1 = fw_wror1(r1);
-      r2 = fw_wror1(r2);
-      acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :440-446 as a product
+      for (int t = 0; t < NS; ++t) {
+        r0 = fw_wror1(r0);
+        r1 = fw_wror1(r1);
+        acc[t] *= fma(r0, u0, r1 * u1);
+        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all 32 sums first (64 VGPRs)
+      }
+    } else {
+      double r0 = c0r, r1 = c1r, r2 = c2r;
+      if (CROSS) {  // one lane ahead: the first rotation then brings cluster kbase + j itself
+        r0 = __shfl(r0, (j + 1) & 63, 64);
+        r1 = __shfl(r1, (j + 1) & 63, 64);
+        r2 = __shfl(r2, (j + 1) & 63, 64);
+      }
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        r0 = fw_wror1(r0);
+        r1 = fw_wror1(r1);
+        r2 = fw_wror1(r2);
+        acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :440-446 as a product
+        if (LIN && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // factors of entry e + 1
     sing = fma(ng2, q8, fma(ng1, q4, ng0 * q0));
-    u0 = fma(ng2, q6, fma(ng1, q3, ng0 * q0));
-    u1 = fma(ng2, q7, fma(ng1, q4, ng0 * q1));
-    u2 = fma(ng2, q8, fma(ng1, q5, ng0 * q2));
-    c0r = CROSS ? np0 : ng0, c1r = CROSS ? np1 : ng1, c2r = CROSS ? np2 : ng2;
+    lin_cur = lin_nx;
+    if (lin_nx) {
+      const double s = (ng0 + ng1) + ng2, E = fma(2.0, ng2, ng1), cc1 = q1 - q0;
+      u0 = fma(cc1, E, q0 * s);
+      u1 = cc1 * s;
+      c0r = CROSS ? (np0 + np1) + np2 : s;
+      c1r = CROSS ? fma(2.0, np2, np1) : E;
+    } else {
+      u0 = fma(ng2, q6, fma(ng1, q3, ng0 * q0));
+      u1 = fma(ng2, q7, fma(ng1, q4, ng0 * q1));
+      u2 = fma(ng2, q8, fma(ng1, q5, ng0 * q2));
+      c0r = CROSS ? np0 : ng0, c1r = CROSS ? np1 : ng1, c2r = CROSS ? np2 : ng2;
+    }
     if (++cnt == 16) {  // a factor is >= ~1e-13 (clamped likelihoods, mixed posteriors): sixteen cannot underflow
       cnt = 0;
 #pragma unroll
       for (int t = 0; t < NS; ++t) {
-        if (CROSS) {
+        if (EXL) {
           int ee;
           acc[t] = frexp(acc[t], &ee);
           exs[t][j] += ee;
@@ -141,7 +188,7 @@ __global__ void __launch_bounds__(64, 2)
       if (live && sk < K) out[sj * (sj + 1) / 2 + sk] = prodacc_log(acc[t], exs[t][j]);  // jbase > kbase: sj > sk
     } else if (live && sk < K && kk != j && (t < 31 || j > kk)) {  // step 32 of 64 lanes meets every pair twice: one writer
       const int hi = sj > sk ? sj : sk, lo = sj > sk ? sk : sj;
-      out[hi * (hi + 1) / 2 + lo] = prodacc_log(acc[t], ex[CROSS ? 0 : t]);
+      out[hi * (hi + 1) / 2 + lo] = prodacc_log(acc[t], EXL ? exs[t][j] : ex[EXL ? 0 : t]);
     }
   }
   if (!CROSS && live) out[sj * (sj + 1) / 2 + sj] = prodacc_log(accS, exS);
@@ -259,15 +306,18 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
   int64_t n_items, n_cuts, n_over;
   if (demux_wave_items(h, &items, &n_items, &cuts, &n_cuts, &n_over) || n_items == 0) return -1;
   const int nblk = (h->K + 63) / 64;
+  const bool use_lin = h->d_flin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);  // two-term form for linear entries
   if (h->K <= 32)
     hipLaunchKernelGGL(fmx_estep_wave32_kernel, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
                        c0 + nc, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, h->d_fll);
   for (int X = 0; X < (h->K <= 32 ? 0 : nblk); ++X) {
-    hipLaunchKernelGGL(fmx_estep_wave_kernel<false>, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
-                       c0 + nc, h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, 64 * X, 64 * X, h->d_fll);
-    for (int Y = 0; Y < X; ++Y)
-      hipLaunchKernelGGL(fmx_estep_wave_kernel<true>, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
-                         c0 + nc, h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, 64 * X, 64 * Y, h->d_fll);
+#define FW_ARGS(XB, YB) \
+  items, n_items, c0, c0 + nc, h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_flin, h->d_cgp, h->K, 64 * (XB), 64 * (YB), h->d_fll
+    if (use_lin) hipLaunchKernelGGL((fmx_estep_wave_kernel<false, true>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
+    else hipLaunchKernelGGL((fmx_estep_wave_kernel<false, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
+    for (int Y = 0; Y < X; ++Y)  // (off-diagonal blocks hold 64 accumulators per lane: no room for a second sweep body)
+      hipLaunchKernelGGL((fmx_estep_wave_kernel<true, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, Y));
+#undef FW_ARGS
   }
   if (n_cuts)
     hipLaunchKernelGGL(fmx_wave_combine_kernel, dim3((unsigned)n_cuts), dim3(256), 0, h->stream, cuts, c0, c0 + nc,

@@ -191,7 +191,8 @@ int muxgl_set_pileup_role(muxgl_handle* h, int role, int64_t C, int64_t S, int64
     if (demux_wave_plan(h, cell_ptr)) return 1;
     tm.lap("set_pileup: wave plan");
     if (plan_build_qent(h)) return 1;  // packed per-entry records of the quad kernel
-    tm.lap("set_pileup: quad entry records");
+    if (plan_build_lin(h)) return 1;   // which entries are linear in the genotypes (one usable read)
+    tm.lap("set_pileup: quad entry records, linear-entry bits");
   }
   h->fmx_prepared = false;
   h->K = 0;
@@ -239,6 +240,8 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_reads);
   dev_free(&h->d_entry_cell);
   dev_free(&h->d_qent);
+  dev_free(&h->d_lin);
+  dev_free(&h->d_flin);
   dev_free(&h->d_lut);
   dev_free(&h->d_gp);
   dev_free(&h->d_has_gp);

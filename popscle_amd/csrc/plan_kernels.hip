@@ -33,6 +33,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// bit e of lin: entry e has at most one usable read (alleles other than 0/1 are skipped, cmd_cram_demuxlet.cpp:664).
+// 64 consecutive entries per wave, the two words of their ballot written by lanes 0 and 32.
+__global__ void __launch_bounds__(256)
+    lin_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
+               uint32_t* __restrict__ lin) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t eb = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; eb < nnz; eb += (int64_t)gridDim.x * 256) {
+    const int64_t e = eb + lane;
+    bool one = false;
+    if (e < nnz) {
+      int usable = 0;
+      for (int64_t r = entry_rptr[e]; r < entry_rptr[e + 1] && usable < 2; ++r) usable += reads[r] != MUXGL_READ_OTHER;
+      one = usable <= 1;
+    }
+    const uint64_t m = __ballot(one);
+    if (lane == 0) lin[eb >> 5] = (uint32_t)m;
+    if (lane == 32 && eb + 32 < nnz) lin[(eb >> 5) + 1] = (uint32_t)(m >> 32);
+  }
+}
+
 // one wave per cell: entry_cell[e] = c, and the identity permutation that the sort carries along
 __global__ void __launch_bounds__(256)
     entry_cell_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int32_t* __restrict__ entry_cell,
@@ -128,6 +148,17 @@ int plan_build_qent(muxgl_handle* h) {
   if (dev_alloc(h, &h->d_qent, (size_t)h->nnz)) return 1;
   hipLaunchKernelGGL(qent_kernel, dim3(grid_for(h->nnz)), dim3(256), 0, h->stream, h->nnz, h->d_entry_snp,
                      h->d_entry_rptr, h->d_reads, h->d_qent);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int plan_build_lin(muxgl_handle* h) {
+  dev_free(&h->d_lin);
+  dev_free(&h->d_flin);
+  if (h->nnz == 0) return 0;
+  if (dev_alloc(h, &h->d_lin, (size_t)((h->nnz + 31) / 32))) return 1;
+  hipLaunchKernelGGL(lin_kernel, dim3(grid_for(h->nnz, 4096)), dim3(256), 0, h->stream, h->nnz, h->d_entry_rptr,
+                     h->d_reads, h->d_lin);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -215,3 +215,42 @@ def test_config1_shape_freemuxlet_old_pair_matrix():
     same = t["s1"][pick][:, None] == t["s1"][pick][None, :]
     m = sng[:, None] & sng[None, :] & ~np.eye(len(pick), dtype=bool)
     assert (ssub[m & same] >= 0).mean() > 0.99 and (ssub[m & ~same] <= 0).mean() > 0.99
+
+
+def test_linear_entry_forms_agree_with_the_general_ones():
+    """Entries with one usable read take a two-term form of the pair sum (demux_wave.hip EM_LINEAR, fmx_wave.hip LIN);
+    MUXGL_FLAG_NO_LINEAR_ENTRIES sends every entry through the general three-term form.  Same calls, log-likelihoods
+    within rounding of each other, and a mix of both kinds of entries in every cell (reads_lambda = 0.6)."""
+    V = 40
+    alphas = (0.0, 0.2, 0.35, 0.45, 0.5)
+    p = synth.make_pileup(120, 3000, V, seed=77, mean_entries=300, min_entries=40, reads_lambda=0.6, other=0.03)
+    res = []
+    for flags in (0, muxgl.FLAG_NO_LINEAR_ENTRIES):
+        with muxgl.Engine(0, flags) as eng:
+            eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+            eng.demux_set_gp(p.gp, p.has_gp)
+            res.append(eng.demux_run(alphas, 0.5, want_full_ll=True))
+    (c1, f1), (c2, f2) = res
+    assert np.array_equal(c1["type"], c2["type"]) and np.array_equal(c1["sBest"], c2["sBest"])
+    assert np.abs(f1 - f2).max() < 1e-9 and (f1 != f2).any()  # two different association orders were really run
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=NT)
+    assert parity.compare_full_ll(f1, wfull, V, alphas) < 1e-7 and parity.compare_full_ll(f2, wfull, V, alphas) < 1e-7
+    K = 40
+    q = synth.make_pileup(100, 3000, 8, seed=78, mean_entries=300, min_entries=40, reads_lambda=0.6, other=0.03, with_gp=False,
+                          cap_bq=60)  # quality 60: the clamp fires on some single-read entries, which must stay general
+    clust0 = (np.arange(q.C) % K).astype(np.int32)
+    out = []
+    for flags in (0, muxgl.FLAG_NO_LINEAR_ENTRIES):
+        with muxgl.Engine(0, flags) as eng:
+            eng.set_pileup(q.S, q.cell_ptr, q.entry_snp, q.entry_rptr, q.reads)
+            eng.fmx_prepare(q.af)
+            eng.fmx_set_clusters(K, clust0)
+            out.append(eng.fmx_iterate(0.5, 0.1, want_full_ll=True))
+    (a, sa, fa), (b, sb, fb) = out
+    assert tuple(sa) == tuple(sb) and np.array_equal(a["type"], b["type"]) and np.array_equal(a["clust"], b["clust"])
+    assert np.abs(fa - fb).max() < 1e-9 and (fa != fb).any()
+    e = ob.fmx_entry_pileup(q)
+    cplp = ob.fmx_build_cluster_pileup(q, e, K, clust0)
+    ocells = ob.fmx_init_cells(clust0)
+    ob.fmx_iterate(q, e, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
+    assert parity.compare_fmx(a, ocells)["max_abs_ll_diff"] < 1e-7

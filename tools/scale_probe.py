@@ -26,7 +26,7 @@ def main():
                           **({"cap_bq": 60} if kind == "fmxold" else {}))
     out = {"kind": kind, "config": idx, "cells": C, "V": cfg["V"], "S": cfg["S"], "entries": p.nnz, "reads": p.R,
            "gen_s": round(time.time() - t0, 1)}
-    eng = muxgl.Engine(0)
+    eng = muxgl.Engine(0, int(os.environ.get("MUXGL_PROBE_FLAGS", "0")))
     t0 = time.time()
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     out["upload_s"] = round(time.time() - t0, 2)
