@@ -48,7 +48,8 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
                                           broadcast-extras kernels (lets tests cover the row kernels behind them) */
 #define MUXGL_FLAG_FORCE_WAVE_KERNEL 4 /* take the wave kernels for V <= 16 too, and the rings of 32 instead of the
                                           two-per-lane row kernels at 17..32 samples / clusters (test coverage) */
-#define MUXGL_FLAG_FORCE_BATCHED_GREEDY 8 /* batched greedy-init kernels for every K <= 64, not only K > 24 (test coverage) */
+#define MUXGL_FLAG_FORCE_BATCHED_GREEDY 8 /* (no effect since the batched greedy-init kernels became the default for K <= 64;
+                                             MUXGL_FLAG_FORCE_TILE_SWEEP selects the serial kernel) */
 #define MUXGL_FLAG_DEMUX_ONLY 16   /* device group: the caller will only run demuxlet, so muxgl_set_pileup need not cut
                                       the SNP-major column slabs freemuxlet's ordered M-step works on */
 #define MUXGL_FLAG_ASYNC_PHASES 32 /* muxgl_fmx_iter_gp / _estep / _mstep return once their kernels are enqueued on the
@@ -174,7 +175,10 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
  * sc_dropseq_lib_t::calculate_droplet_clust_distance, sc_drop_seq.cpp:544-578).  scores[C] = cell_scores (llk2-llk0,
  * possibly shuffled by --randomize-singlet-score on the caller side).  The procedure is sequential over cells by
  * construction (each assignment changes the cluster pileups the next cell is scored against): the cells are sorted on
- * the host, then one persistent workgroup on the device walks them in order (fmx_greedy.hip), parallel inside a step.
+ * the host; the device then decides them in batches of 32, each batch as a fixpoint of the sequential rule (guess from
+ * the state at the start of the batch, replay of the predecessors' merges at shared SNPs, iterate until no guess changes:
+ * the fixpoint IS the sequential result), or, beyond 64 clusters, with one persistent workgroup walking the cells in
+ * order (fmx_greedy.hip).  One device, whole pileup: not available on a device group or a slabbed handle.
  * clust_out[C] receives the cluster id, or -1 for cells skipped by frac_init_clust / singlet_score_thres. */
 int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,
                           double singlet_score_thres, int32_t* clust_out);
