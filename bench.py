@@ -294,7 +294,15 @@ class Ctx:
         self.dev = 0 if args.single_device else local_rank
         torch.cuda.set_device(self.dev)
         self.backend = args.dist_backend
-        if self.world > 1:
+        # --force-dist: the N-rank code path (process group, slabs, collectives on the library's buffers, stream ordering)
+        # with a single rank -- what a 1-GPU box can exercise of the RCCL path
+        self.dist_on = self.world > 1 or args.force_dist
+        if self.dist_on and self.world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if self.dist_on:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             to = datetime.timedelta(seconds=600)
             if self.backend == "nccl":
@@ -304,7 +312,7 @@ class Ctx:
         self.tdev = "cuda" if self.backend == "nccl" else "cpu"
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist_on:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
@@ -395,11 +403,11 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
     # the same job on every rank (same seed): strong scaling
     p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + config, with_gp=False, mean_entries=args.mean_entries,
                           min_entries=min(50, max(1, int(args.mean_entries // 4))))
-    ordered = ctx.world > 1 and ctx.backend == "nccl"
+    ordered = ctx.dist_on and ctx.backend == "nccl"
     eng = muxgl.Engine(ctx.dev, muxgl.FLAG_ASYNC_PHASES if ordered else 0)
     (c_ranges, per_c), (s_ranges, per_s) = freemuxlet.plan_ranges(C, S, ctx.world)
     t0 = time.perf_counter()
-    if ctx.world > 1:
+    if ctx.dist_on:
         freemuxlet.load_rank(eng, p, c_ranges[ctx.rank], s_ranges[ctx.rank])
     else:
         eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
@@ -407,7 +415,8 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
     handover_s = time.perf_counter() - t0
     # a seeded start (--init-cluster style): 90 % of the cells start in their source sample's cluster
     clust0 = np.where(np.random.default_rng(0).random(C) < 0.9, p.truth["s1"], -1).astype(np.int32)
-    ex = freemuxlet.TorchExchange(dist, ctx.rank, ctx.world, device_ordered=ordered) if ctx.world > 1 else None
+    ex = (freemuxlet.TorchExchange(dist, ctx.rank, ctx.world, device_ordered=ordered, always=True)
+          if ctx.dist_on else None)
     stream_ctx = None
     if ordered:
         ext = torch.cuda.ExternalStream(eng.stream(), device=torch.device("cuda", ctx.dev))
@@ -438,8 +447,8 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
                                    f"re-assignment, ordered M-step, exchanges)",
                        "cells": C, "snps": S, "clusters": K, "entries": int(p.nnz),
                        "parallelism": f"E-step by cells x{ctx.world}, ordered M-step by SNPs x{ctx.world}, "
-                                      f"2 all-gathers + 1 all-reduce per iteration" if ctx.world > 1 else "one GPU",
-                       "backend": ctx.backend if ctx.world > 1 else None},
+                                      f"2 all-gathers + 1 all-reduce per iteration" if ctx.dist_on else "one GPU",
+                       "backend": ctx.backend if ctx.dist_on else None},
             "entries_per_s": p.nnz * steps / elapsed,
             "handover_ms": handover_s * 1e3,  # H2D of this rank's slabs + derived tables + entry likelihoods
             "setup_ms": tm["setup_s"] * 1e3,  # initial cluster pileups (muxgl_fmx_set_clusters)
@@ -499,6 +508,8 @@ def main():
     ap.add_argument("--fmx-leg-steps", type=int, default=20, help="EM iterations of the secondary leg (configs[3]: 20)")
     ap.add_argument("--fmx-leg-timeout", type=float, default=420.0)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="freemuxlet: run the N-rank code path (slabs, collectives, stream ordering) even with one rank")
     ap.add_argument("--single-device", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: every rank uses device 0 (use with gloo)")
     ap.add_argument("--cells", type=int, default=0, help="freemuxlet: override the cell count (tests)")
@@ -525,7 +536,7 @@ def main():
         out = fmx_leg(args, ctx, args.config, args.steps, args.warmup)
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
-    if ctx.world > 1:
+    if ctx.dist_on:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
 

@@ -35,11 +35,12 @@ class TorchExchange:
     device_ordered=True (RCCL): the collectives are enqueued behind the engine's stream and nothing waits on the host.
     device_ordered=False (gloo staging, tests on a 1-GPU box or on CPU): every exchange returns when the data has landed."""
 
-    def __init__(self, dist_module, rank: int, world: int, device_ordered: bool = False):
+    def __init__(self, dist_module, rank: int, world: int, device_ordered: bool = False, always: bool = False):
         self.dist = dist_module
         self.rank = rank
         self.world = world
         self.device_ordered = device_ordered
+        self.always = always  # take the exchange path even with one rank
 
     def allgather_equal(self, tensor, per: int):
         """tensor: [>= world*per, row]; rank r owns rows [r*per, (r+1)*per).  One collective, in place."""
@@ -127,7 +128,7 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
     ex = exchange or NoExchange()
     t_start = time.perf_counter()
     eng.fmx_set_clusters(K, np.ascontiguousarray(clust0, dtype=np.int32))  # :277-288, own SNP range
-    multi = ex.world > 1
+    multi = ex.world > 1 or getattr(ex, "always", False)  # (always: the exchange path with a single rank, for tests)
     if multi:
         per_c, per_s = per
         t_cgp, t_clust = exchange_tensor(eng, UNIT_CGP), exchange_tensor(eng, UNIT_CLUST)

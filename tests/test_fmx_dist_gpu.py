@@ -49,3 +49,18 @@ def test_two_processes_match_one(tmp_path, world):
     assert np.array_equal(a["hist"], b["hist"])
     assert a["cells"].tobytes() == b["cells"].tobytes()
     assert (a["cells"]["type"] == 0).sum() > 200
+
+
+def test_single_rank_over_rccl(tmp_path):
+    """What a 1-GPU box can run of the RCCL path: a process group of ONE rank on backend nccl, the rank's slabs (here the
+    whole pileup, twice), the in-place all_gather_into_tensor / all_reduce on the library's device buffers, the library's
+    stream as torch's current stream (ExternalStream), asynchronous phases, the counters fetched behind the M-step --
+    everything the N-GPU run does except moving bytes between devices.  Same records as the plain one-handle run."""
+    one = str(tmp_path / "one.npz")
+    rccl = str(tmp_path / "rccl.npz")
+    run([sys.executable, PROBE, "--gpus", "1", "--dump", one] + SHAPE)
+    j = run([sys.executable, PROBE, "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--dump", rccl] + SHAPE)
+    assert j["config"]["backend"] == "nccl" and j["n_gpus"] == 1
+    a, b = np.load(one), np.load(rccl)
+    assert np.array_equal(a["hist"], b["hist"])
+    assert a["cells"].tobytes() == b["cells"].tobytes()
