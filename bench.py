@@ -475,6 +475,7 @@ def guarded_fmx_leg(args, ctx, headline):
     def give_up(signum=None, frame=None, why="timeout"):
         if ctx.rank == 0:
             headline["freemuxlet_em"] = {"error": f"freemuxlet leg did not finish: {why}"}
+            flush_c_stdio()
             print(json.dumps(headline), flush=True)
         os._exit(0)
 
@@ -491,6 +492,15 @@ def guarded_fmx_leg(args, ctx, headline):
             return {"error": repr(ex)}
         while True:  # the other ranks may be waiting for us in a collective: leave together, when the alarm fires
             time.sleep(1.0)
+
+
+def flush_c_stdio():
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def main():
@@ -534,6 +544,9 @@ def main():
                 out["freemuxlet_em"] = leg
     else:
         out = fmx_leg(args, ctx, args.config, args.steps, args.warmup)
+    if ctx.dist_on:  # RCCL writes a version banner through C stdio: get it out of the way, the JSON line comes last
+        ctx.barrier()
+        flush_c_stdio()
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     if ctx.dist_on:
