@@ -48,6 +48,15 @@ enum { MUXGL_ROLE_FULL = 0, MUXGL_ROLE_ROWS = 1, MUXGL_ROLE_COLS = 2 };
 
 struct muxgl_group;
 
+// records of the wave E-step's entry streams (fmx_wave.hip)
+struct fmx_lrec {  // a linear entry: glis[g1][g2] = c0 + c1 (g1 + g2)
+  double c0, c1;
+  int32_t snp, pad;
+};
+struct fmx_grec {  // any other entry: its index and SNP
+  int64_t e;
+  int32_t snp, pad;
+};
 struct muxgl_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -74,6 +83,14 @@ struct muxgl_handle {
   // two-term form in the samples' moments (sum g, sum l*g) instead of a three-term one -- see demux_wave.hip.
   uint32_t* d_lin = nullptr;        // [ceil(nnz/32)] demuxlet
   uint32_t* d_flin = nullptr;       // [ceil(nnz/32)] freemuxlet: additionally, no clamp fired (checked on the values)
+  // The wave E-step's two streams (fmx_wave.hip, built on first use): a cell's linear entries as 24-byte records
+  // {c0, c1, snp} and its other entries as {entry, snp}, both in entry order; d_flin_rank[w] = linear entries before
+  // entry 32 w (so a cut of a long cell finds its place in both streams); d_cE[S][K] = g1 + 2 g2 of the posteriors.
+  int64_t* d_flin_rank = nullptr;   // [ceil(nnz/32) + 1]
+  fmx_lrec* d_lrec = nullptr;
+  fmx_grec* d_grec = nullptr;
+  double* d_cE = nullptr;
+  int64_t n_lrec = -1, cE_n = 0;
   int64_t max_cell_entries = 0;
 
   // Phred LUT: [0..127] = phred2Err, [128..255] = phred2Mat (bq is 7 bits in the packed read byte)
@@ -230,6 +247,26 @@ __device__ __forceinline__ void prodacc_renorm(double& m, int32_t& e) {
 }
 __device__ __forceinline__ double prodacc_log(double m, int32_t e) { return log(m) + (double)e * 0.6931471805599453094; }
 
+// which entries of a cell a wave-per-cell sweep walks: all of them, or those whose bit in the linear-entry set is
+// set / clear (plan_build_lin, fmx_entry_kernel)
+enum { EM_ALL = 0, EM_LINEAR = 1, EM_GENERAL = 2 };
+// first entry >= e in [e, e1) of the kind the launch sweeps (wave-uniform: scalar loads and bit scans)
+template <int EM>
+__device__ __forceinline__ int64_t wave_next_entry(const uint32_t* __restrict__ lin, int64_t e, int64_t e1) {
+  if (EM == EM_ALL) return e;
+  while (e < e1) {
+    uint32_t w = lin[e >> 5];
+    if (EM == EM_GENERAL) w = ~w;
+    w >>= (uint32_t)(e & 31);
+    if (w) {
+      e += __builtin_ctz(w);
+      return e < e1 ? e : e1;
+    }
+    e = (e | 31) + 1;
+  }
+  return e1;
+}
+
 // Workgroup -> work-unit index with XCD affinity.  The dispatcher is observed to place workgroup b on XCD b % 8
 // (MI355X_MICROARCH.md; used for speed only, nothing depends on it): the work list is cut into 8 contiguous blocks,
 // one per XCD, so that workgroups resident on one XCD walk neighbouring work units -- here neighbouring SNP windows of
@@ -288,6 +325,7 @@ int demux_wave_items(const muxgl_handle* h, const wave_item** items, int64_t* n_
                      int64_t* n_cuts, int64_t* n_over);  // work units of the wave kernels (device)
 int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc);  // 16 < K <= 255; -1: not applicable
 int64_t fmx_wave_fll_rows(const muxgl_handle* h);  // rows of d_fll: C + extra parts of long cells
+void fmx_wave_streams_release(muxgl_handle* h);  // the linear/general entry streams and their rank table
 int demux_ensure_ll(muxgl_handle* h, const muxgl_demux_params* p);  // standard LL tensor allocated and zeroed
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);

@@ -66,24 +66,6 @@ struct wave_blk {
 // entries get a launch each -- EM_LINEAR walks the flagged entries of a cell and writes, EM_GENERAL walks the others and
 // ADDS its log-likelihoods to what is there -- EM_ALL is the single launch without the distinction.  The walk is a
 // scalar scan of the bit set, so an entry of the other kind costs a few scalar instructions and no loads.
-enum { EM_ALL = 0, EM_LINEAR = 1, EM_GENERAL = 2 };
-
-// first entry >= e in [e, e1) of the kind the launch sweeps (wave-uniform: scalar loads and bit scans)
-template <int EM>
-__device__ __forceinline__ int64_t wave_next_entry(const uint32_t* __restrict__ lin, int64_t e, int64_t e1) {
-  if (EM == EM_ALL) return e;
-  while (e < e1) {
-    uint32_t w = lin[e >> 5];
-    if (EM == EM_GENERAL) w = ~w;
-    w >>= (uint32_t)(e & 31);
-    if (w) {
-      e += __builtin_ctz(w);
-      return e < e1 ? e : e1;
-    }
-    e = (e | 31) + 1;
-  }
-  return e1;
-}
 
 // NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise (64 with CROSS).  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
 template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL>

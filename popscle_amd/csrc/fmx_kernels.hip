@@ -771,6 +771,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   if (dev_alloc(h, &h->d_ecnt, (size_t)nnz * 3)) return 1;
   if (dev_alloc(h, &h->d_egls6, (size_t)nnz * 6)) return 1;
   if (dev_alloc(h, &h->d_flin, (size_t)((nnz + 31) / 32))) return 1;
+  fmx_wave_streams_release(h);  // they are made of the likelihoods computed below
   double *d_l0 = nullptr, *d_l2 = nullptr, *d_c0 = nullptr, *d_c2 = nullptr;
   int32_t *d_ns = nullptr, *d_nr = nullptr;
   auto cleanup = [&]() {

@@ -15,7 +15,48 @@
 // cluster 64X + j in lane j and rotates the posteriors of clusters 64Y + k past it, all 64 rotations being pairs.
 #include "common.hpp"
 
+#include <type_traits>
+
+#include <rocprim/device/device_scan.hpp>
+
 namespace {
+
+// rotations of the ring done by DPP moves; the remaining ones are read from the copy in LDS (see the kernel)
+#ifndef FMX_TD_LIN
+#define FMX_TD_LIN 8
+#endif
+#ifndef FMX_TD_GEN
+#define FMX_TD_GEN 6
+#endif
+// entries the walks run ahead of the sweep (ring slots of the software pipeline)
+#ifndef FMX_DEPTH_LIN
+#define FMX_DEPTH_LIN 4
+#endif
+#ifndef FMX_DEPTH_GEN
+#define FMX_DEPTH_GEN 3
+#endif
+// accumulator exponents of the diagonal-block kernels in LDS (1) or in registers (0)
+#ifndef FMX_EXP_LDS
+#define FMX_EXP_LDS 1
+#endif
+
+// One 8-byte read per lane from the ring in LDS, at an immediate offset from the lane's slot.  As an opaque instruction
+// because two such reads with one base are otherwise merged into a ds_read2_b64, which takes 8 LDS cycles instead of
+// 2 + 2 (MI355X_MICROARCH.md, LDS table).  The caller waits (s_waitcnt lgkmcnt) before using the value; "memory" keeps
+// the next entry's ring stores behind it.
+template <int OFF>
+__device__ __forceinline__ double fw_ring_rd(uint32_t a) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void fw_for(F&& f) {  // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    fw_for<I + 1, N>(f);
+  }
+}
 
 __device__ __forceinline__ double fw_wror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -25,33 +66,292 @@ __device__ __forceinline__ double fw_wror1(double x) {
 }
 
 // LIN: entries flagged in `lin` (fmx_entry_kernel: at most one usable read, no clamp) have likelihoods that are linear
-// in g1 + g2, glis[g1][g2] = c0 + c1 (g1 + g2), so that
-//     sum_{l,m} P_j[l] P_k[m] glis[l][m] = s_k (c0 s_j + c1 E_j) + E_k (c1 s_j),   s = sum_l P[l],  E = P[1] + 2 P[2]:
-// two moments of the partner rotate instead of its three posteriors (4 DPP moves instead of 6) and a pair costs a
-// multiply, an FMA and the product update instead of a multiply, two FMAs and the update -- 7 vector instructions per
-// pair instead of 10.  Three quarters of the entries of a typical pileup are such entries.  The branch is wave-uniform
-// (a wave walks one cell, one entry at a time), so the order of a cell's factors is unchanged.
+// in g1 + g2, glis[g1][g2] = c0 + c1 (g1 + g2), so that, with s = sum_l P[l] and E = P[1] + 2 P[2],
+//     sum_{l,m} P_j[l] P_k[m] glis[l][m] = c0 s_j s_k + c1 (E_j s_k + s_j E_k).
+// The posteriors are normalised by the kernel that writes them (s = 1 to within 2 ulp), and the form is taken at s = 1:
+//     (c0 + c1 E_j) + c1 E_k,      singlet  c0 + 2 c1 E_j.
+// That is a relative difference of <= ~4e-16 per factor from the nine-term sum, ~1e-12 on the log-likelihood of a cell
+// of several thousand entries, against the 1e-5 the path is held to (decisions on re-associated arithmetic).
+// What it buys: ONE number per (SNP, cluster) -- E, 8 bytes from the side tensor cE[S][K] instead of the 24-byte
+// triple -- travels from HBM and round the ring, and a pair costs an FMA with a wave-uniform factor and the product
+// update.  Three quarters of the entries of a typical pileup are such entries.  They are read from a stream of their
+// own, 24-byte records {c0, c1, snp} in entry order (the other entries: {entry, snp}), so the wave walks its cell
+// twice -- linear entries, then the others -- each walk with its own sweep body and software pipeline; a product's
+// factors are therefore taken in that order in every run.
+//
+// The ring.  Rotation t brings lane j the value of lane (j - t) mod 64 (one lane further with CROSS, see below).  The
+// first TD rotations are DPP moves of the value itself; the others are read from a copy of the 64 values in LDS, kept
+// twice over so that the wrap needs no address arithmetic: lane j reads ring[j + 64 - t], an immediate offset from one
+// base address.  A DPP rotation of a double costs two vector moves -- as much issue time as the FMA it feeds -- while
+// the LDS read travels on the other pipe (ds_read_b64: 2 LDS cycles per wave, 256 B/clk per CU).
+//
+// The pipeline.  A cell's entries meet SNP rows all over the posterior tensor: every entry is an HBM miss of 512 B
+// (linear) or 1.5 KB (general) per wave, ~1 us away.  The walks therefore run D entries ahead with the stream records
+// (scalar loads) and D - 1 entries ahead with the posterior loads, in rings of D register slots addressed statically
+// (the loop is unrolled D times); the entry's nine likelihoods and the rotation-independent factors (u, the singlet
+// term) are formed one entry ahead, right after the previous sweep.
+
+template <int NS, bool EXL>
+__device__ __forceinline__ void fw_renorm(double (&acc)[NS], int32_t (&ex)[EXL ? 1 : NS], int32_t (*exs)[64], int j) {
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    if (EXL) {
+      int ee;
+      acc[t] = frexp(acc[t], &ee);
+      exs[t][j] += ee;
+    } else {
+      prodacc_renorm(acc[t], ex[t]);
+    }
+  }
+}
+
+// the general sweep over entries [i0, i1) of the stream grec (STREAM), or over the entries i0 .. i1 - 1 themselves
+template <bool CROSS, bool STREAM, int NS, bool EXL>
+__device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_grec* __restrict__ grec,
+                                            const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
+                                            const double* __restrict__ cgp, int K3, int jo, int ko, bool live, bool live2, int j,
+                                            double (*ring)[128], int32_t (*exs)[64], double (&acc)[NS],
+                                            int32_t (&ex)[EXL ? 1 : NS], double& accS, int32_t& exS, int& cnt) {
+  constexpr int D = CROSS ? 2 : FMX_DEPTH_GEN;  // (64 accumulators: two slots is what fits)
+  constexpr int TD = FMX_TD_GEN < NS ? FMX_TD_GEN : NS;
+  constexpr int RB = CROSS ? 65 : 64;  // CROSS: rotation 1 meets cluster kbase + j itself
+  if (i0 >= i1) return;
+  const uint32_t ring_a = (uint32_t)(uintptr_t)&ring[0][j];  // LDS byte address of the lane's ring slot
+  int64_t ide[D];
+  int32_t ids[D];
+  double gp[D][3], gq[CROSS ? D : 1][3];  // posterior of cluster jbase + j (and of kbase + j) at the slot's SNP
+  auto load_id = [&](int64_t i, auto sc) {  // clamped: a valid record is read behind the end, and not used
+    constexpr int s = decltype(sc)::value;
+    const int64_t ic = i < i1 ? i : i1 - 1;
+    if (STREAM) ide[s] = grec[ic].e, ids[s] = grec[ic].snp;
+    else ide[s] = ic, ids[s] = entry_snp[ic];
+  };
+  auto load_gp = [&](int64_t i, auto sc) {
+    constexpr int s = decltype(sc)::value;
+    gp[s][0] = 1.0, gp[s][1] = 0.0, gp[s][2] = 0.0;
+    if (i < i1 && live) {
+      const double* row = cgp + (size_t)ids[s] * K3 + jo;
+      gp[s][0] = row[0], gp[s][1] = row[1], gp[s][2] = row[2];
+    }
+    if (CROSS) {
+      constexpr int sq = CROSS ? s : 0;
+      gq[sq][0] = 1.0, gq[sq][1] = 0.0, gq[sq][2] = 0.0;
+      if (i < i1 && live2) {
+        const double* row = cgp + (size_t)ids[s] * K3 + ko;
+        gq[sq][0] = row[0], gq[sq][1] = row[1], gq[sq][2] = row[2];
+      }
+    }
+  };
+  double u0 = 0, u1 = 0, u2 = 0, sing = 1.0;
+  double c0r = 1.0, c1r = 0, c2r = 0;  // what the ring carries for the current entry
+  auto factors = [&](auto sc, double q0, double q1, double q2, double q3, double q4, double q5, double q6, double q7, double q8) {
+    constexpr int s = decltype(sc)::value, sq = CROSS ? s : 0;
+    const double g0 = gp[s][0], g1 = gp[s][1], g2 = gp[s][2];
+    sing = fma(g2, q8, fma(g1, q4, g0 * q0));
+    u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
+    u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
+    u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
+    c0r = CROSS ? gq[sq][0] : g0, c1r = CROSS ? gq[sq][1] : g1, c2r = CROSS ? gq[sq][2] : g2;
+    ring[0][j] = c0r, ring[0][j + 64] = c0r;
+    ring[1][j] = c1r, ring[1][j + 64] = c1r;
+    ring[2][j] = c2r, ring[2][j + 64] = c2r;
+  };
+  fw_for<0, D>([&](auto sc) { load_id(i0 + decltype(sc)::value, sc); });
+  fw_for<0, D - 1>([&](auto sc) { load_gp(i0 + decltype(sc)::value, sc); });
+  {
+    const double* q = egls + (size_t)ide[0] * 9;
+    factors(std::integral_constant<int, 0>{}, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8]);
+  }
+  for (int64_t ib = i0; ib < i1; ib += D) {
+    fw_for<0, D>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, s1 = (s + 1) % D, sp = (s + D - 1) % D;
+      const int64_t i = ib + s;
+      if (i >= i1) return;
+      load_gp(i + D - 1, std::integral_constant<int, sp>{});  // its record was read a step ago
+      const double* q = egls + (size_t)ide[s1] * 9;          // wave-uniform: glis[g1*3+g2] of the next entry
+      const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
+      load_id(i + D, sc);
+      // sweep of entry i
+      if (!CROSS) accS *= sing;  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
+      constexpr int G = CROSS ? 1 : 2;  // ring reads per group; the reads of group g + 1 are in flight while group g is consumed
+      constexpr int NG = (NS - TD + G - 1) / G;
+      double r0 = c0r, r1 = c1r, r2 = c2r;
+      if (CROSS && TD > 0) {  // one lane ahead: the first rotation then brings cluster kbase + j itself
+        r0 = __shfl(r0, (j + 1) & 63, 64);
+        r1 = __shfl(r1, (j + 1) & 63, 64);
+        r2 = __shfl(r2, (j + 1) & 63, 64);
+      }
+      double rd[2][G][3];
+      auto issue = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        fw_for<0, G>([&](auto ic) {
+          constexpr int k = decltype(ic)::value, t = TD + g * G + k;  // rotation t + 1
+          if constexpr (t < NS) {
+            rd[g & 1][k][0] = fw_ring_rd<(RB - (t + 1)) * 8>(ring_a);
+            rd[g & 1][k][1] = fw_ring_rd<(RB - (t + 1)) * 8 + 1024>(ring_a);
+            rd[g & 1][k][2] = fw_ring_rd<(RB - (t + 1)) * 8 + 2048>(ring_a);
+          } else {
+            rd[g & 1][k][0] = rd[g & 1][k][1] = rd[g & 1][k][2] = 0.0;
+          }
+        });
+      };
+      if constexpr (NG > 0) issue(std::integral_constant<int, 0>{});
+      fw_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int left = NS - TD - (g + 1) * G;
+        constexpr int ahead = g + 1 < NG ? 3 * (left < G ? left : G) : 0;  // younger reads: they may stay in flight
+        if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+        // the DPP rotations are spread over the groups of ring reads: they fill the time the reads take
+        fw_for<g * TD / NG, (g + 1) * TD / NG>([&](auto dc) {
+          r0 = fw_wror1(r0);
+          r1 = fw_wror1(r1);
+          r2 = fw_wror1(r2);
+          acc[decltype(dc)::value] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :440-446 as a product
+        });
+        if constexpr (G == 2)
+          asm volatile("s_waitcnt lgkmcnt(%6)"
+                       : "+v"(rd[g & 1][0][0]), "+v"(rd[g & 1][0][1]), "+v"(rd[g & 1][0][2]), "+v"(rd[g & 1][G - 1][0]),
+                         "+v"(rd[g & 1][G - 1][1]), "+v"(rd[g & 1][G - 1][2])
+                       : "n"(ahead));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(rd[g & 1][0][0]), "+v"(rd[g & 1][0][1]), "+v"(rd[g & 1][0][2]) : "n"(ahead));
+        fw_for<0, G>([&](auto ic) {
+          constexpr int k = decltype(ic)::value, t = TD + g * G + k;
+          if constexpr (t < NS) acc[t] *= fma(rd[g & 1][k][2], u2, fma(rd[g & 1][k][1], u1, rd[g & 1][k][0] * u0));
+        });
+        __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all the sums first
+      });
+      if constexpr (TD == NS) {
+        fw_for<0, NS>([&](auto dc) {
+          r0 = fw_wror1(r0);
+          r1 = fw_wror1(r1);
+          r2 = fw_wror1(r2);
+          acc[decltype(dc)::value] *= fma(r2, u2, fma(r1, u1, r0 * u0));
+        });
+      }
+      // factors of the next entry and its ring (behind the sweep's reads: the LDS serves one wave's requests in order)
+      factors(std::integral_constant<int, s1>{}, q0, q1, q2, q3, q4, q5, q6, q7, q8);
+      if (++cnt == 16) {  // a factor is >= ~1e-13 (clamped likelihoods, mixed posteriors): sixteen cannot underflow
+        cnt = 0;
+        fw_renorm<NS, EXL>(acc, ex, exs, j);
+        if (!CROSS) prodacc_renorm(accS, exS);
+      }
+    });
+  }
+}
+
+// the linear sweep over records [l0, l1) of the stream lrec
+template <int NS, bool EXL>
+__device__ __forceinline__ void fw_walk_lin(int64_t l0, int64_t l1, const fmx_lrec* __restrict__ lrec,
+                                            const double* __restrict__ cE, int K, int sj, bool live, int j,
+                                            double (*ring)[128], int32_t (*exs)[64], double (&acc)[NS],
+                                            int32_t (&ex)[EXL ? 1 : NS], double& accS, int32_t& exS, int& cnt) {
+  constexpr int D = FMX_DEPTH_LIN;
+  constexpr int TD = FMX_TD_LIN < NS ? FMX_TD_LIN : NS;
+  if (l0 >= l1) return;
+  const uint32_t ring_a = (uint32_t)(uintptr_t)&ring[0][j];
+  double rc0[D], rc1[D];
+  int32_t rsnp[D];
+  double En[D];  // E of cluster jbase + j at the slot's SNP
+  auto load_rec = [&](int64_t r, auto sc) {
+    constexpr int s = decltype(sc)::value;
+    const fmx_lrec* p = lrec + (r < l1 ? r : l1 - 1);
+    rc0[s] = p->c0, rc1[s] = p->c1, rsnp[s] = p->snp;
+  };
+  auto load_E = [&](int64_t r, auto sc) {
+    constexpr int s = decltype(sc)::value;
+    En[s] = 0.0;
+    if (r < l1 && live) En[s] = cE[(size_t)rsnp[s] * K + sj];
+  };
+  double u0 = 0, u1 = 0, sing = 1.0, c0r = 0.0;
+  auto factors = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    c0r = En[s];
+    u1 = rc1[s];
+    u0 = fma(u1, c0r, rc0[s]);
+    sing = fma(2.0 * u1, c0r, rc0[s]);
+    ring[0][j] = c0r, ring[0][j + 64] = c0r;
+  };
+  fw_for<0, D>([&](auto sc) { load_rec(l0 + decltype(sc)::value, sc); });
+  fw_for<0, D - 1>([&](auto sc) { load_E(l0 + decltype(sc)::value, sc); });
+  factors(std::integral_constant<int, 0>{});
+  for (int64_t rb = l0; rb < l1; rb += D) {
+    fw_for<0, D>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, s1 = (s + 1) % D, sp = (s + D - 1) % D;
+      const int64_t r = rb + s;
+      if (r >= l1) return;
+      load_E(r + D - 1, std::integral_constant<int, sp>{});  // its record was read a step ago
+      load_rec(r + D, sc);
+      // sweep of entry r
+      accS *= sing;
+      constexpr int G = 4;  // ring reads per group; the reads of group g + 1 are in flight while group g is consumed
+      constexpr int NG = (NS - TD + G - 1) / G;
+      double r0 = c0r;  // the partner's E
+      double rd[2][G];
+      auto issue = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        fw_for<0, G>([&](auto ic) {
+          constexpr int k = decltype(ic)::value, t = TD + g * G + k;  // rotation t + 1
+          if constexpr (t < NS) rd[g & 1][k] = fw_ring_rd<(64 - (t + 1)) * 8>(ring_a);
+          else rd[g & 1][k] = 0.0;
+        });
+      };
+      if constexpr (NG > 0) issue(std::integral_constant<int, 0>{});
+      fw_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int left = NS - TD - (g + 1) * G;
+        constexpr int ahead = g + 1 < NG ? (left < G ? left : G) : 0;
+        if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+        fw_for<g * TD / NG, (g + 1) * TD / NG>([&](auto dc) {
+          r0 = fw_wror1(r0);
+          acc[decltype(dc)::value] *= fma(u1, r0, u0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rd[g & 1][0]), "+v"(rd[g & 1][1]), "+v"(rd[g & 1][2]), "+v"(rd[g & 1][3]) : "n"(ahead));
+        fw_for<0, G>([&](auto ic) {
+          constexpr int k = decltype(ic)::value, t = TD + g * G + k;
+          if constexpr (t < NS) acc[t] *= fma(u1, rd[g & 1][k], u0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (TD == NS) {
+        fw_for<0, NS>([&](auto dc) {
+          r0 = fw_wror1(r0);
+          acc[decltype(dc)::value] *= fma(u1, r0, u0);
+        });
+      }
+      factors(std::integral_constant<int, s1>{});
+      if (++cnt == 16) {
+        cnt = 0;
+        fw_renorm<NS, EXL>(acc, ex, exs, j);
+        prodacc_renorm(accS, exS);
+      }
+    });
+  }
+}
+
 template <bool CROSS, bool LIN>
-__global__ void __launch_bounds__(64, (LIN && !CROSS) ? 3 : 2)
+__global__ void __launch_bounds__(64, CROSS ? 2 : 3)
     fmx_estep_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, int64_t c0, int64_t c1,
-                          const int64_t* __restrict__ cell_ptr, const int32_t* __restrict__ entry_snp,
-                          const double* __restrict__ egls, const uint32_t* __restrict__ lin,
-                          const double* __restrict__ cgp, int K, int jbase, int kbase, double* __restrict__ fll) {
+                          const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
+                          const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank,
+                          const fmx_lrec* __restrict__ lrec, const fmx_grec* __restrict__ grec,
+                          const double* __restrict__ cgp, const double* __restrict__ cE, int K, int jbase, int kbase,
+                          double* __restrict__ fll) {
+  static_assert(!(CROSS && LIN), "off-diagonal blocks hold 64 accumulators per lane: no room for a second sweep body");
   constexpr int NS = CROSS ? 64 : 32;
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];  // a cell, or a part of a long one (common.hpp)
   if (it.cell < c0 || it.cell >= c1) return;  // not in this rank's cell shard
   const int64_t c = it.slab;  // row of fll: the cell, or an overflow row behind the C cell rows
-  const int64_t e0 = it.e0, e1 = it.e1;
   const int j = threadIdx.x;
   const int sj = jbase + j;
   const bool live = sj < K, live2 = kbase + j < K;
-  const int K3 = K * 3;
   const int npairs = K * (K + 1) / 2;
 
   // CROSS: 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
-  constexpr bool EXL = CROSS || LIN;  // exponents in LDS: the two sweep bodies of LIN leave no room for them either
+  constexpr bool EXL = CROSS || FMX_EXP_LDS;
   __shared__ int32_t exs[EXL ? NS : 1][64];
+  __shared__ double ring[3][128];
   double acc[NS], accS = 1.0;
   int32_t ex[EXL ? 1 : NS], exS = 0;
 #pragma unroll
@@ -60,122 +360,21 @@ __global__ void __launch_bounds__(64, (LIN && !CROSS) ? 3 : 2)
     if (EXL) exs[t][j] = 0;
     else ex[t] = 0;
   }
-  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-  double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: posterior of cluster kbase + j
-  if (e0 < e1 && live) {
-    const double* row = cgp + (size_t)entry_snp[e0] * K3 + sj * 3;
-    ng0 = row[0], ng1 = row[1], ng2 = row[2];
-  }
-  if (CROSS && e0 < e1 && live2) {
-    const double* row = cgp + (size_t)entry_snp[e0] * K3 + (kbase + j) * 3;
-    np0 = row[0], np1 = row[1], np2 = row[2];
-  }
-  // Software pipeline over the entries: the posterior triples AND the entry's nine (wave-uniform, scalar-loaded)
-  // likelihoods of entry e + 1 are requested before entry e is swept, and the per-entry factors that do not depend on
-  // the rotation (u, the singlet term) are formed for e + 1 right after the sweep of e: the scalar loads then have a
-  // whole sweep to land instead of stalling the wave at the top of every entry.
-  // u0..u2 of the general form; for a linear entry u0 = c0 s_j + c1 E_j, u1 = c1 s_j and the ring carries (s, E)
-  double u0 = 0, u1 = 0, u2 = 0, sing = 1.0;
-  double c0r = ng0, c1r = ng1, c2r = ng2;  // ring start of the current entry (own triple, or the partner's with CROSS)
-  bool lin_cur = false;
-  auto is_lin = [&](int64_t e) { return LIN && ((lin[e >> 5] >> (e & 31)) & 1u); };
-  if (e0 < e1) {
-    const double* q = egls + (size_t)e0 * 9;
-    sing = fma(ng2, q[8], fma(ng1, q[4], ng0 * q[0]));
-    lin_cur = is_lin(e0);
-    if (lin_cur) {
-      const double s = (ng0 + ng1) + ng2, E = fma(2.0, ng2, ng1), cc1 = q[1] - q[0];
-      u0 = fma(cc1, E, q[0] * s);
-      u1 = cc1 * s;
-      c0r = CROSS ? (np0 + np1) + np2 : s;
-      c1r = CROSS ? fma(2.0, np2, np1) : E;
-    } else {
-      u0 = fma(ng2, q[6], fma(ng1, q[3], ng0 * q[0]));
-      u1 = fma(ng2, q[7], fma(ng1, q[4], ng0 * q[1]));
-      u2 = fma(ng2, q[8], fma(ng1, q[5], ng0 * q[2]));
-      if (CROSS) c0r = np0, c1r = np1, c2r = np2;
-    }
-  }
   int cnt = 0;
-  for (int64_t e = e0; e < e1; ++e) {
-    const bool more = e + 1 < e1;
-    // requests for entry e + 1
-    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    if (more && live) {
-      const double* row = cgp + (size_t)entry_snp[e + 1] * K3 + sj * 3;
-      ng0 = row[0], ng1 = row[1], ng2 = row[2];
-    }
-    if (CROSS) {
-      np0 = 1.0, np1 = 0.0, np2 = 0.0;
-      if (more && live2) {
-        const double* row = cgp + (size_t)entry_snp[e + 1] * K3 + (kbase + j) * 3;
-        np0 = row[0], np1 = row[1], np2 = row[2];
-      }
-    }
-    const int64_t en = more ? e + 1 : e;
-    const double* q = egls + (size_t)en * 9;  // wave-uniform: glis[g1*3+g2] of the next entry
-    const bool lin_nx = is_lin(en);
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
-    // sweep of entry e
-    if (!CROSS) accS *= sing;  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
-    if (lin_cur) {
-      double r0 = c0r, r1 = c1r;  // the partner's (s, E)
-      if (CROSS) {
-        r0 = __shfl(r0, (j + 1) & 63, 64);
-        r1 = __shfl(r1, (j + 1) & 63, 64);
-      }
-#pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        r0 = fw_wror1(r0);
-        r1 = fw_wror1(r1);
-        acc[t] *= fma(r0, u0, r1 * u1);
-        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all 32 sums first (64 VGPRs)
-      }
-    } else {
-      double r0 = c0r, r1 = c1r, r2 = c2r;
-      if (CROSS) {  // one lane ahead: the first rotation then brings cluster kbase + j itself
-        r0 = __shfl(r0, (j + 1) & 63, 64);
-        r1 = __shfl(r1, (j + 1) & 63, 64);
-        r2 = __shfl(r2, (j + 1) & 63, 64);
-      }
-#pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        r0 = fw_wror1(r0);
-        r1 = fw_wror1(r1);
-        r2 = fw_wror1(r2);
-        acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :440-446 as a product
-        if (LIN && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // factors of entry e + 1
-    sing = fma(ng2, q8, fma(ng1, q4, ng0 * q0));
-    lin_cur = lin_nx;
-    if (lin_nx) {
-      const double s = (ng0 + ng1) + ng2, E = fma(2.0, ng2, ng1), cc1 = q1 - q0;
-      u0 = fma(cc1, E, q0 * s);
-      u1 = cc1 * s;
-      c0r = CROSS ? (np0 + np1) + np2 : s;
-      c1r = CROSS ? fma(2.0, np2, np1) : E;
-    } else {
-      u0 = fma(ng2, q6, fma(ng1, q3, ng0 * q0));
-      u1 = fma(ng2, q7, fma(ng1, q4, ng0 * q1));
-      u2 = fma(ng2, q8, fma(ng1, q5, ng0 * q2));
-      c0r = CROSS ? np0 : ng0, c1r = CROSS ? np1 : ng1, c2r = CROSS ? np2 : ng2;
-    }
-    if (++cnt == 16) {  // a factor is >= ~1e-13 (clamped likelihoods, mixed posteriors): sixteen cannot underflow
-      cnt = 0;
-#pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        if (EXL) {
-          int ee;
-          acc[t] = frexp(acc[t], &ee);
-          exs[t][j] += ee;
-        } else {
-          prodacc_renorm(acc[t], ex[t]);
-        }
-      }
-      if (!CROSS) prodacc_renorm(accS, exS);
-    }
+  if constexpr (LIN) {
+    // the part's place in the two streams: linear entries before e = lin_rank[e / 32] + set bits below e in its word
+    auto rank = [&](int64_t e) {
+      int64_t r = lin_rank[e >> 5];
+      if (e & 31) r += __popc(lin[e >> 5] & ((1u << (e & 31)) - 1u));
+      return r;
+    };
+    const int64_t l0 = rank(it.e0), l1 = rank(it.e1);
+    fw_walk_lin<NS, EXL>(l0, l1, lrec, cE, K, sj, live, j, ring, exs, acc, ex, accS, exS, cnt);
+    fw_walk_gen<false, true, NS, EXL>(it.e0 - l0, it.e1 - l1, grec, entry_snp, egls, cgp, K * 3, sj * 3, 0, live, false, j,
+                                      ring, exs, acc, ex, accS, exS, cnt);
+  } else {
+    fw_walk_gen<CROSS, false, NS, EXL>(it.e0, it.e1, grec, entry_snp, egls, cgp, K * 3, sj * 3, (kbase + j) * 3, live, live2, j,
+                                       ring, exs, acc, ex, accS, exS, cnt);
   }
 
   double* out = fll + (size_t)c * npairs;
@@ -192,6 +391,39 @@ __global__ void __launch_bounds__(64, (LIN && !CROSS) ? 3 : 2)
     }
   }
   if (!CROSS && live) out[sj * (sj + 1) / 2 + sj] = prodacc_log(accS, exS);
+}
+
+// ---- the streams ----
+__global__ void __launch_bounds__(256) fw_popc_kernel(int64_t nwords, int64_t nnz, const uint32_t* __restrict__ lin, int64_t* __restrict__ cnt) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > nwords) return;
+  uint32_t v = 0;
+  if (w < nwords) {
+    v = lin[w];
+    const int64_t left = nnz - w * 32;
+    if (left < 32) v &= (1u << left) - 1u;
+  }
+  cnt[w] = __popc(v);
+}
+
+__global__ void __launch_bounds__(256)
+    fw_stream_kernel(int64_t nnz, const uint32_t* __restrict__ lin, const int64_t* __restrict__ rank, const int32_t* __restrict__ entry_snp,
+                     const double* __restrict__ egls, fmx_lrec* __restrict__ lrec, fmx_grec* __restrict__ grec) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  const uint32_t w = lin[e >> 5];
+  const int64_t r = rank[e >> 5] + __popc(w & ((1u << (e & 31)) - 1u));
+  if ((w >> (e & 31)) & 1u) {
+    const double q0 = egls[(size_t)e * 9], q1 = egls[(size_t)e * 9 + 1];
+    lrec[r] = fmx_lrec{q0, q1 - q0, entry_snp[e], 0};
+  } else {
+    grec[e - r] = fmx_grec{e, entry_snp[e], 0};
+  }
+}
+
+__global__ void __launch_bounds__(256) fw_ce_kernel(int64_t n, const double* __restrict__ cgp, double* __restrict__ cE) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cE[i] = fma(2.0, cgp[3 * i + 2], cgp[3 * i + 1]);
 }
 
 // 16 < K <= 32: the wave as a ring of 32.  Both 32-lane halves hold the same 32 posteriors (lane j and j + 32: cluster
@@ -298,6 +530,42 @@ int64_t fmx_wave_fll_rows(const muxgl_handle* h) {
   return h->C + n_over;
 }
 
+void fmx_wave_streams_release(muxgl_handle* h) {
+  dev_free(&h->d_flin_rank);
+  dev_free(&h->d_lrec);
+  dev_free(&h->d_grec);
+  dev_free(&h->d_cE);
+  h->n_lrec = -1;
+  h->cE_n = 0;
+}
+
+// the two entry streams of the linear-entry kernel, made once per fmx_prepare from d_flin and d_egls
+static int fmx_wave_streams_build(muxgl_handle* h) {
+  if (h->n_lrec >= 0) return 0;
+  const int64_t nnz = h->nnz, nwords = (nnz + 31) / 32;
+  if (dev_alloc(h, &h->d_flin_rank, (size_t)nwords + 1)) return 1;
+  hipLaunchKernelGGL(fw_popc_kernel, dim3((unsigned)((nwords + 256) / 256)), dim3(256), 0, h->stream, nwords, nnz, h->d_flin,
+                     h->d_flin_rank);
+  size_t tb = 0;
+  void* tmp = nullptr;
+  HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, h->d_flin_rank, h->d_flin_rank, (int64_t)0, (size_t)nwords + 1,
+                                    rocprim::plus<int64_t>(), h->stream));
+  HIPCHK(h, hipMalloc(&tmp, tb ? tb : 1));
+  hipError_t e = rocprim::exclusive_scan(tmp, tb, h->d_flin_rank, h->d_flin_rank, (int64_t)0, (size_t)nwords + 1,
+                                         rocprim::plus<int64_t>(), h->stream);
+  int64_t n_lin = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_lin, h->d_flin_rank + nwords, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) MUXGL_FAIL(h, "fmx_wave_streams_build: %s", hipGetErrorString(e));
+  if (dev_alloc(h, &h->d_lrec, (size_t)n_lin) || dev_alloc(h, &h->d_grec, (size_t)(nnz - n_lin))) return 1;
+  hipLaunchKernelGGL(fw_stream_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, h->stream, nnz, h->d_flin,
+                     h->d_flin_rank, h->d_entry_snp, h->d_egls, h->d_lrec, h->d_grec);
+  HIPCHK(h, hipGetLastError());
+  h->n_lrec = n_lin;
+  return 0;
+}
+
 // returns -1 when this path does not apply, 0 ok, 1 error
 int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
   if (h->K <= 16 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
@@ -306,13 +574,23 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
   int64_t n_items, n_cuts, n_over;
   if (demux_wave_items(h, &items, &n_items, &cuts, &n_cuts, &n_over) || n_items == 0) return -1;
   const int nblk = (h->K + 63) / 64;
-  const bool use_lin = h->d_flin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);  // two-term form for linear entries
+  const bool use_lin = h->K > 32 && h->d_flin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);  // linear-entry stream
+  if (use_lin) {
+    if (fmx_wave_streams_build(h)) return 1;
+    const int64_t n = h->S * (int64_t)h->K;
+    if (h->cE_n != n) {
+      if (dev_alloc(h, &h->d_cE, (size_t)n)) return 1;
+      h->cE_n = n;
+    }
+    if (n) hipLaunchKernelGGL(fw_ce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, h->d_cgp, h->d_cE);
+  }
   if (h->K <= 32)
     hipLaunchKernelGGL(fmx_estep_wave32_kernel, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
                        c0 + nc, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, h->d_fll);
   for (int X = 0; X < (h->K <= 32 ? 0 : nblk); ++X) {
 #define FW_ARGS(XB, YB) \
-  items, n_items, c0, c0 + nc, h->d_cell_ptr, h->d_entry_snp, h->d_egls, h->d_flin, h->d_cgp, h->K, 64 * (XB), 64 * (YB), h->d_fll
+  items, n_items, c0, c0 + nc, h->d_entry_snp, h->d_egls, h->d_flin, h->d_flin_rank, h->d_lrec, h->d_grec, h->d_cgp, h->d_cE, h->K, \
+      64 * (XB), 64 * (YB), h->d_fll
     if (use_lin) hipLaunchKernelGGL((fmx_estep_wave_kernel<false, true>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
     else hipLaunchKernelGGL((fmx_estep_wave_kernel<false, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
     for (int Y = 0; Y < X; ++Y)  // (off-diagonal blocks hold 64 accumulators per lane: no room for a second sweep body)

@@ -155,6 +155,7 @@ int plan_build_qent(muxgl_handle* h) {
 int plan_build_lin(muxgl_handle* h) {
   dev_free(&h->d_lin);
   dev_free(&h->d_flin);
+  fmx_wave_streams_release(h);
   if (h->nnz == 0) return 0;
   if (dev_alloc(h, &h->d_lin, (size_t)((h->nnz + 31) / 32))) return 1;
   hipLaunchKernelGGL(lin_kernel, dim3(grid_for(h->nnz, 4096)), dim3(256), 0, h->stream, h->nnz, h->d_entry_rptr,

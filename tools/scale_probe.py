@@ -86,10 +86,11 @@ def main():
         llk0, llk2, _, _ = eng.fmx_prepare(p.af)
         out["prepare_s"] = round(time.time() - t0, 2)
         out["prepare_kernel_ms"] = float(eng.timing()[muxgl.T_FMX_ENTRY])
-        t0 = time.time()
-        g = eng.fmx_greedy_init(K, llk2 - llk0)
-        out["greedy_init_s"] = round(time.time() - t0, 3)
-        out["greedy_clusters_used"] = int(len(np.unique(g[g >= 0])))
+        if not os.environ.get("MUXGL_PROBE_NO_GREEDY"):  # (thousands of small launches: skipped under counter collection)
+            t0 = time.time()
+            g = eng.fmx_greedy_init(K, llk2 - llk0)
+            out["greedy_init_s"] = round(time.time() - t0, 3)
+            out["greedy_clusters_used"] = int(len(np.unique(g[g >= 0])))
         clust0 = np.where(np.random.default_rng(0).random(C) < 0.9, p.truth["s1"], -1).astype(np.int32)
         t0 = time.time()
         eng.fmx_set_clusters(K, clust0)
