@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +84,10 @@ struct muxgl_handle {
   // (demuxlet: pG[l][m] = A + Bl*l + Bm*m, cmd_cram_demuxlet.cpp:673-685 for a single factor) and a pair hypothesis is a
   // two-term form in the samples' moments (sum g, sum l*g) instead of a three-term one -- see demux_wave.hip.
   uint32_t* d_lin = nullptr;        // [ceil(nnz/32)] demuxlet
+  int64_t* d_lin_rank = nullptr;    // demuxlet wave kernels, built on first use: plan_build_bit_streams of d_lin
+  fmx_grec* d_lin_rec = nullptr;    // [n_lin_rec] {entry, snp} of the linear entries, in entry order
+  fmx_grec* d_gen_rec = nullptr;    // [nnz - n_lin_rec] the others
+  int64_t n_lin_rec = -1;
   uint32_t* d_flin = nullptr;       // [ceil(nnz/32)] freemuxlet: additionally, no clamp fired (checked on the values)
   // The wave E-step's two streams (fmx_wave.hip, built on first use): a cell's linear entries as 24-byte records
   // {c0, c1, snp} and its other entries as {entry, snp}, both in entry order; d_flin_rank[w] = linear entries before
@@ -247,6 +253,25 @@ __device__ __forceinline__ void prodacc_renorm(double& m, int32_t& e) {
 }
 __device__ __forceinline__ double prodacc_log(double m, int32_t e) { return log(m) + (double)e * 0.6931471805599453094; }
 
+// ---- the ring of partner values of the wave kernels (demux_wave.hip, fmx_wave.hip) ----
+// One 8-byte read per lane from the ring in LDS, at an immediate offset from the lane's slot.  As an opaque instruction
+// because two such reads with one base are otherwise merged into a ds_read2_b64, which takes 8 LDS cycles instead of
+// 2 + 2 (MI355X_MICROARCH.md, LDS table).  The caller waits (s_waitcnt lgkmcnt) before using the value; "memory" keeps
+// the next entry's ring stores behind it.
+template <int OFF>
+__device__ __forceinline__ double wave_ring_rd(uint32_t a) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void wave_for(F&& f) {  // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wave_for<I + 1, N>(f);
+  }
+}
+
 // which entries of a cell a wave-per-cell sweep walks: all of them, or those whose bit in the linear-entry set is
 // set / clear (plan_build_lin, fmx_entry_kernel)
 enum { EM_ALL = 0, EM_LINEAR = 1, EM_GENERAL = 2 };
@@ -265,6 +290,21 @@ __device__ __forceinline__ int64_t wave_next_entry(const uint32_t* __restrict__ 
     e = (e | 31) + 1;
   }
   return e1;
+}
+
+// where the entries [e0, e1) of a work unit lie in the stream of the set (EM_LINEAR) or clear (EM_GENERAL) bits of `bits`
+// (plan_build_bit_streams): set bits before e = rank[e / 32] + set bits below e in its word
+template <int EM>
+__device__ __forceinline__ void wave_stream_range(const uint32_t* __restrict__ bits, const int64_t* __restrict__ rank, int64_t e0,
+                                                  int64_t e1, int64_t& i0, int64_t& i1) {
+  auto before = [&](int64_t e) {
+    int64_t r = rank[e >> 5];
+    if (e & 31) r += __popc(bits[e >> 5] & ((1u << (e & 31)) - 1u));
+    return r;
+  };
+  const int64_t l0 = before(e0), l1 = before(e1);
+  i0 = EM == EM_LINEAR ? l0 : e0 - l0;
+  i1 = EM == EM_LINEAR ? l1 : e1 - l1;
 }
 
 // Workgroup -> work-unit index with XCD affinity.  The dispatcher is observed to place workgroup b on XCD b % 8
@@ -334,6 +374,9 @@ void demux_row_release(muxgl_row_state** st);
 int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
 int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)
 int plan_build_lin(muxgl_handle* h);        // d_lin (plan_kernels.hip)
+int plan_build_bit_streams(muxgl_handle* h, const uint32_t* bits, int64_t** rank, fmx_grec** rec_set, fmx_grec** rec_clr,
+                           int64_t* n_set);
+void plan_lin_streams_release(muxgl_handle* h);
 int plan_build_snp_major(muxgl_handle* h);  // d_entry_cell, d_snp_ptr, d_snp_entry, d_snp_cell (plan_kernels.hip)
 
 // handle plumbing shared by muxgl_api.hip and muxgl_group.hip

@@ -39,11 +39,127 @@ __global__ void __launch_bounds__(256)
   for (int i = 0; i < width; ++i) pg[(size_t)e * width + i] = 1.0;
 }
 
+// The linear entries' table in stream order: lpg[r][n] = (A, Bl, Bm) with pG[l][m] = A + Bl*l + Bm*m for the r-th linear
+// entry of the pileup (plan_build_bit_streams) and alpha n -- 24 bytes per (entry, alpha) instead of 72, and rows a wave
+// reads one after the other.
+__global__ void __launch_bounds__(256)
+    wave_lpg_kernel(int64_t n_lin, int A, const fmx_grec* __restrict__ rec_lin, const double* __restrict__ pg,
+                    double* __restrict__ lpg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (linear entry, alpha)
+  if (i >= n_lin * A) return;
+  const int64_t r = i / A;
+  const int n = (int)(i - r * A);
+  const double* q = pg + ((size_t)rec_lin[r].e * A + n) * 9;
+  const double q0 = q[0];
+  lpg[i * 3] = q0;
+  lpg[i * 3 + 1] = q[3] - q0;
+  lpg[i * 3 + 2] = q[1] - q0;
+}
+
 __device__ __forceinline__ double dpp_wror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1 : lane j <- lane (j-1) mod 64
   hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+
+#ifndef DW_DEPTH
+#define DW_DEPTH 3  // entries the walk runs ahead (ring slots of the software pipeline)
+#endif
+#ifndef DW_TOUCH_AHEAD
+#define DW_TOUCH_AHEAD 8  // ... of the linear entries' table, which is in stream order
+#endif
+#ifndef DW_TOUCH
+#define DW_TOUCH 1  // touch the likelihood rows D - 1 entries ahead (see dw_walk)
+#endif
+#define DW_G_LIN 4  // ring reads per group of the linear / general sweep
+#define DW_G_GEN 2
+
+// The ring.  Rotation t + 1 of a launch that starts at offset s0 brings lane j the value of lane (j - s0 - t - 1) mod 64
+// (one lane further with CROSS).  The 64 values are kept twice over in LDS, ring[i] = ring[i + 64] = value of lane i, so
+// lane j reads ring[j + 64 - s0 - t - 1]: an immediate offset from ONE base address, &ring[j + 64 - s0 - NS].  A DPP
+// rotation of a double is two vector moves, as much issue time as the FMA it feeds; the LDS read travels on the other
+// pipe (ds_read_b64: 2 LDS cycles per wave).  Reads are issued a group ahead of their use.
+// groups [GB, GE) of the sweep (a sweep is cut in two so that work for the next entry can be placed in its middle)
+template <int NA, int NS, int CR, int GB, int GE>
+__device__ __forceinline__ void dw_sweep_lin(uint32_t rb, const double (&u0)[NA], const double (&u1)[NA], double (&acc)[NA * NS]) {
+  constexpr int G = DW_G_LIN;
+  static_assert(G == 4, "the wait below names four values");
+  double rd[2][G];
+  auto issue = [&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    wave_for<0, G>([&](auto ic) {
+      constexpr int k = decltype(ic)::value, t = g * G + k;
+      if constexpr (t < NS) rd[g & 1][k] = wave_ring_rd<(NS - 1 - t + CR) * 8>(rb);
+      else rd[g & 1][k] = 0.0;
+    });
+  };
+  if constexpr (GB < GE) issue(std::integral_constant<int, GB>{});
+  wave_for<GB, GE>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int left = NS - (g + 1) * G;
+    constexpr int ahead = g + 1 < GE ? (left < G ? left : G) : 0;  // younger reads: they may stay in flight
+    if constexpr (g + 1 < GE) issue(std::integral_constant<int, g + 1>{});
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rd[g & 1][0]), "+v"(rd[g & 1][1]), "+v"(rd[g & 1][2]), "+v"(rd[g & 1][3]) : "n"(ahead));
+    wave_for<0, G>([&](auto ic) {
+      constexpr int k = decltype(ic)::value, t = g * G + k;
+      if constexpr (t < NS) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(u1[a], rd[g & 1][k], u0[a]);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all the sums first
+  });
+}
+
+template <int NA, int NS, int CR, int GB, int GE>
+__device__ __forceinline__ void dw_sweep_gen(uint32_t rb, const double (&u)[NA][3], double (&acc)[NA * NS]) {
+  constexpr int G = DW_G_GEN;
+  static_assert(G == 2, "the wait below names two triples");
+  double rd[2][G][3];
+  auto issue = [&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    wave_for<0, G>([&](auto ic) {
+      constexpr int k = decltype(ic)::value, t = g * G + k;
+      if constexpr (t < NS) {
+        rd[g & 1][k][0] = wave_ring_rd<(NS - 1 - t + CR) * 8>(rb);
+        rd[g & 1][k][1] = wave_ring_rd<(NS - 1 - t + CR) * 8 + 1024>(rb);
+        rd[g & 1][k][2] = wave_ring_rd<(NS - 1 - t + CR) * 8 + 2048>(rb);
+      } else {
+        rd[g & 1][k][0] = rd[g & 1][k][1] = rd[g & 1][k][2] = 0.0;
+      }
+    });
+  };
+  if constexpr (GB < GE) issue(std::integral_constant<int, GB>{});
+  wave_for<GB, GE>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int left = NS - (g + 1) * G;
+    constexpr int ahead = g + 1 < GE ? 3 * (left < G ? left : G) : 0;
+    if constexpr (g + 1 < GE) issue(std::integral_constant<int, g + 1>{});
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(rd[g & 1][0][0]), "+v"(rd[g & 1][0][1]), "+v"(rd[g & 1][0][2]), "+v"(rd[g & 1][1][0]),
+                   "+v"(rd[g & 1][1][1]), "+v"(rd[g & 1][1][2])
+                 : "n"(ahead));
+    wave_for<0, G>([&](auto ic) {
+      constexpr int k = decltype(ic)::value, t = g * G + k;
+      if constexpr (t < NS) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          acc[a * NS + t] *= fma(rd[g & 1][k][2], u[a][2], fma(rd[g & 1][k][1], u[a][1], rd[g & 1][k][0] * u[a][0]));  // :738-746
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// the moments of a linear entry: s = sum g, rho = (g1 + 2 g2) / s (0 for an all-zero triple, whose pairs are 0 through s)
+__device__ __forceinline__ void dw_moments(double g0, double g1, double g2, double& sm, double& Em, double& rho) {
+  sm = (g0 + g1) + g2;
+  Em = fma(2.0, g2, g1);
+  double x = __builtin_amdgcn_rcp(sm);  // 1/s by v_rcp_f64 and two Newton steps (<= 1 ulp)
+  x = fma(x, fma(-sm, x, 1.0), x);
+  x = fma(x, fma(-sm, x, 1.0), x);
+  rho = sm > 0.0 ? Em * x : 0.0;
 }
 
 // More than 64 samples: the V x V pair matrix is cut into 64 x 64 blocks (X, Y).  A diagonal block is the kernel as
@@ -58,129 +174,282 @@ struct wave_blk {
 // Entries with at most one usable read (bit set in `lin`, plan_kernels.hip).  A single factor pR*(1-p) + pA*p with
 // p = l/2 + (m-l)*alpha/2 (cmd_cram_demuxlet.cpp:673,685) is LINEAR in the two genotypes, and so is everything the tail
 // (:703-725) makes of it: pG[l][m] = A + Bl*l + Bm*m.  Then
-//     sum_{l,m} g_j[l] g_k[m] pG[l][m] = s_k (A s_j + Bl E_j) + E_k (Bm s_j),     s = sum_l g[l],  E = g[1] + 2 g[2]:
-// the partner's two moments rotate instead of its triple (4 DPP moves instead of 6) and a hypothesis costs a multiply, an
-// FMA and the product update instead of a multiply, two FMAs and the update.  Three quarters of the entries of a typical
-// pileup are such entries.  (A, Bl, Bm are read off the table: pG[0][0], pG[1][0] - pG[0][0], pG[0][1] - pG[0][0].)
+//     sum_{l,m} g_j[l] g_k[m] pG[l][m] = s_k (A s_j + Bl E_j) + E_k (Bm s_j) = s_k ((A s_j + Bl E_j) + (Bm s_j) rho_k),
+// s = sum_l g[l],  E = g[1] + 2 g[2],  rho = E / s.  The factor s_k belongs to the partner alone: every lane keeps the
+// product of its own s over the cell's linear entries (one multiply per entry) and a hypothesis gets log(prod s_k) of
+// its partner at the end.  What is left per hypothesis is an FMA of the partner's rho with two numbers of the lane, and
+// the product update: ONE partner value per step instead of three, two vector instructions per hypothesis instead of
+// four.  Three quarters of the entries of a typical pileup are such entries.  (A, Bl, Bm are read off the table:
+// pG[0][0], pG[1][0] - pG[0][0], pG[0][1] - pG[0][0].)
 // Two sweep bodies in one kernel do not fit the register file next to 64 accumulators per lane, so the two kinds of
 // entries get a launch each -- EM_LINEAR walks the flagged entries of a cell and writes, EM_GENERAL walks the others and
 // ADDS its log-likelihoods to what is there -- EM_ALL is the single launch without the distinction.  The walk is a
 // scalar scan of the bit set, so an entry of the other kind costs a few scalar instructions and no loads.
 
+// The walk of one work unit: entries [i0, i1) of a record stream {entry, snp} (STREAM: the linear or the other entries
+// of the cell, plan_build_bit_streams), or the entries i0 .. i1 - 1 themselves.  A cell's entries meet marker rows all
+// over the genotype tensor and the table of likelihoods is 72 bytes per (entry, alpha): every entry is a chain of
+// misses a microsecond long, and with 64 accumulators per lane only two waves share a SIMD.  So the walk runs ahead:
+//   * records D entries ahead (scalar loads), genotype triples D - 1 ahead, in rings of D register slots addressed
+//     statically (the loop is unrolled D times); the loads are unconditional -- a lane without a sample reads the last
+//     sample's triple, an entry behind the end the last record -- because the compiler cannot count loads under a lane
+//     mask and would wait for all of them at every use;
+//   * the likelihoods of the NEXT entry are requested in two batches, one before the sweep and one in its middle, and
+//     the lane's factors u for the next entry are formed from them in the middle of the sweep and right after it --
+//     two batches because the nine likelihoods of four alphas are 72 scalar registers.
+template <int NA, int NS, bool WITH_SINGLET, bool CROSS, int EM, bool EXL>
+__device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* __restrict__ rec,
+                                        const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, int PG,
+                                        const int32_t (&seln)[NA], const double* __restrict__ gp, int V3, int jo, int ko,
+                                        bool live, bool live2, int j, int s0, double (*ring)[128], int32_t (*exs)[64],
+                                        double (&acc)[NA * NS], int32_t (&ex)[EXL ? 1 : NA * NS], double& accS, int32_t& exS,
+                                        double& accW, int32_t& exW) {
+  constexpr bool L = EM == EM_LINEAR, STREAM = EM != EM_ALL;
+  constexpr int D = (CROSS || NA * NS > 32) ? 2 : DW_DEPTH;  // (64 accumulators per lane: two slots is what fits)
+  constexpr int HA = (NA + 1) / 2, HB = NA - HA;  // alphas of the first / second batch of likelihoods
+  constexpr int QN = L ? 3 : 9;           // numbers per (entry, alpha): A, Bl, Bm of a linear entry (wave_lpg_kernel), or pG
+  constexpr int UN = L ? 2 : 3;
+  constexpr int CR = CROSS ? 1 : 0;
+  constexpr int NG = L ? (NS + DW_G_LIN - 1) / DW_G_LIN : (NS + DW_G_GEN - 1) / DW_G_GEN, NGH = NG / 2;
+  if (i0 >= i1) return;
+  const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - s0 - NS];
+  int64_t ide[D];
+  int32_t ids[D];
+  double g[D][3], p[CROSS ? D : 1][3];  // triple of sample jbase + j (and of kbase + j) at the slot's marker
+  auto load_id = [&](int64_t i, auto sc) {  // clamped: a valid record is read behind the end, and not used
+    constexpr int s = decltype(sc)::value;
+    const int64_t ic = i < i1 ? i : i1 - 1;
+    if (STREAM) ide[s] = rec[ic].e, ids[s] = rec[ic].snp;
+    else ide[s] = ic, ids[s] = entry_snp[ic];
+  };
+  auto load_gp = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    const double* row = gp + (size_t)ids[s] * V3 + jo;
+    g[s][0] = row[0], g[s][1] = row[1], g[s][2] = row[2];
+    if (CROSS) {
+      constexpr int sq = CROSS ? s : 0;
+      const double* rowp = gp + (size_t)ids[s] * V3 + ko;
+      p[sq][0] = rowp[0], p[sq][1] = rowp[1], p[sq][2] = rowp[2];
+    }
+  };
+  // factors of the current entry, and those of the next entry that are formed in the middle of the sweep
+  double u[NA][UN], un[HA][UN], sv = 1.0, sw = 1.0;
+  double rv[3] = {1.0, 0.0, 0.0};  // the next entry's ring values (linear: rho in rv[0])
+  double sm = 1.0, Em = 0.0;       // linear: the next entry's moments
+  double qa[HA][QN], qb[HB > 0 ? HB : 1][QN], qs[WITH_SINGLET ? QN : 1], hs[WITH_SINGLET ? 3 : 1];
+  // row of the table for the entry in slot s / at stream position idx: the linear entries' table is in stream order
+  auto row_of = [&](auto sc, int64_t idx) {
+    constexpr int s = decltype(sc)::value;
+    if (L) return pg + (size_t)(idx < i1 ? idx : i1 - 1) * PG;
+    return pg + (size_t)ide[s] * PG;
+  };
+  auto load_a = [&](auto sc, int64_t idx) {
+    const double* row = row_of(sc, idx);
+#pragma unroll
+    for (int a = 0; a < HA; ++a) {
+      const double* q = row + (size_t)seln[a] * QN;
+#pragma unroll
+      for (int k = 0; k < QN; ++k) qa[a][k] = q[k];
+    }
+  };
+  auto load_b = [&](auto sc, int64_t idx) {
+    constexpr int s = decltype(sc)::value;
+    const double* row = row_of(sc, idx);
+#pragma unroll
+    for (int a = 0; a < HB; ++a) {
+      const double* q = row + (size_t)seln[HA + a] * QN;
+#pragma unroll
+      for (int k = 0; k < QN; ++k) qb[a][k] = q[k];
+    }
+    if (WITH_SINGLET) {
+      const double* h = gp + (size_t)ids[s] * V3;  // sample 0's triple multiplies every singlet (:806,828)
+#pragma unroll
+      for (int k = 0; k < QN; ++k) qs[k] = row[k];
+      hs[0] = h[0], hs[1] = h[1], hs[2] = h[2];
+    }
+  };
+  auto factor = [&](double (&uu)[UN], const double (&q)[QN], double g0, double g1, double g2) {
+    if constexpr (L) {  // q = (A, Bl, Bm)
+      uu[0] = fma(q[1], Em, q[0] * sm);
+      uu[1] = q[2] * sm;
+    } else {
+      uu[0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
+      uu[1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
+      uu[2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
+    }
+  };
+  auto comp_a = [&](auto sc) {  // first batch: the moments / ring values and the factors of alphas 0 .. HA-1
+    constexpr int s = decltype(sc)::value, sq = CROSS ? s : 0;
+    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = live ? g[s][2] : 0.0;
+    if constexpr (L) {
+      dw_moments(g0, g1, g2, sm, Em, rv[0]);
+    } else if constexpr (CROSS) {
+      rv[0] = live2 ? p[sq][0] : 1.0, rv[1] = live2 ? p[sq][1] : 0.0, rv[2] = live2 ? p[sq][2] : 0.0;
+    } else {
+      rv[0] = g0, rv[1] = g1, rv[2] = g2;
+    }
+#pragma unroll
+    for (int a = 0; a < HA; ++a) factor(un[a], qa[a], g0, g1, g2);
+  };
+  auto comp_b = [&](auto sc) {  // behind the sweep: the current entry's factors are free to be overwritten
+    constexpr int s = decltype(sc)::value;
+    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = live ? g[s][2] : 0.0;
+#pragma unroll
+    for (int a = 0; a < HA; ++a)
+#pragma unroll
+      for (int k = 0; k < UN; ++k) u[a][k] = un[a][k];
+    if (L) sw = sm;
+#pragma unroll
+    for (int a = 0; a < HB; ++a) factor(u[HA + a], qb[a], g0, g1, g2);
+    if (WITH_SINGLET) {
+      if constexpr (L) {  // sum_m h[m] sum_l g[l] (A + Bl l + Bm m) of alpha[0], in the moments of both triples
+        const double sh = (hs[0] + hs[1]) + hs[2], Eh = fma(2.0, hs[2], hs[1]);
+        sv = fma(qs[2] * sm, Eh, sh * fma(qs[1], Em, qs[0] * sm));
+      } else {
+        const double v0 = fma(g2, qs[6], fma(g1, qs[3], g0 * qs[0]));
+        const double v1 = fma(g2, qs[7], fma(g1, qs[4], g0 * qs[1]));
+        const double v2 = fma(g2, qs[8], fma(g1, qs[5], g0 * qs[2]));
+        sv = fma(hs[2], v2, fma(hs[1], v1, hs[0] * v0));
+      }
+    }
+  };
+  auto ring_put = [&]() {
+    ring[0][j] = rv[0], ring[0][j + 64] = rv[0];
+    if (!L) {
+      ring[1][j] = rv[1], ring[1][j + 64] = rv[1];
+      ring[2][j] = rv[2], ring[2][j + 64] = rv[2];
+    }
+  };
+  // The table of likelihoods is read through the scalar cache one entry ahead -- not enough for a first touch of its
+  // lines, which come from HBM.  So the row of the entry whose record has just arrived (D - 1 entries ahead) is touched
+  // with one vector load, 8 bytes per lane; the value is folded into a word nobody reads (its consumer sits D steps
+  // later, where the load has long landed) so that the compiler keeps and counts the load.
+  unsigned long long pfv[D], pfx = 0;
+  auto touch = [&](auto sc, int64_t idx) {  // linear entries: the table is in stream order, any distance ahead will do
+    constexpr int s = decltype(sc)::value;
+    pfx ^= pfv[s];
+    pfv[s] = ((const unsigned long long*)row_of(sc, idx + (L ? DW_TOUCH_AHEAD - (D - 1) : 0)))[j < PG ? j : PG - 1];
+  };
+  wave_for<0, D>([&](auto sc) { pfv[decltype(sc)::value] = 0; });
+  wave_for<0, D>([&](auto sc) { load_id(i0 + decltype(sc)::value, sc); });
+  wave_for<0, D - 1>([&](auto sc) { load_gp(sc); });
+  {
+    using S0 = std::integral_constant<int, 0>;
+    load_a(S0{}, i0);
+    load_b(S0{}, i0);
+    comp_a(S0{});
+    comp_b(S0{});
+    ring_put();
+  }
+  int cnt = 0;
+  for (int64_t ib = i0; ib < i1; ib += D) {
+    wave_for<0, D>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, s1 = (s + 1) % D, sp = (s + D - 1) % D;
+      using S1 = std::integral_constant<int, s1>;
+      const int64_t i = ib + s;
+      if (i >= i1) return;  // (the factors formed for the entry behind the last one are not used)
+      load_gp(std::integral_constant<int, sp>{});  // entry i + D - 1: its record was read a step ago
+      if (DW_TOUCH) touch(std::integral_constant<int, sp>{}, i + D - 1);
+      load_a(S1{}, i + 1);
+      load_id(i + D, sc);
+      if (WITH_SINGLET) accS *= sv;
+      if (L) accW *= sw;
+      if constexpr (L) {
+        double u0[NA], u1[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) u0[a] = u[a][0], u1[a] = u[a][1];
+        dw_sweep_lin<NA, NS, CR, 0, NGH>(rb, u0, u1, acc);
+        comp_a(S1{});
+        load_b(S1{}, i + 1);
+        dw_sweep_lin<NA, NS, CR, NGH, NG>(rb, u0, u1, acc);
+      } else {
+        dw_sweep_gen<NA, NS, CR, 0, NGH>(rb, u, acc);
+        comp_a(S1{});
+        load_b(S1{}, i + 1);
+        dw_sweep_gen<NA, NS, CR, NGH, NG>(rb, u, acc);
+      }
+      comp_b(S1{});
+      ring_put();  // behind the sweep's reads: the LDS serves one wave's requests in order
+      if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
+        cnt = 0;
+#pragma unroll
+        for (int t = 0; t < NA * NS; ++t) {
+          if (EXL) {
+            int ee;
+            acc[t] = frexp(acc[t], &ee);
+            exs[t][j] += ee;
+          } else {
+            prodacc_renorm(acc[t], ex[t]);
+          }
+        }
+        if (WITH_SINGLET) prodacc_renorm(accS, exS);
+        if (L) prodacc_renorm(accW, exW);
+      }
+    });
+  }
+  if (DW_TOUCH) {
+    wave_for<0, D>([&](auto sc) { pfx ^= pfv[decltype(sc)::value]; });
+    if (pfx == 0x9E3779B97F4A7C15ull) accS *= 1.0;  // (never: a use the compiler cannot see through)
+    asm volatile("" ::"v"(pfx));
+  }
+}
+
 // NSHIFT = 32 for the symmetric alpha 0.5, 63 otherwise (64 with CROSS).  WITH_SINGLET: also accumulate llksAB[j][0][n=0].
 template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL>
 __global__ void __launch_bounds__(64, 2)
     demux_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
-                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const uint32_t* __restrict__ lin,
-                      const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel,
-                      wave_blk wb, double* __restrict__ ll) {
+                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const double* __restrict__ lpg,
+                      const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank, const fmx_grec* __restrict__ rec_lin,
+                      const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp,
+                      const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel, wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
   const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
-  const int64_t e0 = it.e0, e1 = it.e1;
-  if (e0 == e1) return;
+  if (it.e0 == it.e1) return;
   const int j = threadIdx.x;
   const bool live = wb.jbase + j < V;
   const bool live2 = wb.kbase + j < V;
   const int V3 = V * 3;
-  const int PG = nAlpha * 9;
-  const int jo = (wb.jbase + j) * 3, ko = (wb.kbase + j) * 3;
+  const double* tab = EM == EM_LINEAR ? lpg : pg;  // the table the walk reads, and its row width
+  const int TW = nAlpha * (EM == EM_LINEAR ? 3 : 9);
+  const int jo = (live ? wb.jbase + j : V - 1) * 3, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
 
-  double acc[NSHIFT], accS = 1.0;
-  int32_t ex[NSHIFT], exS = 0;
+  constexpr bool EXL = NSHIFT > 32;  // 63 / 64 accumulators per lane: their exponents live in LDS
+  __shared__ double ring[3][128];    // the partner values of the current entry, see dw_sweep_lin
+  __shared__ int32_t exs[EXL ? NSHIFT : 1][64];
+  const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - NSHIFT];
+  double acc[NSHIFT], accS = 1.0, accW = 1.0;  // accW: product of the own sums s over the linear entries (EM_LINEAR)
+  int32_t ex[EXL ? 1 : NSHIFT], exS = 0, exW = 0;
 #pragma unroll
   for (int t = 0; t < NSHIFT; ++t) {
     acc[t] = 1.0;
-    ex[t] = 0;
+    if (EXL) exs[t][j] = 0;
+    else ex[t] = 0;
   }
-
-  // software pipeline: triples of the next marker with genotypes are loaded while the current one is swept
-  int64_t e = wave_next_entry<EM>(lin, e0, e1);
-  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-  double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
-  if (e < e1 && live) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
-    ng0 = row[0], ng1 = row[1], ng2 = row[2];
-  }
-  if (CROSS && e < e1 && live2) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
-    np0 = row[0], np1 = row[1], np2 = row[2];
-  }
-  int cnt = 0;
-  while (e < e1) {
-    const int64_t ecur = e;
-    const int32_t scur = entry_snp[ecur];
-    const double g0 = ng0, g1 = ng1, g2 = ng2;
-    const double p0 = np0, p1 = np1, p2 = np2;
-    e = wave_next_entry<EM>(lin, ecur + 1, e1);
-    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    if (e < e1 && live) {
-      const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
-      ng0 = row[0], ng1 = row[1], ng2 = row[2];
-    }
-    if (CROSS) {
-      np0 = 1.0, np1 = 0.0, np2 = 0.0;
-      if (e < e1 && live2) {
-        const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
-        np0 = row[0], np1 = row[1], np2 = row[2];
-      }
-    }
-    // wave-uniform operands: the nine likelihoods of the selected alpha (and of alpha[0] for the singlet slot)
-    const double* q = pg + (size_t)ecur * PG + (size_t)n_sel * 9;
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
-    if (WITH_SINGLET) {
-      const double* s = pg + (size_t)ecur * PG;
-      const double* h = gp + (size_t)scur * V3;  // sample 0's triple multiplies every singlet (:806,828)
-      const double v0 = fma(g2, s[6], fma(g1, s[3], g0 * s[0]));
-      const double v1 = fma(g2, s[7], fma(g1, s[4], g0 * s[1]));
-      const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
-      accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
-    }
-    if (EM == EM_LINEAR) {
-      const double sm = (g0 + g1) + g2, Em = fma(2.0, g2, g1);
-      const double u0 = fma(q3 - q0, Em, q0 * sm), u1 = (q1 - q0) * sm;
-      double r0 = sm, r1 = Em;
-#pragma unroll
-      for (int t = 0; t < NSHIFT; ++t) {
-        r0 = dpp_wror1(r0);
-        r1 = dpp_wror1(r1);
-        acc[t] *= fma(r0, u0, r1 * u1);
-      }
-    } else {
-      const double u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
-      const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
-      const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
-      double r0 = g0, r1 = g1, r2 = g2;
-      if (CROSS) {  // one lane ahead: the first rotation then brings sample kbase + j itself
-        r0 = __shfl(p0, (j + 1) & 63, 64);
-        r1 = __shfl(p1, (j + 1) & 63, 64);
-        r2 = __shfl(p2, (j + 1) & 63, 64);
-      }
-#pragma unroll
-      for (int t = 0; t < NSHIFT; ++t) {
-        r0 = dpp_wror1(r0);
-        r1 = dpp_wror1(r1);
-        r2 = dpp_wror1(r2);
-        acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :738-746 as a product
-      }
-    }
-    if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
-      cnt = 0;
-#pragma unroll
-      for (int t = 0; t < NSHIFT; ++t) prodacc_renorm(acc[t], ex[t]);
-      if (WITH_SINGLET) prodacc_renorm(accS, exS);
-    }
-  }
+  int64_t i0 = it.e0, i1 = it.e1;
+  if constexpr (EM != EM_ALL) wave_stream_range<EM>(lin, lin_rank, it.e0, it.e1, i0, i1);
+  const int32_t seln[1] = {n_sel};
+  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gp, V3, jo,
+                                                   ko, live, live2, j, 0, ring, exs, acc, ex, accS, exS, accW, exW);
 
   // Results go to the wave layout llw[c][n][step t][lane j] (coalesced; the partner of (t, j) is re-derived by the
   // readers with the same rotation): lane j, step t holds the hypothesis (j, k = j - t - 1 mod 64).  Alpha = 0.5 fills
   // the mirrored half too: the pair met at step t by lane j is met at step 62 - t by lane k.
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;
   int kk = j;
-#pragma unroll
-  for (int t = 0; t < NSHIFT; ++t) {
+  if constexpr (EM == EM_LINEAR) {  // log prod s of every lane into the ring: the partner's comes out like its values did
+    const double logW = prodacc_log(accW, exW);
+    ring[0][j] = logW, ring[0][j + 64] = logW;
+  }
+  wave_for<0, NSHIFT>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
     kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
-    double v = prodacc_log(acc[t], ex[t]);
+    double v = prodacc_log(acc[t], EXL ? exs[t][j] : ex[EXL ? 0 : t]);
+    if constexpr (EM == EM_LINEAR) {
+      double lw = wave_ring_rd<(NSHIFT - 1 - t) * 8>(rb);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
+      v += lw;
+    }
     if (n_sel > 0) {
       if (NSHIFT >= 63) {
         double* o = out + ((size_t)n_sel * 64 + t) * 64 + j;
@@ -193,7 +462,7 @@ __global__ void __launch_bounds__(64, 2)
         out[((size_t)n_sel * 64 + (62 - t)) * 64 + kk] = v;
       }
     }
-  }
+  });
   if (WITH_SINGLET) {
     double v = prodacc_log(accS, exS);  // llw[c][0][0][j]
     if (EM == EM_GENERAL) v += out[j];
@@ -201,151 +470,87 @@ __global__ void __launch_bounds__(64, 2)
   }
 }
 
-// Several non-symmetric alphas in one launch.  The partner rotation (six DPP moves per step) does not depend on alpha,
-// only u does: with NA alphas per launch a step costs 6 + 4*NA vector instructions for NA hypotheses instead of 10 for
-// one.  The accumulator budget (64 per lane) is kept by giving a launch NS = 64/NA of the 63 rotation steps, starting
-// at offset s0 (one cross-lane permute per entry brings the triple to lane j - s0 first).
+// Several non-symmetric alphas in one launch.  The partner values of a step (three ring reads, one for a linear entry)
+// do not depend on alpha, only u does: with NA alphas a step costs 3 reads + 4*NA vector instructions for NA hypotheses.
+// The accumulator budget (64 per lane) is kept by giving a WAVE NS = 64/NA of the 63 rotation steps, starting at offset
+// s0 = NS * wave: the ring is read at that offset.
 struct wave_sel {
   int32_t n[4];
 };
 template <int NA, int NS, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64 * (64 / NS), 2)
     demux_wave_multi_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                             const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
-                            const uint32_t* __restrict__ lin, const double* __restrict__ gp,
-                            const uint8_t* __restrict__ has_gp, int V, int nAlpha, wave_sel sel, int s0, wave_blk wb,
-                            double* __restrict__ ll) {
+                            const double* __restrict__ lpg, const uint32_t* __restrict__ lin,
+                            const int64_t* __restrict__ lin_rank,
+                            const fmx_grec* __restrict__ rec_lin, const fmx_grec* __restrict__ rec_gen,
+                            const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
+                            wave_sel sel, wave_blk wb, double* __restrict__ ll) {
+  // One workgroup per work unit, one WAVE per range of NS rotation steps (s0 = 0, NS, 2 NS, ...).  The waves are
+  // independent -- own accumulators, own ring and exponents in LDS, no barrier -- but they walk the same entries at the
+  // same pace on one CU, so the marker rows and likelihood tables the first of them pulls from HBM are cache hits for
+  // the others: a launch per step range instead read every row 64 / NS times from HBM.
+  constexpr int NW = 64 / NS;
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
   const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
-  const int64_t e0 = it.e0, e1 = it.e1;
-  if (e0 == e1) return;
-  const int j = threadIdx.x;
+  if (it.e0 == it.e1) return;
+  const int w = threadIdx.x >> 6, j = threadIdx.x & 63;
+  const int s0 = w * NS;
   const bool live = wb.jbase + j < V;
   const bool live2 = wb.kbase + j < V;
   const int V3 = V * 3;
-  const int PG = nAlpha * 9;
-  const int jo = (wb.jbase + j) * 3, ko = (wb.kbase + j) * 3;
-  const int src = (j - s0 + (CROSS ? 1 : 0)) & 63;  // lane whose triple this lane starts from
+  const double* tab = EM == EM_LINEAR ? lpg : pg;  // the table the walk reads, and its row width
+  const int TW = nAlpha * (EM == EM_LINEAR ? 3 : 9);
+  const int jo = (live ? wb.jbase + j : V - 1) * 3, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
 
   // 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
-  __shared__ int32_t exs[NA * NS][64];
-  double acc[NA * NS], accS = 1.0;
-  int32_t exS = 0;
+  __shared__ int32_t exs_all[NW][NA * NS][64];
+  __shared__ double ring_all[NW][3][128];  // the partner values of the current entry, see dw_sweep_lin
+  int32_t (*exs)[64] = exs_all[w];
+  double (*ring)[128] = ring_all[w];
+  const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - s0 - NS];
+  double acc[NA * NS], accS = 1.0, accW = 1.0;  // accW: product of the own sums s over the linear entries (EM_LINEAR)
+  int32_t ex[1] = {0}, exS = 0, exW = 0;
 #pragma unroll
   for (int t = 0; t < NA * NS; ++t) {
     acc[t] = 1.0;
     exs[t][j] = 0;
   }
-
-  int64_t e = wave_next_entry<EM>(lin, e0, e1);
-  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-  double np0 = 1.0, np1 = 0.0, np2 = 0.0;  // CROSS: triple of sample kbase + j
-  if (e < e1 && live) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
-    ng0 = row[0], ng1 = row[1], ng2 = row[2];
-  }
-  if (CROSS && e < e1 && live2) {
-    const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
-    np0 = row[0], np1 = row[1], np2 = row[2];
-  }
-  int cnt = 0;
-  while (e < e1) {
-    const int64_t ecur = e;
-    const int32_t scur = entry_snp[ecur];
-    const double g0 = ng0, g1 = ng1, g2 = ng2;
-    const double p0 = np0, p1 = np1, p2 = np2;
-    e = wave_next_entry<EM>(lin, ecur + 1, e1);
-    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    if (e < e1 && live) {
-      const double* row = gp + (size_t)entry_snp[e] * V3 + jo;
-      ng0 = row[0], ng1 = row[1], ng2 = row[2];
-    }
-    if (CROSS) {
-      np0 = 1.0, np1 = 0.0, np2 = 0.0;
-      if (e < e1 && live2) {
-        const double* row = gp + (size_t)entry_snp[e] * V3 + ko;
-        np0 = row[0], np1 = row[1], np2 = row[2];
-      }
-    }
-    if (WITH_SINGLET) {
-      const double* s = pg + (size_t)ecur * PG;
-      const double* h = gp + (size_t)scur * V3;  // sample 0's triple multiplies every singlet (:806,828)
-      const double v0 = fma(g2, s[6], fma(g1, s[3], g0 * s[0]));
-      const double v1 = fma(g2, s[7], fma(g1, s[4], g0 * s[1]));
-      const double v2 = fma(g2, s[8], fma(g1, s[5], g0 * s[2]));
-      accS *= fma(h[2], v2, fma(h[1], v1, h[0] * v0));
-    }
-    if (EM == EM_LINEAR) {  // two moments instead of three genotypes, see EM_LINEAR above
-      const double sm = (g0 + g1) + g2, Em = fma(2.0, g2, g1);
-      double u[NA][2];
+  int64_t i0 = it.e0, i1 = it.e1;
+  if constexpr (EM != EM_ALL) wave_stream_range<EM>(lin, lin_rank, it.e0, it.e1, i0, i1);
+  int32_t seln[NA];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
-        u[a][0] = fma(q[3] - q[0], Em, q[0] * sm);
-        u[a][1] = (q[1] - q[0]) * sm;
-      }
-      double r0 = sm, r1 = Em;
-      if (s0) {
-        r0 = __shfl(r0, src, 64);
-        r1 = __shfl(r1, src, 64);
-      }
-#pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        r0 = dpp_wror1(r0);
-        r1 = dpp_wror1(r1);
-#pragma unroll
-        for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r0, u[a][0], r1 * u[a][1]);
-      }
-    } else {
-      double u[NA][3];
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {  // wave-uniform likelihoods through the scalar cache
-        const double* q = pg + (size_t)ecur * PG + (size_t)sel.n[a] * 9;
-        u[a][0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
-        u[a][1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
-        u[a][2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
-      }
-      double r0 = CROSS ? p0 : g0, r1 = CROSS ? p1 : g1, r2 = CROSS ? p2 : g2;
-      if (s0 || CROSS) {
-        r0 = __shfl(r0, src, 64);
-        r1 = __shfl(r1, src, 64);
-        r2 = __shfl(r2, src, 64);
-      }
-#pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        r0 = dpp_wror1(r0);
-        r1 = dpp_wror1(r1);
-        r2 = dpp_wror1(r2);
-#pragma unroll
-        for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, u[a][2], fma(r1, u[a][1], r0 * u[a][0]));  // :738-746
-      }
-    }
-    if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
-      cnt = 0;
-#pragma unroll
-      for (int t = 0; t < NA * NS; ++t) {
-        int ee;
-        acc[t] = frexp(acc[t], &ee);
-        exs[t][j] += ee;
-      }
-      if (WITH_SINGLET) prodacc_renorm(accS, exS);
-    }
-  }
+  for (int a = 0; a < NA; ++a) seln[a] = sel.n[a];
+  if (WITH_SINGLET && w == 0)  // the singlet slot rides along with the first step range only
+    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gp, V3, jo,
+                                                   ko, live, live2, j, s0, ring, exs, acc, ex, accS, exS, accW, exW);
+  else
+    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gp, V3, jo, ko, live,
+                                            live2, j, s0, ring, exs, acc, ex, accS, exS, accW, exW);
 
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;  // wave layout, see demux_wave_kernel
-#pragma unroll
-  for (int t = 0; t < NS; ++t)
-    if (s0 + t < (CROSS ? 64 : 63)) {
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        double* o = out + ((size_t)sel.n[a] * 64 + s0 + t) * 64 + j;
-        double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
-        if (EM == EM_GENERAL) v += *o;  // on top of the linear entries' launch
-        *o = v;
-      }
+  if constexpr (EM == EM_LINEAR) {  // log prod s of every lane into the ring: the partner's comes out like its values did
+    const double logW = prodacc_log(accW, exW);
+    ring[0][j] = logW, ring[0][j + 64] = logW;
+  }
+  wave_for<0, NS>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (s0 + t >= (CROSS ? 64 : 63)) return;
+    double lw = 0.0;
+    if constexpr (EM == EM_LINEAR) {
+      lw = wave_ring_rd<(NS - 1 - t) * 8>(rb);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
     }
-  if (WITH_SINGLET) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      double* o = out + ((size_t)sel.n[a] * 64 + s0 + t) * 64 + j;
+      double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]) + lw;
+      if (EM == EM_GENERAL) v += *o;  // on top of the linear entries' launch
+      *o = v;
+    }
+  });
+  if (WITH_SINGLET && w == 0) {
     double v = prodacc_log(accS, exS);
     if (EM == EM_GENERAL) v += out[j];
     out[j] = v;
@@ -366,8 +571,9 @@ __global__ void __launch_bounds__(64, 2)
 template <int NA, bool WITH_SINGLET, bool ALLSYM = false>
 __global__ void __launch_bounds__(64, 2)
     demux_wave32_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
-                        const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                        const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const double* __restrict__,
                         const uint32_t* __restrict__ /*lin: the rings of 32 keep the single launch*/,
+                        const int64_t* __restrict__, const fmx_grec* __restrict__, const fmx_grec* __restrict__,
                         const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
   constexpr int NS = ALLSYM ? 8 : 16;
@@ -527,7 +733,8 @@ struct muxgl_wave_state {
   wave_cut* d_cuts = nullptr;    // cells cut into several units
   int64_t n_items = 0, n_cuts = 0, n_over = 0;
   double* d_pg = nullptr;      // [nnz][A][9]
-  size_t pg_cap = 0;
+  double* d_lpg = nullptr;     // [n_lin][A][3], see wave_lpg_kernel
+  size_t pg_cap = 0, lpg_cap = 0;
 };
 
 namespace {
@@ -573,6 +780,7 @@ void demux_wave_free(muxgl_handle* h) {
   dev_free(&st->d_items);
   dev_free(&st->d_cuts);
   dev_free(&st->d_pg);
+  dev_free(&st->d_lpg);
   delete st;
   h->wave = nullptr;
 }
@@ -650,19 +858,36 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     else symmask |= 1u << n;
   }
   // linear entries (one usable read) in a launch of their own with the two-term form, the others on top: see EM_LINEAR
-  const bool use_lin = h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
-#define KARGS st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_lin, h->d_gp, h->d_has_gp, V, A
-#define MULTI_K(NA, NS, WS, CR, EMODE, S0)                                                                                \
-  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64), 0, h->stream, KARGS, sel, \
-                     S0, wb, h->d_llw)
-#define MULTI_LAUNCH(NA, NS, WS, CR, S0)         \
-  do {                                           \
-    if (use_lin && !(CR)) {                      \
-      MULTI_K(NA, NS, WS, false, EM_LINEAR, S0); \
-      MULTI_K(NA, NS, WS, false, EM_GENERAL, S0); \
-    } else {                                     \
-      MULTI_K(NA, NS, WS, CR, EM_ALL, S0);       \
-    }                                            \
+  const bool use_lin = V > 32 && h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+  if (use_lin && h->n_lin_rec < 0 &&
+      plan_build_bit_streams(h, h->d_lin, &h->d_lin_rank, &h->d_lin_rec, &h->d_gen_rec, &h->n_lin_rec))
+    return 1;
+  if (use_lin) {
+    const size_t need_l = (size_t)h->n_lin_rec * A * 3;
+    if (need_l > st->lpg_cap || !st->d_lpg) {
+      if (dev_alloc(h, &st->d_lpg, need_l)) return 1;
+      st->lpg_cap = need_l;
+    }
+    const int64_t n = h->n_lin_rec * (int64_t)A;
+    if (n)
+      hipLaunchKernelGGL(wave_lpg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->n_lin_rec, A, h->d_lin_rec,
+                         st->d_pg, st->d_lpg);
+  }
+#define KARGS                                                                                                    \
+  st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, st->d_lpg, h->d_lin, h->d_lin_rank, h->d_lin_rec, \
+      h->d_gen_rec,                                                                                                       \
+      h->d_gp, h->d_has_gp, V, A
+#define MULTI_K(NA, NS, WS, CR, EMODE)                                                                                        \
+  hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64 * (64 / NS)), 0, h->stream, KARGS, \
+                     sel, wb, h->d_llw)
+#define MULTI_LAUNCH(NA, NS, WS, CR)         \
+  do {                                       \
+    if (use_lin && !(CR)) {                  \
+      MULTI_K(NA, NS, WS, false, EM_LINEAR); \
+      MULTI_K(NA, NS, WS, false, EM_GENERAL); \
+    } else {                                 \
+      MULTI_K(NA, NS, WS, CR, EM_ALL);       \
+    }                                        \
   } while (0)
 #define WAVE_K(NS, WS, CR, EMODE) \
   hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR, EMODE>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
@@ -718,20 +943,16 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       size_t done = 0;
       while (plain.size() - done >= 4) {
         wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
-        if (first) MULTI_LAUNCH(4, 16, true, false, 0);
-        else MULTI_LAUNCH(4, 16, false, false, 0);
-        MULTI_LAUNCH(4, 16, false, false, 16);
-        MULTI_LAUNCH(4, 16, false, false, 32);
-        MULTI_LAUNCH(4, 16, false, false, 48);
+        if (first) MULTI_LAUNCH(4, 16, true, false);  // (all four step ranges: a wave each)
+        else MULTI_LAUNCH(4, 16, false, false);
         HIPCHK(h, hipGetLastError());
         first = false;
         done += 4;
       }
       while (plain.size() - done >= 2) {
         wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
-        if (first) MULTI_LAUNCH(2, 32, true, false, 0);
-        else MULTI_LAUNCH(2, 32, false, false, 0);
-        MULTI_LAUNCH(2, 32, false, false, 32);
+        if (first) MULTI_LAUNCH(2, 32, true, false);
+        else MULTI_LAUNCH(2, 32, false, false);
         HIPCHK(h, hipGetLastError());
         first = false;
         done += 2;
@@ -755,17 +976,13 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       size_t done = 0;
       while (plain.size() - done >= 4) {
         wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
-        MULTI_LAUNCH(4, 16, false, true, 0);
-        MULTI_LAUNCH(4, 16, false, true, 16);
-        MULTI_LAUNCH(4, 16, false, true, 32);
-        MULTI_LAUNCH(4, 16, false, true, 48);
+        MULTI_LAUNCH(4, 16, false, true);
         HIPCHK(h, hipGetLastError());
         done += 4;
       }
       while (plain.size() - done >= 2) {
         wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
-        MULTI_LAUNCH(2, 32, false, true, 0);
-        MULTI_LAUNCH(2, 32, false, true, 32);
+        MULTI_LAUNCH(2, 32, false, true);
         HIPCHK(h, hipGetLastError());
         done += 2;
       }

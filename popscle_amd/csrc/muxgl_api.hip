@@ -243,6 +243,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_lin);
   dev_free(&h->d_flin);
   fmx_wave_streams_release(h);
+  plan_lin_streams_release(h);
   dev_free(&h->d_lut);
   dev_free(&h->d_gp);
   dev_free(&h->d_has_gp);

@@ -133,6 +133,30 @@ __global__ void __launch_bounds__(256)
   cell_chunks[id] = (int32_t)pos;  // natural ids are (cell, entry) ordered: a cell's chunks in entry order
 }
 
+__global__ void __launch_bounds__(256)
+    bits_popc_kernel(int64_t nwords, int64_t nnz, const uint32_t* __restrict__ bits, int64_t* __restrict__ cnt) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > nwords) return;
+  uint32_t v = 0;
+  if (w < nwords) {
+    v = bits[w];
+    const int64_t left = nnz - w * 32;
+    if (left < 32) v &= (1u << left) - 1u;
+  }
+  cnt[w] = __popc(v);
+}
+
+__global__ void __launch_bounds__(256)
+    bits_stream_kernel(int64_t nnz, const uint32_t* __restrict__ bits, const int64_t* __restrict__ rank,
+                       const int32_t* __restrict__ entry_snp, fmx_grec* __restrict__ rec_set, fmx_grec* __restrict__ rec_clr) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  const uint32_t w = bits[e >> 5];
+  const int64_t r = rank[e >> 5] + __popc(w & ((1u << (e & 31)) - 1u));
+  if ((w >> (e & 31)) & 1u) rec_set[r] = fmx_grec{e, entry_snp[e], 0};
+  else rec_clr[e - r] = fmx_grec{e, entry_snp[e], 0};
+}
+
 unsigned grid_for(int64_t n, int64_t cap = 16384) {
   int64_t b = (n + 255) / 256;
   if (b > cap) b = cap;
@@ -152,10 +176,45 @@ int plan_build_qent(muxgl_handle* h) {
   return 0;
 }
 
+// The entries of a bit set and of its complement as two streams of {entry, snp} records in entry order, and the table
+// rank[w] = set bits before entry 32 w that places any entry in both (wave kernels: a cell's entries of one kind are
+// then contiguous records instead of a scan of the bits).
+int plan_build_bit_streams(muxgl_handle* h, const uint32_t* bits, int64_t** rank, fmx_grec** rec_set, fmx_grec** rec_clr,
+                           int64_t* n_set) {
+  const int64_t nnz = h->nnz, nwords = (nnz + 31) / 32;
+  if (dev_alloc(h, rank, (size_t)nwords + 1)) return 1;
+  hipLaunchKernelGGL(bits_popc_kernel, dim3((unsigned)((nwords + 256) / 256)), dim3(256), 0, h->stream, nwords, nnz, bits, *rank);
+  size_t tb = 0;
+  void* tmp = nullptr;
+  HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, *rank, *rank, (int64_t)0, (size_t)nwords + 1, rocprim::plus<int64_t>(), h->stream));
+  HIPCHK(h, hipMalloc(&tmp, tb ? tb : 1));
+  hipError_t e = rocprim::exclusive_scan(tmp, tb, *rank, *rank, (int64_t)0, (size_t)nwords + 1, rocprim::plus<int64_t>(), h->stream);
+  int64_t n = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n, *rank + nwords, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) MUXGL_FAIL(h, "plan_build_bit_streams: %s", hipGetErrorString(e));
+  if (dev_alloc(h, rec_set, (size_t)n) || dev_alloc(h, rec_clr, (size_t)(nnz - n))) return 1;
+  if (nnz)
+    hipLaunchKernelGGL(bits_stream_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, h->stream, nnz, bits, *rank,
+                       h->d_entry_snp, *rec_set, *rec_clr);
+  HIPCHK(h, hipGetLastError());
+  *n_set = n;
+  return 0;
+}
+
+void plan_lin_streams_release(muxgl_handle* h) {
+  dev_free(&h->d_lin_rank);
+  dev_free(&h->d_lin_rec);
+  dev_free(&h->d_gen_rec);
+  h->n_lin_rec = -1;
+}
+
 int plan_build_lin(muxgl_handle* h) {
   dev_free(&h->d_lin);
   dev_free(&h->d_flin);
   fmx_wave_streams_release(h);
+  plan_lin_streams_release(h);
   if (h->nnz == 0) return 0;
   if (dev_alloc(h, &h->d_lin, (size_t)((h->nnz + 31) / 32))) return 1;
   hipLaunchKernelGGL(lin_kernel, dim3(grid_for(h->nnz, 4096)), dim3(256), 0, h->stream, h->nnz, h->d_entry_rptr,
