@@ -56,6 +56,17 @@ __global__ void __launch_bounds__(256)
   lpg[i * 3 + 2] = q[1] - q0;
 }
 
+// The moments of every genotype triple the linear entries use: gm[marker][sample] = (s, rho), s = g0 + g1 + g2,
+// rho = (g1 + 2 g2) / s (0 for an all-zero triple, whose hypotheses are 0 through s).
+__global__ void __launch_bounds__(256) wave_gm_kernel(int64_t n, const double* __restrict__ gp, double* __restrict__ gm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double g0 = gp[3 * i], g1 = gp[3 * i + 1], g2 = gp[3 * i + 2];
+  const double sm = (g0 + g1) + g2;
+  gm[2 * i] = sm;
+  gm[2 * i + 1] = sm > 0.0 ? fma(2.0, g2, g1) / sm : 0.0;
+}
+
 __device__ __forceinline__ double dpp_wror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);  // wave_ror:1 : lane j <- lane (j-1) mod 64
@@ -152,16 +163,6 @@ __device__ __forceinline__ void dw_sweep_gen(uint32_t rb, const double (&u)[NA][
   });
 }
 
-// the moments of a linear entry: s = sum g, rho = (g1 + 2 g2) / s (0 for an all-zero triple, whose pairs are 0 through s)
-__device__ __forceinline__ void dw_moments(double g0, double g1, double g2, double& sm, double& Em, double& rho) {
-  sm = (g0 + g1) + g2;
-  Em = fma(2.0, g2, g1);
-  double x = __builtin_amdgcn_rcp(sm);  // 1/s by v_rcp_f64 and two Newton steps (<= 1 ulp)
-  x = fma(x, fma(-sm, x, 1.0), x);
-  x = fma(x, fma(-sm, x, 1.0), x);
-  rho = sm > 0.0 ? Em * x : 0.0;
-}
-
 // More than 64 samples: the V x V pair matrix is cut into 64 x 64 blocks (X, Y).  A diagonal block is the kernel as
 // described above on the samples 64X .. 64X+63 (jbase).  An off-diagonal block (CROSS) keeps sample 64X + j in lane j and
 // rotates the triples of the samples 64Y + k (kbase) past it: all 64 rotations are pairs, including the unrotated one,
@@ -174,13 +175,15 @@ struct wave_blk {
 // Entries with at most one usable read (bit set in `lin`, plan_kernels.hip).  A single factor pR*(1-p) + pA*p with
 // p = l/2 + (m-l)*alpha/2 (cmd_cram_demuxlet.cpp:673,685) is LINEAR in the two genotypes, and so is everything the tail
 // (:703-725) makes of it: pG[l][m] = A + Bl*l + Bm*m.  Then
-//     sum_{l,m} g_j[l] g_k[m] pG[l][m] = s_k (A s_j + Bl E_j) + E_k (Bm s_j) = s_k ((A s_j + Bl E_j) + (Bm s_j) rho_k),
-// s = sum_l g[l],  E = g[1] + 2 g[2],  rho = E / s.  The factor s_k belongs to the partner alone: every lane keeps the
-// product of its own s over the cell's linear entries (one multiply per entry) and a hypothesis gets log(prod s_k) of
-// its partner at the end.  What is left per hypothesis is an FMA of the partner's rho with two numbers of the lane, and
-// the product update: ONE partner value per step instead of three, two vector instructions per hypothesis instead of
-// four.  Three quarters of the entries of a typical pileup are such entries.  (A, Bl, Bm are read off the table:
-// pG[0][0], pG[1][0] - pG[0][0], pG[0][1] - pG[0][0].)
+//     sum_{l,m} g_j[l] g_k[m] pG[l][m] = A s_j s_k + Bl E_j s_k + Bm s_j E_k = s_j s_k (A + Bl rho_j + Bm rho_k),
+// s = sum_l g[l],  E = g[1] + 2 g[2],  rho = E / s (wave_gm_kernel keeps (s, rho) per marker and sample: 16 bytes
+// instead of the triple's 24).  The factor s_j s_k does not depend on alpha or on the pairing of the other entries:
+// every lane keeps the product of its own s over the cell's linear entries (one multiply per entry) and a hypothesis
+// gets log(prod s_j) + log(prod s_k) at the end.  What is left per hypothesis is an FMA of the partner's rho with a
+// wave-uniform number (Bm) and a number of the lane (A + Bl rho_j), and the product update: ONE partner value per step
+// instead of three, two vector instructions per hypothesis instead of four.  Three quarters of the entries of a
+// typical pileup are such entries.  (A, Bl, Bm are read off the table: pG[0][0], pG[1][0] - pG[0][0], pG[0][1] - pG[0][0],
+// wave_lpg_kernel.)
 // Two sweep bodies in one kernel do not fit the register file next to 64 accumulators per lane, so the two kinds of
 // entries get a launch each -- EM_LINEAR walks the flagged entries of a cell and writes, EM_GENERAL walks the others and
 // ADDS its log-likelihoods to what is there -- EM_ALL is the single launch without the distinction.  The walk is a
@@ -208,14 +211,15 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   constexpr int D = (CROSS || NA * NS > 32) ? 2 : DW_DEPTH;  // (64 accumulators per lane: two slots is what fits)
   constexpr int HA = (NA + 1) / 2, HB = NA - HA;  // alphas of the first / second batch of likelihoods
   constexpr int QN = L ? 3 : 9;           // numbers per (entry, alpha): A, Bl, Bm of a linear entry (wave_lpg_kernel), or pG
-  constexpr int UN = L ? 2 : 3;
+  constexpr int UN = L ? 1 : 3;           // factors of the lane per alpha (linear: X = A + Bl rho_j; Bm is wave-uniform)
+  constexpr int GN = L ? 2 : 3;           // numbers per (marker, sample): the moments (s, rho) of the triple, or the triple
   constexpr int CR = CROSS ? 1 : 0;
   constexpr int NG = L ? (NS + DW_G_LIN - 1) / DW_G_LIN : (NS + DW_G_GEN - 1) / DW_G_GEN, NGH = NG / 2;
   if (i0 >= i1) return;
   const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - s0 - NS];
   int64_t ide[D];
   int32_t ids[D];
-  double g[D][3], p[CROSS ? D : 1][3];  // triple of sample jbase + j (and of kbase + j) at the slot's marker
+  double g[D][GN], p[CROSS ? D : 1][3];  // triple of sample jbase + j (and of kbase + j) at the slot's marker
   auto load_id = [&](int64_t i, auto sc) {  // clamped: a valid record is read behind the end, and not used
     constexpr int s = decltype(sc)::value;
     const int64_t ic = i < i1 ? i : i1 - 1;
@@ -225,7 +229,8 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   auto load_gp = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
     const double* row = gp + (size_t)ids[s] * V3 + jo;
-    g[s][0] = row[0], g[s][1] = row[1], g[s][2] = row[2];
+#pragma unroll
+    for (int k = 0; k < GN; ++k) g[s][k] = row[k];
     if (CROSS) {
       constexpr int sq = CROSS ? s : 0;
       const double* rowp = gp + (size_t)ids[s] * V3 + ko;
@@ -234,9 +239,10 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   };
   // factors of the current entry, and those of the next entry that are formed in the middle of the sweep
   double u[NA][UN], un[HA][UN], sv = 1.0, sw = 1.0;
+  double bu[L ? NA : 1], bun[L ? HA : 1];  // linear: Bm of the current entry's alphas / of the next entry's first batch
   double rv[3] = {1.0, 0.0, 0.0};  // the next entry's ring values (linear: rho in rv[0])
-  double sm = 1.0, Em = 0.0;       // linear: the next entry's moments
-  double qa[HA][QN], qb[HB > 0 ? HB : 1][QN], qs[WITH_SINGLET ? QN : 1], hs[WITH_SINGLET ? 3 : 1];
+  double sm = 1.0;                 // linear: the next entry's sum s
+  double qa[HA][QN], qb[HB > 0 ? HB : 1][QN], qs[WITH_SINGLET ? QN : 1], hs[WITH_SINGLET ? GN : 1];
   // row of the table for the entry in slot s / at stream position idx: the linear entries' table is in stream order
   auto row_of = [&](auto sc, int64_t idx) {
     constexpr int s = decltype(sc)::value;
@@ -265,13 +271,13 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
       const double* h = gp + (size_t)ids[s] * V3;  // sample 0's triple multiplies every singlet (:806,828)
 #pragma unroll
       for (int k = 0; k < QN; ++k) qs[k] = row[k];
-      hs[0] = h[0], hs[1] = h[1], hs[2] = h[2];
+#pragma unroll
+      for (int k = 0; k < GN; ++k) hs[k] = h[k];
     }
   };
   auto factor = [&](double (&uu)[UN], const double (&q)[QN], double g0, double g1, double g2) {
-    if constexpr (L) {  // q = (A, Bl, Bm)
-      uu[0] = fma(q[1], Em, q[0] * sm);
-      uu[1] = q[2] * sm;
+    if constexpr (L) {  // q = (A, Bl, Bm); g1 = rho_j
+      uu[0] = fma(q[1], g1, q[0]);
     } else {
       uu[0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
       uu[1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
@@ -280,9 +286,11 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   };
   auto comp_a = [&](auto sc) {  // first batch: the moments / ring values and the factors of alphas 0 .. HA-1
     constexpr int s = decltype(sc)::value, sq = CROSS ? s : 0;
-    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = live ? g[s][2] : 0.0;
+    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = (!L && live) ? g[s][GN - 1] : 0.0;
     if constexpr (L) {
-      dw_moments(g0, g1, g2, sm, Em, rv[0]);
+      sm = g0, rv[0] = g1;
+#pragma unroll
+      for (int a = 0; a < HA; ++a) bun[a] = qa[a][2];
     } else if constexpr (CROSS) {
       rv[0] = live2 ? p[sq][0] : 1.0, rv[1] = live2 ? p[sq][1] : 0.0, rv[2] = live2 ? p[sq][2] : 0.0;
     } else {
@@ -293,18 +301,23 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   };
   auto comp_b = [&](auto sc) {  // behind the sweep: the current entry's factors are free to be overwritten
     constexpr int s = decltype(sc)::value;
-    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = live ? g[s][2] : 0.0;
+    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = (!L && live) ? g[s][GN - 1] : 0.0;
 #pragma unroll
     for (int a = 0; a < HA; ++a)
 #pragma unroll
       for (int k = 0; k < UN; ++k) u[a][k] = un[a][k];
-    if (L) sw = sm;
+    if constexpr (L) {
+      sw = sm;
+#pragma unroll
+      for (int a = 0; a < HA; ++a) bu[a] = bun[a];
+#pragma unroll
+      for (int a = 0; a < HB; ++a) bu[HA + a] = qb[a][2];
+    }
 #pragma unroll
     for (int a = 0; a < HB; ++a) factor(u[HA + a], qb[a], g0, g1, g2);
     if (WITH_SINGLET) {
-      if constexpr (L) {  // sum_m h[m] sum_l g[l] (A + Bl l + Bm m) of alpha[0], in the moments of both triples
-        const double sh = (hs[0] + hs[1]) + hs[2], Eh = fma(2.0, hs[2], hs[1]);
-        sv = fma(qs[2] * sm, Eh, sh * fma(qs[1], Em, qs[0] * sm));
+      if constexpr (L) {  // sum_m h[m] sum_l g[l] (A + Bl l + Bm m) of alpha[0] = s_h s_g (A + Bl rho_g + Bm rho_h)
+        sv = (sm * hs[0]) * fma(qs[2], hs[1], fma(qs[1], g1, qs[0]));
       } else {
         const double v0 = fma(g2, qs[6], fma(g1, qs[3], g0 * qs[0]));
         const double v1 = fma(g2, qs[7], fma(g1, qs[4], g0 * qs[1]));
@@ -357,7 +370,7 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
       if constexpr (L) {
         double u0[NA], u1[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) u0[a] = u[a][0], u1[a] = u[a][1];
+        for (int a = 0; a < NA; ++a) u0[a] = u[a][0], u1[a] = bu[a];
         dw_sweep_lin<NA, NS, CR, 0, NGH>(rb, u0, u1, acc);
         comp_a(S1{});
         load_b(S1{}, i + 1);
@@ -400,7 +413,7 @@ __global__ void __launch_bounds__(64, 2)
     demux_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                       const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const double* __restrict__ lpg,
                       const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank, const fmx_grec* __restrict__ rec_lin,
-                      const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp,
+                      const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp, const double* __restrict__ gm,
                       const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel, wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
@@ -409,10 +422,12 @@ __global__ void __launch_bounds__(64, 2)
   const int j = threadIdx.x;
   const bool live = wb.jbase + j < V;
   const bool live2 = wb.kbase + j < V;
-  const int V3 = V * 3;
+  constexpr int GW = EM == EM_LINEAR ? 2 : 3;  // numbers per (marker, sample): moments (s, rho) for linear entries, else the triple
+  const double* gsrc = EM == EM_LINEAR ? gm : gp;
+  const int V3 = V * GW;
   const double* tab = EM == EM_LINEAR ? lpg : pg;  // the table the walk reads, and its row width
   const int TW = nAlpha * (EM == EM_LINEAR ? 3 : 9);
-  const int jo = (live ? wb.jbase + j : V - 1) * 3, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
+  const int jo = (live ? wb.jbase + j : V - 1) * GW, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
 
   constexpr bool EXL = NSHIFT > 32;  // 63 / 64 accumulators per lane: their exponents live in LDS
   __shared__ double ring[3][128];    // the partner values of the current entry, see dw_sweep_lin
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(64, 2)
   int64_t i0 = it.e0, i1 = it.e1;
   if constexpr (EM != EM_ALL) wave_stream_range<EM>(lin, lin_rank, it.e0, it.e1, i0, i1);
   const int32_t seln[1] = {n_sel};
-  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gp, V3, jo,
+  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gsrc, V3, jo,
                                                    ko, live, live2, j, 0, ring, exs, acc, ex, accS, exS, accW, exW);
 
   // Results go to the wave layout llw[c][n][step t][lane j] (coalesced; the partner of (t, j) is re-derived by the
@@ -437,8 +452,9 @@ __global__ void __launch_bounds__(64, 2)
   // the mirrored half too: the pair met at step t by lane j is met at step 62 - t by lane k.
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;
   int kk = j;
+  double logW = 0.0;
   if constexpr (EM == EM_LINEAR) {  // log prod s of every lane into the ring: the partner's comes out like its values did
-    const double logW = prodacc_log(accW, exW);
+    logW = prodacc_log(accW, exW);
     ring[0][j] = logW, ring[0][j + 64] = logW;
   }
   wave_for<0, NSHIFT>([&](auto tc) {
@@ -448,7 +464,7 @@ __global__ void __launch_bounds__(64, 2)
     if constexpr (EM == EM_LINEAR) {
       double lw = wave_ring_rd<(NSHIFT - 1 - t) * 8>(rb);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
-      v += lw;
+      v += lw + logW;  // both samples' sums
     }
     if (n_sel > 0) {
       if (NSHIFT >= 63) {
@@ -484,8 +500,8 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
                             const double* __restrict__ lpg, const uint32_t* __restrict__ lin,
                             const int64_t* __restrict__ lin_rank,
                             const fmx_grec* __restrict__ rec_lin, const fmx_grec* __restrict__ rec_gen,
-                            const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
-                            wave_sel sel, wave_blk wb, double* __restrict__ ll) {
+                            const double* __restrict__ gp, const double* __restrict__ gm,
+                            const uint8_t* __restrict__ has_gp, int V, int nAlpha, wave_sel sel, wave_blk wb, double* __restrict__ ll) {
   // One workgroup per work unit, one WAVE per range of NS rotation steps (s0 = 0, NS, 2 NS, ...).  The waves are
   // independent -- own accumulators, own ring and exponents in LDS, no barrier -- but they walk the same entries at the
   // same pace on one CU, so the marker rows and likelihood tables the first of them pulls from HBM are cache hits for
@@ -499,10 +515,12 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
   const int s0 = w * NS;
   const bool live = wb.jbase + j < V;
   const bool live2 = wb.kbase + j < V;
-  const int V3 = V * 3;
+  constexpr int GW = EM == EM_LINEAR ? 2 : 3;  // numbers per (marker, sample): moments (s, rho) for linear entries, else the triple
+  const double* gsrc = EM == EM_LINEAR ? gm : gp;
+  const int V3 = V * GW;
   const double* tab = EM == EM_LINEAR ? lpg : pg;  // the table the walk reads, and its row width
   const int TW = nAlpha * (EM == EM_LINEAR ? 3 : 9);
-  const int jo = (live ? wb.jbase + j : V - 1) * 3, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
+  const int jo = (live ? wb.jbase + j : V - 1) * GW, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
 
   // 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
   __shared__ int32_t exs_all[NW][NA * NS][64];
@@ -523,15 +541,16 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
 #pragma unroll
   for (int a = 0; a < NA; ++a) seln[a] = sel.n[a];
   if (WITH_SINGLET && w == 0)  // the singlet slot rides along with the first step range only
-    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gp, V3, jo,
+    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gsrc, V3, jo,
                                                    ko, live, live2, j, s0, ring, exs, acc, ex, accS, exS, accW, exW);
   else
-    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gp, V3, jo, ko, live,
+    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gsrc, V3, jo, ko, live,
                                             live2, j, s0, ring, exs, acc, ex, accS, exS, accW, exW);
 
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;  // wave layout, see demux_wave_kernel
+  double logW = 0.0;
   if constexpr (EM == EM_LINEAR) {  // log prod s of every lane into the ring: the partner's comes out like its values did
-    const double logW = prodacc_log(accW, exW);
+    logW = prodacc_log(accW, exW);
     ring[0][j] = logW, ring[0][j + 64] = logW;
   }
   wave_for<0, NS>([&](auto tc) {
@@ -541,6 +560,7 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
     if constexpr (EM == EM_LINEAR) {
       lw = wave_ring_rd<(NS - 1 - t) * 8>(rb);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
+      lw += logW;  // both samples' sums
     }
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
@@ -574,7 +594,8 @@ __global__ void __launch_bounds__(64, 2)
                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const double* __restrict__,
                         const uint32_t* __restrict__ /*lin: the rings of 32 keep the single launch*/,
                         const int64_t* __restrict__, const fmx_grec* __restrict__, const fmx_grec* __restrict__,
-                        const double* __restrict__ gp, const uint8_t* __restrict__ has_gp, int V, int nAlpha,
+                        const double* __restrict__ gp, const double* __restrict__ /*gm*/,
+                        const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
   constexpr int NS = ALLSYM ? 8 : 16;
   if ((int64_t)blockIdx.x >= n_items) return;
@@ -734,6 +755,8 @@ struct muxgl_wave_state {
   int64_t n_items = 0, n_cuts = 0, n_over = 0;
   double* d_pg = nullptr;      // [nnz][A][9]
   double* d_lpg = nullptr;     // [n_lin][A][3], see wave_lpg_kernel
+  double* d_gm = nullptr;      // [S][V][2], see wave_gm_kernel
+  size_t gm_cap = 0;
   size_t pg_cap = 0, lpg_cap = 0;
 };
 
@@ -781,6 +804,7 @@ void demux_wave_free(muxgl_handle* h) {
   dev_free(&st->d_cuts);
   dev_free(&st->d_pg);
   dev_free(&st->d_lpg);
+  dev_free(&st->d_gm);
   delete st;
   h->wave = nullptr;
 }
@@ -868,6 +892,13 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       if (dev_alloc(h, &st->d_lpg, need_l)) return 1;
       st->lpg_cap = need_l;
     }
+    const size_t need_g = (size_t)h->S * V * 2;
+    if (need_g > st->gm_cap || !st->d_gm) {
+      if (dev_alloc(h, &st->d_gm, need_g)) return 1;
+      st->gm_cap = need_g;
+    }
+    const int64_t ng = h->S * (int64_t)V;
+    if (ng) hipLaunchKernelGGL(wave_gm_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, h->stream, ng, h->d_gp, st->d_gm);
     const int64_t n = h->n_lin_rec * (int64_t)A;
     if (n)
       hipLaunchKernelGGL(wave_lpg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->n_lin_rec, A, h->d_lin_rec,
@@ -875,8 +906,8 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
 #define KARGS                                                                                                    \
   st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, st->d_lpg, h->d_lin, h->d_lin_rank, h->d_lin_rec, \
-      h->d_gen_rec,                                                                                                       \
-      h->d_gp, h->d_has_gp, V, A
+      h->d_gen_rec, h->d_gp, st->d_gm,                                                                                    \
+      h->d_has_gp, V, A
 #define MULTI_K(NA, NS, WS, CR, EMODE)                                                                                        \
   hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64 * (64 / NS)), 0, h->stream, KARGS, \
                      sel, wb, h->d_llw)
