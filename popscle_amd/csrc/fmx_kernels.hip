@@ -379,10 +379,55 @@ __global__ void __launch_bounds__(256)
 // ------------------------------------------------------------------------------------------------ scans + re-assignment
 
 // cmd_cram_freemux2.cpp:458-584 for one cell per lane; stat[0..2] = nsingle, namb, nchanged
+// top two of a scan under the reference's update rule (strict >, first come first kept): the two largest under the
+// total order (value descending, scan position ascending), which is associative -- lanes scan strided positions and
+// merge their lists
+struct fmx_top2 {
+  double v1, v2;
+  int32_t p1, p2;
+};
+__device__ __forceinline__ bool fmx_better(double va, int32_t pa, double vb, int32_t pb) {
+  return va > vb || (va == vb && pa < pb);
+}
+__device__ __forceinline__ void fmx_top2_push(fmx_top2& t, double v, int32_t p) {
+  if (fmx_better(v, p, t.v1, t.p1)) {
+    t.v2 = t.v1, t.p2 = t.p1;
+    t.v1 = v, t.p1 = p;
+  } else if (fmx_better(v, p, t.v2, t.p2)) {
+    t.v2 = v, t.p2 = p;
+  }
+}
+__device__ __forceinline__ fmx_top2 fmx_top2_wave(fmx_top2 t) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    fmx_top2 o;
+    o.v1 = __shfl_xor(t.v1, off, 64), o.p1 = __shfl_xor(t.p1, off, 64);
+    o.v2 = __shfl_xor(t.v2, off, 64), o.p2 = __shfl_xor(t.p2, off, 64);
+    fmx_top2_push(t, o.v1, o.p1);
+    fmx_top2_push(t, o.v2, o.p2);
+  }
+  return t;
+}
+__device__ __forceinline__ double fmx_wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double fmx_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// WAVE: one wave per cell -- the K (K + 1) / 2 log-likelihoods of a cell are read once, coalesced, by 64 lanes (one lane
+// per cell reads them 16 KB apart from its neighbours' at K = 64: 0.7 TB/s); the evidence sums become max-shifted
+// log-sum-exps (independent exps, one log) instead of the reference's serial logAdd chain -- the same value to ~1e-16
+// relative.  !WAVE: one lane per cell, the reference's loop as written (kept behind MUXGL_FLAG_FORCE_TILE_SWEEP).
+template <bool WAVE>
 __global__ void __launch_bounds__(64)
     fmx_call_kernel(int64_t c0, int64_t c1, int K, double doublet_prior, const double* __restrict__ fll,
                     muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat) {
-  const int64_t i = c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = WAVE ? c0 + (int64_t)blockIdx.x : c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c1) return;
   const int nSamples = K;
   const int npairs = K * (K + 1) / 2;
@@ -392,6 +437,59 @@ __global__ void __launch_bounds__(64)
   int32_t sBest = -1, sNext = -1, dBest1 = -1, dBest2 = -1, dNext1 = -1, dNext2 = -1;
   double sngBestLLK = -1e300, sngNextLLK = -1e300, dblBestLLK = -1e300, dblNextLLK = -1e300;
   double sumLLK = -1e300, sngLLK = -1e300;
+  if constexpr (WAVE) {
+    const int lane = threadIdx.x;
+    fmx_top2 ts = {-1e300, -1e300, 0x7fffffff, 0x7fffffff}, td = ts;
+    double mall = -1e300, msng = -1e300;
+    // position p = j (j + 1) / 2 + k of the scan order; the row j of a position is followed through the strides
+    int j = (int)((sqrt(8.0 * lane + 1.0) - 1.0) * 0.5);
+    while ((j + 1) * (j + 2) / 2 <= lane) ++j;
+    while (j * (j + 1) / 2 > lane) --j;
+    int jj = j;
+    for (int p = lane; p < npairs; p += 64) {
+      while ((jj + 1) * (jj + 2) / 2 <= p) ++jj;
+      const double v = llks[p];
+      if (p - jj * (jj + 1) / 2 == jj) {
+        fmx_top2_push(ts, v, p);
+        msng = fmax(msng, v);
+        mall = fmax(mall, v + log_single_prior);
+      } else {
+        fmx_top2_push(td, v, p);
+        mall = fmax(mall, v + log_double_prior);
+      }
+    }
+    ts = fmx_top2_wave(ts);
+    td = fmx_top2_wave(td);
+    mall = fmx_wave_max(mall);
+    msng = fmx_wave_max(msng);
+    double sall = 0.0, ssng = 0.0;
+    jj = j;
+    for (int p = lane; p < npairs; p += 64) {  // (second pass: the row is in the cache)
+      while ((jj + 1) * (jj + 2) / 2 <= p) ++jj;
+      const double v = llks[p];
+      if (p - jj * (jj + 1) / 2 == jj) {
+        sall += exp(v + log_single_prior - mall);
+        ssng += exp(v - msng);
+      } else {
+        sall += exp(v + log_double_prior - mall);
+      }
+    }
+    sall = fmx_wave_sum(sall);
+    ssng = fmx_wave_sum(ssng);
+    if (lane != 0) return;
+    sumLLK = mall + log(sall);
+    sngLLK = msng + log_single_prior + log(ssng);
+    auto row_of = [](int p) {
+      int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= p) ++r;
+      while (r * (r + 1) / 2 > p) --r;
+      return r;
+    };
+    if (ts.p1 != 0x7fffffff) sBest = row_of(ts.p1), sngBestLLK = ts.v1;
+    if (ts.p2 != 0x7fffffff) sNext = row_of(ts.p2), sngNextLLK = ts.v2;
+    if (td.p1 != 0x7fffffff) dBest1 = row_of(td.p1), dBest2 = td.p1 - dBest1 * (dBest1 + 1) / 2, dblBestLLK = td.v1;
+    if (td.p2 != 0x7fffffff) dNext1 = row_of(td.p2), dNext2 = td.p2 - dNext1 * (dNext1 + 1) / 2, dblNextLLK = td.v2;
+  } else {
   for (int j = 0; j < nSamples; ++j) {  // :469-497
     for (int k = 0; k < j; ++k) {
       const double v = llks[j * (j + 1) / 2 + k];
@@ -421,6 +519,7 @@ __global__ void __launch_bounds__(64)
     }
     sumLLK = dev_logadd(sumLLK, v + log_single_prior);
     sngLLK = dev_logadd(sngLLK, v + log_single_prior);
+  }
   }
   muxgl_fmx_cell c = cells[i];
   c.sBest = sBest;
@@ -1015,8 +1114,15 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   tic(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipMemsetAsync(h->d_fstat, 0, 4 * sizeof(int32_t), h->stream));
   if (nc > 0)
-    hipLaunchKernelGGL(fmx_call_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, c0, c1, K,
-                       p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+  {
+    if ((h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP) || K <= 24)  // (few hypotheses per cell: a wave per cell is mostly overhead,
+                                                             //  0.54 against 0.13 ms at configs[3])
+      hipLaunchKernelGGL(fmx_call_kernel<false>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, c0, c1, K,
+                         p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+    else
+      hipLaunchKernelGGL(fmx_call_kernel<true>, dim3((unsigned)nc), dim3(64), 0, h->stream, c0, c1, K, p->doublet_prior,
+                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+  }
   toc(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipGetLastError());
   if (h->col && h->C)  // the new assignments of the own cells, at their place in the job-wide array the M-step reads

@@ -70,6 +70,9 @@ def test_golden(eng, name):
     (29, (0.0, 0.3, 0.6), 20, 3000, 400),         #   two: 1 + 1
     (33, (0.0, 0.5), 30, 4000, 400),              # more pairs than one 256-thread tile
     (64, GRID6, 12, 6000, 500),                   # config-3 shape, few cells
+    (64, GRID6, 6, 9000, 3000),                   #   cells walked in parts: their place in the linear / other entry streams
+    (48, (0.0, 0.3, 0.5), 10, 5000, 2300),        #   one non-symmetric alpha: 63 rotation steps in one wave, plus alpha 0.5
+    (40, (0.0, 0.2, 0.4, 0.5), 10, 5000, 600),    #   two: two waves of 32 steps
     (65, (0.0, 0.5), 10, 6000, 1500),             # first V of the general tile sweep + one-lane-per-cell call
     (100, (0.0, 0.25, 0.5), 8, 8000, 2500),       # V > 96: a staging chunk holds fewer than 16 entries; deep cells
     (130, (0.0, 0.5), 6, 8000, 2500),             # (their products leave the double range without renormalisation)
