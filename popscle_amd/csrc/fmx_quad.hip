@@ -47,18 +47,18 @@ __host__ __device__ constexpr int fq_t2(int c, int d) { return 26 + (c == 0 ? d 
 __global__ void __launch_bounds__(256)
     fmx_cgpq_kernel(int64_t S, int K, const double* __restrict__ cgp, double* __restrict__ cgpq) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (S + 1) * 48) return;  // row S: the neutral row (1, 0, 0) that dead entries point at
+  if (tid >= S * 48) return;
   const int64_t s = tid / 48;
   const int w = (int)(tid - s * 48);  // position inside the quad row: ((t*4 + r)*2 + half)
   const int half = w & 1, r = (w >> 1) & 3, t = w >> 3;
   const int d = 2 * t + half, j = 4 * r + d / 3, l = d % 3;
-  cgpq[tid] = (j < K && s < S) ? cgp[((size_t)s * K + j) * 3 + l] : (l == 0 ? 1.0 : 0.0);
+  cgpq[tid] = (j < K) ? cgp[((size_t)s * K + j) * 3 + l] : (l == 0 ? 1.0 : 0.0);
 }
 
 __global__ void __launch_bounds__(64, 2)
     fmx_estep_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
-                          const double* __restrict__ egls6, const double* __restrict__ cgpq, int32_t S_dummy,
-                          double* __restrict__ part_m, int32_t* __restrict__ part_e) {
+                          const double* __restrict__ egls6, const double* __restrict__ cgpq, double* __restrict__ part_m,
+                          int32_t* __restrict__ part_e) {
   __shared__ __align__(16) double gl[16 * FQ_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
 
@@ -83,40 +83,48 @@ __global__ void __launch_bounds__(64, 2)
   }
 
   // the entry of the batch to come (SNP id + its nine likelihoods) is fetched one batch ahead
-  // (Loads are unconditional: behind the end of its chunk a lane re-reads the chunk's last entry -- entry 0 for a slot
-  // without a chunk -- and the values are made neutral afterwards; with loads under a lane mask the compiler cannot
-  // count the ones in flight and waits for all of them at every use.)
-  int32_t psnp = S_dummy;
+  int32_t psnp = -1;
   double pgl[6];
   auto fetch_entry = [&](int b) {
     const int idx = b * 4 + r;
-    const bool in = idx < len;
-    const int64_t e = e0 + (in ? idx : (len > 0 ? len - 1 : 0));
-    const int32_t sn = entry_snp[e];
-    const double2* src = reinterpret_cast<const double2*>(egls6 + (size_t)e * 6);  // 48 B, 16-byte aligned
+    psnp = -1;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double2 v = src[i];
-      pgl[2 * i] = in ? v.x : 1.0;  // dead entry: with g = (1,0,0) every factor is exactly 1
-      pgl[2 * i + 1] = in ? v.y : 1.0;
+    for (int i = 0; i < 6; ++i) pgl[i] = 1.0;  // dead entry: with g = (1,0,0) every factor is exactly 1
+    if (idx < len) {
+      const int64_t e = e0 + idx;
+      psnp = entry_snp[e];
+      const double2* src = reinterpret_cast<const double2*>(egls6 + (size_t)e * 6);  // 48 B, 16-byte aligned
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double2 v = src[i];
+        pgl[2 * i] = v.x;
+        pgl[2 * i + 1] = v.y;
+      }
     }
-    psnp = in ? sn : S_dummy;  // ... and it points at the neutral row
   };
   double nG[4][3];
   auto load_row = [&](int32_t s) {
-    const double2* pc = reinterpret_cast<const double2*>(cgpq + (size_t)s * 48) + r;
-    double f[12];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      const double2 v = pc[t * 4];
-      f[2 * t] = v.x;
-      f[2 * t + 1] = v.y;
-    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      nG[c][0] = f[3 * c];
-      nG[c][1] = f[3 * c + 1];
-      nG[c][2] = f[3 * c + 2];
+      nG[c][0] = 1.0;
+      nG[c][1] = 0.0;
+      nG[c][2] = 0.0;
+    }
+    if (s >= 0) {
+      const double2* pc = reinterpret_cast<const double2*>(cgpq + (size_t)s * 48) + r;
+      double f[12];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const double2 v = pc[t * 4];
+        f[2 * t] = v.x;
+        f[2 * t + 1] = v.y;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        nG[c][0] = f[3 * c];
+        nG[c][1] = f[3 * c + 1];
+        nG[c][2] = f[3 * c + 2];
+      }
     }
   };
   fetch_entry(0);
@@ -277,7 +285,7 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
     if (dev_alloc(h, &st->d_part_e, need)) return 1;
     st->part_e_cap = need;
   }
-  const size_t nq = ((size_t)h->S + 1) * 48;  // + the neutral row
+  const size_t nq = (size_t)h->S * 48;
   if (nq > h->cgpq_cap) {
     if (dev_alloc(h, &h->d_cgpq, nq)) return 1;
     h->cgpq_cap = nq;
@@ -288,7 +296,7 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);
   if (blocks)
     hipLaunchKernelGGL(fmx_estep_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       h->d_entry_snp, h->d_egls6, h->d_cgpq, (int32_t)h->S, st->d_part, st->d_part_e);
+                       h->d_entry_snp, h->d_egls6, h->d_cgpq, st->d_part, st->d_part_e);
   if (nc > 0)
     hipLaunchKernelGGL(fmx_quad_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->K, c0, h->d_fll);
