@@ -39,6 +39,8 @@ struct muxgl_row_state {
   int32_t* d_kmap = nullptr;            // [16][16]: sample held by lane j after t DPP row rotations
   int32_t* d_tmap = nullptr;            // [2][4]: tile seen by a quad lane after row_ror:4 / row_ror:8
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
+  quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
+  int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_quad.hip, built on first use)
   int32_t* d_part_e = nullptr;          // per-chunk partial exponents (quad kernel)
   size_t part_cap = 0, part_e_cap = 0;
   int64_t n_chunks = 0;
@@ -108,6 +110,7 @@ struct muxgl_handle {
   uint8_t* d_has_gp = nullptr;
   double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_quad.hip)
   double* d_gp0s = nullptr;  // V <= 16: per-SNP sum of sample 0's triple (the factor every singlet carries, :806)
+  double* d_gmq = nullptr;   // V <= 16: moments (s, rho) of every triple in the quad layout, [S + 1][4][4][2] (demux_quad.hip)
   double* d_ll = nullptr;  // [C][V][V][A]
   double* d_llw = nullptr; // wave path: [C][A][64 rotation steps][64 lanes], see demux_wave.hip
   size_t llw_cap = 0;

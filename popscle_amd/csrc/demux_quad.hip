@@ -52,6 +52,27 @@ __global__ void quad_tmap_kernel(int32_t* tmap /*[2][4]*/) {
   }
 }
 
+// A chunk's entry records with its linear entries (at most one usable read, plan_kernels.hip: lin_kernel) first, both
+// kinds in entry order, and the number of linear ones.  One thread per chunk (<= 128 records), once per pileup.
+__global__ void __launch_bounds__(64)
+    quad_partition_kernel(int n_chunks, const row_chunk* __restrict__ chunks, const quad_entry* __restrict__ qent,
+                          const uint32_t* __restrict__ lin, quad_entry* __restrict__ out, int32_t* __restrict__ nlin) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_chunks) return;
+  const int64_t e0 = chunks[q].e0;
+  const int len = chunks[q].len;
+  int w = 0;
+  for (int i = 0; i < len; ++i) {
+    const int64_t e = e0 + i;
+    if ((lin[e >> 5] >> (e & 31)) & 1u) out[e0 + w++] = qent[e];
+  }
+  nlin[q] = w;
+  for (int i = 0; i < len; ++i) {
+    const int64_t e = e0 + i;
+    if (!((lin[e >> 5] >> (e & 31)) & 1u)) out[e0 + w++] = qent[e];
+  }
+}
+
 // accumulator index layout
 __host__ __device__ constexpr int q_acc_single(int c) { return c; }
 __host__ __device__ constexpr int q_acc_within(int c1, int c2) {  // c1 < c2
@@ -76,7 +97,8 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
 // work itself (energy per entry under the power cap), not by latency or issue slots.
 __global__ void __launch_bounds__(64, 2)
     demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
-                       const uint8_t* __restrict__ reads, const double* __restrict__ gpq,
+                       const int32_t* __restrict__ chunk_nlin, const uint8_t* __restrict__ reads,
+                       const double* __restrict__ gpq, const double* __restrict__ gmq,
                        const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
                        double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
@@ -98,11 +120,18 @@ __global__ void __launch_bounds__(64, 2)
     e0 = chunks[q].e0;
     len = chunks[q].len;
   }
-  const int nb = (wave_max_i32(len) + 3) >> 2;  // trip count of the wave = its longest chunk
+  // The chunk's first nl records are its linear entries (quad_partition_kernel; 0 when that form is off): they are swept
+  // first, by a loop of their own (below), the others by the nine-term loop.  Trip counts of the wave = the longest
+  // run of either kind among its 16 chunks.
+  const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
+  const int nbL = (wave_max_i32(nl) + 3) >> 2;
+  const int nb = (wave_max_i32(len - nl) + 3) >> 2;
 
   double acc[QN_ACC];
 #pragma unroll
   for (int a = 0; a < QN_ACC; ++a) acc[a] = 1.0;
+  double accW[4] = {1.0, 1.0, 1.0, 1.0};  // linear entries: products of the sums s of the lane's four samples
+  int32_t exW[4] = {0, 0, 0, 0};
 
   // records {snp, read count, first four read bytes, read offset} of the lane's own entry: batch b in precA, b+1 in
   // precB, b+2 requested during phase 1 of batch b
@@ -110,10 +139,10 @@ __global__ void __launch_bounds__(64, 2)
   // merge with the defaults makes the compiler wait for the load on the spot)
   const int last = len > 0 ? len - 1 : 0;
   auto fetch_meta = [&](int b) {
-    const int idx = b * 4 + r;
+    const int idx = nl + b * 4 + r;
     return qent[e0 + (idx < last ? idx : last)];
   };
-  auto snp_of = [&](const quad_entry& p, int b) { return (b * 4 + r < len) ? p.snp : -1; };
+  auto snp_of = [&](const quad_entry& p, int b) { return (nl + b * 4 + r < len) ? p.snp : -1; };
   quad_entry precA = fetch_meta(0), precB = fetch_meta(1);
   // sum of sample 0's triple at the lane's own entry (negative: marker without genotypes), one batch ahead as well
   double hs_cur = gp0s[precA.snp];
@@ -322,6 +351,8 @@ __global__ void __launch_bounds__(64, 2)
       acc[a] = frexp(acc[a], &e);
       exs[a][lane] += e;
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) prodacc_renorm(accW[c], exW[c]);
   };
 
   // One batch: phase 1, then its four entries.  X holds the row of entry 0, Y of entry 1 (both requested earlier); Z is
@@ -349,6 +380,152 @@ __global__ void __launch_bounds__(64, 2)
     __syncthreads();
   };
 
+  // ---- the linear entries (at most one usable read).  The single factor pR + (pA - pR) p, p = l/2 (alpha 0) or
+  //      (l+m)/4 (alpha 0.5), stays linear through the tail (:703-725): q0[l] = A + 2B l, q1[l+m] = A + B (l+m).  With the
+  //      moments s = g0 + g1 + g2 and rho = (g1 + 2 g2) / s of a triple (gmq),
+  //          singlet  sum_l g_j[l] q0[l]            = s_j (A + 2B rho_j),
+  //          pair     sum_lm g_j[l] g_k[m] q1[l+m]  = s_j s_k (A + B rho_j + B rho_k):
+  //      the sums s go into products of their own (accW, folded into the accumulators at the end) and a hypothesis costs
+  //      an FMA and the product update instead of a three-term dot product and the update; a row is 8 doubles instead
+  //      of 12, and one double per sample rotates instead of three.
+  if (nbL > 0) {
+    struct rowl_t {
+      double m[4][2];
+    };
+    auto load_rowl = [&](rowl_t& R, int32_t sidx) {
+      const double2* pc = reinterpret_cast<const double2*>(gmq + (size_t)sidx * 32) + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 v = pc[c * 4];
+        R.m[c][0] = v.x;
+        R.m[c][1] = v.y;
+      }
+    };
+    const int lastL = nl > 0 ? nl - 1 : 0;
+    auto fetchL = [&](int b) {
+      const int idx = b * 4 + r;
+      return qent[e0 + (idx < lastL ? idx : lastL)];
+    };
+    quad_entry pa = fetchL(0), pb = fetchL(1);
+    double hsc = gp0s[pa.snp];
+    auto phase1L = [&](int b) {
+      const bool in = b * 4 + r < nl;
+      const int32_t sidx = (in && hsc >= 0.0) ? pa.snp : -1;  // no genotypes: the entry is skipped (:733)
+      const double hs_out = (sidx >= 0) ? hsc : 1.0;
+      const uint32_t nr = (sidx >= 0) ? pa.nreads : 0u;
+      const uint32_t first4 = pa.first4;
+      const int64_t r0 = pa.r0;
+      pa = pb;
+      pb = fetchL(b + 2);
+      hsc = gp0s[pa.snp];
+      double pR = 1.0, pA = 1.0;  // the one usable read (none: a factor of exactly 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t bb = (first4 >> (8 * k)) & 0xffu;
+        const uint32_t bq = bb & 0x7f;
+        const double e3 = lut[256 + bq], mt = lut[128 + bq];
+        const bool use = (uint32_t)k < nr && bb != MUXGL_READ_OTHER;
+        const bool ref = (bb >> 7) == 0;
+        pR = use ? (ref ? mt : e3) : pR;  // :666-667
+        pA = use ? (ref ? e3 : mt) : pA;
+      }
+      if (nr > 4) {  // (rare: an entry of many reads of which at most one counts)
+        for (int64_t rr = r0 + 4; rr < r0 + (int64_t)nr; ++rr) {
+          const uint32_t bb = (uint32_t)reads[rr];
+          if (bb == MUXGL_READ_OTHER) continue;  // :664
+          const uint32_t al = bb >> 7, bq = bb & 0x7f;
+          const double e3 = lut[256 + bq], mt = lut[128 + bq];
+          pR = (al == 0) ? mt : e3;
+          pA = (al == 0) ? e3 : mt;
+        }
+      }
+      const double mx = fmax(pR, pA);
+      double x = __builtin_amdgcn_rcp(mx);
+      x = fma(x, fma(-mx, x, 1.0), x);
+      x = fma(x, fma(-mx, x, 1.0), x);
+      const double cc = 1.0 / (1.0 + 1e-10);
+      const double sc = (sidx >= 0) ? cc * x : 1.0, tt = (sidx >= 0) ? 1e-10 * cc : 0.0;
+      double* dst = pgs + slot * Q_SLOT_STRIDE + r * 8;
+      dst[0] = fma(pR, sc, tt);             // A
+      dst[1] = (pA - pR) * (0.25 * sc);     // B
+      pgs[slot * Q_SLOT_STRIDE + 32 + r] = hs_out;
+      snps[slot * 4 + r] = (sidx >= 0) ? sidx : S_dummy;
+      snps_nx[slot * 4 + r] = ((b + 1) * 4 + r < nl) ? pa.snp : S_dummy;  // next batch; no-genotype rows are (1, 0)
+    };
+    auto sweepL = [&](const rowl_t& R, int i) {
+      const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
+      const double A = qq[0], B = qq[1], B2 = B + B;
+      const double hs = pgs[slot * Q_SLOT_STRIDE + 32 + i];
+      double X[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        accW[c] *= R.m[c][0];
+        acc[q_acc_single(c)] *= fma(B2, R.m[c][1], A) * hs;  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+        X[c] = fma(B, R.m[c][1], A);
+      }
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1)  // pairs inside the lane
+#pragma unroll
+        for (int c2 = c1 + 1; c2 < 4; ++c2) acc[q_acc_within(c1, c2)] *= fma(B, R.m[c2][1], X[c1]);
+      {  // neighbouring tile
+        double P[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) P[d] = dpp_ror4(R.m[d][1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) acc[q_acc_t1(c, d)] *= fma(B, P[d], X[c]);
+      }
+      {  // opposite tile: the two lanes facing each other split the 16 pairs (c <= d here, d < c over there)
+        double Q[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) Q[d] = dpp_ror8(R.m[d][1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = c; d < 4; ++d) acc[q_acc_t2(c, d)] *= fma(B, Q[d], X[c]);
+      }
+    };
+    // the same rotation of three row sets as below
+    auto batchL = [&](int b, rowl_t& X, rowl_t& Y, rowl_t& Z) {
+      phase1L(b);
+      __syncthreads();
+      load_rowl(Z, snps[slot * 4 + 2]);
+      asm volatile("" ::: "memory");
+      sweepL(X, 0);
+      pin();
+      load_rowl(X, snps[slot * 4 + 3]);
+      asm volatile("" ::: "memory");
+      sweepL(Y, 1);
+      pin();
+      load_rowl(Y, snps_nx[slot * 4 + 0]);
+      asm volatile("" ::: "memory");
+      sweepL(Z, 2);
+      pin();
+      load_rowl(Z, snps_nx[slot * 4 + 1]);
+      asm volatile("" ::: "memory");
+      sweepL(X, 3);
+      pin();
+      if ((b & 3) == 3) renorm();
+      __syncthreads();
+    };
+    rowl_t L0, L1, L2;
+    snps_nx[slot * 4 + r] = (r < nl) ? pa.snp : S_dummy;
+    __syncthreads();
+    load_rowl(L0, snps_nx[slot * 4 + 0]);
+    load_rowl(L1, snps_nx[slot * 4 + 1]);
+    __syncthreads();
+    for (int b = 0; b < nbL; b += 3) {
+      batchL(b, L0, L1, L2);
+      if (b + 1 >= nbL) break;
+      batchL(b + 1, L1, L2, L0);
+      if (b + 2 >= nbL) break;
+      batchL(b + 2, L2, L0, L1);
+    }
+    renorm();
+    __syncthreads();
+  }
+
   row_t R0, R1, R2;
   snps_nx[slot * 4 + r] = (snp_of(precA, 0) >= 0) ? precA.snp : S_dummy;
   __syncthreads();
@@ -363,13 +540,56 @@ __global__ void __launch_bounds__(64, 2)
     batch(b + 2, R2, R0, R1);
   }
 
+  // the sums of the linear entries: every hypothesis gets the products of its two samples (the partner's through the
+  // same rotation that brought its values)
+  int32_t exa[QN_ACC];
+#pragma unroll
+  for (int a = 0; a < QN_ACC; ++a) exa[a] = 0;
+  if (nbL > 0) {
+    double Wn[4], Wo[4];
+    int32_t en[4], eo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      prodacc_renorm(accW[c], exW[c]);
+      Wn[c] = dpp_ror4(accW[c]);
+      Wo[c] = dpp_ror8(accW[c]);
+      en[c] = __builtin_amdgcn_mov_dpp(exW[c], 0x124, 0xF, 0xF, false);
+      eo[c] = __builtin_amdgcn_mov_dpp(exW[c], 0x128, 0xF, 0xF, false);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[q_acc_single(c)] *= accW[c];
+      exa[q_acc_single(c)] = exW[c];
+    }
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+      for (int c2 = c1 + 1; c2 < 4; ++c2) {
+        acc[q_acc_within(c1, c2)] *= accW[c1] * accW[c2];
+        exa[q_acc_within(c1, c2)] = exW[c1] + exW[c2];
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        acc[q_acc_t1(c, d)] *= accW[c] * Wn[d];
+        exa[q_acc_t1(c, d)] = exW[c] + en[d];
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = c; d < 4; ++d) {
+        acc[q_acc_t2(c, d)] *= accW[c] * Wo[d];
+        exa[q_acc_t2(c, d)] = exW[c] + eo[d];
+      }
+  }
   if (q < n_chunks) {
 #pragma unroll
     for (int a = 0; a < QN_ACC; ++a) {
       int e;
       acc[a] = frexp(acc[a], &e);
       part_m[((size_t)q * QN_ACC + a) * 4 + r] = acc[a];
-      part_e[((size_t)q * QN_ACC + a) * 4 + r] = exs[a][lane] + e;
+      part_e[((size_t)q * QN_ACC + a) * 4 + r] = exs[a][lane] + e + exa[a];
     }
   }
 }
@@ -543,11 +763,19 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (dev_alloc(h, &st->d_part_e, need)) return 1;
     st->part_e_cap = need;
   }
+  const bool use_lin = h->d_lin && h->d_gmq && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+  if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup: every chunk's linear entries first
+    if (dev_alloc(h, &st->d_qent_lin, (size_t)h->nnz) || dev_alloc(h, &st->d_chunk_nlin, (size_t)st->n_chunks)) return 1;
+    hipLaunchKernelGGL(quad_partition_kernel, dim3((unsigned)((st->n_chunks + 63) / 64)), dim3(64), 0, h->stream,
+                       (int)st->n_chunks, st->d_chunks, h->d_qent, h->d_lin, st->d_qent_lin, st->d_chunk_nlin);
+    HIPCHK(h, hipGetLastError());
+  }
   tic(h, MUXGL_T_DEMUX_SWEEP);
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL(demux_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       h->d_qent, h->d_reads, h->d_gpq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
+                       use_lin ? st->d_qent_lin : h->d_qent, use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr, h->d_reads,
+                       h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }
   toc(h, MUXGL_T_DEMUX_SWEEP);

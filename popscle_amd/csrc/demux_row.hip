@@ -290,6 +290,8 @@ void demux_row_release(muxgl_row_state** pst) {
   dev_free(&st->d_tmap);
   dev_free(&st->d_part);
   dev_free(&st->d_part_e);
+  dev_free(&st->d_qent_lin);
+  dev_free(&st->d_chunk_nlin);
   delete st;
   *pst = nullptr;
 }

@@ -249,6 +249,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_has_gp);
   dev_free(&h->d_gpq);
   dev_free(&h->d_gp0s);
+  dev_free(&h->d_gmq);
   dev_free(&h->d_ll);
   dev_free(&h->d_dcells);
   dev_free(&h->d_llw);
@@ -304,6 +305,7 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   if (h->S) HIPCHK(h, hipMemcpyAsync(h->d_has_gp, has_gp, (size_t)h->S, hipMemcpyHostToDevice, h->stream));
   dev_free(&h->d_gpq);
   dev_free(&h->d_gp0s);
+  dev_free(&h->d_gmq);
   if (V <= 16 && h->S > 0) {
     // Layout for the quad kernel (demux_quad.hip): lane r of a quad owns samples 4r..4r+3 = 12 doubles d = 3c+l, read as
     // six 16-byte pieces; piece t of the four lanes is stored contiguously ([S][6][4][2]) so that one load instruction
@@ -329,6 +331,24 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
         q[(size_t)h->S * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = 1.0;
       }
     g0[(size_t)h->S] = 1.0;
+    // The same rows as moments (s, rho = (g1 + 2 g2) / s) for the entries with one usable read (demux_quad.hip): lane r
+    // of a quad reads its four samples' pairs as four 16-byte pieces, piece c of the four lanes contiguous.
+    std::vector<double> gm((size_t)(h->S + 1) * 32);
+    for (int64_t s = 0; s <= h->S; ++s)
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+          const int j = 4 * r + c;
+          double sm = 1.0, rho = 0.0;
+          if (s < h->S && j < V && has_gp[s]) {
+            const double* t = gp + ((size_t)s * V + j) * 3;
+            sm = (t[0] + t[1]) + t[2];
+            rho = sm > 0.0 ? std::fma(2.0, t[2], t[1]) / sm : 0.0;
+          }
+          gm[(size_t)s * 32 + ((size_t)c * 4 + r) * 2] = sm;
+          gm[(size_t)s * 32 + ((size_t)c * 4 + r) * 2 + 1] = rho;
+        }
+    if (dev_alloc(h, &h->d_gmq, gm.size())) return 1;
+    HIPCHK(h, hipMemcpy(h->d_gmq, gm.data(), sizeof(double) * gm.size(), hipMemcpyHostToDevice));
     if (dev_alloc(h, &h->d_gpq, q.size())) return 1;
     if (dev_alloc(h, &h->d_gp0s, g0.size())) return 1;
     HIPCHK(h, hipMemcpy(h->d_gpq, q.data(), sizeof(double) * q.size(), hipMemcpyHostToDevice));

@@ -215,6 +215,10 @@ int plan_build_lin(muxgl_handle* h) {
   dev_free(&h->d_flin);
   fmx_wave_streams_release(h);
   plan_lin_streams_release(h);
+  if (h->qrow) {  // the quad kernel's records with the linear entries first: made from the bits, on first use
+    dev_free(&h->qrow->d_qent_lin);
+    dev_free(&h->qrow->d_chunk_nlin);
+  }
   if (h->nnz == 0) return 0;
   if (dev_alloc(h, &h->d_lin, (size_t)((h->nnz + 31) / 32))) return 1;
   hipLaunchKernelGGL(lin_kernel, dim3(grid_for(h->nnz, 4096)), dim3(256), 0, h->stream, h->nnz, h->d_entry_rptr,
