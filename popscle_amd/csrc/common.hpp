@@ -41,6 +41,12 @@ struct muxgl_row_state {
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
   quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
   int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_quad.hip, built on first use)
+  // freemuxlet quad E-step (fmx_quad.hip, built on first use after muxgl_fmx_prepare): per chunk, its linear entries
+  // as {c0, c1, snp} records in front, then the SNP ids and six likelihoods of the others
+  struct fmx_lrec* d_fq_lrec = nullptr;
+  int32_t* d_fq_gsnp = nullptr;
+  double* d_fq_gl6 = nullptr;
+  int32_t* d_fq_nlin = nullptr;
   int32_t* d_part_e = nullptr;          // per-chunk partial exponents (quad kernel)
   size_t part_cap = 0, part_e_cap = 0;
   int64_t n_chunks = 0;
@@ -158,6 +164,8 @@ struct muxgl_handle {
   muxgl_row_state* frow = nullptr;             // chunk tables restricted to the cell shard
   muxgl_row_state* fqrow = nullptr;            // same for the quad E-step
   double* d_cgpq = nullptr;                    // [S][6][4][2] cluster-GP rows re-laid per quad (fmx_quad.hip)
+  double* d_ceq = nullptr;                     // [S + 1][2][4][2] their moments E = g1 + 2 g2 (fmx_quad.hip)
+  size_t ceq_cap = 0;
   size_t cgpq_cap = 0;
 
   // freemuxlet-old (fmx_old.hip)

@@ -55,9 +55,58 @@ __global__ void __launch_bounds__(256)
   cgpq[tid] = (j < K) ? cgp[((size_t)s * K + j) * 3 + l] : (l == 0 ? 1.0 : 0.0);
 }
 
+// E = g1 + 2 g2 of the cluster posteriors in the quad layout, [S + 1][2][4][2]: lane r reads its four clusters' moments
+// as two 16-byte pieces, piece t of the four lanes contiguous.  Clusters >= K and the neutral row S: 0.
+__global__ void __launch_bounds__(256) fmx_ceq_kernel(int64_t S, int K, const double* __restrict__ cgp, double* __restrict__ ceq) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (S + 1) * 16) return;
+  const int64_t s = tid >> 4;
+  const int w = (int)(tid & 15), half = w & 1, r = (w >> 1) & 3, t = w >> 3;
+  const int j = 4 * r + 2 * t + half;
+  double E = 0.0;
+  if (s < S && j < K) {
+    const double* g = cgp + ((size_t)s * K + j) * 3;
+    E = fma(2.0, g[2], g[1]);
+  }
+  ceq[tid] = E;
+}
+
+// A chunk's linear entries (fmx_entry_kernel: glis[g1][g2] = c0 + c1 (g1 + g2)) as records {c0, c1, snp} in front, the SNP
+// ids and six likelihoods of its other entries behind them, both kinds in entry order; one thread per chunk, once per
+// muxgl_fmx_prepare.
+__global__ void __launch_bounds__(64)
+    fq_partition_kernel(int n_chunks, const row_chunk* __restrict__ chunks, const uint32_t* __restrict__ flin,
+                        const int32_t* __restrict__ entry_snp, const double* __restrict__ egls6, fmx_lrec* __restrict__ lrec,
+                        int32_t* __restrict__ gsnp, double* __restrict__ gl6, int32_t* __restrict__ nlin) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_chunks) return;
+  const int64_t e0 = chunks[q].e0;
+  const int len = chunks[q].len;
+  int w = 0;
+  for (int i = 0; i < len; ++i) {
+    const int64_t e = e0 + i;
+    if ((flin[e >> 5] >> (e & 31)) & 1u) {
+      const double g00 = egls6[(size_t)e * 6];
+      lrec[e0 + w++] = fmx_lrec{g00, egls6[(size_t)e * 6 + 3] - g00, entry_snp[e], 0};
+    }
+  }
+  nlin[q] = w;
+  for (int i = 0; i < len; ++i) {
+    const int64_t e = e0 + i;
+    if (!((flin[e >> 5] >> (e & 31)) & 1u)) {
+      gsnp[e0 + w] = entry_snp[e];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) gl6[(size_t)(e0 + w) * 6 + t] = egls6[(size_t)e * 6 + t];
+      ++w;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(64, 2)
     fmx_estep_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
-                          const double* __restrict__ egls6, const double* __restrict__ cgpq, double* __restrict__ part_m,
+                          const double* __restrict__ egls6, const fmx_lrec* __restrict__ lrec,
+                          const int32_t* __restrict__ chunk_nlin, const double* __restrict__ cgpq,
+                          const double* __restrict__ ceq, int32_t S_dummy, double* __restrict__ part_m,
                           int32_t* __restrict__ part_e) {
   __shared__ __align__(16) double gl[16 * FQ_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
@@ -72,7 +121,11 @@ __global__ void __launch_bounds__(64, 2)
     e0 = chunks[q].e0;
     len = chunks[q].len;
   }
-  const int nb = (wave_max_i32(len) + 3) >> 2;
+  // The chunk's first nl entries are its linear ones (fq_partition_kernel; 0 when that form is off; entry_snp / egls6
+  // are then the partitioned copies): a loop of their own below, the nine-term loop for the rest.
+  const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
+  const int nbL = (wave_max_i32(nl) + 3) >> 2;
+  const int nb = (wave_max_i32(len - nl) + 3) >> 2;
 
   double acc[FQ_ACC];
   int32_t ex[FQ_ACC];
@@ -86,7 +139,7 @@ __global__ void __launch_bounds__(64, 2)
   int32_t psnp = -1;
   double pgl[6];
   auto fetch_entry = [&](int b) {
-    const int idx = b * 4 + r;
+    const int idx = nl + b * 4 + r;
     psnp = -1;
 #pragma unroll
     for (int i = 0; i < 6; ++i) pgl[i] = 1.0;  // dead entry: with g = (1,0,0) every factor is exactly 1
@@ -127,6 +180,84 @@ __global__ void __launch_bounds__(64, 2)
       }
     }
   };
+  // ---- the linear entries: glis[g1][g2] = c0 + c1 (g1 + g2), taken at s = 1 (posteriors normalised in FP64, see
+  //      fmx_wave.hip): singlet c0 + 2 c1 E_j, pair (c0 + c1 E_j) + c1 E_k with E = g1 + 2 g2 -- a row is 4 doubles
+  //      instead of 12, one double per cluster rotates instead of three, a pair is an FMA and the product update.
+  if (nbL > 0) {
+    struct rowl_t {
+      double E[4];
+    };
+    auto load_rowl = [&](rowl_t& R, int32_t sidx) {
+      const double2* pc = reinterpret_cast<const double2*>(ceq + (size_t)sidx * 16) + r;
+      const double2 v0 = pc[0], v1 = pc[4];
+      R.E[0] = v0.x, R.E[1] = v0.y, R.E[2] = v1.x, R.E[3] = v1.y;
+    };
+    const int lastL = nl > 0 ? nl - 1 : 0;
+    auto fetchL = [&](int b) {
+      const int idx = b * 4 + r;
+      return lrec[e0 + (idx < lastL ? idx : lastL)];  // (unconditional; invalidated where used)
+    };
+    fmx_lrec pa = fetchL(0);
+    rowl_t L[4];
+    snps_nx[slot * 4 + r] = (r < nl) ? pa.snp : S_dummy;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_rowl(L[i], snps_nx[slot * 4 + i]);
+    __syncthreads();
+    for (int b = 0; b < nbL; ++b) {
+      {  // phase 1: lane <-> entry
+        const bool in = b * 4 + r < nl;
+        double* dst = gl + slot * FQ_SLOT_STRIDE + r * FQ_ENTRY;
+        dst[0] = in ? pa.c0 : 1.0;  // dead entry: a factor of exactly 1
+        dst[1] = in ? pa.c1 : 0.0;
+        pa = fetchL(b + 1);
+        snps_nx[slot * 4 + r] = ((b + 1) * 4 + r < nl) ? pa.snp : S_dummy;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double* p = gl + slot * FQ_SLOT_STRIDE + i * FQ_ENTRY;
+        const double c0v = p[0], c1v = p[1], c2v = c1v + c1v;
+        double X[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[c] *= fma(c2v, L[i].E[c], c0v);  // singlet (:448-452)
+          X[c] = fma(c1v, L[i].E[c], c0v);
+        }
+#pragma unroll
+        for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+          for (int c2 = c1 + 1; c2 < 4; ++c2) acc[fq_within(c1, c2)] *= fma(c1v, L[i].E[c2], X[c1]);
+        {
+          double P[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) P[d] = fq_ror4(L[i].E[d]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[fq_t1(c, d)] *= fma(c1v, P[d], X[c]);  // :440-446
+        }
+        {
+          double Q[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) Q[d] = fq_ror8(L[i].E[d]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = c; d < 4; ++d) acc[fq_t2(c, d)] *= fma(c1v, Q[d], X[c]);
+        }
+        load_rowl(L[i], snps_nx[slot * 4 + i]);  // entry i of the next batch
+      }
+      if ((b & 3) == 3) {
+#pragma unroll
+        for (int a = 0; a < FQ_ACC; ++a) prodacc_renorm(acc[a], ex[a]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < FQ_ACC; ++a) prodacc_renorm(acc[a], ex[a]);
+  }
+
   fetch_entry(0);
   snps_nx[slot * 4 + r] = psnp;
   __syncthreads();
@@ -293,10 +424,30 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
   if (nq)
     hipLaunchKernelGGL(fmx_cgpq_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, h->S, h->K, h->d_cgp,
                        h->d_cgpq);
+  const bool use_lin = h->d_flin && h->nnz > 0 && st->n_chunks > 0 && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+  if (use_lin && !st->d_fq_nlin) {  // once per muxgl_fmx_prepare and chunk table: every chunk's linear entries in front
+    if (dev_alloc(h, &st->d_fq_lrec, (size_t)h->nnz) || dev_alloc(h, &st->d_fq_gsnp, (size_t)h->nnz) ||
+        dev_alloc(h, &st->d_fq_gl6, (size_t)h->nnz * 6) || dev_alloc(h, &st->d_fq_nlin, (size_t)st->n_chunks))
+      return 1;
+    hipLaunchKernelGGL(fq_partition_kernel, dim3((unsigned)((st->n_chunks + 63) / 64)), dim3(64), 0, h->stream,
+                       (int)st->n_chunks, st->d_chunks, h->d_flin, h->d_entry_snp, h->d_egls6, st->d_fq_lrec, st->d_fq_gsnp,
+                       st->d_fq_gl6, st->d_fq_nlin);
+    HIPCHK(h, hipGetLastError());
+  }
+  if (use_lin) {
+    const size_t ne = ((size_t)h->S + 1) * 16;
+    if (ne > h->ceq_cap) {
+      if (dev_alloc(h, &h->d_ceq, ne)) return 1;
+      h->ceq_cap = ne;
+    }
+    hipLaunchKernelGGL(fmx_ceq_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, h->S, h->K, h->d_cgp, h->d_ceq);
+  }
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);
   if (blocks)
     hipLaunchKernelGGL(fmx_estep_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       h->d_entry_snp, h->d_egls6, h->d_cgpq, st->d_part, st->d_part_e);
+                       use_lin ? st->d_fq_gsnp : h->d_entry_snp, use_lin ? st->d_fq_gl6 : h->d_egls6,
+                       use_lin ? st->d_fq_lrec : (const fmx_lrec*)nullptr, use_lin ? st->d_fq_nlin : (const int32_t*)nullptr,
+                       h->d_cgpq, h->d_ceq, (int32_t)h->S, st->d_part, st->d_part_e);
   if (nc > 0)
     hipLaunchKernelGGL(fmx_quad_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->K, c0, h->d_fll);

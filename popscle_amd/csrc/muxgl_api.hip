@@ -270,6 +270,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_segls);
   dev_free(&h->d_egls6);
   dev_free(&h->d_cgpq);
+  dev_free(&h->d_ceq);
   dev_free(&h->d_secnt);
   dev_free(&h->d_sgn);
   demux_row_free(h);
