@@ -41,12 +41,14 @@ struct muxgl_row_state {
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
   quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
   int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_quad.hip, built on first use)
+  int32_t* d_quad_order = nullptr;      // ... and the launch order of the chunks (sorted by trip count within buckets)
   // freemuxlet quad E-step (fmx_quad.hip, built on first use after muxgl_fmx_prepare): per chunk, its linear entries
   // as {c0, c1, snp} records in front, then the SNP ids and six likelihoods of the others
   struct fmx_lrec* d_fq_lrec = nullptr;
   int32_t* d_fq_gsnp = nullptr;
   double* d_fq_gl6 = nullptr;
   int32_t* d_fq_nlin = nullptr;
+  int32_t* d_fq_order = nullptr;        // launch order of the chunks, as d_quad_order
   int32_t* d_part_e = nullptr;          // per-chunk partial exponents (quad kernel)
   size_t part_cap = 0, part_e_cap = 0;
   int64_t n_chunks = 0;
@@ -384,6 +386,7 @@ int demux_gp_neutral_rows(muxgl_handle* h, int V);  // d_gp rows of markers with
 void demux_row_release(muxgl_row_state** st);
 int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
 int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)
+int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t* d_nlin, int64_t n, int32_t** order);
 int plan_build_lin(muxgl_handle* h);        // d_lin (plan_kernels.hip)
 int plan_build_bit_streams(muxgl_handle* h, const uint32_t* bits, int64_t** rank, fmx_grec** rec_set, fmx_grec** rec_clr,
                            int64_t* n_set);

@@ -19,6 +19,8 @@
 //     of a cell in chunk order and takes ONE log per hypothesis and cell (the row kernel took one per chunk).
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "demux_call_body.hpp"
 
 namespace {
@@ -73,6 +75,21 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// Launch order: a wave's trip counts are the maxima over its 16 chunks, so within every bucket of QUAD_BUCKET
+// consecutive chunks of the plan's order (non-increasing length, then first SNP -- the rows gathered by co-resident
+// workgroups stay a sliding window at that grain) the chunks are sorted by their number of non-linear batches.
+constexpr int QUAD_BUCKET = 1024;
+__global__ void __launch_bounds__(256)
+    quad_order_key_kernel(int n_chunks, int bucket, const row_chunk* __restrict__ chunks,
+                          const int32_t* __restrict__ chunk_nlin, uint64_t* __restrict__ key, int32_t* __restrict__ iota) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_chunks) return;
+  const int nl = chunk_nlin[w], len = chunks[w].len;
+  const uint64_t bg = (uint64_t)((len - nl + 3) >> 2), bl = (uint64_t)((nl + 3) >> 2);  // <= 32 each
+  key[w] = ((uint64_t)(w / bucket) << 36) | ((63u - bg) << 26) | ((63u - bl) << 20) | (uint64_t)(w % bucket);
+  iota[w] = w;
+}
+
 // accumulator index layout
 __host__ __device__ constexpr int q_acc_single(int c) { return c; }
 __host__ __device__ constexpr int q_acc_within(int c1, int c2) {  // c1 < c2
@@ -97,7 +114,8 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
 // work itself (energy per entry under the power cap), not by latency or issue slots.
 __global__ void __launch_bounds__(64, 2)
     demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
-                       const int32_t* __restrict__ chunk_nlin, const uint8_t* __restrict__ reads,
+                       const int32_t* __restrict__ chunk_nlin, const int32_t* __restrict__ order,
+                       const uint8_t* __restrict__ reads,
                        const double* __restrict__ gpq, const double* __restrict__ gmq,
                        const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
                        double* __restrict__ part_m, int32_t* __restrict__ part_e) {
@@ -113,7 +131,8 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
   for (int a = 0; a < QN_ACC; ++a) exs[a][lane] = 0;
 
-  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;
+  const int wq = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;  // place in the launch order
+  const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
   int64_t e0 = 0;
   int len = 0;
   if (q < n_chunks) {
@@ -743,6 +762,38 @@ __global__ void __launch_bounds__(256)
 
 }  // namespace
 
+// the launch order of the chunks of a quad kernel (quad_order_key_kernel), shared with fmx_quad.hip
+int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t* d_nlin, int64_t n, int32_t** order) {
+  int32_t* d_iota = nullptr;
+  uint64_t *d_key = nullptr, *d_key2 = nullptr;
+  void* d_tmp = nullptr;
+  auto cleanup = [&]() {
+    dev_free(&d_iota);
+    dev_free(&d_key);
+    dev_free(&d_key2);
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_tmp = nullptr;
+  };
+  if (dev_alloc(h, order, (size_t)n) || dev_alloc(h, &d_iota, (size_t)n) || dev_alloc(h, &d_key, (size_t)n) ||
+      dev_alloc(h, &d_key2, (size_t)n)) {
+    cleanup();
+    return 1;
+  }
+  int bucket = QUAD_BUCKET;
+  if (const char* ev = getenv("MUXGL_QUAD_BUCKET")) bucket = atoi(ev) > 0 ? atoi(ev) : bucket;  // (tuning)
+  if (bucket > (1 << 20)) bucket = 1 << 20;
+  hipLaunchKernelGGL(quad_order_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (int)n, bucket, d_chunks,
+                     d_nlin, d_key, d_iota);
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key, d_key2, d_iota, *order, (size_t)n, 0u, 64u, h->stream);
+  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_iota, *order, (size_t)n, 0u, 64u, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  cleanup();
+  if (e != hipSuccess) MUXGL_FAIL(h, "quad_launch_order: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // returns -1 when the quad path does not apply, 0 ok, 1 error
 int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (h->V > 16 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
@@ -769,12 +820,14 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     hipLaunchKernelGGL(quad_partition_kernel, dim3((unsigned)((st->n_chunks + 63) / 64)), dim3(64), 0, h->stream,
                        (int)st->n_chunks, st->d_chunks, h->d_qent, h->d_lin, st->d_qent_lin, st->d_chunk_nlin);
     HIPCHK(h, hipGetLastError());
+    if (quad_launch_order(h, st->d_chunks, st->d_chunk_nlin, st->n_chunks, &st->d_quad_order)) return 1;
   }
   tic(h, MUXGL_T_DEMUX_SWEEP);
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL(demux_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       use_lin ? st->d_qent_lin : h->d_qent, use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr, h->d_reads,
+                       use_lin ? st->d_qent_lin : h->d_qent, use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
+                       use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
                        h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }

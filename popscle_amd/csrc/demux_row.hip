@@ -292,10 +292,12 @@ void demux_row_release(muxgl_row_state** pst) {
   dev_free(&st->d_part_e);
   dev_free(&st->d_qent_lin);
   dev_free(&st->d_chunk_nlin);
+  dev_free(&st->d_quad_order);
   dev_free(&st->d_fq_lrec);
   dev_free(&st->d_fq_gsnp);
   dev_free(&st->d_fq_gl6);
   dev_free(&st->d_fq_nlin);
+  dev_free(&st->d_fq_order);
   delete st;
   *pst = nullptr;
 }

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(64, 2)
     fmx_estep_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
                           const double* __restrict__ egls6, const fmx_lrec* __restrict__ lrec,
-                          const int32_t* __restrict__ chunk_nlin, const double* __restrict__ cgpq,
+                          const int32_t* __restrict__ chunk_nlin, const int32_t* __restrict__ order,
+                          const double* __restrict__ cgpq,
                           const double* __restrict__ ceq, int32_t S_dummy, double* __restrict__ part_m,
                           int32_t* __restrict__ part_e) {
   __shared__ __align__(16) double gl[16 * FQ_SLOT_STRIDE];
@@ -114,7 +115,8 @@ __global__ void __launch_bounds__(64, 2)
   const int lane = threadIdx.x;
   const int r = (lane >> 2) & 3;
   const int slot = ((lane >> 4) << 2) | (lane & 3);
-  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;
+  const int wq = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 16 + slot;  // place in the launch order (quad_order_key_kernel)
+  const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
   int64_t e0 = 0;
   int len = 0;
   if (q < n_chunks) {
@@ -433,6 +435,7 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
                        (int)st->n_chunks, st->d_chunks, h->d_flin, h->d_entry_snp, h->d_egls6, st->d_fq_lrec, st->d_fq_gsnp,
                        st->d_fq_gl6, st->d_fq_nlin);
     HIPCHK(h, hipGetLastError());
+    if (quad_launch_order(h, st->d_chunks, st->d_fq_nlin, st->n_chunks, &st->d_fq_order)) return 1;
   }
   if (use_lin) {
     const size_t ne = ((size_t)h->S + 1) * 16;
@@ -447,7 +450,7 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
     hipLaunchKernelGGL(fmx_estep_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
                        use_lin ? st->d_fq_gsnp : h->d_entry_snp, use_lin ? st->d_fq_gl6 : h->d_egls6,
                        use_lin ? st->d_fq_lrec : (const fmx_lrec*)nullptr, use_lin ? st->d_fq_nlin : (const int32_t*)nullptr,
-                       h->d_cgpq, h->d_ceq, (int32_t)h->S, st->d_part, st->d_part_e);
+                       use_lin ? st->d_fq_order : (const int32_t*)nullptr, h->d_cgpq, h->d_ceq, (int32_t)h->S, st->d_part, st->d_part_e);
   if (nc > 0)
     hipLaunchKernelGGL(fmx_quad_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->K, c0, h->d_fll);

@@ -518,6 +518,7 @@ void fmx_wave_streams_release(muxgl_handle* h) {
       dev_free(&st->d_fq_gsnp);
       dev_free(&st->d_fq_gl6);
       dev_free(&st->d_fq_nlin);
+      dev_free(&st->d_fq_order);
     }
   dev_free(&h->d_flin_rank);
   dev_free(&h->d_lrec);
