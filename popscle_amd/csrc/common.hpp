@@ -158,7 +158,8 @@ struct muxgl_handle {
   int64_t* d_snp_ptr = nullptr;   // [S+1]
   int64_t* d_snp_entry = nullptr; // [nnz] entry index
   int32_t* d_snp_cell = nullptr;  // [nnz] cell id of the same SNP-major element
-  double* d_segls = nullptr;      // [nnz][9] entry likelihoods in SNP-major order (the M-step streams them)
+  double* d_segls = nullptr;      // [nnz][9] entry likelihoods in SNP-major order (freemuxlet-old's kernels)
+  double* d_segls6 = nullptr;     // [nnz][6] their six distinct values {00,11,22,01,02,12}: the ordered M-step streams them
   double* d_egls6 = nullptr;      // [nnz][6] the six distinct likelihoods {00,11,22,01,02,12} (quad E-step)
   int32_t* d_secnt = nullptr;     // [nnz][3] entry counts in SNP-major order
   bool fmx_prepared = false;

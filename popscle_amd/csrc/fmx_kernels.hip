@@ -665,11 +665,18 @@ __global__ void __launch_bounds__(256)
 // one-time gather of the entry likelihoods and counts into SNP-major order
 __global__ void __launch_bounds__(256)
     fmx_snp_major_kernel(int64_t nnz, const int64_t* __restrict__ snp_entry, const double* __restrict__ egls,
-                         const int32_t* __restrict__ ecnt, double* __restrict__ segls, int32_t* __restrict__ secnt) {
+                         const int32_t* __restrict__ ecnt, double* __restrict__ segls, double* __restrict__ segls6,
+                         int32_t* __restrict__ secnt) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = snp_entry[p];
+    double g[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) segls[(size_t)p * 9 + i] = egls[(size_t)e * 9 + i];
+    for (int i = 0; i < 9; ++i) g[i] = egls[(size_t)e * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) segls[(size_t)p * 9 + i] = g[i];
+    // the six distinct values {00, 11, 22, 01, 02, 12} of the symmetric matrix: what the ordered M-step streams
+    double* o6 = segls6 + (size_t)p * 6;
+    o6[0] = g[0], o6[1] = g[4], o6[2] = g[8], o6[3] = g[1], o6[4] = g[2], o6[5] = g[5];
 #pragma unroll
     for (int i = 0; i < 3; ++i) secnt[(size_t)p * 3 + i] = ecnt[(size_t)e * 3 + i];
   }
@@ -687,12 +694,16 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(64)
     fmx_mstep_snp_kernel(int64_t S, int64_t s0, int64_t s1, int K, int P, int KL, const int64_t* __restrict__ snp_ptr,
                          const int32_t* __restrict__ snp_cell, const int32_t* __restrict__ clust,
-                         const double* __restrict__ segls, double* __restrict__ cgls) {
+                         const double* __restrict__ segls6, double* __restrict__ cgls) {
+  // The likelihood matrix of an entry is symmetric (calculate_snp_droplet_pileup) and a cluster state starts at all
+  // ones, so every state stays symmetric: six numbers {00, 11, 22, 01, 02, 12} per state and entry instead of nine --
+  // a third fewer LDS bytes per marker (more markers in flight), three 16-byte loads per entry instead of nine 8-byte
+  // ones.  The sums over the nine elements become  d0 + d1 + d2 + 2 (o01 + o02 + o12).
   extern __shared__ double sm[];
   const int lane = threadIdx.x;
-  const int STR = KL * 9 + 1;
+  const int STR = KL * 6 + 1;
   double* st = sm + (size_t)lane * STR;
-  for (int i = 0; i < KL * 9; ++i) st[i] = 1.0;
+  for (int i = 0; i < KL * 6; ++i) st[i] = 1.0;
   const int per = 64 / P;                       // markers per wave
   const int part = lane / per;                  // this lane owns clusters [part*KL, part*KL + KL)
   const int64_t s = s0 + (int64_t)blockIdx.x * per + (lane - part * per);
@@ -703,14 +714,14 @@ __global__ void __launch_bounds__(64)
   }
   // Software pipeline in blocks of MU entries, two register sets: while block n is merged (a strictly sequential chain
   // through the LDS states), the likelihoods and assignments of block n+1 and the cell ids of block n+2 are in flight.
-  // The number of chains in flight is capped by LDS (K*72 B per marker, ~140 markers per CU), so the time per chain
+  // The number of chains in flight is capped by LDS (K*48 B per marker, ~210 markers per CU), so the time per chain
   // step is what counts: it was one full memory round trip with a single entry of look-ahead.
   // (all loads are unconditional from clamped positions: a predicated load merged with a default makes the compiler
   // wait for it on the spot)
   constexpr int MU = 4;
   struct blk_t {
     int32_t k[MU];
-    double g[MU][9];
+    double g[MU][6];
   };
   const int64_t plast = (p1 > p) ? p1 - 1 : 0;
   auto load_ids = [&](int32_t (&c)[MU], int64_t base) {
@@ -722,9 +733,13 @@ __global__ void __launch_bounds__(64)
     for (int u = 0; u < MU; ++u) {
       const int64_t e = (base + u < p1) ? base + u : plast;
       B.k[u] = clust[c[u]];
-      const double* o = segls + (size_t)e * 9;
+      const double2* o = reinterpret_cast<const double2*>(segls6 + (size_t)e * 6);  // 48 B, 16-byte aligned
 #pragma unroll
-      for (int i = 0; i < 9; ++i) B.g[u][i] = o[i];
+      for (int i = 0; i < 3; ++i) {
+        const double2 v = o[i];
+        B.g[u][2 * i] = v.x;
+        B.g[u][2 * i + 1] = v.y;
+      }
     }
   };
   auto merge_blk = [&](const blk_t& B, int64_t base) {
@@ -732,24 +747,19 @@ __global__ void __launch_bounds__(64)
     for (int u = 0; u < MU; ++u) {
       const int32_t k = B.k[u] - part * KL;
       if (base + u < p1 && k >= 0 && k < KL) {  // only cells called singlets carry a cluster (b8, :590-596)
-        double* q = st + k * 9;
-        double v[9], tmp = 0.0;
+        double* q = st + k * 6;
+        double v[6];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          v[i] = q[i] * B.g[u][i];
-          tmp += v[i];
-        }
-        double inv = fast_rcp(tmp);
-        tmp = 0.0;
+        for (int i = 0; i < 6; ++i) v[i] = q[i] * B.g[u][i];
+        double inv = fast_rcp(((v[0] + v[1]) + v[2]) + 2.0 * ((v[3] + v[4]) + v[5]));
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < 6; ++i) {
           v[i] *= inv;
           if (v[i] < kMinNormGL) v[i] = kMinNormGL;
-          tmp += v[i];
         }
-        inv = fast_rcp(tmp);
+        inv = fast_rcp(((v[0] + v[1]) + v[2]) + 2.0 * ((v[3] + v[4]) + v[5]));
 #pragma unroll
-        for (int i = 0; i < 9; ++i) q[i] = v[i] * inv;
+        for (int i = 0; i < 6; ++i) q[i] = v[i] * inv;
       }
     }
   };
@@ -772,8 +782,10 @@ __global__ void __launch_bounds__(64)
   if (s < s1) {
     for (int k = 0; k < KL && part * KL + k < K; ++k) {
       double* og = cgls + ((size_t)(part * KL + k) * S + s) * 9;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) og[i] = st[k * 9 + i];
+      const double* q = st + k * 6;
+      og[0] = q[0], og[1] = q[3], og[2] = q[4];
+      og[3] = q[3], og[4] = q[1], og[5] = q[5];
+      og[6] = q[4], og[7] = q[5], og[8] = q[2];
     }
   }
 }
@@ -786,13 +798,13 @@ static int fmx_mstep_launch(muxgl_handle* h) {
   int P = 1;  // lanes per SNP, each holding at most 16 of its cluster states
   while (P * 16 < h->K) P *= 2;
   const int KL = (h->K + P - 1) / P;
-  const size_t lds = (size_t)64 * (KL * 9 + 1) * sizeof(double);
+  const size_t lds = (size_t)64 * (KL * 6 + 1) * sizeof(double);
   if (P <= 16 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // lane(s) per SNP, cluster states in LDS
     const int64_t ns = h->fs1 - h->fs0;
     const int per = 64 / P;
     HIPCHK(h, hipFuncSetAttribute((const void*)fmx_mstep_snp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fmx_mstep_snp_kernel, dim3((unsigned)((ns + per - 1) / per)), dim3(64), lds, h->stream, h->S,
-                       h->fs0, h->fs1, h->K, P, KL, h->d_snp_ptr, h->d_snp_cell, h->d_clust, h->d_segls, h->d_cgls);
+                       h->fs0, h->fs1, h->K, P, KL, h->d_snp_ptr, h->d_snp_cell, h->d_clust, h->d_segls6, h->d_cgls);
     HIPCHK(h, hipGetLastError());
     return 0;
   }
@@ -810,12 +822,13 @@ static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm) {
   if (plan_build_snp_major(h)) return 1;
   tm.lap("fmx_prepare: SNP-major view (device sort)");
   if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
+  if (dev_alloc(h, &h->d_segls6, (size_t)nnz * 6)) return 1;
   if (dev_alloc(h, &h->d_secnt, (size_t)nnz * 3)) return 1;
   if (nnz) {
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
-                       h->d_egls, h->d_ecnt, h->d_segls, h->d_secnt);
+                       h->d_egls, h->d_ecnt, h->d_segls, h->d_segls6, h->d_secnt);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
@@ -914,6 +927,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
       return 1;
     }
     dev_free(&h->d_segls);
+    dev_free(&h->d_segls6);
     dev_free(&h->d_secnt);
   } else if (fmx_build_snp_major(h, tm)) {
     return 1;
