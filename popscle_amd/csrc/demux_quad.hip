@@ -17,6 +17,10 @@
 //     singlet slot factorises into (sum_l g_j[l] q0[l]) * (g_0[0]+g_0[1]+g_0[2]).
 //   * products leave the kernel as (mantissa, exponent) pairs; demux_quad_reduce_kernel multiplies the chunk partials
 //     of a cell in chunk order and takes ONE log per hypothesis and cell (the row kernel took one per chunk).
+//   * entries with at most one usable read (three quarters of a typical pileup) are linear in the genotypes: a chunk's
+//     records are partitioned (quad_partition_kernel), the linear ones are swept first by a loop of their own from rows of
+//     moments (s, rho) -- one FMA and the product update per hypothesis, the sums s folded in at the end -- and the
+//     launch order sorts chunks of similar trip counts into the same waves (quad_order_key_kernel).
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>

@@ -13,7 +13,7 @@
 //                         lane = cluster, partner triples by DPP row rotation; the entry's 3x3 likelihood matrix is
 //                         symmetric, so 8 shifts cover all unordered pairs), product accumulators, one log per chunk
 //   fmx_estep_pair_kernel K > 16: workgroup <-> cell, lane <-> cluster pair (general fallback)
-//   fmx_call_kernel       lane <-> cell: scans, evidence, re-assignment, change counters
+//   fmx_call_kernel       scans, evidence, re-assignment, change counters: lane <-> cell (K <= 24) or wave <-> cell
 //   fmx_mstep_kernel      lane <-> (SNP, cluster): walks the SNP's entries in ascending cell id (SNP-major view) and
 //                         applies merge() for the cells assigned to the cluster -- the exact sequential order of the
 //                         reference, parallel over the S*K independent chains

@@ -8,6 +8,9 @@
 //   product accumulator (6 pairs inside the lane, 16 with the neighbouring tile via row_ror:4, 10 with the opposite tile
 //   via row_ror:8).  Products leave as (mantissa, exponent) per chunk; fmx_quad_reduce_kernel takes one log per
 //   (cell, pair).  The cluster-GP rows are re-laid per quad ([S][6][4][2], fmx_cgpq_kernel) once per iteration.
+// Entries whose likelihoods are linear in the genotypes (fmx_entry_kernel: glis[g1][g2] = c0 + c1 (g1 + g2)) come first in
+// every chunk (fq_partition_kernel) and are swept by a loop of their own from the clusters' moments E = g1 + 2 g2
+// (fmx_ceq_kernel): pair (c0 + c1 E_j) + c1 E_k, singlet c0 + 2 c1 E_j -- an FMA and the product update per hypothesis.
 #include "common.hpp"
 
 namespace {
