@@ -254,3 +254,46 @@ def test_linear_entry_forms_agree_with_the_general_ones():
     ocells = ob.fmx_init_cells(clust0)
     ob.fmx_iterate(q, e, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
     assert parity.compare_fmx(a, ocells)["max_abs_ll_diff"] < 1e-7
+
+
+def test_linear_entry_loops_of_the_quad_kernels_agree_with_the_general_ones():
+    """The quad kernels (V, K <= 16) sweep a chunk's entries with one usable read in a loop of their own (moments of the
+    triples, demux_quad.hip / fmx_quad.hip); MUXGL_FLAG_NO_LINEAR_ENTRIES keeps every entry in the nine-term loop.  Mixed
+    chunks (reads_lambda = 0.6), alleles other than 0/1 among the reads, several chunks per cell, markers without
+    genotypes."""
+    V, alphas = 16, (0.0, 0.5)
+    p = synth.make_pileup(150, 3000, V, seed=79, mean_entries=400, min_entries=40, reads_lambda=0.6, other=0.05,
+                          missing_gp_frac=0.04)
+    res = []
+    for flags in (0, muxgl.FLAG_NO_LINEAR_ENTRIES):
+        with muxgl.Engine(0, flags) as eng:
+            eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+            eng.demux_set_gp(p.gp, p.has_gp)
+            full = eng.demux_run(alphas, 0.5, want_full_ll=True)
+            cells = eng.demux_run(alphas, 0.5)  # the fused finish kernel
+            assert np.array_equal(cells["sBest"], full[0]["sBest"]) and np.array_equal(cells["type"], full[0]["type"])
+            res.append(full)
+    (c1, f1), (c2, f2) = res
+    assert np.array_equal(c1["type"], c2["type"]) and np.array_equal(c1["sBest"], c2["sBest"])
+    assert np.abs(f1 - f2).max() < 1e-9 and (f1 != f2).any()
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=NT)
+    assert parity.compare_full_ll(f1, wfull, V, alphas) < 1e-7 and parity.compare_full_ll(f2, wfull, V, alphas) < 1e-7
+    K = 13
+    q = synth.make_pileup(120, 3000, 8, seed=80, mean_entries=400, min_entries=40, reads_lambda=0.6, other=0.03, with_gp=False,
+                          cap_bq=60)
+    clust0 = (np.arange(q.C) % K).astype(np.int32)
+    out = []
+    for flags in (0, muxgl.FLAG_NO_LINEAR_ENTRIES):
+        with muxgl.Engine(0, flags) as eng:
+            eng.set_pileup(q.S, q.cell_ptr, q.entry_snp, q.entry_rptr, q.reads)
+            eng.fmx_prepare(q.af)
+            eng.fmx_set_clusters(K, clust0)
+            out.append(eng.fmx_iterate(0.5, 0.1, want_full_ll=True))
+    (a, sa, fa), (b, sb, fb) = out
+    assert tuple(sa) == tuple(sb) and np.array_equal(a["type"], b["type"]) and np.array_equal(a["clust"], b["clust"])
+    assert np.abs(fa - fb).max() < 1e-9 and (fa != fb).any()
+    e = ob.fmx_entry_pileup(q)
+    cplp = ob.fmx_build_cluster_pileup(q, e, K, clust0)
+    ocells = ob.fmx_init_cells(clust0)
+    ob.fmx_iterate(q, e, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
+    assert parity.compare_fmx(a, ocells)["max_abs_ll_diff"] < 1e-7
