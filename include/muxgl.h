@@ -58,7 +58,8 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
                                       against that stream (popscle_amd/freemuxlet.py) */
 #define MUXGL_FLAG_NO_LINEAR_ENTRIES 64 /* sweep every entry through the general three-term form, also those whose
                                           likelihoods are linear in the genotypes (one usable read) and would take the
-                                          two-term form (lets tests compare the two) */
+                                          one-moment form of the quad (V, K <= 16) and wave (V, K > 32) kernels
+                                          (lets tests compare the two) */
 
 typedef struct muxgl_handle muxgl_handle;
 

@@ -111,11 +111,13 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
 // everything that reads a set is complete before the set is reloaded, and a reload is issued before the sweep behind
 // it -- otherwise the scheduler renames registers to hoist loads, runs out of VGPRs and spills.
 //
-// What the time is made of (config 1, ablations of this kernel on MI355X): FP64 arithmetic alone 0.28 ms, + DPP moves
-// 0.06, + phase 1 0.09, + row gathers 0.12 = 0.55 ms at the clocks of a 20-launch run (0.49 ms sustained).  The parts
-// add up instead of overlapping, and neither a fifth fewer instructions (dummy row instead of predicated loads), nor
-// deeper prefetch, nor a branch-free phase 1 moved the total by more than 2 %: the launch behaves as if limited by the
-// work itself (energy per entry under the power cap), not by latency or issue slots.
+// What the time is made of (config 1, ablations of the nine-term loop on MI355X, round 1): FP64 arithmetic alone 0.28 ms,
+// + DPP moves 0.06, + phase 1 0.09, + row gathers 0.12 = 0.55 ms at the clocks of a 20-launch run (0.49 ms sustained).
+// The parts add up instead of overlapping, and neither a fifth fewer instructions (dummy row instead of predicated
+// loads), nor deeper prefetch, nor a branch-free phase 1 moved the total by more than 2 %.  (Not the power cap: the
+// launch runs at 2.4 GHz and 1.2 kW of 1.4.)  What did move it in round 2 is less work per entry: the loop of the
+// linear entries (0.49 -> 0.43 ms) and the launch order (-> 0.41 ms); a whole batch of row look-ahead and the linear
+// entries' phase 1 done once per pileup instead of per launch changed nothing again.
 __global__ void __launch_bounds__(64, 2)
     demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
                        const int32_t* __restrict__ chunk_nlin, const int32_t* __restrict__ order,

@@ -11,12 +11,15 @@
 //   * lane j keeps sample j's triple g_j (loaded straight from the contiguous 1.5 KB GP row) and, per alpha,
 //     u[m] = sum_l g_j[l] * pG[alpha][l][m]; the entry's nine pG values are wave-uniform and are fetched through the
 //     scalar cache into SGPRs, so they cost no vector instruction and no LDS traffic;
-//   * the partner triple g_k reaches lane j by rotating the whole wave one lane per step (DPP wave_ror:1, 6 moves);
-//     after t steps lane j faces sample (j - t) mod 64: 3 FMA + 1 multiply per hypothesis;
+//   * at rotation step t lane j faces sample (j - t) mod 64; the partner's values are read from a copy of the 64 values
+//     in LDS (the "ring", see dw_sweep_lin; round 1 rotated them with DPP moves, which cost as much issue time as the
+//     arithmetic they fed): 3 FMA + 1 multiply per hypothesis, or 1 FMA + 1 multiply for the entries with one usable
+//     read (EM_LINEAR below);
 //   * 64 accumulators per lane: alpha = 0.5 (symmetric in (j,k): 32 steps) and a lone alpha (63 steps) get a launch of
-//     their own, other alphas go four (or two) at a time with 16 (32) of the rotation steps per launch
-//     (demux_wave_multi_kernel: the rotation is paid once for all of them); the singlet slot (j,0,n=0) rides along
-//     with the first launch;
+//     their own, other alphas go four (or two) at a time, the rotation steps cut into ranges of 16 (32) that are the
+//     waves of one workgroup (demux_wave_multi_kernel: the ring reads are shared by the alphas); the singlet slot
+//     (j,0,n=0) rides along with the first range;
+//   * the walk over a cell's entries is a software pipeline over record streams (dw_walk);
 //   * products are kept as mantissa * 2^exponent and turned into one log per (cell, hypothesis).
 // Work unit = cell, or a part of a cell longer than 2048 entries (wave_item; 100 k waves at BASELINE configs[2]); the
 // units are launched longest first.  Markers without genotypes are neutral by construction (wave_neutral_pg_kernel).

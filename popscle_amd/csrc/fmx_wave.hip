@@ -2,11 +2,13 @@
 // lane per cluster, the design of demux_wave.hip with the entry's nine genotype-pair likelihoods in the role of pG.
 //
 //   * lane j keeps cluster j's genotype posterior gp_j (three doubles from the per-iteration tensor cgp[S][K][3], loaded
-//     one entry ahead) and u[m] = sum_l gp_j[l] * glis[l][m]; the entry's likelihoods are wave-uniform and come through
-//     the scalar cache;
-//   * the partner posterior reaches lane j by rotating the wave one lane per step (DPP wave_ror:1); the pair likelihood
-//     (:440-446) is symmetric in the two clusters, so 32 steps meet every unordered pair (the last step meets each pair
-//     from both sides: one writer); the singlet (:448-452) uses the diagonal of glis only;
+//     two to three entries ahead) and u[m] = sum_l gp_j[l] * glis[l][m]; the entry's likelihoods are wave-uniform and
+//     come through the scalar cache; entries whose likelihoods are linear in the genotypes need one moment per cluster
+//     and one FMA per pair instead (LIN below);
+//   * at rotation step t lane j faces cluster (j - t) mod 64: a few rotations are DPP moves (wave_ror:1), the others
+//     reads of a copy of the 64 values in LDS (the ring, below); the pair likelihood (:440-446) is symmetric in the two
+//     clusters, so 32 steps meet every unordered pair (the last step meets each pair from both sides: one writer); the
+//     singlet (:448-452) uses the diagonal of glis only;
 //   * products as mantissa * 2^exponent, one log per (cell, hypothesis), written to llks[j(j+1)/2 + k] directly.
 // The general pair kernel this replaces for K = 64 ran at 5 % of the FP64 issue rate (one thread per pair, every thread
 // fetching both posteriors of every entry).
