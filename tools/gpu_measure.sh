@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 2, final measurement pass: GPU tests, bench lines of all configs, kernel trace + PMC passes of each
+# measurement pass: GPU tests, then kernel trace + PMC passes of every BASELINE config (summaries: tools/prof_summary.py,
+# tools/traffic_update.py; bench lines: tools/bench_all.sh)
 cd /root/repo
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/pytest_gpu_full.log
 rm -rf gpurun_out/prof_c[1-4]_*
