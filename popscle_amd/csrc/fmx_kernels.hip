@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(256)
       const double tol = 1e-14 * fmax(gls[0], gls[8]);  // a few roundings apart at most; 1e-14 per factor is 1e-11 per cell
       linear = nref + nalt <= 1 && fabs(gls[2] - fma(2.0, c1, c0)) <= tol && fabs(gls[5] - fma(3.0, c1, c0)) <= tol &&
                fabs(gls[8] - fma(4.0, c1, c0)) <= tol && gls[3] == gls[1] && gls[6] == gls[2] && gls[4] == gls[2] &&
-               gls[7] == gls[5];
+               gls[7] == gls[5] &&
+               // the moment forms reach the small end of the line through cancellation: relative error ~1e-16 * max / min
+               fmin(gls[0], gls[8]) >= 1e-7 * fmax(gls[0], gls[8]);
     }
     if (l0) {
     // cmd_cram_freemux2.cpp:138-149

@@ -33,7 +33,10 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// bit e of lin: entry e has at most one usable read (alleles other than 0/1 are skipped, cmd_cram_demuxlet.cpp:664).
+// bit e of lin: entry e has at most one usable read (alleles other than 0/1 are skipped, cmd_cram_demuxlet.cpp:664), and
+// that read's base quality is at most 60: the moment forms of the sweeps reach the small end of the linear likelihood
+// through cancellation, at a relative error of ~1e-16 * max / min = 3e-16 * 10^(Q/10) -- 3e-10 at Q60; anything above
+// (no sequencer in use writes it) stays on the nine-term path.
 // 64 consecutive entries per wave, the two words of their ballot written by lanes 0 and 32.
 __global__ void __launch_bounds__(256)
     lin_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads,
@@ -44,8 +47,14 @@ __global__ void __launch_bounds__(256)
     bool one = false;
     if (e < nnz) {
       int usable = 0;
-      for (int64_t r = entry_rptr[e]; r < entry_rptr[e + 1] && usable < 2; ++r) usable += reads[r] != MUXGL_READ_OTHER;
-      one = usable <= 1;
+      bool lowq = true;
+      for (int64_t r = entry_rptr[e]; r < entry_rptr[e + 1] && usable < 2; ++r) {
+        const uint8_t bb = reads[r];
+        if (bb == MUXGL_READ_OTHER) continue;
+        ++usable;
+        lowq = lowq && (bb & 0x7f) <= 60;
+      }
+      one = usable <= 1 && lowq;
     }
     const uint64_t m = __ballot(one);
     if (lane == 0) lin[eb >> 5] = (uint32_t)m;
