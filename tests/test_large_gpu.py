@@ -297,3 +297,19 @@ def test_linear_entry_loops_of_the_quad_kernels_agree_with_the_general_ones():
     ocells = ob.fmx_init_cells(clust0)
     ob.fmx_iterate(q, e, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
     assert parity.compare_fmx(a, ocells)["max_abs_ll_diff"] < 1e-7
+
+
+@pytest.mark.parametrize("V,alphas", [(16, (0.0, 0.5)), (40, (0.0, 0.3, 0.5))])
+def test_high_base_qualities_stay_on_the_nine_term_path(V, alphas):
+    """The moment forms of the linear-entry class lose relative accuracy in proportion to the dynamic range of an entry's
+    likelihoods, so reads above Q60 (lin_kernel) keep their entries on the nine-term path: with qualities up to 93 the
+    log-likelihoods still match the oracle to the usual bar."""
+    p = synth.make_pileup(60, 2500, V, seed=81 + V, mean_entries=300, min_entries=40, reads_lambda=0.4, min_bq=30, max_bq=93, cap_bq=93)
+    assert (p.reads[p.reads != 0xFF] & 0x7F).max() > 60
+    with muxgl.Engine(0) as eng:
+        eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        eng.demux_set_gp(p.gp, p.has_gp)
+        got, full = eng.demux_run(alphas, 0.5, want_full_ll=True)
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=NT)
+    assert parity.compare_full_ll(full, wfull, V, alphas) < 1e-7
+    assert parity.compare_demux(got, want, alphas, want_full=wfull)["max_abs_ll_diff"] < 1e-7
