@@ -360,7 +360,7 @@ struct wave_cut {
 
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
-int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg);
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, double* d_lpg = nullptr);
 int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);

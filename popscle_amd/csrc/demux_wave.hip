@@ -872,19 +872,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (dev_alloc(h, &h->d_llw, llw_need)) return 1;
     h->llw_cap = llw_need;
   }
-  tic(h, MUXGL_T_DEMUX_SWEEP);
-  if (demux_entry_pg_launch(h, p, st->d_pg)) return 1;
-  if (h->nnz)
-    hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
-                       A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
-  const unsigned blocks = (unsigned)st->n_items;
-  std::vector<int> plain;  // non-symmetric alphas
-  uint32_t symmask = 0;
-  for (int n = 1; n < A; ++n) {
-    if (p->alpha[n] != 0.5) plain.push_back(n);
-    else symmask |= 1u << n;
-  }
-  // linear entries (one usable read) in a launch of their own with the two-term form, the others on top: see EM_LINEAR
+  // linear entries (one usable read) in a launch of their own with the one-moment form, the others on top: see EM_LINEAR
   const bool use_lin = V > 32 && h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
   if (use_lin && h->n_lin_rec < 0 &&
       plan_build_bit_streams(h, h->d_lin, &h->d_lin_rank, &h->d_lin_rec, &h->d_gen_rec, &h->n_lin_rec))
@@ -900,10 +888,28 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       if (dev_alloc(h, &st->d_gm, need_g)) return 1;
       st->gm_cap = need_g;
     }
+  }
+  // one block of the pair matrix (V <= 64): nobody reads the linear entries' rows of the nine-value table, the kernel that
+  // computes the likelihoods writes their (A, Bl, Bm) rows instead; beyond, the off-diagonal blocks walk every entry
+  // through the nine-value table and the rows are made from it afterwards
+  const bool fused_lpg = use_lin && nblk == 1;
+  tic(h, MUXGL_T_DEMUX_SWEEP);
+  if (demux_entry_pg_launch(h, p, st->d_pg, fused_lpg ? st->d_lpg : nullptr)) return 1;
+  if (h->nnz)
+    hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
+                       A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
+  const unsigned blocks = (unsigned)st->n_items;
+  std::vector<int> plain;  // non-symmetric alphas
+  uint32_t symmask = 0;
+  for (int n = 1; n < A; ++n) {
+    if (p->alpha[n] != 0.5) plain.push_back(n);
+    else symmask |= 1u << n;
+  }
+  if (use_lin) {
     const int64_t ng = h->S * (int64_t)V;
     if (ng) hipLaunchKernelGGL(wave_gm_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, h->stream, ng, h->d_gp, st->d_gm);
     const int64_t n = h->n_lin_rec * (int64_t)A;
-    if (n)
+    if (n && !fused_lpg)
       hipLaunchKernelGGL(wave_lpg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->n_lin_rec, A, h->d_lin_rec,
                          st->d_pg, st->d_lpg);
   }
