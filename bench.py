@@ -4,8 +4,9 @@
     python bench.py --gpus 1 --steps 2000 --warmup 200              # BASELINE.json's metric on configs[1] (headline)
     python bench.py --config 2 --steps 3 --warmup 1                 # demuxlet 100k x 64 x 200k, six alphas
     python bench.py --config 3 --steps 20 --warmup 2                # freemuxlet K=16, 50k x 100k, 20 EM iterations
+    python bench.py --gpus N ...                                    # starts N ranks of itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W [--config I]
+        bench.py --gpus N --steps K --warmup W [--config I]         # the same, launched from outside
 
 One process per GPU.
   * demuxlet (configs 1, 2): a "step" is one full pass of the hot path (entry likelihoods + sample-pair sweep +
@@ -15,9 +16,13 @@ One process per GPU.
   * freemuxlet (configs 3, 4): a "step" is one EM iteration (cluster posteriors, E-step, scans, re-assignment, ordered
     M-step and the two all-gathers + one all-reduce between them) of the fixed job (STRONG scaling): the E-step is
     sharded by cells, the ordered M-step by SNPs, each rank holding 2/N of the pileup (popscle_amd/freemuxlet.py).
-  * The default run (config 1) also times the freemuxlet EM of configs[3] on the same ranks and reports it as
-    "freemuxlet_em" inside the same JSON line, so that a scaling run of the default command exercises the one path
-    that has a collective (--no-fmx-leg skips it).
+  * The default run (config 1) also times, on the same ranks and inside the same JSON line, the other BASELINE.json
+    configs: "freemuxlet_em" (configs[3], 20 EM iterations), "demuxlet_config2" (configs[2], the north_star's
+    100 k x 64 x 200 k shape, 3 passes) and "freemuxlet_config4" (configs[4], 500 k x 500 k, K = 64: 2 EM iterations;
+    sharded over the ranks for N > 1) -- each with its own roofline and CPU baseline, each behind a watchdog so that it
+    can never cost the headline (--no-legs skips them; --legs 3,2,4 selects).  Their inputs are generated on the GPU
+    (synth.make_pileup_device: the numpy generator needs minutes for 5 x 10^8 entries); a sharded leg moves only the
+    rank's two slabs to the host.
 
 Prints ONE JSON line (rank 0).  LL = one hypothesis log-likelihood feeding a call: demuxlet V singlets +
 V(V-1)(A-1) ordered doublets per cell, freemuxlet K(K+1)/2 per cell and iteration.
@@ -289,8 +294,8 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        if self.world != max(1, args.gpus):
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
         self.dev = 0 if args.single_device else local_rank
         torch.cuda.set_device(self.dev)
         self.backend = args.dist_backend
@@ -331,28 +336,73 @@ class Ctx:
         return [float(v) for v in t.tolist()]
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: start N ranks of this very command under torch.distributed.run (one
+    process per GPU, RCCL or gloo rendezvous on 127.0.0.1) and hand their output through; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def use_device_synth(args, entries_estimate):
+    """large inputs are generated on the GPU (torch), small ones and every test-sized run by the numpy generator"""
+    if args.synth == "numpy":
+        return False
+    return args.synth == "device" or entries_estimate > 2.0e7
+
+
+def free_torch_cache(ctx):
+    import gc
+
+    gc.collect()
+    ctx.torch.cuda.empty_cache()
+
+
 # ---- demuxlet leg (configs 1, 2): weak scaling -----------------------------------------------------------------------
-def demux_leg(args, ctx, config):
+def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu_budget_s=9.0):
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    ramp_seconds = args.ramp_seconds if ramp_seconds is None else ramp_seconds
     cfg = synth.CONFIGS[config]
     alphas = tuple(cfg["alphas"])
     V, A = cfg["V"], len(alphas)
     # weak scaling: every rank owns a full config-sized shard of cells (its own seed), GP tensor replicated
     C = max(1, int(round(cfg["C"] * args.scale)))
-    p = synth.make_pileup(C, cfg["S"], V, seed=synth.BASE_SEED + config + 1000 * ctx.rank,
-                          donor_seed=synth.BASE_SEED + config)
+    seeds = dict(seed=synth.BASE_SEED + config + 1000 * ctx.rank, donor_seed=synth.BASE_SEED + config)
+    t_gen = time.perf_counter()
+    on_device = use_device_synth(args, C * 950.0)
+    if on_device:
+        p = synth.make_pileup_device(C, cfg["S"], V, device=f"cuda:{ctx.dev}", **seeds).host()
+        free_torch_cache(ctx)
+    else:
+        p = synth.make_pileup(C, cfg["S"], V, **seeds)
+    gen_s = time.perf_counter() - t_gen
     eng = muxgl.Engine(ctx.dev)
+    t_h = time.perf_counter()
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.demux_set_gp(p.gp, p.has_gp)
+    handover_s = time.perf_counter() - t_h
 
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
+    ramp_passes = 0
+    while time.perf_counter() - t_ramp < ramp_seconds:
         eng.demux_run(alphas, 0.5, want_cells=False)
-    for _ in range(args.warmup):
+        ramp_passes += 1
+    for _ in range(warmup):
         eng.demux_run(alphas, 0.5, want_cells=False)
     ctx.barrier()
     kern_ms = np.zeros(muxgl.T_COUNT)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         eng.demux_run(alphas, 0.5, want_cells=False)
         kern_ms += eng.timing()
     ctx.barrier()
@@ -361,15 +411,19 @@ def demux_leg(args, ctx, config):
     out = None
     if ctx.rank == 0:
         lls_per_cell = V + V * (V - 1) * (A - 1)
-        step_s = elapsed / args.steps
-        kern_ms /= args.steps
+        step_s = elapsed / steps
+        kern_ms /= steps
         rpe = p.R / max(p.nnz, 1)
         sweep_s = kern_ms[muxgl.T_DEMUX_SWEEP] * 1e-3
         out = {
             "metric": METRIC if config == 1 else f"cell-sample-pair LLs/sec (singlet+doublet), demuxlet BASELINE.json configs[{config}]",
-            "value": total_cells * lls_per_cell / step_s, "unit": "LLs/s", "n_gpus": ctx.world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": total_cells * lls_per_cell / step_s, "unit": "LLs/s", "n_gpus": ctx.world, "steps": steps,
+            "warmup": warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # untimed passes before the W warmup steps (the engine clock ramps up over a few hundred launches)
+            "ramp": {"seconds": ramp_seconds, "untimed_passes": ramp_passes},
+            "input": {"generator": "torch on the GPU (synth.make_pileup_device)" if on_device else "numpy (synth.make_pileup)",
+                      "generate_s": gen_s, "handover_s": handover_s},
             "config": {
                 "workload": f"demuxlet synthetic PLP (BASELINE.json configs[{config}]): {C} cells x {V} samples x "
                             f"{cfg['S']} SNPs per GPU, alpha grid {list(alphas)}, {p.nnz} entries, {p.R} reads",
@@ -386,7 +440,7 @@ def demux_leg(args, ctx, config):
                                  demux_issued_flops_model(V, alphas, rpe) * p.nnz, config, scale=float(p.nnz)),
         }
         if not args.no_cpu_baseline and ctx.world == 1:
-            out["cpu_baseline"] = cpu_baseline_demux(p, alphas, eng.demux_results_view().copy())
+            out["cpu_baseline"] = cpu_baseline_demux(p, alphas, eng.demux_results_view().copy(), budget_s=cpu_budget_s)
         else:
             out["cpu_baseline"] = None
     eng.close()
@@ -394,27 +448,54 @@ def demux_leg(args, ctx, config):
 
 
 # ---- freemuxlet leg (configs 3, 4): strong scaling -------------------------------------------------------------------
-def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
+def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10.0):
     torch, dist = ctx.torch, ctx.dist
     cfg = synth.CONFIGS[config]
     C = args.cells or max(1, int(round(cfg["C"] * args.scale)))
     S = args.snps or cfg["S"]
     K = args.clusters or cfg["V"]
-    # the same job on every rank (same seed): strong scaling
-    p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + config, with_gp=False, mean_entries=args.mean_entries,
-                          min_entries=min(50, max(1, int(args.mean_entries // 4))))
     ordered = ctx.dist_on and ctx.backend == "nccl"
-    eng = muxgl.Engine(ctx.dev, muxgl.FLAG_ASYNC_PHASES if ordered else 0)
     (c_ranges, per_c), (s_ranges, per_s) = freemuxlet.plan_ranges(C, S, ctx.world)
+    # the same job on every rank (same seed): strong scaling.  A rank keeps only its row slab (its cells) and its
+    # column slab (its SNPs) on the host and on the device: 2/N of the pileup.
+    gen = dict(seed=synth.BASE_SEED + config, with_gp=False, mean_entries=args.mean_entries,
+               min_entries=min(50, max(1, int(args.mean_entries // 4))))
+    t_gen = time.perf_counter()
+    on_device = use_device_synth(args, C * args.mean_entries * 1.2)
+    p = rows = cols = None
+    if on_device:
+        d = synth.make_pileup_device(C, S, K, device=f"cuda:{ctx.dev}", **gen)
+        nnz_total, my_entries = d.nnz, float(d.cell_ptr[c_ranges[0][1]] - d.cell_ptr[c_ranges[0][0]])
+        af, truth_s1 = d.af.cpu().numpy(), d.truth["s1"].cpu().numpy()
+        if ctx.dist_on:
+            rows = d.take_cells(*c_ranges[ctx.rank])
+            cols = d.take_snps(*s_ranges[ctx.rank])
+        if not ctx.dist_on or (ctx.rank == 0 and cpu_baseline and ctx.world == 1 and not args.no_cpu_baseline):
+            p = d.host()
+        del d
+        free_torch_cache(ctx)
+    else:
+        p = synth.make_pileup(C, S, K, **gen)
+        nnz_total, my_entries = p.nnz, float(p.cell_ptr[c_ranges[0][1]] - p.cell_ptr[c_ranges[0][0]])
+        af, truth_s1 = p.af, p.truth["s1"]
+        if ctx.dist_on:
+            rows = shard.take_cells(p, *c_ranges[ctx.rank])
+            cols = shard.take_snps(p, *s_ranges[ctx.rank])
+    gen_s = time.perf_counter() - t_gen
+    eng = muxgl.Engine(ctx.dev, muxgl.FLAG_ASYNC_PHASES if ordered else 0)
     t0 = time.perf_counter()
     if ctx.dist_on:
-        freemuxlet.load_rank(eng, p, c_ranges[ctx.rank], s_ranges[ctx.rank])
+        eng.set_pileup(S, rows.cell_ptr, rows.entry_snp, rows.entry_rptr, rows.reads)
+        eng.fmx_set_column_slab(C, c_ranges[ctx.rank][0], *s_ranges[ctx.rank], *cols)
+        slab_bytes = sum(a.nbytes for a in (rows.cell_ptr, rows.entry_snp, rows.entry_rptr, rows.reads) + tuple(cols))
+        del rows, cols
     else:
         eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
-        eng.fmx_prepare(p.af)
+        slab_bytes = sum(a.nbytes for a in (p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads))
+    eng.fmx_prepare(af)
     handover_s = time.perf_counter() - t0
     # a seeded start (--init-cluster style): 90 % of the cells start in their source sample's cluster
-    clust0 = np.where(np.random.default_rng(0).random(C) < 0.9, p.truth["s1"], -1).astype(np.int32)
+    clust0 = np.where(np.random.default_rng(0).random(C) < 0.9, truth_s1, -1).astype(np.int32)
     ex = (freemuxlet.TorchExchange(dist, ctx.rank, ctx.world, device_ordered=ordered, always=True)
           if ctx.dist_on else None)
     stream_ctx = None
@@ -436,23 +517,27 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
     out = None
     if ctx.rank == 0:
         npairs = K * (K + 1) // 2
-        est_s = float(kern[muxgl.T_FMX_ESTEP]) * 1e-3
-        my_entries = float(p.cell_ptr[c_ranges[0][1]] - p.cell_ptr[c_ranges[0][0]])
+        # the roofline prices the pair-sweep kernel(s) alone -- the kernels the PMC traffic belongs to -- not the whole
+        # E-step bracket (which also holds the relayout of the posteriors and the reduction of the chunk partials)
+        est_s = float(kern[muxgl.T_FMX_ESTEP_SWEEP] or kern[muxgl.T_FMX_ESTEP]) * 1e-3
         out = {
             "metric": FMX_METRIC, "value": C * npairs * steps / elapsed, "unit": "LLs/s", "n_gpus": ctx.world,
             "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"freemuxlet EM (BASELINE.json configs[{config}]): {C} cells x {S} SNPs, K = {K}, "
-                                   f"{p.nnz} entries, {steps} EM iterations (cluster posteriors, E-step, scans, "
+                                   f"{nnz_total} entries, {steps} EM iterations (cluster posteriors, E-step, scans, "
                                    f"re-assignment, ordered M-step, exchanges)",
-                       "cells": C, "snps": S, "clusters": K, "entries": int(p.nnz),
+                       "cells": C, "snps": S, "clusters": K, "entries": int(nnz_total),
                        "parallelism": f"E-step by cells x{ctx.world}, ordered M-step by SNPs x{ctx.world}, "
                                       f"2 all-gathers + 1 all-reduce per iteration" if ctx.dist_on else "one GPU",
                        "backend": ctx.backend if ctx.dist_on else None},
-            "entries_per_s": p.nnz * steps / elapsed,
+            "entries_per_s": nnz_total * steps / elapsed,
+            "input": {"generator": "torch on the GPU (synth.make_pileup_device)" if on_device else "numpy (synth.make_pileup)",
+                      "generate_s": gen_s, "rank0_host_bytes": int(slab_bytes)},
             "handover_ms": handover_s * 1e3,  # H2D of this rank's slabs + derived tables + entry likelihoods
             "setup_ms": tm["setup_s"] * 1e3,  # initial cluster pileups (muxgl_fmx_set_clusters)
             "kernel_ms_rank0_last_iteration": {"gp": float(kern[muxgl.T_FMX_GP]), "estep": float(kern[muxgl.T_FMX_ESTEP]),
+                                               "estep_sweep": float(kern[muxgl.T_FMX_ESTEP_SWEEP]),
                                                "call": float(kern[muxgl.T_FMX_CALL]), "mstep": float(kern[muxgl.T_FMX_MSTEP])},
             "last_iteration": {"nsingle": hist[-1][0], "namb": hist[-1][1], "nchanged": hist[-1][2]},
             "roofline": roofline(fmx_estep_kernel(K), est_s, fmx_bytes_per_entry(K) * my_entries,
@@ -460,7 +545,7 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
                                  scale=my_entries),
         }
         if cpu_baseline and ctx.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_fmx(p, K, clust0)
+            out["cpu_baseline"] = cpu_baseline_fmx(p, K, clust0, budget_s=cpu_budget_s)
         else:
             out["cpu_baseline"] = None
         if args.dump:
@@ -469,26 +554,41 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True):
     return out
 
 
-def guarded_fmx_leg(args, ctx, headline):
-    """The secondary freemuxlet leg of the default run must never cost the headline line: a watchdog prints the line
-    without it (rank 0) and ends every rank cleanly if the leg hangs (a collective waiting for a rank that failed)."""
+LEGS = {  # secondary legs of the default run: JSON key, config, (steps, warmup), CPU-baseline budget, watchdog share
+    3: ("freemuxlet_em", "fmx"),
+    2: ("demuxlet_config2", "demux"),
+    4: ("freemuxlet_config4", "fmx"),
+}
+
+
+def guarded_leg(args, ctx, headline, config):
+    """A secondary leg of the default run must never cost the headline line: a watchdog prints the line without it
+    (rank 0, with the legs finished so far) and ends every rank cleanly if the leg hangs (a collective waiting for a
+    rank that failed)."""
+    key, kind = LEGS[config]
+
     def give_up(signum=None, frame=None, why="timeout"):
         if ctx.rank == 0:
-            headline["freemuxlet_em"] = {"error": f"freemuxlet leg did not finish: {why}"}
+            headline[key] = {"error": f"{key} did not finish: {why}"}
             flush_c_stdio()
             print(json.dumps(headline), flush=True)
         os._exit(0)
 
     signal.signal(signal.SIGALRM, give_up)
-    signal.alarm(int(args.fmx_leg_timeout))
+    signal.alarm(int(args.leg_timeout))
     try:
-        leg = fmx_leg(args, ctx, 3, args.fmx_leg_steps, 2, cpu_baseline=False)
+        if kind == "fmx":
+            st, wu = (args.fmx_leg_steps, 2) if config == 3 else (2, 1)
+            leg = fmx_leg(args, ctx, config, st, wu, cpu_baseline=True, cpu_budget_s=5.0)
+        else:
+            leg = demux_leg(args, ctx, config, steps=3, warmup=1, ramp_seconds=0.0, cpu_budget_s=5.0)
         signal.alarm(0)
         return leg
     except BaseException as ex:  # noqa: BLE001 -- includes a failed collective on this rank
-        sys.stderr.write(f"[bench rank {ctx.rank}] freemuxlet leg failed: {ex!r}\n")
+        sys.stderr.write(f"[bench rank {ctx.rank}] {key} failed: {ex!r}\n")
         if ctx.world == 1:
             signal.alarm(0)
+            free_torch_cache(ctx)
             return {"error": repr(ex)}
         while True:  # the other ranks may be waiting for us in a collective: leave together, when the alarm fires
             time.sleep(1.0)
@@ -514,9 +614,15 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="index into BASELINE.json configs: 1, 2 demuxlet; 3, 4 freemuxlet")
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the config's cells (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fmx-leg", action="store_true", help="default run: skip the secondary freemuxlet EM leg")
-    ap.add_argument("--fmx-leg-steps", type=int, default=20, help="EM iterations of the secondary leg (configs[3]: 20)")
-    ap.add_argument("--fmx-leg-timeout", type=float, default=420.0)
+    ap.add_argument("--no-legs", "--no-fmx-leg", dest="no_legs", action="store_true",
+                    help="default run: only the headline (configs[1]), none of the secondary legs")
+    ap.add_argument("--legs", default="3,2,4", help="default run: secondary legs (BASELINE.json config indices), in order")
+    ap.add_argument("--fmx-leg-steps", type=int, default=20, help="EM iterations of the configs[3] leg")
+    ap.add_argument("--leg-timeout", "--fmx-leg-timeout", dest="leg_timeout", type=float, default=300.0,
+                    help="watchdog per secondary leg, seconds")
+    ap.add_argument("--synth", default="auto", choices=("auto", "numpy", "device"),
+                    help="input generator: numpy (seeded, the tests' generator), device (torch on the GPU), "
+                         "auto = device beyond 2e7 entries")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests)")
     ap.add_argument("--force-dist", action="store_true",
                     help="freemuxlet: run the N-rank code path (slabs, collectives, stream ordering) even with one rank")
@@ -535,13 +641,18 @@ def main():
     if args.warmup is None:
         args.warmup = {1: 200, 2: 1, 3: 2, 4: 1}[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     ctx = Ctx(args)
     if args.config in (1, 2):
         out = demux_leg(args, ctx, args.config)
-        if args.config == 1 and not args.no_fmx_leg and args.scale == 1.0:
-            leg = guarded_fmx_leg(args, ctx, out)
-            if ctx.rank == 0:
-                out["freemuxlet_em"] = leg
+        if args.config == 1 and not args.no_legs and args.scale == 1.0:
+            for cfg in [int(x) for x in args.legs.split(",") if x.strip()]:
+                if cfg not in LEGS:
+                    raise SystemExit("--legs: a comma-separated subset of 3,2,4")
+                leg = guarded_leg(args, ctx, out, cfg)
+                if ctx.rank == 0:
+                    out[LEGS[cfg][0]] = leg
     else:
         out = fmx_leg(args, ctx, args.config, args.steps, args.warmup)
     if ctx.dist_on:  # RCCL writes a version banner through C stdio: get it out of the way, the JSON line comes last

@@ -132,6 +132,8 @@ enum {
   MUXGL_T_FMX_MSTEP = 8,   /* ordered clamped merge (b5,b8) */
   MUXGL_T_FMXOLD_PAIR = 9, /* freemuxlet-old: pairwise droplet distance matrix (c1) */
   MUXGL_T_FMXOLD_VOTE = 10, /* freemuxlet-old: one voting pass (c1) */
+  MUXGL_T_FMX_ESTEP_SWEEP = 11, /* the pair-sweep kernel(s) alone, inside MUXGL_T_FMX_ESTEP (which also brackets the
+                                   relayout of the cluster posteriors and the reduction of the chunk partials) */
   MUXGL_T_COUNT = 16
 };
 

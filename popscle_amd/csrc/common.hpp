@@ -24,6 +24,13 @@ struct quad_entry {
   uint32_t r0;      // offset of read 0 in the reads array (used only beyond four reads)
 };
 
+// Record of a linear entry (at most one usable read) of the quad kernel's sweep: its marker and the read byte that
+// counts.  code 0xFF (MUXGL_READ_OTHER never counts) = no usable read, or a marker without genotypes.
+struct quad_lrec {
+  int32_t snp;
+  uint32_t code;
+};
+
 // one work unit of the row kernels (demux_row.hip, fmx_kernels.hip): <= 128 consecutive entries of one cell
 struct row_chunk {
   int64_t e0;
@@ -41,6 +48,7 @@ struct muxgl_row_state {
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
   quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
   int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_quad.hip, built on first use)
+  quad_lrec* d_qlrec = nullptr;              // ... and the linear ones as {snp, read byte} records (quad_lrec, demux_quad.hip)
   int32_t* d_quad_order = nullptr;      // ... and the launch order of the chunks (sorted by trip count within buckets)
   // freemuxlet quad E-step (fmx_quad.hip, built on first use after muxgl_fmx_prepare): per chunk, its linear entries
   // as {c0, c1, snp} records in front, then the SNP ids and six likelihoods of the others

@@ -29,6 +29,7 @@
 
 namespace {
 
+constexpr int QL_SLACK = 256;   // records the linear loop may read behind the last chunk's list
 constexpr int QN_ACC = 36;      // per lane: 4 singlets, 6 in-lane pairs, 16 pairs with the neighbour tile, 10 with the opposite
 constexpr int Q_SLOT_STRIDE = 38;  // doubles: 4 entries x 8 likelihoods + 4 singlet factors + 2 pad => the 16 slots of a
                                    // wave hit distinct banks (76 dwords apart)
@@ -58,11 +59,17 @@ __global__ void quad_tmap_kernel(int32_t* tmap /*[2][4]*/) {
   }
 }
 
+// The likelihoods of a linear entry depend on ONE read byte (quad_lrec::code, common.hpp; 256 values: a table in LDS),
+// so the sweep needs neither the read array nor a per-entry phase 1 for such entries.
+
 // A chunk's entry records with its linear entries (at most one usable read, plan_kernels.hip: lin_kernel) first, both
-// kinds in entry order, and the number of linear ones.  One thread per chunk (<= 128 records), once per pileup.
+// kinds in entry order, and the number of linear ones; the linear ones also as quad_lrec.  One thread per chunk
+// (<= 128 records), once per pileup and GP tensor (has_gp enters the codes).
 __global__ void __launch_bounds__(64)
     quad_partition_kernel(int n_chunks, const row_chunk* __restrict__ chunks, const quad_entry* __restrict__ qent,
-                          const uint32_t* __restrict__ lin, quad_entry* __restrict__ out, int32_t* __restrict__ nlin) {
+                          const uint32_t* __restrict__ lin, const uint8_t* __restrict__ reads,
+                          const double* __restrict__ gp0s, quad_entry* __restrict__ out, quad_lrec* __restrict__ lrec,
+                          int32_t* __restrict__ nlin) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_chunks) return;
   const int64_t e0 = chunks[q].e0;
@@ -70,7 +77,17 @@ __global__ void __launch_bounds__(64)
   int w = 0;
   for (int i = 0; i < len; ++i) {
     const int64_t e = e0 + i;
-    if ((lin[e >> 5] >> (e & 31)) & 1u) out[e0 + w++] = qent[e];
+    if ((lin[e >> 5] >> (e & 31)) & 1u) {
+      const quad_entry p = qent[e];
+      uint32_t code = MUXGL_READ_OTHER;
+      for (uint32_t k = 0; k < p.nreads; ++k) {  // the usable read (:664)
+        const uint32_t bb = k < 4 ? (p.first4 >> (8 * k)) & 0xffu : (uint32_t)reads[(int64_t)p.r0 + k];
+        if (bb != MUXGL_READ_OTHER) code = bb;
+      }
+      if (gp0s[p.snp] < 0.0) code = MUXGL_READ_OTHER;  // no genotypes: the entry is skipped (:733)
+      lrec[e0 + w] = quad_lrec{p.snp, code};
+      out[e0 + w++] = p;
+    }
   }
   nlin[q] = w;
   for (int i = 0; i < len; ++i) {
@@ -120,20 +137,42 @@ __host__ __device__ constexpr int q_acc_t2(int c, int d) {  // c <= d
 // entries' phase 1 done once per pileup instead of per launch changed nothing again.
 __global__ void __launch_bounds__(64, 2)
     demux_quad_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
+                       const quad_lrec* __restrict__ qlrec,
                        const int32_t* __restrict__ chunk_nlin, const int32_t* __restrict__ order,
                        const uint8_t* __restrict__ reads,
                        const double* __restrict__ gpq, const double* __restrict__ gmq,
                        const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
                        double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
+  __shared__ __align__(16) double ablut[256 * 2];
   __shared__ __align__(16) double pgs[16 * Q_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
-  __shared__ int32_t exs[QN_ACC][64];
+  // exponents of the accumulators since the start of the chunk: a factor is >= 1e-10 / (1 + 1e-10) > 2^-34, a chunk
+  // has at most MUXGL_QUAD_CH of them
+  __shared__ int16_t exs[QN_ACC][64];
+  static_assert(MUXGL_QUAD_CH * 36 < 32000, "accumulator exponents are kept as int16");
 
   const int lane = threadIdx.x;
   const int r = (lane >> 2) & 3;                       // tile: samples 4r..4r+3
   const int slot = ((lane >> 4) << 2) | (lane & 3);    // 16 entry streams per wave
   for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
+  // (A, B) of a linear entry by the read byte that counts (quad_lrec::code): the one factor pR + (pA - pR) p of
+  // :673,685 through the tail (q / q_max + 1e-10) / (1 + 1e-10) of :703-725; q0[l] = A + 2B l, q1[l+m] = A + B (l+m)
+  for (int i = lane; i < 256; i += 64) {
+    const uint32_t bq = (uint32_t)i & 0x7f;
+    const bool ref = (i >> 7) == 0;
+    const double e3 = lut_g[256 + bq], mt = lut_g[128 + bq];
+    const double pR = ref ? mt : e3, pA = ref ? e3 : mt;  // :666-667
+    const double mx = fmax(pR, pA);
+    double x = __builtin_amdgcn_rcp(mx);
+    x = fma(x, fma(-mx, x, 1.0), x);
+    x = fma(x, fma(-mx, x, 1.0), x);
+    const double cc = 1.0 / (1.0 + 1e-10);
+    const double sc = cc * x, tt = 1e-10 * cc;
+    const bool none = i == MUXGL_READ_OTHER;  // no usable read / no genotypes: factors of exactly 1
+    ablut[2 * i] = none ? 1.0 : fma(pR, sc, tt);
+    ablut[2 * i + 1] = none ? 0.0 : (pA - pR) * (0.25 * sc);
+  }
 #pragma unroll
   for (int a = 0; a < QN_ACC; ++a) exs[a][lane] = 0;
 
@@ -149,7 +188,7 @@ __global__ void __launch_bounds__(64, 2)
   // first, by a loop of their own (below), the others by the nine-term loop.  Trip counts of the wave = the longest
   // run of either kind among its 16 chunks.
   const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
-  const int nbL = (wave_max_i32(nl) + 3) >> 2;
+  const int nLmax = wave_max_i32(nl);
   const int nb = (wave_max_i32(len - nl) + 3) >> 2;
 
   double acc[QN_ACC];
@@ -374,7 +413,7 @@ __global__ void __launch_bounds__(64, 2)
     for (int a = 0; a < QN_ACC; ++a) {
       int e;
       acc[a] = frexp(acc[a], &e);
-      exs[a][lane] += e;
+      exs[a][lane] = (int16_t)(exs[a][lane] + e);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) prodacc_renorm(accW[c], exW[c]);
@@ -408,12 +447,17 @@ __global__ void __launch_bounds__(64, 2)
   // ---- the linear entries (at most one usable read).  The single factor pR + (pA - pR) p, p = l/2 (alpha 0) or
   //      (l+m)/4 (alpha 0.5), stays linear through the tail (:703-725): q0[l] = A + 2B l, q1[l+m] = A + B (l+m).  With the
   //      moments s = g0 + g1 + g2 and rho = (g1 + 2 g2) / s of a triple (gmq),
-  //          singlet  sum_l g_j[l] q0[l]            = s_j (A + 2B rho_j),
+  //          singlet  sum_l g_j[l] q0[l] * s_0      = s_j s_0 (A + 2B rho_j)          (s_0: sample 0's sum, :806),
   //          pair     sum_lm g_j[l] g_k[m] q1[l+m]  = s_j s_k (A + B rho_j + B rho_k):
   //      the sums s go into products of their own (accW, folded into the accumulators at the end) and a hypothesis costs
   //      an FMA and the product update instead of a three-term dot product and the update; a row is 8 doubles instead
   //      of 12, and one double per sample rotates instead of three.
-  if (nbL > 0) {
+  //      There is no phase 1 here: (A, B) depend on one read byte, so the four lanes of a slot read the entry's 8-byte
+  //      record {snp, code} themselves and look (A, B) up in LDS.  A pipeline over rings of three register sets
+  //      (unrolled three times, so that ring positions are names): record three entries ahead, row two ahead, (A, B)
+  //      one ahead; loads are unconditional and a slot behind the end of its list sweeps neutral entries (code 0xFF,
+  //      the dummy row: every factor exactly 1).
+  if (nLmax > 0) {
     struct rowl_t {
       double m[4][2];
     };
@@ -426,66 +470,20 @@ __global__ void __launch_bounds__(64, 2)
         R.m[c][1] = v.y;
       }
     };
-    const int lastL = nl > 0 ? nl - 1 : 0;
-    auto fetchL = [&](int b) {
-      const int idx = b * 4 + r;
-      return qent[e0 + (idx < lastL ? idx : lastL)];
+    const int2* lr = reinterpret_cast<const int2*>(qlrec + e0);
+    auto settle = [&](int2& rc, int i) {  // a record behind the end of the slot's list: neutral
+      const bool in = i < nl;
+      rc.x = in ? rc.x : S_dummy;
+      rc.y = in ? rc.y : (int)MUXGL_READ_OTHER;
     };
-    quad_entry pa = fetchL(0), pb = fetchL(1);
-    double hsc = gp0s[pa.snp];
-    auto phase1L = [&](int b) {
-      const bool in = b * 4 + r < nl;
-      const int32_t sidx = (in && hsc >= 0.0) ? pa.snp : -1;  // no genotypes: the entry is skipped (:733)
-      const double hs_out = (sidx >= 0) ? hsc : 1.0;
-      const uint32_t nr = (sidx >= 0) ? pa.nreads : 0u;
-      const uint32_t first4 = pa.first4;
-      const int64_t r0 = pa.r0;
-      pa = pb;
-      pb = fetchL(b + 2);
-      hsc = gp0s[pa.snp];
-      double pR = 1.0, pA = 1.0;  // the one usable read (none: a factor of exactly 1)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t bb = (first4 >> (8 * k)) & 0xffu;
-        const uint32_t bq = bb & 0x7f;
-        const double e3 = lut[256 + bq], mt = lut[128 + bq];
-        const bool use = (uint32_t)k < nr && bb != MUXGL_READ_OTHER;
-        const bool ref = (bb >> 7) == 0;
-        pR = use ? (ref ? mt : e3) : pR;  // :666-667
-        pA = use ? (ref ? e3 : mt) : pA;
-      }
-      if (nr > 4) {  // (rare: an entry of many reads of which at most one counts)
-        for (int64_t rr = r0 + 4; rr < r0 + (int64_t)nr; ++rr) {
-          const uint32_t bb = (uint32_t)reads[rr];
-          if (bb == MUXGL_READ_OTHER) continue;  // :664
-          const uint32_t al = bb >> 7, bq = bb & 0x7f;
-          const double e3 = lut[256 + bq], mt = lut[128 + bq];
-          pR = (al == 0) ? mt : e3;
-          pA = (al == 0) ? e3 : mt;
-        }
-      }
-      const double mx = fmax(pR, pA);
-      double x = __builtin_amdgcn_rcp(mx);
-      x = fma(x, fma(-mx, x, 1.0), x);
-      x = fma(x, fma(-mx, x, 1.0), x);
-      const double cc = 1.0 / (1.0 + 1e-10);
-      const double sc = (sidx >= 0) ? cc * x : 1.0, tt = (sidx >= 0) ? 1e-10 * cc : 0.0;
-      double* dst = pgs + slot * Q_SLOT_STRIDE + r * 8;
-      dst[0] = fma(pR, sc, tt);             // A
-      dst[1] = (pA - pR) * (0.25 * sc);     // B
-      pgs[slot * Q_SLOT_STRIDE + 32 + r] = hs_out;
-      snps[slot * 4 + r] = (sidx >= 0) ? sidx : S_dummy;
-      snps_nx[slot * 4 + r] = ((b + 1) * 4 + r < nl) ? pa.snp : S_dummy;  // next batch; no-genotype rows are (1, 0)
-    };
-    auto sweepL = [&](const rowl_t& R, int i) {
-      const double* qq = pgs + slot * Q_SLOT_STRIDE + i * 8;
-      const double A = qq[0], B = qq[1], B2 = B + B;
-      const double hs = pgs[slot * Q_SLOT_STRIDE + 32 + i];
+    auto ab_of = [&](const int2& rc) { return *reinterpret_cast<const double2*>(ablut + 2 * rc.y); };
+    auto sweepL = [&](const rowl_t& R, const double2& ab) {
+      const double A = ab.x, B = ab.y, B2 = B + B;
       double X[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         accW[c] *= R.m[c][0];
-        acc[q_acc_single(c)] *= fma(B2, R.m[c][1], A) * hs;  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+        acc[q_acc_single(c)] *= fma(B2, R.m[c][1], A);  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
         X[c] = fma(B, R.m[c][1], A);
       }
 #pragma unroll
@@ -511,44 +509,37 @@ __global__ void __launch_bounds__(64, 2)
           for (int d = c; d < 4; ++d) acc[q_acc_t2(c, d)] *= fma(B, Q[d], X[c]);
       }
     };
-    // the same rotation of three row sets as below
-    auto batchL = [&](int b, rowl_t& X, rowl_t& Y, rowl_t& Z) {
-      phase1L(b);
-      __syncthreads();
-      load_rowl(Z, snps[slot * 4 + 2]);
+    // entry i: its row in Rc and (A, B) in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
+    auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const double2& abc, double2& abn, int2& rc0, const int2& rc1,
+                    int2& rc2) {
+      rc0 = lr[i + 3];
+      settle(rc2, i + 2);
+      load_rowl(Rnn, rc2.x);
+      abn = ab_of(rc1);
       asm volatile("" ::: "memory");
-      sweepL(X, 0);
+      sweepL(Rc, abc);
       pin();
-      load_rowl(X, snps[slot * 4 + 3]);
-      asm volatile("" ::: "memory");
-      sweepL(Y, 1);
-      pin();
-      load_rowl(Y, snps_nx[slot * 4 + 0]);
-      asm volatile("" ::: "memory");
-      sweepL(Z, 2);
-      pin();
-      load_rowl(Z, snps_nx[slot * 4 + 1]);
-      asm volatile("" ::: "memory");
-      sweepL(X, 3);
-      pin();
-      if ((b & 3) == 3) renorm();
-      __syncthreads();
     };
     rowl_t L0, L1, L2;
-    snps_nx[slot * 4 + r] = (r < nl) ? pa.snp : S_dummy;
-    __syncthreads();
-    load_rowl(L0, snps_nx[slot * 4 + 0]);
-    load_rowl(L1, snps_nx[slot * 4 + 1]);
-    __syncthreads();
-    for (int b = 0; b < nbL; b += 3) {
-      batchL(b, L0, L1, L2);
-      if (b + 1 >= nbL) break;
-      batchL(b + 1, L1, L2, L0);
-      if (b + 2 >= nbL) break;
-      batchL(b + 2, L2, L0, L1);
+    double2 ab0, ab1, ab2;
+    int2 ra = lr[0], rb = lr[1], rc = lr[2];
+    settle(ra, 0);
+    settle(rb, 1);
+    load_rowl(L0, ra.x);
+    load_rowl(L1, rb.x);
+    __syncthreads();  // ablut is complete
+    ab0 = ab_of(ra);
+    int since = 0;
+    for (int i = 0; i < nLmax; i += 3) {  // (up to two neutral entries behind the longest list of the wave)
+      step(i, L0, L2, ab0, ab1, ra, rb, rc);
+      step(i + 1, L1, L0, ab1, ab2, rb, rc, ra);
+      step(i + 2, L2, L1, ab2, ab0, rc, ra, rb);
+      if (++since == 5) {  // 15 entries per slot since the last renormalisation
+        since = 0;
+        renorm();
+      }
     }
     renorm();
-    __syncthreads();
   }
 
   row_t R0, R1, R2;
@@ -570,7 +561,7 @@ __global__ void __launch_bounds__(64, 2)
   int32_t exa[QN_ACC];
 #pragma unroll
   for (int a = 0; a < QN_ACC; ++a) exa[a] = 0;
-  if (nbL > 0) {
+  if (nLmax > 0) {
     double Wn[4], Wo[4];
     int32_t en[4], eo[4];
 #pragma unroll
@@ -581,10 +572,13 @@ __global__ void __launch_bounds__(64, 2)
       en[c] = __builtin_amdgcn_mov_dpp(exW[c], 0x124, 0xF, 0xF, false);
       eo[c] = __builtin_amdgcn_mov_dpp(exW[c], 0x128, 0xF, 0xF, false);
     }
+    // singlets: the lane's own sum and sample 0's (tile 0, c = 0 of the same slot), which every singlet carries (:806)
+    const double W0 = __shfl(accW[0], lane & ~12, 64);
+    const int32_t e0w = __shfl(exW[0], lane & ~12, 64);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      acc[q_acc_single(c)] *= accW[c];
-      exa[q_acc_single(c)] = exW[c];
+      acc[q_acc_single(c)] *= accW[c] * W0;
+      exa[q_acc_single(c)] = exW[c] + e0w;
     }
 #pragma unroll
     for (int c1 = 0; c1 < 4; ++c1)
@@ -614,7 +608,7 @@ __global__ void __launch_bounds__(64, 2)
       int e;
       acc[a] = frexp(acc[a], &e);
       part_m[((size_t)q * QN_ACC + a) * 4 + r] = acc[a];
-      part_e[((size_t)q * QN_ACC + a) * 4 + r] = exs[a][lane] + e + exa[a];
+      part_e[((size_t)q * QN_ACC + a) * 4 + r] = (int32_t)exs[a][lane] + e + exa[a];
     }
   }
 }
@@ -821,10 +815,15 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     st->part_e_cap = need;
   }
   const bool use_lin = h->d_lin && h->d_gmq && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
-  if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup: every chunk's linear entries first
-    if (dev_alloc(h, &st->d_qent_lin, (size_t)h->nnz) || dev_alloc(h, &st->d_chunk_nlin, (size_t)st->n_chunks)) return 1;
+  if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup and GP tensor: every chunk's linear entries first
+    // (the sweep reads up to QL_SLACK records behind a chunk's list, unconditionally: slack behind the array)
+    if (dev_alloc(h, &st->d_qent_lin, (size_t)h->nnz) || dev_alloc(h, &st->d_chunk_nlin, (size_t)st->n_chunks) ||
+        dev_alloc(h, &st->d_qlrec, (size_t)h->nnz + QL_SLACK))
+      return 1;
+    HIPCHK(h, hipMemsetAsync(st->d_qlrec, 0xFF, sizeof(quad_lrec) * ((size_t)h->nnz + QL_SLACK), h->stream));
     hipLaunchKernelGGL(quad_partition_kernel, dim3((unsigned)((st->n_chunks + 63) / 64)), dim3(64), 0, h->stream,
-                       (int)st->n_chunks, st->d_chunks, h->d_qent, h->d_lin, st->d_qent_lin, st->d_chunk_nlin);
+                       (int)st->n_chunks, st->d_chunks, h->d_qent, h->d_lin, h->d_reads, h->d_gp0s, st->d_qent_lin,
+                       st->d_qlrec, st->d_chunk_nlin);
     HIPCHK(h, hipGetLastError());
     if (quad_launch_order(h, st->d_chunks, st->d_chunk_nlin, st->n_chunks, &st->d_quad_order)) return 1;
   }
@@ -832,7 +831,8 @@ int demux_quad_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL(demux_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       use_lin ? st->d_qent_lin : h->d_qent, use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
+                       use_lin ? st->d_qent_lin : h->d_qent, st->d_qlrec,
+                       use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
                        use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
                        h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());

@@ -449,11 +449,13 @@ int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int6
     hipLaunchKernelGGL(fmx_ceq_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, h->S, h->K, h->d_cgp, h->d_ceq);
   }
   const unsigned blocks = (unsigned)((((st->n_chunks + 15) / 16) + 7) / 8 * 8);
+  tic(h, MUXGL_T_FMX_ESTEP_SWEEP);
   if (blocks)
     hipLaunchKernelGGL(fmx_estep_quad_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
                        use_lin ? st->d_fq_gsnp : h->d_entry_snp, use_lin ? st->d_fq_gl6 : h->d_egls6,
                        use_lin ? st->d_fq_lrec : (const fmx_lrec*)nullptr, use_lin ? st->d_fq_nlin : (const int32_t*)nullptr,
                        use_lin ? st->d_fq_order : (const int32_t*)nullptr, h->d_cgpq, h->d_ceq, (int32_t)h->S, st->d_part, st->d_part_e);
+  toc(h, MUXGL_T_FMX_ESTEP_SWEEP);
   if (nc > 0)
     hipLaunchKernelGGL(fmx_quad_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->K, c0, h->d_fll);

@@ -575,6 +575,7 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
     }
     if (n) hipLaunchKernelGGL(fw_ce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, h->d_cgp, h->d_cE);
   }
+  tic(h, MUXGL_T_FMX_ESTEP_SWEEP);
   if (h->K <= 32)
     hipLaunchKernelGGL(fmx_estep_wave32_kernel, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
                        c0 + nc, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, h->d_fll);
@@ -588,6 +589,7 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
       hipLaunchKernelGGL((fmx_estep_wave_kernel<true, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, Y));
 #undef FW_ARGS
   }
+  toc(h, MUXGL_T_FMX_ESTEP_SWEEP);
   if (n_cuts)
     hipLaunchKernelGGL(fmx_wave_combine_kernel, dim3((unsigned)n_cuts), dim3(256), 0, h->stream, cuts, c0, c0 + nc,
                        h->K * (h->K + 1) / 2, h->d_fll);

@@ -308,6 +308,12 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   dev_free(&h->d_gpq);
   dev_free(&h->d_gp0s);
   dev_free(&h->d_gmq);
+  if (h->qrow) {  // the quad kernel's partitioned records carry has_gp (quad_lrec::code): rebuilt on the next run
+    dev_free(&h->qrow->d_qent_lin);
+    dev_free(&h->qrow->d_chunk_nlin);
+    dev_free(&h->qrow->d_qlrec);
+    dev_free(&h->qrow->d_quad_order);
+  }
   if (V <= 16 && h->S > 0) {
     // Layout for the quad kernel (demux_quad.hip): lane r of a quad owns samples 4r..4r+3 = 12 doubles d = 3c+l, read as
     // six 16-byte pieces; piece t of the four lanes is stored contiguously ([S][6][4][2]) so that one load instruction

@@ -32,6 +32,7 @@ MAX_DEVICES = 16
 XCHG_PAD = 64
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
 T_FMXOLD_PAIR, T_FMXOLD_VOTE = 9, 10
+T_FMX_ESTEP_SWEEP = 11
 T_COUNT = 16
 BUF_CGP, BUF_CLUST, BUF_CELLS, BUF_STAT = 0, 1, 2, 3
 

@@ -8,7 +8,9 @@ is Bernoulli(g/2) of the source sample's genotype with 1 % flips and 0.5 % "othe
 load_from_plp builds from hard GT calls: one-hot (through float) then (1-err)*gp + err*avgGP with err = 0.1
 (sc_drop_seq.cpp:287-315).
 
-Everything is numpy and seeded; the same call yields the same bytes on every machine.
+Everything is numpy and seeded; the same call yields the same bytes on every machine.  make_pileup_device() is the
+same generator family written in torch for a GPU (bench.py's large configs: 10^8 entries take minutes in numpy and a
+second on the device); it is seeded too, but its bytes are torch's, not numpy's.
 """
 from __future__ import annotations
 
@@ -154,3 +156,142 @@ def make_config(index: int, scale: float = 1.0, **kw) -> Pileup:
     cfg = CONFIGS[index]
     C = max(1, int(round(cfg["C"] * scale)))
     return make_pileup(C, cfg["S"], cfg["V"], seed=BASE_SEED + index, **kw)
+
+
+# ---- the same generator family on a GPU (torch): bench inputs of the large configs --------------------------------
+class DevicePileup:
+    """A synthetic packed pileup held as torch tensors on a device (same fields as Pileup).  host() copies it to numpy;
+    take_cells / take_snps cut a rank's row / column slab on the device, so a rank of a sharded run moves only its
+    2/N of the job to the host (shard.take_cells / shard.take_snps are the numpy counterparts)."""
+
+    def __init__(self, C, S, cell_ptr, entry_snp, entry_rptr, reads, af, gp, has_gp, truth):
+        self.C, self.S = int(C), int(S)
+        self.cell_ptr, self.entry_snp, self.entry_rptr, self.reads = cell_ptr, entry_snp, entry_rptr, reads
+        self.af, self.gp, self.has_gp, self.truth = af, gp, has_gp, truth
+
+    @property
+    def nnz(self):
+        return int(self.entry_snp.numel())
+
+    @property
+    def R(self):
+        return int(self.reads.numel())
+
+    @staticmethod
+    def _np(t):
+        return None if t is None else t.cpu().numpy()
+
+    def host(self) -> Pileup:
+        n = self._np
+        return Pileup(self.C, self.S, n(self.cell_ptr), n(self.entry_snp), n(self.entry_rptr), n(self.reads), n(self.af),
+                      n(self.gp), n(self.has_gp), {k: n(v) for k, v in self.truth.items()})
+
+    def _cut(self, keep_entries, cell_counts):
+        """(cell_ptr, entry_snp, entry_rptr, reads) of the entries picked by the boolean mask, as numpy"""
+        import torch
+
+        eidx = torch.nonzero(keep_entries, as_tuple=False).flatten()
+        cell_ptr = torch.zeros(cell_counts.numel() + 1, dtype=torch.int64, device=eidx.device)
+        torch.cumsum(cell_counts, 0, out=cell_ptr[1:])
+        r0 = self.entry_rptr[eidx]
+        rl = self.entry_rptr[eidx + 1] - r0
+        entry_rptr = torch.zeros(eidx.numel() + 1, dtype=torch.int64, device=eidx.device)
+        torch.cumsum(rl, 0, out=entry_rptr[1:])
+        ridx = torch.repeat_interleave(r0 - entry_rptr[:-1], rl) + torch.arange(int(entry_rptr[-1]), device=eidx.device)
+        n = self._np
+        return n(cell_ptr), n(self.entry_snp[eidx]), n(entry_rptr), n(self.reads[ridx])
+
+    def take_cells(self, c0, c1) -> Pileup:
+        """row slab: cells [c0, c1) with every SNP, cells renumbered from 0"""
+        import torch
+
+        e0, e1 = int(self.cell_ptr[c0]), int(self.cell_ptr[c1])
+        keep = torch.zeros(self.nnz, dtype=torch.bool, device=self.entry_snp.device)
+        keep[e0:e1] = True
+        cp, es, er, rd = self._cut(keep, self.cell_ptr[c0 + 1:c1 + 1] - self.cell_ptr[c0:c1])
+        return Pileup(c1 - c0, self.S, cp, es, er, rd, self._np(self.af), self._np(self.gp), self._np(self.has_gp), {})
+
+    def take_snps(self, s0, s1):
+        """column slab: every cell, the entries with s0 <= SNP < s1 (arguments of muxgl_fmx_set_column_slab)"""
+        import torch
+
+        keep = (self.entry_snp >= s0) & (self.entry_snp < s1)
+        csum = torch.zeros(self.nnz + 1, dtype=torch.int64, device=keep.device)
+        torch.cumsum(keep, 0, out=csum[1:])
+        counts = csum[self.cell_ptr[1:]] - csum[self.cell_ptr[:-1]]
+        return self._cut(keep, counts)
+
+
+def make_pileup_device(C: int, S: int, V: int, seed: int = BASE_SEED, device="cuda", mean_entries: float = 800.0,
+                       sigma: float = 0.6, min_entries: int = 50, max_entries: int = 8000, reads_lambda: float = 0.3,
+                       doublet_frac: float = 0.10, flip: float = 0.01, other: float = 0.005, min_bq: int = 13,
+                       max_bq: int = 40, cap_bq: int = 20, geno_err: float = 0.1, with_gp: bool = True,
+                       donor_seed: int | None = None) -> DevicePileup:
+    """make_pileup() on a torch device: same distributions and the same GP rule, torch's random streams."""
+    import torch
+
+    dev = torch.device(device)
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(int(seed if donor_seed is None else donor_seed))
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) * 7919 + 1)
+    f64, i64 = torch.float64, torch.int64
+
+    af = torch.rand(S, generator=gd, device=dev, dtype=f64) * 0.9 + 0.05
+    G = ((torch.rand(S, V, generator=gd, device=dev, dtype=f64) < af[:, None]).to(torch.int8)
+         + (torch.rand(S, V, generator=gd, device=dev, dtype=f64) < af[:, None]).to(torch.int8))  # Binomial(2, af)
+
+    max_entries = min(max_entries, S)
+    min_entries = min(min_entries, max_entries)
+    L = torch.exp(torch.randn(C, generator=g, device=dev, dtype=f64) * sigma + float(np.log(mean_entries)))
+    L = torch.clamp(torch.round(L), min_entries, max_entries).to(i64)
+    cell_of = torch.repeat_interleave(torch.arange(C, device=dev, dtype=i64), L)
+    key = cell_of * S + torch.randint(0, S, (cell_of.numel(),), generator=g, device=dev, dtype=i64)
+    del cell_of
+    key = torch.unique(key)  # sorted by (cell, snp); duplicates within a cell dropped
+    cell_of = torch.div(key, S, rounding_mode="floor")
+    entry_snp = (key - cell_of * S).to(torch.int32)
+    del key
+    cell_ptr = torch.zeros(C + 1, dtype=i64, device=dev)
+    torch.cumsum(torch.bincount(cell_of, minlength=C), 0, out=cell_ptr[1:])
+    nnz = entry_snp.numel()
+
+    nreads = 1 + torch.poisson(torch.full((nnz,), reads_lambda, device=dev, dtype=torch.float32), generator=g).to(i64)
+    entry_rptr = torch.zeros(nnz + 1, dtype=i64, device=dev)
+    torch.cumsum(nreads, 0, out=entry_rptr[1:])
+    R = int(entry_rptr[-1])
+    read_entry = torch.repeat_interleave(torch.arange(nnz, device=dev, dtype=i64), nreads)
+    del nreads
+    read_cell = cell_of[read_entry]
+    read_snp = entry_snp[read_entry].to(i64)
+    del read_entry, cell_of
+
+    is_dbl = torch.rand(C, generator=g, device=dev) < doublet_frac
+    s1 = torch.randint(0, V, (C,), generator=g, device=dev, dtype=i64)
+    s2 = (s1 + 1 + torch.randint(0, max(V - 1, 1), (C,), generator=g, device=dev, dtype=i64)) % V if V > 1 else s1.clone()
+    pick2 = is_dbl[read_cell] & (torch.rand(R, generator=g, device=dev) < 0.5)
+    src = torch.where(pick2, s2[read_cell], s1[read_cell])
+    del pick2, read_cell
+    gg = G.flatten()[read_snp * V + src].to(torch.float32)
+    del read_snp, src
+    allele = (torch.rand(R, generator=g, device=dev) < gg * 0.5).to(torch.uint8)
+    del gg
+    allele ^= (torch.rand(R, generator=g, device=dev) < flip).to(torch.uint8)
+    bq = torch.clamp(torch.randint(min_bq, max_bq + 1, (R,), generator=g, device=dev, dtype=torch.int32), max=cap_bq).to(torch.uint8)
+    reads = (allele << 7) | bq
+    del allele, bq
+    reads[torch.rand(R, generator=g, device=dev) < other] = READ_OTHER
+
+    gp = has_gp = None
+    if with_gp:  # gt_to_gp(): one-hot through float, avgGP accumulated over the samples in order, (1-err) gp + err avg
+        gp = torch.zeros(S, V, 3, dtype=f64, device=dev)
+        gp.scatter_(2, G.to(i64)[:, :, None], 1.0)
+        avg = torch.full((S, 3), 1e-10, dtype=f64, device=dev)
+        for v in range(V):
+            avg += gp[:, v, :]
+        avg /= (avg[:, 0] + avg[:, 1] + avg[:, 2])[:, None]
+        if geno_err > 0:
+            gp = (1 - geno_err) * gp + geno_err * avg[:, None, :]
+        has_gp = torch.ones(S, dtype=torch.uint8, device=dev)
+    truth = {"is_doublet": is_dbl, "s1": s1.to(torch.int32), "s2": s2.to(torch.int32)}
+    return DevicePileup(C, S, cell_ptr, entry_snp, entry_rptr, reads, af, gp, has_gp, truth)

@@ -59,6 +59,27 @@ def test_single_gpu_line():
     assert abs(fx["value"] - 50000 * 136 / (fx["ms_per_step"] * 1e-3)) / fx["value"] < 1e-9
     assert fx["kernel_ms_rank0_last_iteration"]["estep"] > 0 and fx["roofline"]["kernel"] == "fmx_estep_quad_kernel"
     assert fx["roofline"]["frac"] is not None and 0 < fx["roofline"]["frac"] <= 1.0
+    # the roofline prices the sweep kernel alone, inside the E-step bracket
+    km = fx["kernel_ms_rank0_last_iteration"]
+    assert 0 < km["estep_sweep"] <= km["estep"] and abs(fx["roofline"]["kernel_ms"] - km["estep_sweep"]) < 1e-6
+    assert fx["cpu_baseline"]["kind"] == "port" and fx["cpu_baseline"]["cores"] == 1 and fx["cpu_baseline"]["value"] > 0
+    assert d["ramp"]["untimed_passes"] > 0
+    # the north_star shapes, in the same line: configs[2] (demuxlet 100 k x 64 x 200 k, six alphas) ...
+    d2 = d["demuxlet_config2"]
+    assert "error" not in d2, d2
+    assert d2["config"]["cells_per_gpu"] == 100000 and d2["config"]["samples"] == 64 and d2["config"]["snps"] == 200000
+    assert d2["config"]["alphas"] == [0.0, 0.1, 0.2, 0.3, 0.4, 0.5] and d2["steps"] == 3 and d2["scaling"] == "weak"
+    assert d2["config"]["entries_per_gpu"] > 90_000_000 and d2["roofline"]["kernel"] == "demux_wave_kernel"
+    assert abs(d2["value"] - 100000 * (64 + 64 * 63 * 5) / (d2["ms_per_step"] * 1e-3)) / d2["value"] < 1e-9
+    assert d2["ms_per_step"] < 60e3  # the north_star's "< 60 s" with room to spare
+    assert 0 < d2["roofline"]["frac"] <= 1.0 and d2["cpu_baseline"]["parity_max_abs_ll_diff"] < 1e-5
+    # ... and configs[4] (freemuxlet 500 k x 500 k, K = 64)
+    f4 = d["freemuxlet_config4"]
+    assert "error" not in f4, f4
+    assert f4["config"]["cells"] == 500000 and f4["config"]["snps"] == 500000 and f4["config"]["clusters"] == 64
+    assert f4["config"]["entries"] > 450_000_000 and f4["steps"] == 2 and f4["scaling"] == "strong"
+    assert f4["roofline"]["kernel"] == "fmx_estep_wave_kernel" and 0 < f4["roofline"]["frac"] <= 1.0
+    assert f4["cpu_baseline"]["value"] > 0
 
 
 def test_two_rank_launch_line():
@@ -68,10 +89,18 @@ def test_two_rank_launch_line():
     s.close()
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
              "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "30", "--warmup", "3",
-             "--ramp-seconds", "0.1", "--dist-backend", "gloo", "--single-device", "--fmx-leg-steps", "3"])
+             "--ramp-seconds", "0.1", "--dist-backend", "gloo", "--single-device", "--fmx-leg-steps", "3", "--legs", "3"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     fx = d["freemuxlet_em"]  # two ranks, slabs, one in-place all-gather per exchange (gloo staging on this box)
     assert "error" not in fx, fx
     assert fx["n_gpus"] == 2 and fx["steps"] == 3 and fx["scaling"] == "strong" and fx["config"]["backend"] == "gloo"
     # whole-job aggregate: both ranks' cells
     assert abs(d["value"] - 2 * 10000 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
+def test_plain_shell_gpus_n_launches_itself():
+    """`python bench.py --gpus 2` from a plain shell (the form the driver uses) starts its own two ranks"""
+    d = run([sys.executable, BENCH, "--gpus", "2", "--steps", "10", "--warmup", "2", "--ramp-seconds", "0.1",
+             "--dist-backend", "gloo", "--single-device", "--fmx-leg-steps", "2", "--legs", "3", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["freemuxlet_em"]["n_gpus"] == 2
+    assert "error" not in d["freemuxlet_em"], d["freemuxlet_em"]
