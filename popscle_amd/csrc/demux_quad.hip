@@ -29,6 +29,12 @@
 
 namespace {
 
+#ifndef QUAD_EXP
+#define QUAD_EXP 0  // timing experiments (tools/gpu_quadx.sh): 1 no nine-term loop, 2 no linear loop, 4 hot rows, 8 no renorm
+#endif
+#ifndef QL_TOUCH
+#define QL_TOUCH 0  // records ahead (0: off -- measured: one more load per entry costs 10 % of the sweep)
+#endif
 constexpr int QL_SLACK = 256;   // records the linear loop may read behind the last chunk's list
 constexpr int QN_ACC = 36;      // per lane: 4 singlets, 6 in-lane pairs, 16 pairs with the neighbour tile, 10 with the opposite
 constexpr int Q_SLOT_STRIDE = 38;  // doubles: 4 entries x 8 likelihoods + 4 singlet factors + 2 pad => the 16 slots of a
@@ -188,8 +194,8 @@ __global__ void __launch_bounds__(64, 2)
   // first, by a loop of their own (below), the others by the nine-term loop.  Trip counts of the wave = the longest
   // run of either kind among its 16 chunks.
   const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
-  const int nLmax = wave_max_i32(nl);
-  const int nb = (wave_max_i32(len - nl) + 3) >> 2;
+  const int nLmax = (QUAD_EXP & 2) ? 0 : wave_max_i32(nl);
+  const int nb = (QUAD_EXP & 1) ? 0 : (wave_max_i32(len - nl) + 3) >> 2;
 
   double acc[QN_ACC];
 #pragma unroll
@@ -462,6 +468,71 @@ __global__ void __launch_bounds__(64, 2)
       double m[4][2];
     };
     auto load_rowl = [&](rowl_t& R, int32_t sidx) {
+      if (QUAD_EXP & 4) sidx &= 255;
+      if (QUAD_EXP & 64) sidx &= 15;
+      if (QUAD_EXP & 128) sidx = 0;
+      if (QUAD_EXP & 256) {  // (experiment) half the row loads
+        const double2* pc = reinterpret_cast<const double2*>(gmq + (size_t)sidx * 32) + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const double2 v = pc[c * 4];
+          R.m[c][0] = R.m[c + 2][0] = v.x;
+          R.m[c][1] = R.m[c + 2][1] = v.y;
+        }
+        return;
+      }
+      if (QUAD_EXP & 4096) {  // (experiment) every 16-lane group reads one whole row (two full lines) per instruction
+        const int ln = lane & 15;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int sk = c == 0 ? __builtin_amdgcn_mov_dpp(sidx, 0x00, 0xF, 0xF, false)
+                       : c == 1 ? __builtin_amdgcn_mov_dpp(sidx, 0x55, 0xF, 0xF, false)
+                       : c == 2 ? __builtin_amdgcn_mov_dpp(sidx, 0xAA, 0xF, 0xF, false)
+                                : __builtin_amdgcn_mov_dpp(sidx, 0xFF, 0xF, 0xF, false);
+          const double2 v = (reinterpret_cast<const double2*>(gmq + (size_t)sk * 32))[ln];
+          R.m[c][0] = v.x;
+          R.m[c][1] = v.y;
+        }
+        return;
+      }
+      if (QUAD_EXP & 1024) {  // (experiment) the sixteen slots of an instruction spread over the four pieces of their rows
+        const double2* pc = reinterpret_cast<const double2*>(gmq + (size_t)sidx * 32) + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double2 v = pc[((c + slot) & 3) * 4];
+          R.m[c][0] = v.x;
+          R.m[c][1] = v.y;
+        }
+        return;
+      }
+      if (QUAD_EXP & 2048) {  // (experiment) same, over sixteen 16-byte pieces
+        const double2* pc = reinterpret_cast<const double2*>(gmq + (size_t)sidx * 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double2 v = pc[(c * 4 + r + slot) & 15];
+          R.m[c][0] = v.x;
+          R.m[c][1] = v.y;
+        }
+        return;
+      }
+      if (QUAD_EXP & 512) {  // (experiment) the lane's eight doubles as 64 contiguous bytes
+        const double2* pc = reinterpret_cast<const double2*>(gmq + (size_t)sidx * 32) + r * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double2 v = pc[c];
+          R.m[c][0] = v.x;
+          R.m[c][1] = v.y;
+        }
+        return;
+      }
+      if (QUAD_EXP & 32) {  // (experiment) no row loads at all
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          R.m[c][0] = 1.0;
+          R.m[c][1] = 1e-9 * (double)(sidx & 3);
+        }
+        return;
+      }
       const double2* pc = reinterpret_cast<const double2*>(gmq + (size_t)sidx * 32) + r;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -510,15 +581,21 @@ __global__ void __launch_bounds__(64, 2)
       }
     };
     // entry i: its row in Rc and (A, B) in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
+    // (tch: the line QL_TOUCH records ahead, requested so that its first touch -- an HBM miss, which a wave would meet
+    //  in one of its sixteen record streams at almost every entry -- has two sweeps to land: loads return in order)
     auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const double2& abc, double2& abn, int2& rc0, const int2& rc1,
-                    int2& rc2) {
+                    int2& rc2, int& tch) {
+      if (QL_TOUCH) {
+        asm volatile("" ::"v"(tch));
+        tch = lr[i + 3 + QL_TOUCH].x;
+      }
       rc0 = lr[i + 3];
       settle(rc2, i + 2);
       load_rowl(Rnn, rc2.x);
       abn = ab_of(rc1);
-      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
       sweepL(Rc, abc);
-      pin();
+      __builtin_amdgcn_sched_barrier(0);
     };
     rowl_t L0, L1, L2;
     double2 ab0, ab1, ab2;
@@ -529,17 +606,21 @@ __global__ void __launch_bounds__(64, 2)
     load_rowl(L1, rb.x);
     __syncthreads();  // ablut is complete
     ab0 = ab_of(ra);
-    int since = 0;
+    int since = 0, t0 = 0, t1 = 0, t2 = 0;
+    const long long tl0 = (QUAD_EXP & 16) ? clock64() : 0;
     for (int i = 0; i < nLmax; i += 3) {  // (up to two neutral entries behind the longest list of the wave)
-      step(i, L0, L2, ab0, ab1, ra, rb, rc);
-      step(i + 1, L1, L0, ab1, ab2, rb, rc, ra);
-      step(i + 2, L2, L1, ab2, ab0, rc, ra, rb);
-      if (++since == 5) {  // 15 entries per slot since the last renormalisation
+      step(i, L0, L2, ab0, ab1, ra, rb, rc, t0);
+      step(i + 1, L1, L0, ab1, ab2, rb, rc, ra, t1);
+      step(i + 2, L2, L1, ab2, ab0, rc, ra, rb, t2);
+      if (++since == 5 && !(QUAD_EXP & 8)) {  // 15 entries per slot since the last renormalisation
         since = 0;
         renorm();
       }
     }
     renorm();
+    if ((QUAD_EXP & 16) && (blockIdx.x % 331) == 0 && lane == 0)
+      printf("wave %d: linear loop %d entries, %lld cycles per entry, wall start %lld us\n", (int)blockIdx.x, nLmax,
+             (clock64() - tl0) / (nLmax > 0 ? nLmax : 1), wall_clock64() / 100);
   }
 
   row_t R0, R1, R2;

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmuxgl.so")
+LIB_PATH = os.environ.get("MUXGL_LIB") or os.path.join(HERE, "lib", "libmuxgl.so")  # (MUXGL_LIB: kernel experiments)
 
 MAX_ALPHA = 16
 READ_OTHER = 0xFF

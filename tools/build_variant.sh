@@ -1,0 +1,12 @@
+#!/bin/bash
+# builds popscle_amd/lib/var/libmuxgl_<tag>.so with one translation unit recompiled under extra flags (kernel timing
+# experiments; select with MUXGL_LIB=...):  bash tools/build_variant.sh <tag> <file.hip> "<flags>"
+set -e
+tag=$1; src=$2; flags=$3
+cd "$(dirname "$0")/../popscle_amd/csrc"
+mkdir -p ../lib/var
+base=$(basename $src .hip)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-function -I../../include $flags -c $src -o ../lib/var/${base}_$tag.o
+objs=$(ls ../lib/*.o | grep -v "/${base}.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/var/libmuxgl_$tag.so $objs ../lib/var/${base}_$tag.o
+echo built ../lib/var/libmuxgl_$tag.so
