@@ -96,7 +96,7 @@ def fmx_issued_flops_model(K):
 def demux_sweep_kernel(V, alphas):
     """the kernel libmuxgl dispatches for this shape (popscle_amd/csrc/demux_kernels.hip: demux_launch)"""
     if V <= 16 and tuple(alphas) == (0.0, 0.5):
-        return "demux_quad_kernel"
+        return "demux_oct_kernel"
     if V <= 16 and sum(1 for a in alphas[1:] if a != 0.5) <= 5 and sum(1 for a in alphas[1:] if a == 0.5) <= 1:
         return "demux_row_kernel"
     if V <= 24 and tuple(alphas) == (0.0, 0.5):

@@ -526,7 +526,7 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   int rc = -1;
   if (h->V <= 16) {
     if (demux_ensure_ll(h, p)) return 1;
-    rc = demux_quad_launch(h, p);               // the reference's default grid {0, 0.5}: quad kernel
+    rc = demux_oct_launch(h, p);               // the reference's default grid {0, 0.5}: quad kernel
     if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the quad path's finish kernel
     if (rc < 0) rc = demux_row_launch(h, p);    // other grids: row kernel
   }

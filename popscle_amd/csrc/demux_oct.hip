@@ -1,0 +1,818 @@
+// demux_oct.hip -- the demuxlet sweep for the reference's DEFAULT configuration: V <= 16 samples and the alpha grid
+// {0, 0.5} that cmdCramDemuxlet installs when no --alpha is given (cmd_cram_demuxlet.cpp:85-89).
+//
+// Reference being replaced: cmd_cram_demuxlet.cpp:655-747.  Same mathematics as demux_row.hip; what changes is the
+// tiling: EIGHT lanes per entry, lane p of an entry owns the two samples p and p + 8.
+//
+//   * Why eight.  Measured on MI355X (round 3, tools/gpu_quadx.sh): the four-lanes-per-entry tiling of rounds 1-2 (lane =
+//     4 samples, 36 accumulators, 250 VGPRs, two waves per SIMD) was bound by its row gathers, not by VALU issue -- its
+//     loop over the linear entries took 0.257 ms, 0.092 ms with the row loads removed, 0.241 ms with every row an L1
+//     hit, 0.123 ms with all sixteen slots of a wave reading the same row and 0.162 ms when every 16-lane group read
+//     whole rows: what a gather costs in the vector cache is the number of distinct 128-byte lines an instruction
+//     touches (64-byte pieces of sixteen different rows per instruction there), hits or misses alike.  With eight lanes
+//     per entry an instruction's eight lanes read 128 contiguous bytes -- one whole line per entry -- so a row of
+//     moments (256 B) costs two line accesses instead of four half lines and a row of triples (384 B) three instead of
+//     six; and a lane holds 18 accumulators instead of 36, which lets three to four waves share a SIMD instead of two.
+//   * Two entries share a 16-lane DPP row, interleaved (lane = 16 g + 2 p + h: entry h of row g, position p), so that
+//     row_ror:2t rotates the eight positions of both entries by t.  Rotations t = 1, 2, 3 bring the partner's two
+//     samples: four pairs each; t = 4 faces lane p with lane p + 4: of their four pairs each lane takes (a, b'),
+//     and both take (a, a') and (b, b') (published once): 1 + 12 + 3 pairs + 2 singlets = 18 accumulators.
+//   * the grid {0, 0.5} has structure the general code cannot assume: for alpha = 0 the mixing proportion is
+//     p = l/2, independent of m (3 distinct likelihoods per entry instead of 9), and for alpha = 0.5 it is
+//     p = (l+m)/4 (5 distinct instead of 9).  Phase 1 therefore carries 8 products per read instead of 18, and the
+//     singlet slot factorises into (sum_l g_j[l] q0[l]) * (g_0[0]+g_0[1]+g_0[2]).
+//   * products leave the kernel as (mantissa, exponent) pairs; the finish kernel multiplies the chunk partials
+//     of a cell in chunk order and takes ONE log per hypothesis and cell.
+//   * entries with at most one usable read (three quarters of a typical pileup) are linear in the genotypes: a chunk's
+//     records are partitioned (oct_partition_kernel), the linear ones are swept first by a loop of their own from rows of
+//     moments (s, rho) -- one FMA and the product update per hypothesis, the sums s folded in at the end.  Their
+//     likelihoods depend on ONE read byte (quad_lrec::code, common.hpp; 256 values: a table in LDS), so that loop has
+//     no phase 1: the lanes read the entry's 8-byte record themselves.
+//   * the launch order sorts chunks of similar trip counts into the same waves (quad_order_key_kernel).
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "demux_call_body.hpp"
+
+namespace {
+
+#ifndef OCT_EXP
+#define OCT_EXP 0  // timing experiments (tools/gpu_quadx.sh): 1 no nine-term loop, 2 no linear loop
+#endif
+constexpr int QL_SLACK = 256;      // records the linear loop may read behind the last chunk's list
+constexpr int ON_ACC = 18;         // per lane: 2 singlets, 1 in-lane pair, 3 x 4 pairs with the partners at 1..3, 3 at 4
+constexpr int O_SLOTS = 8;         // entry streams (chunks) per wave
+constexpr int O_BATCH = 8;         // entries per slot and phase 1 (64 lanes <-> 8 slots x 8 entries)
+constexpr int O_SLOT_STRIDE = 74;  // doubles: 8 entries x 8 likelihoods + 8 singlet factors + 2 pad (bank spread)
+constexpr int O_NHYP = ON_ACC * 8; // accumulators of a chunk: 144 slots for the 136 hypotheses
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int ROR2 = 0x122, ROR4 = 0x124, ROR6 = 0x126, ROR8 = 0x128;  // row_ror:2t = the ring of eight positions by t
+
+// position (0..7) whose samples a lane sees after row_ror:2t, t = 1..4, measured rather than assumed
+__global__ void oct_pmap_kernel(int32_t* pmap /*[4][8]*/) {
+  const int lane = threadIdx.x;
+  const int p = (lane >> 1) & 7;
+  const int p1 = __builtin_amdgcn_mov_dpp(p, ROR2, 0xF, 0xF, false);
+  const int p2 = __builtin_amdgcn_mov_dpp(p, ROR4, 0xF, 0xF, false);
+  const int p3 = __builtin_amdgcn_mov_dpp(p, ROR6, 0xF, 0xF, false);
+  const int p4 = __builtin_amdgcn_mov_dpp(p, ROR8, 0xF, 0xF, false);
+  if (lane < 16 && (lane & 1) == 0) {
+    pmap[p] = p1;
+    pmap[8 + p] = p2;
+    pmap[16 + p] = p3;
+    pmap[24 + p] = p4;
+  }
+}
+
+// A chunk's entry records with its linear entries (at most one usable read, plan_kernels.hip: lin_kernel) first, both
+// kinds in entry order, and the number of linear ones; the linear ones also as quad_lrec {snp, the read byte that
+// counts}.  One thread per chunk (<= 128 records), once per pileup and GP tensor (has_gp enters the codes).
+__global__ void __launch_bounds__(64)
+    oct_partition_kernel(int n_chunks, const row_chunk* __restrict__ chunks, const quad_entry* __restrict__ qent,
+                         const uint32_t* __restrict__ lin, const uint8_t* __restrict__ reads,
+                         const double* __restrict__ gp0s, quad_entry* __restrict__ out, quad_lrec* __restrict__ lrec,
+                         int32_t* __restrict__ nlin) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_chunks) return;
+  const int64_t e0 = chunks[q].e0;
+  const int len = chunks[q].len;
+  int w = 0;
+  for (int i = 0; i < len; ++i) {
+    const int64_t e = e0 + i;
+    if ((lin[e >> 5] >> (e & 31)) & 1u) {
+      const quad_entry p = qent[e];
+      uint32_t code = MUXGL_READ_OTHER;
+      for (uint32_t k = 0; k < p.nreads; ++k) {  // the usable read (:664)
+        const uint32_t bb = k < 4 ? (p.first4 >> (8 * k)) & 0xffu : (uint32_t)reads[(int64_t)p.r0 + k];
+        if (bb != MUXGL_READ_OTHER) code = bb;
+      }
+      if (gp0s[p.snp] < 0.0) code = MUXGL_READ_OTHER;  // no genotypes: the entry is skipped (:733)
+      lrec[e0 + w] = quad_lrec{p.snp, code};
+      out[e0 + w++] = p;
+    }
+  }
+  nlin[q] = w;
+  for (int i = 0; i < len; ++i) {
+    const int64_t e = e0 + i;
+    if (!((lin[e >> 5] >> (e & 31)) & 1u)) out[e0 + w++] = qent[e];
+  }
+}
+
+// Launch order: a wave's trip counts are the maxima over its chunks, so within every bucket of QUAD_BUCKET
+// consecutive chunks of the plan's order (ascending first SNP -- the rows gathered by co-resident workgroups stay a
+// sliding window at that grain) the chunks are sorted by their number of non-linear batches.
+constexpr int QUAD_BUCKET = 1024;
+__global__ void __launch_bounds__(256)
+    quad_order_key_kernel(int n_chunks, int bucket, const row_chunk* __restrict__ chunks,
+                          const int32_t* __restrict__ chunk_nlin, uint64_t* __restrict__ key, int32_t* __restrict__ iota) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_chunks) return;
+  const int nl = chunk_nlin[w], len = chunks[w].len;
+  const uint64_t bg = (uint64_t)((len - nl + 3) >> 2), bl = (uint64_t)((nl + 3) >> 2);  // <= 32 each
+  key[w] = ((uint64_t)(w / bucket) << 36) | ((63u - bg) << 26) | ((63u - bl) << 20) | (uint64_t)(w % bucket);
+  iota[w] = w;
+}
+
+// accumulator index layout of a lane (own samples a = p, b = p + 8; partner at rotation t: a' = p_t, b' = p_t + 8)
+__host__ __device__ constexpr int o_acc_single(int c) { return c; }              // c = 0: a, 1: b
+constexpr int O_ACC_AB = 2;                                                       // (a, b)
+__host__ __device__ constexpr int o_acc_rot(int t, int c, int d) { return 3 + (t - 1) * 4 + c * 2 + d; }  // t = 1..3
+constexpr int O_ACC_F_AB = 15, O_ACC_F_AA = 16, O_ACC_F_BB = 17;                  // t = 4: (a, b'), (a, a'), (b, b')
+
+// The sweep kernel.  Lane = 16 g + 2 p + h: slot 2 g + h of the wave (one chunk), position p (samples p, p + 8).
+__global__ void __launch_bounds__(64, 3)
+    demux_oct_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
+                     const quad_lrec* __restrict__ qlrec, const int32_t* __restrict__ chunk_nlin,
+                     const int32_t* __restrict__ order, const uint8_t* __restrict__ reads,
+                     const double* __restrict__ gpo, const double* __restrict__ gmo,
+                     const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
+                     double* __restrict__ part_m, int32_t* __restrict__ part_e) {
+  __shared__ double lut[384];
+  __shared__ __align__(16) double ablut[256 * 2];
+  __shared__ __align__(16) double pgs[O_SLOTS * O_SLOT_STRIDE];
+  __shared__ int32_t snps[64], snps_nx[64];
+
+  const int lane = threadIdx.x;
+  const int p = (lane >> 1) & 7;                    // position: samples p and p + 8
+  const int slot = ((lane >> 4) << 1) | (lane & 1);  // 8 entry streams per wave
+  for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
+  // (A, B) of a linear entry by the read byte that counts (quad_lrec::code): the one factor pR + (pA - pR) p of
+  // :673,685 through the tail (q / q_max + 1e-10) / (1 + 1e-10) of :703-725; q0[l] = A + 2B l, q1[l+m] = A + B (l+m)
+  for (int i = lane; i < 256; i += 64) {
+    const uint32_t bq = (uint32_t)i & 0x7f;
+    const bool ref = (i >> 7) == 0;
+    const double e3 = lut_g[256 + bq], mt = lut_g[128 + bq];
+    const double pR = ref ? mt : e3, pA = ref ? e3 : mt;  // :666-667
+    const double mx = fmax(pR, pA);
+    double x = __builtin_amdgcn_rcp(mx);
+    x = fma(x, fma(-mx, x, 1.0), x);
+    x = fma(x, fma(-mx, x, 1.0), x);
+    const double cc = 1.0 / (1.0 + 1e-10);
+    const double sc = cc * x, tt = 1e-10 * cc;
+    const bool none = i == MUXGL_READ_OTHER;  // no usable read / no genotypes: factors of exactly 1
+    ablut[2 * i] = none ? 1.0 : fma(pR, sc, tt);
+    ablut[2 * i + 1] = none ? 0.0 : (pA - pR) * (0.25 * sc);
+  }
+
+  const int wq = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * O_SLOTS + slot;  // place in the launch order
+  const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
+  int64_t e0 = 0;
+  int len = 0;
+  if (q < n_chunks) {
+    e0 = chunks[q].e0;
+    len = chunks[q].len;
+  }
+  // The chunk's first nl records are its linear entries (oct_partition_kernel; 0 when that form is off): they are swept
+  // first, by a loop of their own (below), the others by the nine-term loop.  Trip counts of the wave = the longest
+  // run of either kind among its chunks.
+  const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
+  const int nLmax = (OCT_EXP & 2) ? 0 : wave_max_i32(nl);
+  const int nb = (OCT_EXP & 1) ? 0 : (wave_max_i32(len - nl) + O_BATCH - 1) / O_BATCH;
+
+  double acc[ON_ACC];
+  int32_t exs[ON_ACC];
+#pragma unroll
+  for (int a = 0; a < ON_ACC; ++a) {
+    acc[a] = 1.0;
+    exs[a] = 0;
+  }
+  double accW[2] = {1.0, 1.0};  // linear entries: products of the sums s of the lane's two samples
+  int32_t exW[2] = {0, 0};
+  double accH = 1.0;            // nine-term entries: product of sample 0's sums, which every singlet carries (:806)
+  int32_t exH = 0;
+
+  auto renorm = [&]() {
+#pragma unroll
+    for (int a = 0; a < ON_ACC; ++a) prodacc_renorm(acc[a], exs[a]);
+    prodacc_renorm(accW[0], exW[0]);
+    prodacc_renorm(accW[1], exW[1]);
+    prodacc_renorm(accH, exH);
+  };
+
+  // ---- the linear entries (at most one usable read).  The single factor pR + (pA - pR) p, p = l/2 (alpha 0) or
+  //      (l+m)/4 (alpha 0.5), stays linear through the tail (:703-725): q0[l] = A + 2B l, q1[l+m] = A + B (l+m).  With the
+  //      moments s = g0 + g1 + g2 and rho = (g1 + 2 g2) / s of a triple (gmo),
+  //          singlet  sum_l g_j[l] q0[l] * s_0      = s_j s_0 (A + 2B rho_j)          (s_0: sample 0's sum, :806),
+  //          pair     sum_lm g_j[l] g_k[m] q1[l+m]  = s_j s_k (A + B rho_j + B rho_k):
+  //      the sums s go into products of their own (accW, folded into the accumulators at the end) and a hypothesis costs
+  //      an FMA and the product update instead of a three-term dot product and the update; a row is 2 x 16 bytes per
+  //      lane, and one double per sample rotates instead of three.
+  //      A pipeline over rings of three register sets (unrolled three times, so that ring positions are names): record
+  //      three entries ahead, row two ahead, (A, B) one ahead; loads are unconditional and a slot behind the end of its
+  //      list sweeps neutral entries (code 0xFF, the dummy row: every factor exactly 1).
+  if (nLmax > 0) {
+    struct rowl_t {
+      double sa, ra, sb, rb;  // (s, rho) of samples p and p + 8
+    };
+    auto load_rowl = [&](rowl_t& R, int32_t sidx) {
+      const double2* pc = reinterpret_cast<const double2*>(gmo + (size_t)sidx * 32) + p;
+      const double2 va = pc[0], vb = pc[8];
+      R.sa = va.x;
+      R.ra = va.y;
+      R.sb = vb.x;
+      R.rb = vb.y;
+    };
+    const int2* lr = reinterpret_cast<const int2*>(qlrec + e0);
+    auto settle = [&](int2& rc, int i) {  // a record behind the end of the slot's list: neutral
+      const bool in = i < nl;
+      rc.x = in ? rc.x : S_dummy;
+      rc.y = in ? rc.y : (int)MUXGL_READ_OTHER;
+    };
+    auto ab_of = [&](const int2& rc) { return *reinterpret_cast<const double2*>(ablut + 2 * rc.y); };
+    auto sweepL = [&](const rowl_t& R, const double2& ab) {
+      const double A = ab.x, B = ab.y, B2 = B + B;
+      accW[0] *= R.sa;
+      accW[1] *= R.sb;
+      acc[o_acc_single(0)] *= fma(B2, R.ra, A);  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+      acc[o_acc_single(1)] *= fma(B2, R.rb, A);
+      const double Xa = fma(B, R.ra, A), Xb = fma(B, R.rb, A);
+      acc[O_ACC_AB] *= fma(B, R.rb, Xa);
+      {
+        const double Pa = dpp_rot<ROR2>(R.ra), Pb = dpp_rot<ROR2>(R.rb);
+        acc[o_acc_rot(1, 0, 0)] *= fma(B, Pa, Xa);
+        acc[o_acc_rot(1, 0, 1)] *= fma(B, Pb, Xa);
+        acc[o_acc_rot(1, 1, 0)] *= fma(B, Pa, Xb);
+        acc[o_acc_rot(1, 1, 1)] *= fma(B, Pb, Xb);
+      }
+      {
+        const double Pa = dpp_rot<ROR4>(R.ra), Pb = dpp_rot<ROR4>(R.rb);
+        acc[o_acc_rot(2, 0, 0)] *= fma(B, Pa, Xa);
+        acc[o_acc_rot(2, 0, 1)] *= fma(B, Pb, Xa);
+        acc[o_acc_rot(2, 1, 0)] *= fma(B, Pa, Xb);
+        acc[o_acc_rot(2, 1, 1)] *= fma(B, Pb, Xb);
+      }
+      {
+        const double Pa = dpp_rot<ROR6>(R.ra), Pb = dpp_rot<ROR6>(R.rb);
+        acc[o_acc_rot(3, 0, 0)] *= fma(B, Pa, Xa);
+        acc[o_acc_rot(3, 0, 1)] *= fma(B, Pb, Xa);
+        acc[o_acc_rot(3, 1, 0)] *= fma(B, Pa, Xb);
+        acc[o_acc_rot(3, 1, 1)] *= fma(B, Pb, Xb);
+      }
+      {  // the lane facing this one: (a, b') here and (a', b) over there; (a, a') and (b, b') on both sides
+        const double Pa = dpp_rot<ROR8>(R.ra), Pb = dpp_rot<ROR8>(R.rb);
+        acc[O_ACC_F_AB] *= fma(B, Pb, Xa);
+        acc[O_ACC_F_AA] *= fma(B, Pa, Xa);
+        acc[O_ACC_F_BB] *= fma(B, Pb, Xb);
+      }
+    };
+    // entry i: its row in Rc and (A, B) in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
+    auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const double2& abc, double2& abn, int2& rc0, const int2& rc1,
+                    int2& rc2) {
+      rc0 = lr[i + 3];
+      settle(rc2, i + 2);
+      load_rowl(Rnn, rc2.x);
+      abn = ab_of(rc1);
+      __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
+      sweepL(Rc, abc);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    rowl_t L0, L1, L2;
+    double2 ab0, ab1, ab2;
+    int2 ra = lr[0], rb = lr[1], rc = lr[2];
+    settle(ra, 0);
+    settle(rb, 1);
+    load_rowl(L0, ra.x);
+    load_rowl(L1, rb.x);
+    __syncthreads();  // ablut is complete
+    ab0 = ab_of(ra);
+    int since = 0;
+    for (int i = 0; i < nLmax; i += 3) {  // (up to two neutral entries behind the longest list of the wave)
+      step(i, L0, L2, ab0, ab1, ra, rb, rc);
+      step(i + 1, L1, L0, ab1, ab2, rb, rc, ra);
+      step(i + 2, L2, L1, ab2, ab0, rc, ra, rb);
+      if (++since == 5) {  // 15 entries per slot since the last renormalisation
+        since = 0;
+        renorm();
+      }
+    }
+    renorm();
+  }
+
+  // ---- the other entries: phase 1 (lane <-> entry: 8 slots x 8 entries per batch), then phase 2 per entry ----
+  // records {snp, read count, first four read bytes, read offset} of the lane's own entry: batch b in precA, b+1 in
+  // precB, b+2 requested during phase 1 of batch b (loaded unconditionally from a clamped index and invalidated where
+  // it is used: a predicated load followed by a merge with the defaults makes the compiler wait for the load on the spot)
+  if (nb > 0) {
+    const int last = len > 0 ? len - 1 : 0;
+    auto fetch_meta = [&](int b) {
+      const int idx = nl + b * O_BATCH + p;
+      return qent[e0 + (idx < last ? idx : last)];
+    };
+    auto snp_of = [&](const quad_entry& r, int b) { return (nl + b * O_BATCH + p < len) ? r.snp : -1; };
+    quad_entry precA = fetch_meta(0), precB = fetch_meta(1);
+    // sum of sample 0's triple at the lane's own entry (negative: marker without genotypes), one batch ahead as well
+    double hs_cur = gp0s[precA.snp];
+
+    struct row_t {
+      double a[3], b[3];  // triples of samples p and p + 8
+    };
+    auto load_row = [&](row_t& R, int32_t s) {
+      // three 16-byte pieces of this lane's 6 doubles; piece t of the entry's eight lanes is 128 contiguous bytes.  Rows
+      // of padding entries and of markers without genotypes are (1,0,0) -- the dummy row S_dummy resp. the host's fill
+      // -- which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1 (:733).
+      const double2* pc = reinterpret_cast<const double2*>(gpo + (size_t)s * 48) + p;
+      const double2 v0 = pc[0], v1 = pc[8], v2 = pc[16];
+      R.a[0] = v0.x;
+      R.a[1] = v0.y;
+      R.a[2] = v1.x;
+      R.b[0] = v1.y;
+      R.b[1] = v2.x;
+      R.b[2] = v2.y;
+    };
+
+    // phase 1 of a batch.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
+    //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR
+    auto phase1 = [&](int b) {
+      const int32_t sa = snp_of(precA, b);
+      const int32_t s = (hs_cur >= 0.0) ? sa : -1;  // no genotypes: the entry is skipped (:733)
+      const double hs_out = (s >= 0) ? hs_cur : 1.0;       // multiplies every singlet (:806)
+      const int64_t r0 = precA.r0, r1 = (int64_t)precA.r0 + precA.nreads;
+      const uint32_t first4 = precA.first4;
+      precA = precB;
+      precB = fetch_meta(b + 2);
+      hs_cur = gp0s[precA.snp];
+      // The first four reads (all of them for > 99 % of the entries) come out of the record and are handled without a
+      // branch: a read that does not exist, an allele other than 0/1 (:664) or a skipped entry multiplies by exactly 1
+      // (pR = pA = 1).  The eight LUT reads are issued together.
+      double q0[3], q1[5];
+      {
+        double pRk[4], pAk[4];
+        const uint32_t nr = (s >= 0) ? (uint32_t)(r1 - r0) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t bb = (first4 >> (8 * k)) & 0xffu;
+          const uint32_t bq = bb & 0x7f;
+          const double e3 = lut[256 + bq], mt = lut[128 + bq];
+          const bool use = (uint32_t)k < nr && bb != MUXGL_READ_OTHER;
+          const bool ref = (bb >> 7) == 0;
+          pRk[k] = use ? (ref ? mt : e3) : 1.0;  // :666-667
+          pAk[k] = use ? (ref ? e3 : mt) : 1.0;
+        }
+        {
+          const double d = pAk[0] - pRk[0];
+          const double mid = fma(d, 0.5, pRk[0]);
+          q0[0] = pRk[0];
+          q0[1] = mid;
+          q0[2] = pAk[0];
+          q1[0] = pRk[0];
+          q1[1] = fma(d, 0.25, pRk[0]);
+          q1[2] = mid;
+          q1[3] = fma(d, 0.75, pRk[0]);
+          q1[4] = pAk[0];
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const double d = pAk[k] - pRk[k];
+          const double mid = fma(d, 0.5, pRk[k]);
+          q0[0] *= pRk[k];
+          q0[1] *= mid;
+          q0[2] *= pAk[k];
+          q1[0] *= pRk[k];
+          q1[1] *= fma(d, 0.25, pRk[k]);
+          q1[2] *= mid;
+          q1[3] *= fma(d, 0.75, pRk[k]);
+          q1[4] *= pAk[k];
+        }
+        if (nr > 4) {  // deep entries: the rest from the read array
+          int since = 4;
+          for (int64_t rr = r0 + 4; rr < r1; ++rr) {
+            const uint32_t bb = (uint32_t)reads[rr];
+            if (bb == MUXGL_READ_OTHER) continue;  // :664
+            const uint32_t al = bb >> 7, bq = bb & 0x7f;
+            const double e3 = lut[256 + bq], mt = lut[128 + bq];
+            const double pR = (al == 0) ? mt : e3, pA = (al == 0) ? e3 : mt;
+            const double d = pA - pR;
+            const double mid = fma(d, 0.5, pR);
+            q0[0] *= pR;
+            q0[1] *= mid;
+            q0[2] *= pA;
+            q1[0] *= pR;
+            q1[1] *= fma(d, 0.25, pR);
+            q1[2] *= mid;
+            q1[3] *= fma(d, 0.75, pR);
+            q1[4] *= pA;
+            if (++since >= 32) {  // common rescaling, only against underflow (cancels in q/q_max)
+              since = 0;
+              double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
+#pragma unroll
+              for (int t = 0; t < 5; ++t) mx = fmax(mx, q1[t]);
+              const double inv = 1.0 / mx;
+#pragma unroll
+              for (int l = 0; l < 3; ++l) q0[l] *= inv;
+#pragma unroll
+              for (int t = 0; t < 5; ++t) q1[t] *= inv;
+            }
+          }
+        }
+        // (q/q_max + 1e-10) / (1 + 1e-10), :703-725; the maximum over all 18 elements is the maximum over these 8.
+        // 1/q_max by v_rcp_f64 and two Newton steps (<= 1 ulp; the factor is common to the entry's likelihoods).  For
+        // a skipped entry everything is 1 and must stay exactly 1.
+        double mx = fmax(fmax(q0[0], q0[1]), q0[2]);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) mx = fmax(mx, q1[t]);
+        double x = __builtin_amdgcn_rcp(mx);
+        x = fma(x, fma(-mx, x, 1.0), x);
+        x = fma(x, fma(-mx, x, 1.0), x);
+        const double cc = 1.0 / (1.0 + 1e-10);
+        const double sc = (s >= 0) ? cc * x : 1.0, tt = (s >= 0) ? 1e-10 * cc : 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) q0[l] = fma(q0[l], sc, tt);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) q1[t] = fma(q1[t], sc, tt);
+      }
+      double* dst = pgs + slot * O_SLOT_STRIDE + p * 8;
+      dst[0] = q0[0];
+      dst[1] = q0[1];
+      dst[2] = q0[2];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) dst[3 + t] = q1[t];
+      pgs[slot * O_SLOT_STRIDE + 64 + p] = hs_out;
+      snps[slot * 8 + p] = (s >= 0) ? s : S_dummy;
+      const int32_t sn = snp_of(precA, b + 1);
+      snps_nx[slot * 8 + p] = (sn >= 0) ? sn : S_dummy;  // next batch; its no-genotype rows are (1,0,0)
+    };
+
+    // phase 2 for entry i of the slot's batch: lane <-> 2 samples
+    auto sweep_entry = [&](const row_t& R, int i) {
+      const double* qq = pgs + slot * O_SLOT_STRIDE + i * 8;
+      const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
+      const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
+      accH *= pgs[slot * O_SLOT_STRIDE + 64 + i];
+      // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+      acc[o_acc_single(0)] *= fma(R.a[2], a2, fma(R.a[1], a1, R.a[0] * a0));
+      acc[o_acc_single(1)] *= fma(R.b[2], a2, fma(R.b[1], a1, R.b[0] * a0));
+      // u[m] = sum_l g_j[l] * pG[alpha=.5][l][m],  pG[l][m] = b[l+m]
+      double ua[3], ub[3];
+      ua[0] = fma(R.a[2], b2, fma(R.a[1], b1, R.a[0] * b0));
+      ua[1] = fma(R.a[2], b3, fma(R.a[1], b2, R.a[0] * b1));
+      ua[2] = fma(R.a[2], b4, fma(R.a[1], b3, R.a[0] * b2));
+      ub[0] = fma(R.b[2], b2, fma(R.b[1], b1, R.b[0] * b0));
+      ub[1] = fma(R.b[2], b3, fma(R.b[1], b2, R.b[0] * b1));
+      ub[2] = fma(R.b[2], b4, fma(R.b[1], b3, R.b[0] * b2));
+      auto dot = [](const double* g, const double* u) { return fma(g[2], u[2], fma(g[1], u[1], g[0] * u[0])); };  // :738-746
+      acc[O_ACC_AB] *= dot(R.b, ua);
+#define OCT_ROT(T, CTRL)                                                                             \
+  {                                                                                                  \
+    double Pa[3], Pb[3];                                                                             \
+    Pa[0] = dpp_rot<CTRL>(R.a[0]);                                                                   \
+    Pa[1] = dpp_rot<CTRL>(R.a[1]);                                                                   \
+    Pa[2] = dpp_rot<CTRL>(R.a[2]);                                                                   \
+    Pb[0] = dpp_rot<CTRL>(R.b[0]);                                                                   \
+    Pb[1] = dpp_rot<CTRL>(R.b[1]);                                                                   \
+    Pb[2] = dpp_rot<CTRL>(R.b[2]);                                                                   \
+    acc[o_acc_rot(T, 0, 0)] *= dot(Pa, ua);                                                          \
+    acc[o_acc_rot(T, 0, 1)] *= dot(Pb, ua);                                                          \
+    acc[o_acc_rot(T, 1, 0)] *= dot(Pa, ub);                                                          \
+    acc[o_acc_rot(T, 1, 1)] *= dot(Pb, ub);                                                          \
+  }
+      OCT_ROT(1, ROR2)
+      OCT_ROT(2, ROR4)
+      OCT_ROT(3, ROR6)
+#undef OCT_ROT
+      {  // the lane facing this one: (a, b') here and (a', b) over there; (a, a') and (b, b') on both sides
+        double Pa[3], Pb[3];
+        Pa[0] = dpp_rot<ROR8>(R.a[0]);
+        Pa[1] = dpp_rot<ROR8>(R.a[1]);
+        Pa[2] = dpp_rot<ROR8>(R.a[2]);
+        Pb[0] = dpp_rot<ROR8>(R.b[0]);
+        Pb[1] = dpp_rot<ROR8>(R.b[1]);
+        Pb[2] = dpp_rot<ROR8>(R.b[2]);
+        acc[O_ACC_F_AB] *= dot(Pb, ua);
+        acc[O_ACC_F_AA] *= dot(Pa, ua);
+        acc[O_ACC_F_BB] *= dot(Pb, ub);
+      }
+    };
+
+    // One batch: phase 1, then its eight entries.  Rows are requested TWO entries ahead into three register sets that
+    // rotate without copies; eight entries against three sets give a period of three batches, which are written out,
+    // each starting one set later.  On entry X holds the row of entry 0, Y of entry 1 (both requested earlier), Z is free.
+    auto batch = [&](int b, row_t& X, row_t& Y, row_t& Z) {
+      phase1(b);
+      __syncthreads();
+      const int32_t* sn = snps + slot * 8;
+      const int32_t* sx = snps_nx + slot * 8;
+#define OCT_E(LD, SRC, SW, I)                \
+  load_row(LD, SRC);                         \
+  __builtin_amdgcn_sched_barrier(0);         \
+  sweep_entry(SW, I);                        \
+  __builtin_amdgcn_sched_barrier(0);
+      OCT_E(Z, sn[2], X, 0)
+      OCT_E(X, sn[3], Y, 1)
+      OCT_E(Y, sn[4], Z, 2)
+      OCT_E(Z, sn[5], X, 3)
+      OCT_E(X, sn[6], Y, 4)
+      OCT_E(Y, sn[7], Z, 5)
+      OCT_E(Z, sx[0], X, 6)
+      OCT_E(X, sx[1], Y, 7)
+#undef OCT_E
+      if (b & 1) renorm();  // 16 entries per slot since the last renormalisation
+      __syncthreads();
+    };
+    // (after a batch that started with (X, Y, Z) the next batch's entries 0 and 1 sit in Z and X)
+
+    row_t R0, R1, R2;
+    snps_nx[slot * 8 + p] = (snp_of(precA, 0) >= 0) ? precA.snp : S_dummy;
+    __syncthreads();
+    load_row(R0, snps_nx[slot * 8 + 0]);
+    load_row(R1, snps_nx[slot * 8 + 1]);
+    __syncthreads();
+    for (int b = 0; b < nb; b += 3) {
+      batch(b, R0, R1, R2);
+      if (b + 1 >= nb) break;
+      batch(b + 1, R2, R0, R1);
+      if (b + 2 >= nb) break;
+      batch(b + 2, R1, R2, R0);
+    }
+    renorm();
+  }
+
+  // the sums of the linear entries: every hypothesis gets the products of its two samples (the partner's through the
+  // same rotation that brought its values); every singlet the product of sample 0's sums, which for the linear entries
+  // is accW of position 0's sample a, for the others accH (:806)
+  {
+    int32_t exa[ON_ACC];
+    const double wa = accW[0], wb = accW[1];
+    const int32_t ea = exW[0], eb = exW[1];
+    const int src0 = lane & ~14;  // position 0 of the same slot
+    const double W0 = __shfl(wa, src0, 64) * accH;
+    const int32_t e0w = __shfl(ea, src0, 64) + exH;
+    acc[o_acc_single(0)] *= wa * W0;
+    exa[o_acc_single(0)] = ea + e0w;
+    acc[o_acc_single(1)] *= wb * W0;
+    exa[o_acc_single(1)] = eb + e0w;
+    acc[O_ACC_AB] *= wa * wb;
+    exa[O_ACC_AB] = ea + eb;
+#define OCT_FOLD(T, CTRL)                                                          \
+  {                                                                                \
+    const double pa = dpp_rot<CTRL>(wa), pb = dpp_rot<CTRL>(wb);                   \
+    const int32_t qa = __builtin_amdgcn_mov_dpp(ea, CTRL, 0xF, 0xF, false);        \
+    const int32_t qb = __builtin_amdgcn_mov_dpp(eb, CTRL, 0xF, 0xF, false);        \
+    acc[o_acc_rot(T, 0, 0)] *= wa * pa;                                            \
+    exa[o_acc_rot(T, 0, 0)] = ea + qa;                                             \
+    acc[o_acc_rot(T, 0, 1)] *= wa * pb;                                            \
+    exa[o_acc_rot(T, 0, 1)] = ea + qb;                                             \
+    acc[o_acc_rot(T, 1, 0)] *= wb * pa;                                            \
+    exa[o_acc_rot(T, 1, 0)] = eb + qa;                                             \
+    acc[o_acc_rot(T, 1, 1)] *= wb * pb;                                            \
+    exa[o_acc_rot(T, 1, 1)] = eb + qb;                                             \
+  }
+    OCT_FOLD(1, ROR2)
+    OCT_FOLD(2, ROR4)
+    OCT_FOLD(3, ROR6)
+#undef OCT_FOLD
+    {
+      const double pa = dpp_rot<ROR8>(wa), pb = dpp_rot<ROR8>(wb);
+      const int32_t qa = __builtin_amdgcn_mov_dpp(ea, ROR8, 0xF, 0xF, false);
+      const int32_t qb = __builtin_amdgcn_mov_dpp(eb, ROR8, 0xF, 0xF, false);
+      acc[O_ACC_F_AB] *= wa * pb;
+      exa[O_ACC_F_AB] = ea + qb;
+      acc[O_ACC_F_AA] *= wa * pa;
+      exa[O_ACC_F_AA] = ea + qa;
+      acc[O_ACC_F_BB] *= wb * pb;
+      exa[O_ACC_F_BB] = eb + qb;
+    }
+    if (q < n_chunks) {
+#pragma unroll
+      for (int a = 0; a < ON_ACC; ++a) {
+        int e;
+        const double m = frexp(acc[a], &e);
+        part_m[((size_t)q * ON_ACC + a) * 8 + p] = m;
+        part_e[((size_t)q * ON_ACC + a) * 8 + p] = exs[a] + e + exa[a];
+      }
+    }
+  }
+}
+
+// Decodes accumulator idx = a*8 + p of the oct kernel into its hypothesis (j, k) and multiplies the chunk partials of
+// one cell in chunk order: ONE log per hypothesis.  Returns false for slots nobody reads (pairs held twice, j/k >= V).
+__device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, const int32_t* __restrict__ cell_chunks,
+                                               const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                                               const int32_t* __restrict__ pmap, int V, int& j, int& k, double& v) {
+  const int a = idx >> 3, p = idx & 7;
+  bool publish = true;
+  if (a < 2) {
+    j = p + 8 * a;
+    k = 0;
+  } else if (a == O_ACC_AB) {
+    j = p + 8;
+    k = p;
+  } else if (a < 15) {
+    const int t = (a - 3) >> 2, c = ((a - 3) >> 1) & 1, d = (a - 3) & 1;
+    j = p + 8 * c;
+    k = pmap[t * 8 + p] + 8 * d;
+  } else {
+    const int pf = pmap[24 + p];
+    if (a == O_ACC_F_AB) {
+      j = p;
+      k = pf + 8;
+    } else if (a == O_ACC_F_AA) {
+      j = p;
+      k = pf;
+      publish = p < pf;  // the facing lane holds the same pair
+    } else {
+      j = p + 8;
+      k = pf + 8;
+      publish = p < pf;
+    }
+  }
+  if (!publish || j >= V || k >= V) return false;
+  // eight chunks per trip: the sixteen loads are independent and in flight together, the products stay in chunk order
+  double m = 1.0;
+  int64_t e = 0;
+  int cnt = 0;
+  for (int64_t ci = c0; ci < c1; ci += 8) {
+    double pm[8];
+    int32_t pe[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = ci + u < c1;
+      const size_t o = (size_t)cell_chunks[ok ? ci + u : c0] * O_NHYP + idx;
+      pm[u] = ok ? part_m[o] : 1.0;
+      pe[u] = ok ? part_e[o] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      m *= pm[u];
+      e += pe[u];
+    }
+    if (++cnt == 64) {  // mantissas are in [0.5,1): 512 factors cannot underflow
+      cnt = 0;
+      int ee;
+      m = frexp(m, &ee);
+      e += ee;
+    }
+  }
+  v = log(m) + (double)e * 0.6931471805599453094;
+  return true;
+}
+
+// writes ll[c][j][k][n] (+ mirror) of one cell to the LL tensor in HBM (needed when the caller asks for the tensor)
+__global__ void __launch_bounds__(192)
+    demux_oct_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
+                            const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                            const int32_t* __restrict__ pmap, int V, double* __restrict__ ll) {
+  const int64_t c = blockIdx.x;
+  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+  const int idx = threadIdx.x;
+  if (c0 == c1 || idx >= O_NHYP) return;
+  int j, k;
+  double v;
+  if (!oct_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, pmap, V, j, k, v)) return;
+  double* out = ll + (size_t)c * V * V * 2;
+  if (idx < 16) {
+    out[((size_t)j * V + k) * 2 + 0] = v;  // singlet: alpha index 0
+  } else {
+    out[((size_t)j * V + k) * 2 + 1] = v;
+    out[((size_t)k * V + j) * 2 + 1] = v;
+  }
+}
+
+// The same reduction, but the hypotheses of four cells stay in LDS and the call (demux_call_body.hpp) follows at once,
+// sixteen lanes per cell in wave 0: no LL tensor round trip through HBM, one launch less, and the 160-byte records go
+// straight to the caller's pinned host buffer (16-byte stores of consecutive lanes), which removes the separate
+// device-to-host copy.
+constexpr int QF_CELLS = 4;
+__global__ void __launch_bounds__(256)
+    demux_oct_finish_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, const int64_t* __restrict__ cell_chunk_ptr,
+                            const int32_t* __restrict__ cell_chunks, const double* __restrict__ part_m,
+                            const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
+                            muxgl_call::call_alpha al, double doublet_prior, muxgl_demux_cell* __restrict__ out) {
+  __shared__ double llt[QF_CELLS][16 * 16 * 2];
+  __shared__ __align__(16) muxgl_demux_cell rec[QF_CELLS];
+  static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
+  const int64_t cbase = (int64_t)blockIdx.x * QF_CELLS;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < QF_CELLS * 512; t += 256) (&llt[0][0])[t] = 0.0;
+  __syncthreads();
+  for (int w = tid; w < QF_CELLS * O_NHYP; w += 256) {
+    const int lc = w / O_NHYP, idx = w - lc * O_NHYP;
+    const int64_t c = cbase + lc;
+    if (c >= C) break;
+    const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
+    int j, k;
+    double v;
+    if (c0 != c1 && oct_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, pmap, V, j, k, v)) {
+      if (idx < 16) {
+        llt[lc][(j * V + k) * 2 + 0] = v;
+      } else {
+        llt[lc][(j * V + k) * 2 + 1] = v;
+        llt[lc][(k * V + j) * 2 + 1] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lc = tid >> 4;
+    const int64_t c = cbase + lc;
+    const bool ok = c < C;
+    muxgl_call::demux_call_group<16>(tid, ok, ok ? (int32_t)(cell_ptr[c + 1] - cell_ptr[c]) : 0, V, 2, al.a,
+                                     doublet_prior, llt[lc], &rec[lc]);
+  }
+  __syncthreads();
+  constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
+  if (tid < QF_CELLS * NQ && cbase + tid / NQ < C)
+    reinterpret_cast<uint4*>(out + cbase)[tid] = reinterpret_cast<const uint4*>(&rec[0])[tid];
+}
+
+}  // namespace
+
+// the launch order of the chunks of the oct / quad kernels (quad_order_key_kernel), shared with fmx_quad.hip
+int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t* d_nlin, int64_t n, int32_t** order) {
+  int32_t* d_iota = nullptr;
+  uint64_t *d_key = nullptr, *d_key2 = nullptr;
+  void* d_tmp = nullptr;
+  auto cleanup = [&]() {
+    dev_free(&d_iota);
+    dev_free(&d_key);
+    dev_free(&d_key2);
+    if (d_tmp) (void)hipFree(d_tmp);
+    d_tmp = nullptr;
+  };
+  if (dev_alloc(h, order, (size_t)n) || dev_alloc(h, &d_iota, (size_t)n) || dev_alloc(h, &d_key, (size_t)n) ||
+      dev_alloc(h, &d_key2, (size_t)n)) {
+    cleanup();
+    return 1;
+  }
+  int bucket = QUAD_BUCKET;
+  if (const char* ev = getenv("MUXGL_QUAD_BUCKET")) bucket = atoi(ev) > 0 ? atoi(ev) : bucket;  // (tuning)
+  if (bucket > (1 << 20)) bucket = 1 << 20;
+  hipLaunchKernelGGL(quad_order_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (int)n, bucket, d_chunks,
+                     d_nlin, d_key, d_iota);
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key, d_key2, d_iota, *order, (size_t)n, 0u, 64u, h->stream);
+  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_iota, *order, (size_t)n, 0u, 64u, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  cleanup();
+  if (e != hipSuccess) MUXGL_FAIL(h, "quad_launch_order: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// returns -1 when the path does not apply, 0 ok, 1 error
+int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  if (h->V > 16 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
+  if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL | MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;
+  if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
+  muxgl_row_state* st = h->qrow;
+  if (!st->d_tmap) {  // positions met by the four rotations
+    if (dev_alloc(h, &st->d_tmap, 32)) return 1;
+    hipLaunchKernelGGL(oct_pmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
+    HIPCHK(h, hipGetLastError());
+  }
+  const size_t need = (size_t)st->n_chunks * O_NHYP;
+  if (need > st->part_cap) {
+    if (dev_alloc(h, &st->d_part, need)) return 1;
+    st->part_cap = need;
+  }
+  if (need > st->part_e_cap) {
+    if (dev_alloc(h, &st->d_part_e, need)) return 1;
+    st->part_e_cap = need;
+  }
+  const bool use_lin = h->d_lin && h->d_gmq && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+  if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup and GP tensor: every chunk's linear entries first
+    // (the sweep reads up to QL_SLACK records behind a chunk's list, unconditionally: slack behind the array)
+    if (dev_alloc(h, &st->d_qent_lin, (size_t)h->nnz) || dev_alloc(h, &st->d_chunk_nlin, (size_t)st->n_chunks) ||
+        dev_alloc(h, &st->d_qlrec, (size_t)h->nnz + QL_SLACK))
+      return 1;
+    HIPCHK(h, hipMemsetAsync(st->d_qlrec, 0xFF, sizeof(quad_lrec) * ((size_t)h->nnz + QL_SLACK), h->stream));
+    hipLaunchKernelGGL(oct_partition_kernel, dim3((unsigned)((st->n_chunks + 63) / 64)), dim3(64), 0, h->stream,
+                       (int)st->n_chunks, st->d_chunks, h->d_qent, h->d_lin, h->d_reads, h->d_gp0s, st->d_qent_lin,
+                       st->d_qlrec, st->d_chunk_nlin);
+    HIPCHK(h, hipGetLastError());
+    if (quad_launch_order(h, st->d_chunks, st->d_chunk_nlin, st->n_chunks, &st->d_quad_order)) return 1;
+  }
+  tic(h, MUXGL_T_DEMUX_SWEEP);
+  const unsigned blocks = (unsigned)((((st->n_chunks + O_SLOTS - 1) / O_SLOTS) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
+  if (blocks) {
+    hipLaunchKernelGGL(demux_oct_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
+                       use_lin ? st->d_qent_lin : h->d_qent, st->d_qlrec,
+                       use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
+                       use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
+                       h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
+    HIPCHK(h, hipGetLastError());
+  }
+  toc(h, MUXGL_T_DEMUX_SWEEP);
+  tic(h, MUXGL_T_DEMUX_REDUCE);
+  if (h->want_full_ll) {
+    hipLaunchKernelGGL(demux_oct_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+                       st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);
+  } else {  // reduce + call fused, records written to the pinned host buffer
+    muxgl_call::call_alpha al;
+    for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+    hipLaunchKernelGGL(demux_oct_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(256), 0,
+                       h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
+                       p->doublet_prior, h->h_dcells);
+    h->records_on_host = true;
+  }
+  HIPCHK(h, hipGetLastError());
+  toc(h, MUXGL_T_DEMUX_REDUCE);
+  return 0;
+}

@@ -308,53 +308,45 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   dev_free(&h->d_gpq);
   dev_free(&h->d_gp0s);
   dev_free(&h->d_gmq);
-  if (h->qrow) {  // the quad kernel's partitioned records carry has_gp (quad_lrec::code): rebuilt on the next run
+  if (h->qrow) {  // the oct kernel's partitioned records carry has_gp (quad_lrec::code): rebuilt on the next run
     dev_free(&h->qrow->d_qent_lin);
     dev_free(&h->qrow->d_chunk_nlin);
     dev_free(&h->qrow->d_qlrec);
     dev_free(&h->qrow->d_quad_order);
   }
   if (V <= 16 && h->S > 0) {
-    // Layout for the quad kernel (demux_quad.hip): lane r of a quad owns samples 4r..4r+3 = 12 doubles d = 3c+l, read as
-    // six 16-byte pieces; piece t of the four lanes is stored contiguously ([S][6][4][2]) so that one load instruction
-    // of a quad covers 64 consecutive bytes.  Samples >= V are padded with (1,0,0), which makes their factors exactly 1.
-    // Row S is a dummy marker, (1,0,0) for every sample and sum 1: padding entries and markers without genotypes are
-    // pointed at it, so the kernel loads rows unconditionally.
+    // Layout for the oct kernel (demux_oct.hip): lane p of an entry's eight lanes owns samples p and p + 8 = 6 doubles
+    // d = 3c + l, read as three 16-byte pieces; piece t of the eight lanes is stored contiguously ([S][3][8][2]) so that
+    // one load instruction of an entry covers one whole 128-byte line.  Samples >= V are padded with (1,0,0), which
+    // makes their factors exactly 1.  Row S is a dummy marker, (1,0,0) for every sample and sum 1: padding entries and
+    // markers without genotypes are pointed at it, so the kernel loads rows unconditionally.
     std::vector<double> q((size_t)(h->S + 1) * 48), g0((size_t)h->S + 1);
-    for (int64_t s = 0; s < h->S; ++s) {
-      const double* row = gp + (size_t)s * V * 3;
-      for (int r = 0; r < 4; ++r)
-        for (int d = 0; d < 12; ++d) {
-          const int j = 4 * r + d / 3, l = d % 3;
-          const double v = (j < V && has_gp[s]) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);  // no genotypes: neutral row
-          q[(size_t)s * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = v;
+    for (int64_t s = 0; s <= h->S; ++s) {
+      const double* row = s < h->S ? gp + (size_t)s * V * 3 : nullptr;
+      const bool have = row && has_gp[s];
+      for (int pp = 0; pp < 8; ++pp)
+        for (int d = 0; d < 6; ++d) {
+          const int j = pp + 8 * (d / 3), l = d % 3;
+          const double v = (j < V && have) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);  // no genotypes: neutral row
+          q[(size_t)s * 48 + ((size_t)(d / 2) * 8 + pp) * 2 + (d & 1)] = v;
         }
       // a SNP without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) is marked by a negative sum
-      g0[(size_t)s] = has_gp[s] ? (row[0] + row[1]) + row[2] : -1.0;
+      g0[(size_t)s] = s == h->S ? 1.0 : (have ? (row[0] + row[1]) + row[2] : -1.0);
     }
-    for (int t = 0; t < 48; ++t) q[(size_t)h->S * 48 + t] = 0.0;
-    for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) {
-        const int d = 3 * c;  // l == 0 of sample c
-        q[(size_t)h->S * 48 + ((size_t)(d / 2) * 4 + r) * 2 + (d & 1)] = 1.0;
-      }
-    g0[(size_t)h->S] = 1.0;
-    // The same rows as moments (s, rho = (g1 + 2 g2) / s) for the entries with one usable read (demux_quad.hip): lane r
-    // of a quad reads its four samples' pairs as four 16-byte pieces, piece c of the four lanes contiguous.
+    // The same rows as moments (s, rho = (g1 + 2 g2) / s) for the entries with one usable read: 16 bytes per sample in
+    // sample order ([S + 1][16][2]; lane p reads samples p and p + 8, each a whole line per entry).
     std::vector<double> gm((size_t)(h->S + 1) * 32);
     for (int64_t s = 0; s <= h->S; ++s)
-      for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-          const int j = 4 * r + c;
-          double sm = 1.0, rho = 0.0;
-          if (s < h->S && j < V && has_gp[s]) {
-            const double* t = gp + ((size_t)s * V + j) * 3;
-            sm = (t[0] + t[1]) + t[2];
-            rho = sm > 0.0 ? std::fma(2.0, t[2], t[1]) / sm : 0.0;
-          }
-          gm[(size_t)s * 32 + ((size_t)c * 4 + r) * 2] = sm;
-          gm[(size_t)s * 32 + ((size_t)c * 4 + r) * 2 + 1] = rho;
+      for (int j = 0; j < 16; ++j) {
+        double sm = 1.0, rho = 0.0;
+        if (s < h->S && j < V && has_gp[s]) {
+          const double* t = gp + ((size_t)s * V + j) * 3;
+          sm = (t[0] + t[1]) + t[2];
+          rho = sm > 0.0 ? std::fma(2.0, t[2], t[1]) / sm : 0.0;
         }
+        gm[(size_t)s * 32 + (size_t)j * 2] = sm;
+        gm[(size_t)s * 32 + (size_t)j * 2 + 1] = rho;
+      }
     if (dev_alloc(h, &h->d_gmq, gm.size())) return 1;
     HIPCHK(h, hipMemcpy(h->d_gmq, gm.data(), sizeof(double) * gm.size(), hipMemcpyHostToDevice));
     if (dev_alloc(h, &h->d_gpq, q.size())) return 1;

@@ -33,7 +33,7 @@ def test_single_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     # two roofs are priced, "bound" names the larger fraction and the top-level numbers are that roof's
-    assert rf["bound"] in ("hbm", "fp64_valu") and rf["kernel"] == "demux_quad_kernel"
+    assert rf["bound"] in ("hbm", "fp64_valu") and rf["kernel"] == "demux_oct_kernel"
     top = rf["hbm"] if rf["bound"] == "hbm" else rf["fp64"]
     assert rf["unit"] == top["unit"] and rf["peak"] == top["peak"] and rf["frac"] == top["frac"]
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
