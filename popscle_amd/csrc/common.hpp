@@ -47,8 +47,9 @@ struct muxgl_row_state {
   int32_t* d_tmap = nullptr;            // [2][4]: tile seen by a quad lane after row_ror:4 / row_ror:8
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
   quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
-  int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_quad.hip, built on first use)
-  quad_lrec* d_qlrec = nullptr;              // ... and the linear ones as {snp, read byte} records (quad_lrec, demux_quad.hip)
+  int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_oct.hip, built on first use)
+  uint2* d_orec = nullptr;              // ... and the linear ones as {row offset, table offset} records, step-major per
+  int64_t* d_unit_ptr = nullptr;        //     unit of eight chunks: unit u starts at d_orec[d_unit_ptr[u]] (demux_oct.hip)
   int32_t* d_quad_order = nullptr;      // ... and the launch order of the chunks (sorted by trip count within buckets)
   // freemuxlet quad E-step (fmx_quad.hip, built on first use after muxgl_fmx_prepare): per chunk, its linear entries
   // as {c0, c1, snp} records in front, then the SNP ids and six likelihoods of the others
@@ -124,9 +125,9 @@ struct muxgl_handle {
   int32_t V = 0;
   double* d_gp = nullptr;
   uint8_t* d_has_gp = nullptr;
-  double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_quad.hip)
+  double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_oct.hip)
   double* d_gp0s = nullptr;  // V <= 16: per-SNP sum of sample 0's triple (the factor every singlet carries, :806)
-  double* d_gmq = nullptr;   // V <= 16: moments (s, rho) of every triple in the quad layout, [S + 1][4][4][2] (demux_quad.hip)
+  double* d_gmq = nullptr;   // V <= 16: moments (s, rho) of every triple in the quad layout, [S + 1][4][4][2] (demux_oct.hip)
   double* d_ll = nullptr;  // [C][V][V][A]
   double* d_llw = nullptr; // wave path: [C][A][64 rotation steps][64 lanes], see demux_wave.hip
   size_t llw_cap = 0;
@@ -145,7 +146,7 @@ struct muxgl_handle {
   bool have_dp = false;
   bool pairs_valid = false;
   struct muxgl_row_state* row = nullptr;  // chunk tables of the V<=16 row kernel (demux_row.hip)
-  struct muxgl_row_state* qrow = nullptr; // chunk tables of the default-grid quad kernel (demux_quad.hip)
+  struct muxgl_row_state* qrow = nullptr; // chunk tables of the default-grid quad kernel (demux_oct.hip)
   struct muxgl_wave_state* wave = nullptr; // cell order + pG table of the 16 < V <= 64 wave kernel (demux_wave.hip)
   int32_t flags = 0;
 

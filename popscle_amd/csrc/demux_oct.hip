@@ -28,7 +28,12 @@
 //     moments (s, rho) -- one FMA and the product update per hypothesis, the sums s folded in at the end.  Their
 //     likelihoods depend on ONE read byte (quad_lrec::code, common.hpp; 256 values: a table in LDS), so that loop has
 //     no phase 1: the lanes read the entry's 8-byte record themselves.
-//   * the launch order sorts chunks of similar trip counts into the same waves (quad_order_key_kernel).
+//   * the launch order sorts chunks of similar trip counts into the same waves (quad_order_key_kernel).  One wave per
+//     unit of eight chunks, handed out by the hardware as slots free up.  (Measured and dropped: a persistent launch of
+//     as many waves as the chip holds, each with a work list balanced by instruction counts (LPT), 0.32 ms against
+//     0.28 ms -- co-resident waves do not run at equal speed, the dispatcher's greedy hand-out balances better than a
+//     static plan; and units in descending cost order instead of SNP windows, +-0.)
+#include <algorithm>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -40,7 +45,8 @@ namespace {
 #ifndef OCT_EXP
 #define OCT_EXP 0  // timing experiments (tools/gpu_quadx.sh): 1 no nine-term loop, 2 no linear loop
 #endif
-constexpr int QL_SLACK = 256;      // records the linear loop may read behind the last chunk's list
+constexpr int O_NLUT = 129;        // {A, B, 2B} by (allele << 6 | base quality <= 63), and one neutral entry
+constexpr int O_LPAD = 3;          // steps of neutral records behind a unit's longest linear list (the loop reads ahead)
 constexpr int ON_ACC = 18;         // per lane: 2 singlets, 1 in-lane pair, 3 x 4 pairs with the partners at 1..3, 3 at 4
 constexpr int O_SLOTS = 8;         // entry streams (chunks) per wave
 constexpr int O_BATCH = 8;         // entries per slot and phase 1 (64 lanes <-> 8 slots x 8 entries)
@@ -121,6 +127,52 @@ __global__ void __launch_bounds__(256)
   iota[w] = w;
 }
 
+// Steps of a unit's linear loop: the longest linear list among its eight chunks, rounded to the loop's unrolling, plus
+// the read-ahead (0 for a unit without linear entries).
+__global__ void __launch_bounds__(256)
+    oct_unit_steps_kernel(int n_units, int n_chunks, const int32_t* __restrict__ order, const int32_t* __restrict__ nlin,
+                          int32_t* __restrict__ steps) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_units) return;
+  int m = 0;
+  for (int k = 0; k < O_SLOTS; ++k) {
+    const int w = u * O_SLOTS + k;
+    if (w < n_chunks) m = max(m, nlin[order[w]]);
+  }
+  steps[u] = m > 0 ? (m + 2) / 3 * 3 + O_LPAD : 0;
+}
+
+// The linear entries' records in the order the sweep reads them: orec[unit_ptr[u] + i * 8 + slot], one 64-byte line per
+// step of a wave.  {byte offset of the marker's row of moments, byte offset of the entry's {A, B, 2B}}.
+__global__ void __launch_bounds__(256)
+    oct_repack_kernel(int n_units, int n_chunks, const row_chunk* __restrict__ chunks, const int32_t* __restrict__ order,
+                      const int32_t* __restrict__ nlin, const quad_lrec* __restrict__ lrec,
+                      const int32_t* __restrict__ steps, const int64_t* __restrict__ unit_ptr, uint32_t S_dummy,
+                      uint2* __restrict__ orec) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int u = t / O_SLOTS, slot = t % O_SLOTS;
+  if (u >= n_units) return;
+  const int w = u * O_SLOTS + slot;
+  int64_t e0 = 0;
+  int nl = 0;
+  if (w < n_chunks) {
+    const int q = order[w];
+    e0 = chunks[q].e0;
+    nl = nlin[q];
+  }
+  uint2* dst = orec + unit_ptr[u] + slot;
+  const int n = steps[u];
+  for (int i = 0; i < n; ++i) {
+    uint2 r{S_dummy * 256u, (uint32_t)(O_NLUT - 1) * 32u};
+    if (i < nl) {
+      const quad_lrec x = lrec[e0 + i];
+      const uint32_t idx = x.code == MUXGL_READ_OTHER ? (uint32_t)(O_NLUT - 1) : ((x.code >> 7) << 6) | (x.code & 0x3fu);
+      r = uint2{(uint32_t)x.snp * 256u, idx * 32u};
+    }
+    dst[(size_t)i * O_SLOTS] = r;
+  }
+}
+
 // accumulator index layout of a lane (own samples a = p, b = p + 8; partner at rotation t: a' = p_t, b' = p_t + 8)
 __host__ __device__ constexpr int o_acc_single(int c) { return c; }              // c = 0: a, 1: b
 constexpr int O_ACC_AB = 2;                                                       // (a, b)
@@ -130,13 +182,14 @@ constexpr int O_ACC_F_AB = 15, O_ACC_F_AA = 16, O_ACC_F_BB = 17;                
 // The sweep kernel.  Lane = 16 g + 2 p + h: slot 2 g + h of the wave (one chunk), position p (samples p, p + 8).
 __global__ void __launch_bounds__(64, 3)
     demux_oct_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
-                     const quad_lrec* __restrict__ qlrec, const int32_t* __restrict__ chunk_nlin,
+                     const uint2* __restrict__ orec, const int64_t* __restrict__ unit_ptr,
+                     const int32_t* __restrict__ chunk_nlin,
                      const int32_t* __restrict__ order, const uint8_t* __restrict__ reads,
                      const double* __restrict__ gpo, const double* __restrict__ gmo,
                      const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
                      double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
-  __shared__ __align__(16) double ablut[256 * 2];
+  __shared__ __align__(16) double ablut[O_NLUT * 4];
   __shared__ __align__(16) double pgs[O_SLOTS * O_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
 
@@ -144,11 +197,12 @@ __global__ void __launch_bounds__(64, 3)
   const int p = (lane >> 1) & 7;                    // position: samples p and p + 8
   const int slot = ((lane >> 4) << 1) | (lane & 1);  // 8 entry streams per wave
   for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
-  // (A, B) of a linear entry by the read byte that counts (quad_lrec::code): the one factor pR + (pA - pR) p of
-  // :673,685 through the tail (q / q_max + 1e-10) / (1 + 1e-10) of :703-725; q0[l] = A + 2B l, q1[l+m] = A + B (l+m)
-  for (int i = lane; i < 256; i += 64) {
-    const uint32_t bq = (uint32_t)i & 0x7f;
-    const bool ref = (i >> 7) == 0;
+  // {A, B, 2B} of a linear entry by the read byte that counts (allele << 6 | base quality; O_NLUT - 1: none): the one
+  // factor pR + (pA - pR) p of :673,685 through the tail (q / q_max + 1e-10) / (1 + 1e-10) of :703-725;
+  // q0[l] = A + 2B l, q1[l+m] = A + B (l+m)
+  for (int i = lane; i < O_NLUT; i += 64) {
+    const uint32_t bq = (uint32_t)i & 0x3f;
+    const bool ref = (i >> 6) == 0;
     const double e3 = lut_g[256 + bq], mt = lut_g[128 + bq];
     const double pR = ref ? mt : e3, pA = ref ? e3 : mt;  // :666-667
     const double mx = fmax(pR, pA);
@@ -157,12 +211,18 @@ __global__ void __launch_bounds__(64, 3)
     x = fma(x, fma(-mx, x, 1.0), x);
     const double cc = 1.0 / (1.0 + 1e-10);
     const double sc = cc * x, tt = 1e-10 * cc;
-    const bool none = i == MUXGL_READ_OTHER;  // no usable read / no genotypes: factors of exactly 1
-    ablut[2 * i] = none ? 1.0 : fma(pR, sc, tt);
-    ablut[2 * i + 1] = none ? 0.0 : (pA - pR) * (0.25 * sc);
+    const bool none = i == O_NLUT - 1;  // no usable read / no genotypes: factors of exactly 1
+    const double B = none ? 0.0 : (pA - pR) * (0.25 * sc);
+    ablut[4 * i] = none ? 1.0 : fma(pR, sc, tt);
+    ablut[4 * i + 1] = B;
+    ablut[4 * i + 2] = B + B;
+    ablut[4 * i + 3] = 0.0;
   }
+  __syncthreads();  // the tables are complete
 
-  const int wq = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * O_SLOTS + slot;  // place in the launch order
+  const int unit = xcd_swizzle(blockIdx.x, gridDim.x >> 3);  // eight chunks that are neighbours in the launch order
+  const int wq = unit * O_SLOTS + slot;
+  const uint32_t p16 = (uint32_t)p * 16u;
   const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
   int64_t e0 = 0;
   int len = 0;
@@ -212,23 +272,42 @@ __global__ void __launch_bounds__(64, 3)
     struct rowl_t {
       double sa, ra, sb, rb;  // (s, rho) of samples p and p + 8
     };
-    auto load_rowl = [&](rowl_t& R, int32_t sidx) {
-      const double2* pc = reinterpret_cast<const double2*>(gmo + (size_t)sidx * 32) + p;
+    auto load_rowl = [&](rowl_t& R, uint32_t row_off) {
+      if (OCT_EXP & 16) {  // (experiment) no row loads
+        R.sa = R.sb = 1.0;
+        R.ra = 1e-9 * (double)(row_off & 1023u);
+        R.rb = 2e-9 * (double)(row_off & 1023u);
+        return;
+      }
+      if (OCT_EXP & 64) row_off &= 0xFF00u;  // (experiment) 256 hot rows
+      const double2* pc = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gmo) + (size_t)(row_off + p16));
       const double2 va = pc[0], vb = pc[8];
       R.sa = va.x;
       R.ra = va.y;
       R.sb = vb.x;
       R.rb = vb.y;
     };
-    const int2* lr = reinterpret_cast<const int2*>(qlrec + e0);
-    auto settle = [&](int2& rc, int i) {  // a record behind the end of the slot's list: neutral
-      const bool in = i < nl;
-      rc.x = in ? rc.x : S_dummy;
-      rc.y = in ? rc.y : (int)MUXGL_READ_OTHER;
+    // records of the unit, step-major: step i of the wave reads orec[i][slot] = {byte offset of the marker's row of
+    // moments, byte offset of the entry's {A, B, 2B}}; a slot whose list has ended finds neutral records (the dummy
+    // row, the table's neutral entry: every factor exactly 1), O_LPAD steps of them behind the longest list
+    const uint2* lr = orec + unit_ptr[unit] + slot;
+    struct ab_t {
+      double A, B, B2;
     };
-    auto ab_of = [&](const int2& rc) { return *reinterpret_cast<const double2*>(ablut + 2 * rc.y); };
-    auto sweepL = [&](const rowl_t& R, const double2& ab) {
-      const double A = ab.x, B = ab.y, B2 = B + B;
+    auto ab_of = [&](const uint2& rc) {
+      const double* t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ablut) + rc.y);
+      const double2 v = *reinterpret_cast<const double2*>(t);
+      return ab_t{v.x, v.y, t[2]};
+    };
+    auto sweepL = [&](const rowl_t& R, const ab_t& ab) {
+      const double A = ab.A, B = ab.B, B2 = ab.B2;
+      if (OCT_EXP & 128) {  // (experiment) the loads with next to no arithmetic
+        accW[0] *= R.sa;
+        accW[1] *= R.sb;
+        acc[0] *= fma(B2, R.ra, A);
+        acc[1] *= fma(B2, R.rb, A);
+        return;
+      }
       accW[0] *= R.sa;
       accW[1] *= R.sb;
       acc[o_acc_single(0)] *= fma(B2, R.ra, A);  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
@@ -263,11 +342,14 @@ __global__ void __launch_bounds__(64, 3)
         acc[O_ACC_F_BB] *= fma(B, Pb, Xb);
       }
     };
-    // entry i: its row in Rc and (A, B) in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
-    auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const double2& abc, double2& abn, int2& rc0, const int2& rc1,
-                    int2& rc2) {
-      rc0 = lr[i + 3];
-      settle(rc2, i + 2);
+    // entry i: its row in Rc and {A, B, 2B} in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
+    auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const ab_t& abc, ab_t& abn, uint2& rc0, const uint2& rc1,
+                    const uint2& rc2) {
+      if (OCT_EXP & 32) {  // (experiment) no record loads: a cheap pseudo-random record
+        rc0.x = (rc0.x * 1664525u + 1013904223u) & 0x00FFFF00u;
+      } else {
+        rc0 = lr[(i + 3) * O_SLOTS];
+      }
       load_rowl(Rnn, rc2.x);
       abn = ab_of(rc1);
       __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
@@ -275,20 +357,19 @@ __global__ void __launch_bounds__(64, 3)
       __builtin_amdgcn_sched_barrier(0);
     };
     rowl_t L0, L1, L2;
-    double2 ab0, ab1, ab2;
-    int2 ra = lr[0], rb = lr[1], rc = lr[2];
-    settle(ra, 0);
-    settle(rb, 1);
+    ab_t ab0, ab1, ab2;
+    uint2 ra = lr[0], rb = lr[O_SLOTS], rc = lr[2 * O_SLOTS];
     load_rowl(L0, ra.x);
     load_rowl(L1, rb.x);
-    __syncthreads();  // ablut is complete
     ab0 = ab_of(ra);
     int since = 0;
     for (int i = 0; i < nLmax; i += 3) {  // (up to two neutral entries behind the longest list of the wave)
       step(i, L0, L2, ab0, ab1, ra, rb, rc);
       step(i + 1, L1, L0, ab1, ab2, rb, rc, ra);
       step(i + 2, L2, L1, ab2, ab0, rc, ra, rb);
-      if (++since == 5) {  // 15 entries per slot since the last renormalisation
+      // a factor of a linear entry is > 2^-23 (one read of quality <= 60, lin_kernel): 30 of them between two
+      // renormalisations cannot underflow
+      if (++since == 10) {
         since = 0;
         renorm();
       }
@@ -759,6 +840,7 @@ int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t*
 // returns -1 when the path does not apply, 0 ok, 1 error
 int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (h->V > 16 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
+  if (h->S + 1 >= ((int64_t)1 << 24)) return -1;  // (row offsets of the linear entries' records are 32-bit byte offsets)
   if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL | MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;
   if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
   muxgl_row_state* st = h->qrow;
@@ -777,23 +859,56 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     st->part_e_cap = need;
   }
   const bool use_lin = h->d_lin && h->d_gmq && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+  const unsigned blocks = (unsigned)((((st->n_chunks + O_SLOTS - 1) / O_SLOTS) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup and GP tensor: every chunk's linear entries first
-    // (the sweep reads up to QL_SLACK records behind a chunk's list, unconditionally: slack behind the array)
+    quad_lrec* d_lrec = nullptr;  // chunk-major records, repacked below
+    int32_t* d_steps = nullptr;
+    auto cleanup = [&]() {
+      dev_free(&d_lrec);
+      dev_free(&d_steps);
+    };
     if (dev_alloc(h, &st->d_qent_lin, (size_t)h->nnz) || dev_alloc(h, &st->d_chunk_nlin, (size_t)st->n_chunks) ||
-        dev_alloc(h, &st->d_qlrec, (size_t)h->nnz + QL_SLACK))
+        dev_alloc(h, &d_lrec, (size_t)h->nnz)) {
+      cleanup();
       return 1;
-    HIPCHK(h, hipMemsetAsync(st->d_qlrec, 0xFF, sizeof(quad_lrec) * ((size_t)h->nnz + QL_SLACK), h->stream));
+    }
     hipLaunchKernelGGL(oct_partition_kernel, dim3((unsigned)((st->n_chunks + 63) / 64)), dim3(64), 0, h->stream,
                        (int)st->n_chunks, st->d_chunks, h->d_qent, h->d_lin, h->d_reads, h->d_gp0s, st->d_qent_lin,
-                       st->d_qlrec, st->d_chunk_nlin);
-    HIPCHK(h, hipGetLastError());
-    if (quad_launch_order(h, st->d_chunks, st->d_chunk_nlin, st->n_chunks, &st->d_quad_order)) return 1;
+                       d_lrec, st->d_chunk_nlin);
+    if (hipGetLastError() != hipSuccess || quad_launch_order(h, st->d_chunks, st->d_chunk_nlin, st->n_chunks, &st->d_quad_order)) {
+      cleanup();
+      MUXGL_FAIL(h, "demux_oct_launch: partition failed");
+    }
+    // the linear entries' records, step-major per unit (what the sweep streams)
+    const int n_units = (int)blocks;
+    std::vector<int32_t> steps((size_t)n_units);
+    std::vector<int64_t> uptr((size_t)n_units + 1, 0);
+    if (dev_alloc(h, &d_steps, (size_t)n_units)) {
+      cleanup();
+      return 1;
+    }
+    hipLaunchKernelGGL(oct_unit_steps_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, h->stream, n_units,
+                       (int)st->n_chunks, st->d_quad_order, st->d_chunk_nlin, d_steps);
+    hipError_t e = hipMemcpyAsync(steps.data(), d_steps, sizeof(int32_t) * (size_t)n_units, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    for (int u = 0; u < n_units; ++u) uptr[(size_t)u + 1] = uptr[(size_t)u] + (int64_t)steps[(size_t)u] * O_SLOTS;
+    if (e != hipSuccess || dev_alloc(h, &st->d_unit_ptr, uptr.size()) || dev_alloc(h, &st->d_orec, (size_t)uptr.back() + 1)) {
+      cleanup();
+      MUXGL_FAIL(h, "demux_oct_launch: record tables");
+    }
+    e = hipMemcpyAsync(st->d_unit_ptr, uptr.data(), sizeof(int64_t) * uptr.size(), hipMemcpyHostToDevice, h->stream);
+    hipLaunchKernelGGL(oct_repack_kernel, dim3((unsigned)(((size_t)n_units * O_SLOTS + 255) / 256)), dim3(256), 0, h->stream,
+                       n_units, (int)st->n_chunks, st->d_chunks, st->d_quad_order, st->d_chunk_nlin, d_lrec, d_steps,
+                       st->d_unit_ptr, (uint32_t)h->S, st->d_orec);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (uptr is a host buffer; d_lrec is freed)
+    cleanup();
+    if (e != hipSuccess) MUXGL_FAIL(h, "demux_oct_launch: %s", hipGetErrorString(e));
   }
   tic(h, MUXGL_T_DEMUX_SWEEP);
-  const unsigned blocks = (unsigned)((((st->n_chunks + O_SLOTS - 1) / O_SLOTS) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (blocks) {
     hipLaunchKernelGGL(demux_oct_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                       use_lin ? st->d_qent_lin : h->d_qent, st->d_qlrec,
+                       use_lin ? st->d_qent_lin : h->d_qent, st->d_orec, st->d_unit_ptr,
                        use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
                        use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
                        h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);

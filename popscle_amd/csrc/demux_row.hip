@@ -292,7 +292,8 @@ void demux_row_release(muxgl_row_state** pst) {
   dev_free(&st->d_part_e);
   dev_free(&st->d_qent_lin);
   dev_free(&st->d_chunk_nlin);
-  dev_free(&st->d_qlrec);
+  dev_free(&st->d_orec);
+  dev_free(&st->d_unit_ptr);
   dev_free(&st->d_quad_order);
   dev_free(&st->d_fq_lrec);
   dev_free(&st->d_fq_gsnp);

@@ -311,7 +311,8 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   if (h->qrow) {  // the oct kernel's partitioned records carry has_gp (quad_lrec::code): rebuilt on the next run
     dev_free(&h->qrow->d_qent_lin);
     dev_free(&h->qrow->d_chunk_nlin);
-    dev_free(&h->qrow->d_qlrec);
+    dev_free(&h->qrow->d_orec);
+    dev_free(&h->qrow->d_unit_ptr);
     dev_free(&h->qrow->d_quad_order);
   }
   if (V <= 16 && h->S > 0) {

@@ -227,7 +227,8 @@ int plan_build_lin(muxgl_handle* h) {
   if (h->qrow) {  // the quad kernel's records with the linear entries first: made from the bits, on first use
     dev_free(&h->qrow->d_qent_lin);
     dev_free(&h->qrow->d_chunk_nlin);
-    dev_free(&h->qrow->d_qlrec);
+    dev_free(&h->qrow->d_orec);
+    dev_free(&h->qrow->d_unit_ptr);
     dev_free(&h->qrow->d_quad_order);
   }
   if (h->nnz == 0) return 0;
