@@ -126,6 +126,7 @@ struct muxgl_handle {
   double* d_gp = nullptr;
   uint8_t* d_has_gp = nullptr;
   double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_oct.hip)
+  bool gp_unit_sums = false;  // V <= 16: every triple sums to 1 within 4 ulp; d_gpq / d_gmq then carry no sums (demux_oct.hip)
   double* d_gp0s = nullptr;  // V <= 16: per-SNP sum of sample 0's triple (the factor every singlet carries, :806)
   double* d_gmq = nullptr;   // V <= 16: moments (s, rho) of every triple in the quad layout, [S + 1][4][4][2] (demux_oct.hip)
   double* d_ll = nullptr;  // [C][V][V][A]

@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(256)
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_chunks) return;
   const int nl = chunk_nlin[w], len = chunks[w].len;
-  const uint64_t bg = (uint64_t)((len - nl + 3) >> 2), bl = (uint64_t)((nl + 3) >> 2);  // <= 32 each
-  key[w] = ((uint64_t)(w / bucket) << 36) | ((63u - bg) << 26) | ((63u - bl) << 20) | (uint64_t)(w % bucket);
+  const uint64_t bg = (uint64_t)(len - nl), bl = (uint64_t)nl;  // <= 128 each
+  key[w] = ((uint64_t)(w / bucket) << 40) | ((255u - bg) << 30) | ((255u - bl) << 20) | (uint64_t)(w % bucket);
   iota[w] = w;
 }
 
@@ -180,6 +180,14 @@ __host__ __device__ constexpr int o_acc_rot(int t, int c, int d) { return 3 + (t
 constexpr int O_ACC_F_AB = 15, O_ACC_F_AA = 16, O_ACC_F_BB = 17;                  // t = 4: (a, b'), (a, a'), (b, b')
 
 // The sweep kernel.  Lane = 16 g + 2 p + h: slot 2 g + h of the wave (one chunk), position p (samples p, p + 8).
+// UNIT_S: every triple of the GP tensor sums to 1 within 4 ulp (muxgl_demux_set_gp checks; hard calls through the
+// reference's error mixing do, sc_drop_seq.cpp:287-315).  The rows of moments then carry no sums -- rho alone, 128
+// bytes per marker: ONE line per linear entry -- and the products of sums (accW, accH) are 1.  The sweep is bound by
+// the bytes its row gathers move (see the file header), so this halves the linear entries' cost; each factor changes
+// by <= 8 ulp.  (Rows of triples stay whole: g0 = 1 - g1 - g2 has an absolute error of an ulp of 1, which is a
+// relative error of 1e-4 where a genotype no sample carries has probability 0.1 * 1e-10 / V after the mixing -- tried,
+// and caught by the test with qualities up to 93.)
+template <bool UNIT_S>
 __global__ void __launch_bounds__(64, 3)
     demux_oct_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
                      const uint2* __restrict__ orec, const int64_t* __restrict__ unit_ptr,
@@ -235,7 +243,8 @@ __global__ void __launch_bounds__(64, 3)
   // run of either kind among its chunks.
   const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
   const int nLmax = (OCT_EXP & 2) ? 0 : wave_max_i32(nl);
-  const int nb = (OCT_EXP & 1) ? 0 : (wave_max_i32(len - nl) + O_BATCH - 1) / O_BATCH;
+  const int ngmax = (OCT_EXP & 1) ? 0 : wave_max_i32(len - nl);
+  const int nb = (ngmax + O_BATCH - 1) / O_BATCH;
 
   double acc[ON_ACC];
   int32_t exs[ON_ACC];
@@ -273,13 +282,13 @@ __global__ void __launch_bounds__(64, 3)
       double sa, ra, sb, rb;  // (s, rho) of samples p and p + 8
     };
     auto load_rowl = [&](rowl_t& R, uint32_t row_off) {
-      if (OCT_EXP & 16) {  // (experiment) no row loads
+      if (UNIT_S) {  // rows of 16 x rho, (rho_p, rho_p+8) adjacent: [8][2]
+        const double2 v = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gmo) + (size_t)((row_off >> 1) + p16));
         R.sa = R.sb = 1.0;
-        R.ra = 1e-9 * (double)(row_off & 1023u);
-        R.rb = 2e-9 * (double)(row_off & 1023u);
+        R.ra = v.x;
+        R.rb = v.y;
         return;
       }
-      if (OCT_EXP & 64) row_off &= 0xFF00u;  // (experiment) 256 hot rows
       const double2* pc = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gmo) + (size_t)(row_off + p16));
       const double2 va = pc[0], vb = pc[8];
       R.sa = va.x;
@@ -308,8 +317,10 @@ __global__ void __launch_bounds__(64, 3)
         acc[1] *= fma(B2, R.rb, A);
         return;
       }
-      accW[0] *= R.sa;
-      accW[1] *= R.sb;
+      if (!UNIT_S) {
+        accW[0] *= R.sa;
+        accW[1] *= R.sb;
+      }
       acc[o_acc_single(0)] *= fma(B2, R.ra, A);  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
       acc[o_acc_single(1)] *= fma(B2, R.rb, A);
       const double Xa = fma(B, R.ra, A), Xb = fma(B, R.rb, A);
@@ -396,9 +407,9 @@ __global__ void __launch_bounds__(64, 3)
       double a[3], b[3];  // triples of samples p and p + 8
     };
     auto load_row = [&](row_t& R, int32_t s) {
-      // three 16-byte pieces of this lane's 6 doubles; piece t of the entry's eight lanes is 128 contiguous bytes.  Rows
-      // of padding entries and of markers without genotypes are (1,0,0) -- the dummy row S_dummy resp. the host's fill
-      // -- which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1 (:733).
+      // 16-byte pieces of this lane's doubles; a piece of the entry's eight lanes is 128 contiguous bytes.  Rows of
+      // padding entries and of markers without genotypes are (1,0,0) -- the dummy row S_dummy resp. the host's fill --
+      // which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1 (:733).
       const double2* pc = reinterpret_cast<const double2*>(gpo + (size_t)s * 48) + p;
       const double2 v0 = pc[0], v1 = pc[8], v2 = pc[16];
       R.a[0] = v0.x;
@@ -526,7 +537,7 @@ __global__ void __launch_bounds__(64, 3)
       const double* qq = pgs + slot * O_SLOT_STRIDE + i * 8;
       const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
       const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
-      accH *= pgs[slot * O_SLOT_STRIDE + 64 + i];
+      if (!UNIT_S) accH *= pgs[slot * O_SLOT_STRIDE + 64 + i];
       // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
       acc[o_acc_single(0)] *= fma(R.a[2], a2, fma(R.a[1], a1, R.a[0] * a0));
       acc[o_acc_single(1)] *= fma(R.b[2], a2, fma(R.b[1], a1, R.b[0] * a0));
@@ -584,15 +595,19 @@ __global__ void __launch_bounds__(64, 3)
   load_row(LD, SRC);                         \
   __builtin_amdgcn_sched_barrier(0);         \
   sweep_entry(SW, I);                        \
-  __builtin_amdgcn_sched_barrier(0);
-      OCT_E(Z, sn[2], X, 0)
-      OCT_E(X, sn[3], Y, 1)
-      OCT_E(Y, sn[4], Z, 2)
-      OCT_E(Z, sn[5], X, 3)
-      OCT_E(X, sn[6], Y, 4)
-      OCT_E(Y, sn[7], Z, 5)
-      OCT_E(Z, sx[0], X, 6)
-      OCT_E(X, sx[1], Y, 7)
+  __builtin_amdgcn_sched_barrier(0);         \
+  if (lim <= I + 1) break;
+      const int lim = (b == nb - 1) ? ngmax - b * O_BATCH : O_BATCH;  // the last batch ends with the longest list
+      do {
+        OCT_E(Z, sn[2], X, 0)
+        OCT_E(X, sn[3], Y, 1)
+        OCT_E(Y, sn[4], Z, 2)
+        OCT_E(Z, sn[5], X, 3)
+        OCT_E(X, sn[6], Y, 4)
+        OCT_E(Y, sn[7], Z, 5)
+        OCT_E(Z, sx[0], X, 6)
+        OCT_E(X, sx[1], Y, 7)
+      } while (false);
 #undef OCT_E
       if (b & 1) renorm();  // 16 entries per slot since the last renormalisation
       __syncthreads();
@@ -907,7 +922,8 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   tic(h, MUXGL_T_DEMUX_SWEEP);
   if (blocks) {
-    hipLaunchKernelGGL(demux_oct_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
+    hipLaunchKernelGGL(h->gp_unit_sums ? demux_oct_kernel<true> : demux_oct_kernel<false>, dim3(blocks), dim3(64), 0,
+                       h->stream, st->d_chunks, (int)st->n_chunks,
                        use_lin ? st->d_qent_lin : h->d_qent, st->d_orec, st->d_unit_ptr,
                        use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
                        use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
