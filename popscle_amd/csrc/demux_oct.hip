@@ -775,8 +775,11 @@ __global__ void __launch_bounds__(192)
 // sixteen lanes per cell in wave 0: no LL tensor round trip through HBM, one launch less, and the 160-byte records go
 // straight to the caller's pinned host buffer (16-byte stores of consecutive lanes), which removes the separate
 // device-to-host copy.
-constexpr int QF_CELLS = 4;
-__global__ void __launch_bounds__(256)
+#ifndef QF_CELLS_N
+#define QF_CELLS_N 4
+#endif
+constexpr int QF_CELLS = QF_CELLS_N;
+__global__ void __launch_bounds__(64 * QF_CELLS)
     demux_oct_finish_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, const int64_t* __restrict__ cell_chunk_ptr,
                             const int32_t* __restrict__ cell_chunks, const double* __restrict__ part_m,
                             const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
@@ -786,9 +789,9 @@ __global__ void __launch_bounds__(256)
   static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
   const int64_t cbase = (int64_t)blockIdx.x * QF_CELLS;
   const int tid = threadIdx.x;
-  for (int t = tid; t < QF_CELLS * 512; t += 256) (&llt[0][0])[t] = 0.0;
+  for (int t = tid; t < QF_CELLS * 512; t += 64 * QF_CELLS) (&llt[0][0])[t] = 0.0;
   __syncthreads();
-  for (int w = tid; w < QF_CELLS * O_NHYP; w += 256) {
+  for (int w = tid; w < QF_CELLS * O_NHYP; w += 64 * QF_CELLS) {
     const int lc = w / O_NHYP, idx = w - lc * O_NHYP;
     const int64_t c = cbase + lc;
     if (c >= C) break;
@@ -805,7 +808,7 @@ __global__ void __launch_bounds__(256)
     }
   }
   __syncthreads();
-  if (tid < 64) {
+  if (tid < 16 * QF_CELLS) {
     const int lc = tid >> 4;
     const int64_t c = cbase + lc;
     const bool ok = c < C;
@@ -938,7 +941,7 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   } else {  // reduce + call fused, records written to the pinned host buffer
     muxgl_call::call_alpha al;
     for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
-    hipLaunchKernelGGL(demux_oct_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(256), 0,
+    hipLaunchKernelGGL(demux_oct_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(64 * QF_CELLS), 0,
                        h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
                        p->doublet_prior, h->h_dcells);
     h->records_on_host = true;
