@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MUXGL_VERSION 2
+#define MUXGL_VERSION 3
 #define MUXGL_READ_OTHER 0xFF
 #define MUXGL_MAX_ALPHA 16
 #define MUXGL_MAX_DEVICES 16
@@ -69,11 +69,14 @@ typedef struct muxgl_handle muxgl_handle;
  * several workers is the same cut at file level (--group-list, README.md:168; sc_drop_seq.cpp:93-101,164-170).  A
  * device may be named more than once (virtual ranks on one GPU: tests). */
 typedef struct {
+  int32_t struct_size; /* sizeof(muxgl_config) of the header the caller was built against (MUXGL_CONFIG_INIT sets it):
+                          muxgl_create rejects any other value instead of reading past a shorter struct */
   int32_t device_id; /* HIP device ordinal this handle runs on (n_devices == 0) */
   int32_t flags;     /* MUXGL_FLAG_* bits, normally 0 */
   int32_t n_devices; /* 0: device_id; >= 1: device_ids[0 .. n_devices) */
   int32_t device_ids[MUXGL_MAX_DEVICES];
 } muxgl_config;
+#define MUXGL_CONFIG_INIT {(int32_t)sizeof(muxgl_config), 0, 0, 0, {0}}
 
 /* demuxlet parameters: --alpha grid and --doublet-prior (cmd_cram_demuxlet.cpp:32,62-63,85-89) */
 typedef struct {

@@ -107,7 +107,9 @@ __global__ void __launch_bounds__(256)
     // cap, a second read) keeps the entry on the general path.
     {
       const double c0 = gls[0], c1 = gls[1] - gls[0];
-      const double tol = 1e-14 * fmax(gls[0], gls[8]);  // a few roundings apart at most; 1e-14 per factor is 1e-11 per cell
+      // a few roundings apart at most, measured at the SMALL end of the line (a value moved by the 1e-6 clamp must not
+      // pass as a point of the line: 1e-14 of the maximum would be 1e-7 of a minimum that is 1e-7 of it)
+      const double tol = fmin(1e-14 * fmax(gls[0], gls[8]), 1e-9 * fmin(gls[0], gls[8]));
       linear = nref + nalt <= 1 && fabs(gls[2] - fma(2.0, c1, c0)) <= tol && fabs(gls[5] - fma(3.0, c1, c0)) <= tol &&
                fabs(gls[8] - fma(4.0, c1, c0)) <= tol && gls[3] == gls[1] && gls[6] == gls[2] && gls[4] == gls[2] &&
                gls[7] == gls[5] &&

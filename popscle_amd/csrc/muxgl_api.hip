@@ -214,6 +214,11 @@ int muxgl_create(const muxgl_config* cfg, muxgl_handle** out) {
     return 1;
   }
   *out = nullptr;
+  if (cfg && cfg->struct_size != (int32_t)sizeof(muxgl_config)) {
+    g_muxgl_create_error = "muxgl_create: muxgl_config.struct_size is not sizeof(muxgl_config) of this library (MUXGL_VERSION " +
+                           std::to_string(MUXGL_VERSION) + "): initialise the struct with MUXGL_CONFIG_INIT";
+    return 1;
+  }
   if (cfg && (cfg->n_devices < 0 || cfg->n_devices > MUXGL_MAX_DEVICES)) {
     g_muxgl_create_error = "muxgl_create: n_devices outside [0, MUXGL_MAX_DEVICES]";
     return 1;

@@ -46,6 +46,9 @@ class TorchExchange:
         """tensor: [>= world*per, row]; rank r owns rows [r*per, (r+1)*per).  One collective, in place."""
         if per <= 0:
             return
+        if self.world * per > tensor.shape[0]:  # slices of ceil(n / world) units overrun the buffer's XCHG_PAD slack
+            raise ValueError(f"in-place all-gather of {self.world} x {per} rows needs {self.world * per} rows, the exchange "
+                             f"buffer has {tensor.shape[0]} (slack of muxgl.XCHG_PAD = 64 units: at most 65 ranks)")
         out = tensor[: self.world * per]
         inp = tensor[self.rank * per:(self.rank + 1) * per]
         self.dist.all_gather_into_tensor(out, inp)

@@ -41,8 +41,7 @@ struct CommonFlags {
   }
   // the handle the command computes on: one device, or the group named by --devices
   muxgl_config config(int32_t flags) const {
-    muxgl_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
+    muxgl_config cfg = MUXGL_CONFIG_INIT;
     cfg.device_id = device;
     cfg.flags = flags;
     if (!devices.empty()) {
@@ -322,13 +321,28 @@ int cmd_freemuxlet(int argc, char** argv) {
 
   muxgl_config cfg = cf.config(0);
   muxgl_handle* h = nullptr;
-  if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
-  upload(h, p);
   std::vector<double> af((size_t)S), llk0((size_t)C), llk2((size_t)C);
   std::vector<int32_t> nSNPs((size_t)C), nReads((size_t)C);
   for (int64_t s = 0; s < S; ++s) af[(size_t)s] = p.snps[(size_t)s].af;
-  tmr.lap("freemuxlet: device init+hand-over");
-  check(h, muxgl_fmx_prepare(h, af.data(), llk0.data(), llk2.data(), nSNPs.data(), nReads.data()), "muxgl_fmx_prepare");
+  // A device group with a greedy start: the greedy procedure is sequential over all cells, each step scoring one cell
+  // against the cluster pileups of all earlier ones, so it runs on ONE device holding the whole pileup (the group's
+  // first) -- BEFORE the group exists, so that this device never holds the whole pileup next to its slabs.  The scores
+  // it starts from (muxgl_fmx_prepare) are the same numbers on either kind of handle.
+  const bool greedy_first = cf.grouped() && initClusterFile.empty();
+  muxgl_handle* g = nullptr;
+  if (greedy_first) {
+    muxgl_config one = MUXGL_CONFIG_INIT;
+    one.device_id = cfg.device_ids[0];
+    if (muxgl_create(&one, &g) != 0) fatal("%s", muxgl_last_error(nullptr));
+    upload(g, p);
+    tmr.lap("freemuxlet: device init+hand-over (one device, for the greedy start)");
+    check(g, muxgl_fmx_prepare(g, af.data(), llk0.data(), llk2.data(), nSNPs.data(), nReads.data()), "muxgl_fmx_prepare");
+  } else {
+    if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
+    upload(h, p);
+    tmr.lap("freemuxlet: device init+hand-over");
+    check(h, muxgl_fmx_prepare(h, af.data(), llk0.data(), llk2.data(), nSNPs.data(), nReads.data()), "muxgl_fmx_prepare");
+  }
   tmr.lap("freemuxlet: muxgl_fmx_prepare");
 
   std::vector<double> scores((size_t)C);
@@ -359,22 +373,18 @@ int cmd_freemuxlet(int argc, char** argv) {
       else clusts[(size_t)i] = it->second;
     }
     if (nmiss > 0) notice("WARNING: %d of %d droplets do not have initial cluster assignment", nmiss, (int)C);
-  } else if (!cf.grouped()) {  // greedy clustering, :217-261
+  } else if (!greedy_first) {  // greedy clustering, :217-261
     check(h, muxgl_fmx_greedy_init(h, K, scores.data(), fracInitClust, singletScoreThres, clusts.data()),
           "muxgl_fmx_greedy_init");
-  } else {
-    // The greedy procedure is sequential over all cells, each step scoring one cell against the cluster pileups of
-    // all earlier ones: it runs on ONE device holding the whole pileup (the group's first), then the group takes over.
-    muxgl_config one;
-    memset(&one, 0, sizeof(one));
-    one.device_id = cfg.device_ids[0];
-    muxgl_handle* g = nullptr;
-    if (muxgl_create(&one, &g) != 0) fatal("%s", muxgl_last_error(nullptr));
-    upload(g, p);
-    check(g, muxgl_fmx_prepare(g, af.data(), nullptr, nullptr, nullptr, nullptr), "muxgl_fmx_prepare");
+  } else {  // on the one-device handle; then the group is made and takes over
     check(g, muxgl_fmx_greedy_init(g, K, scores.data(), fracInitClust, singletScoreThres, clusts.data()),
           "muxgl_fmx_greedy_init");
     muxgl_destroy(g);
+    g = nullptr;
+    if (muxgl_create(&cfg, &h) != 0) fatal("%s", muxgl_last_error(nullptr));
+    upload(h, p);
+    check(h, muxgl_fmx_prepare(h, af.data(), nullptr, nullptr, nullptr, nullptr), "muxgl_fmx_prepare");
+    tmr.lap("freemuxlet: device group init+hand-over");
   }
   tmr.lap("freemuxlet: .lmix + initial clusters");
   notice("Finished assigning initial identity of the cluster..");

@@ -58,7 +58,7 @@ assert FMX_CELL.itemsize == 12 * 4 + 10 * 8
 
 
 class _Config(C.Structure):
-    _fields_ = [("device_id", C.c_int32), ("flags", C.c_int32), ("n_devices", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32), ("device_id", C.c_int32), ("flags", C.c_int32), ("n_devices", C.c_int32),
                 ("device_ids", C.c_int32 * MAX_DEVICES)]
 
 
@@ -151,6 +151,7 @@ class Engine:
         self.lib = load_library()
         self.h = _VP()
         cfg = _Config()
+        cfg.struct_size = C.sizeof(_Config)
         cfg.flags = flags
         if isinstance(device_id, (list, tuple)):
             if not 1 <= len(device_id) <= MAX_DEVICES:

@@ -39,7 +39,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_version(lib):
-    assert lib.muxgl_version() == 2
+    assert lib.muxgl_version() == 3
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -52,6 +52,8 @@ def test_struct_layouts_match_header(tmp_path):
         'printf("%zu %zu %zu\\n", offsetof(muxgl_demux_cell, sngBestLLK), offsetof(muxgl_demux_cell, sngOnlyPP), offsetof(muxgl_fmx_cell, bestLLK));\n'
         'printf("%zu %zu\\n", offsetof(muxgl_demux_params, alpha), offsetof(muxgl_demux_params, doublet_prior));\n'
         'printf("%zu %zu %zu\\n", sizeof(muxgl_config), offsetof(muxgl_config, n_devices), offsetof(muxgl_config, device_ids));\n'
+        'muxgl_config c = MUXGL_CONFIG_INIT;\n'
+        'printf("%d %zu %zu\\n", (int)c.struct_size, offsetof(muxgl_config, struct_size), offsetof(muxgl_config, device_id));\n'
         "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -68,6 +70,17 @@ def test_struct_layouts_match_header(tmp_path):
     assert vals[8] == muxgl._DemuxParams.doublet_prior.offset
     assert vals[9] == ctypes.sizeof(muxgl._Config)
     assert vals[10] == muxgl._Config.n_devices.offset and vals[11] == muxgl._Config.device_ids.offset
+    # the struct names its own size first, so that a caller built against another header is rejected, not misread
+    assert vals[12] == vals[9] and vals[13] == 0 == muxgl._Config.struct_size.offset
+    assert vals[14] == muxgl._Config.device_id.offset
+
+
+def test_create_rejects_a_config_of_another_size(lib):
+    cfg = muxgl._Config()
+    cfg.struct_size = 8  # what a caller built against MUXGL_VERSION 1 would pass
+    h = ctypes.c_void_p()
+    assert lib.muxgl_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"struct_size" in lib.muxgl_last_error(None)
 
 
 def test_oracle_and_library_records_share_a_layout():
