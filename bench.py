@@ -401,10 +401,11 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
         eng.demux_run(alphas, 0.5, want_cells=False)
     ctx.barrier()
     kern_ms = np.zeros(muxgl.T_COUNT)
+    tbuf = np.zeros(muxgl.T_COUNT, dtype=np.float32)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.demux_run(alphas, 0.5, want_cells=False)
-        kern_ms += eng.timing()
+        kern_ms += eng.timing(tbuf)  # hipEvent times of this pass (the live kernel durations of the roofline)
     ctx.barrier()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
     total_cells, total_entries = ctx.sum_over_ranks([p.C, p.nnz])

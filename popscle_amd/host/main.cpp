@@ -5,6 +5,7 @@
 //   popscle-amd freemuxlet --plp P --nsample K --out O [...]                   mirrors cmdCramFreemux2 (cmd_cram_freemux2.cpp)
 //   popscle-amd freemuxlet-old --plp P --nsample K --out O [...]               mirrors cmdCramFreemuxlet (cmd_cram_freemuxlet.cpp)
 //   popscle-amd dump-plp   --plp P [--vcf V --field F] --out FILE              loader only: packed pileup to a binary file
+//   popscle-amd synth-plp  --cells C --snps S --samples V --out P              a synthetic data set in the real file formats
 //
 // Everything here is host plumbing: flag surface, loaders (plp.hpp, vcf.hpp), the sequential control flow of
 // the reference commands, and the text writers with the reference's printf formats.  All arithmetic of the path is
@@ -12,6 +13,7 @@
 #include <cmath>
 
 #include "plp.hpp"
+#include "synthplp.hpp"
 
 using namespace pa;
 
@@ -757,6 +759,7 @@ int main(int argc, char** argv) {
     if (cmd == "freemuxlet-old") return cmd_freemuxlet_old(argc - 2, argv + 2);
     if (cmd == "dump-plp") return cmd_dump_plp(argc - 2, argv + 2);
     if (cmd == "bgzf") return cmd_bgzf(argc - 2, argv + 2);
+    if (cmd == "synth-plp") return cmd_synth_plp(argc - 2, argv + 2);
     fprintf(stderr, "Cannot recognize the command %s\n", argv[1]);
     return 1;
   } catch (const std::exception&) {

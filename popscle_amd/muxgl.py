@@ -235,13 +235,17 @@ class Engine:
         self.V = gp.shape[1]
 
     def demux_run(self, alphas=(0.0, 0.5), doublet_prior=0.5, want_cells=True, want_full_ll=False):
-        p = _DemuxParams()
-        p.n_alpha = len(alphas)
-        if len(alphas) > MAX_ALPHA:
-            raise ValueError("too many alphas")
-        for i, a in enumerate(alphas):
-            p.alpha[i] = float(a)
-        p.doublet_prior = float(doublet_prior)
+        key = (tuple(alphas), float(doublet_prior))
+        if getattr(self, "_dp_key", None) != key:  # (the struct of the last call is kept: a tight loop re-uses it)
+            if len(alphas) > MAX_ALPHA:
+                raise ValueError("too many alphas")
+            p = _DemuxParams()
+            p.n_alpha = len(alphas)
+            for i, a in enumerate(alphas):
+                p.alpha[i] = float(a)
+            p.doublet_prior = float(doublet_prior)
+            self._dp, self._dp_key = p, key
+        p = self._dp
         out = np.zeros(self.C, dtype=DEMUX_CELL) if want_cells else None
         full = np.zeros((self.C, self.V, self.V, len(alphas)), dtype=np.float64) if want_full_ll else None
         self._check(self.lib.muxgl_demux_run(self.h, C.byref(p), _ptr(out), _ptr(full)))
@@ -378,7 +382,8 @@ class Engine:
         return gls, cnt
 
     # ---- measurement
-    def timing(self):
-        ms = np.zeros(T_COUNT, dtype=np.float32)
+    def timing(self, out=None):
+        """kernel times of the last run / iterate call, ms (out: a float32[T_COUNT] array to fill instead of a new one)"""
+        ms = np.zeros(T_COUNT, dtype=np.float32) if out is None else out
         self._check(self.lib.muxgl_get_timing(self.h, _ptr(ms)))
         return ms

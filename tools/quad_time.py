@@ -19,9 +19,12 @@ eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
 eng.demux_set_gp(p.gp, p.has_gp)
 for _ in range(n // 2):
     eng.demux_run(cfg["alphas"], 0.5, want_cells=False)
+import time
 ms = np.zeros(muxgl.T_COUNT)
+t0 = time.perf_counter()
 for _ in range(n):
     eng.demux_run(cfg["alphas"], 0.5, want_cells=False)
     ms += eng.timing()
+wall = (time.perf_counter() - t0) / n * 1e3
 ms /= n
-print(f"{os.environ.get('MUXGL_LIB', 'default')[-28:]:28s} sweep {ms[muxgl.T_DEMUX_SWEEP]:.4f} ms  finish {ms[muxgl.T_DEMUX_REDUCE]:.4f} ms")
+print(f"wall {wall:.4f} ms/step  {os.environ.get('MUXGL_LIB', 'default')[-28:]:28s} sweep {ms[muxgl.T_DEMUX_SWEEP]:.4f} ms  finish {ms[muxgl.T_DEMUX_REDUCE]:.4f} ms")
