@@ -78,6 +78,9 @@ def compare_demux(got, want, alphas, tol=LL_TOL, tie_eps=1e-7, want_full=None):
     tie_s = np.abs(w["sngBestLLK"] - w["sngNextLLK"]) < tie_eps
     bad = (g["sBest"] != w["sBest"]) & ~tie_s
     assert not bad.any(), f"sBest differs in {int(bad.sum())} cells"
+    # how often each relaxation of "exact" was actually USED (a difference that only a tie or the canonical pair order
+    # excuses): reported so that full-size runs can bound them
+    used = {"singlet_tie": int(((g["sBest"] != w["sBest"]) | (g["sNext"] != w["sNext"])).sum())}
     # sNext: exact unless the runner-up itself is tied with a third sample (cannot tell from the record): require
     # equal LL then
     bad = (g["sNext"] != w["sNext"]) & ~tie_s & ~_close(g["sngNextLLK"], w["sngNextLLK"], 1e-9)
@@ -102,6 +105,10 @@ def compare_demux(got, want, alphas, tol=LL_TOL, tie_eps=1e-7, want_full=None):
         okd |= (np.abs(lb - w["dblBestLLK"]) < tie_eps) & (np.abs(ln - w["dblNextLLK"]) < tie_eps)
     assert okd.all(), f"doublet best/next guesses differ in {int((~okd).sum())} cells"
     report["doublet_tie_swaps"] = int((tie_d & ~same_best).sum())
+    raw_same = (g["dBest1"] == w["dBest1"]) & (g["dBest2"] == w["dBest2"]) & (g["dNext1"] == w["dNext1"]) & \
+               (g["dNext2"] == w["dNext2"])
+    used["mirrored_pair_order"] = int((same_best & same_next & ~raw_same).sum())  # same pairs, other order at alpha 0.5
+    used["doublet_tie"] = int((~(same_best & same_next)).sum())                    # other pairs, tied in the oracle's numbers
 
     # droplet type and the derived best/next guesses
     assert np.array_equal(g["type"], w["type"]), "DROPLET.TYPE differs"
@@ -119,6 +126,9 @@ def compare_demux(got, want, alphas, tol=LL_TOL, tie_eps=1e-7, want_full=None):
         okn |= _close(g["nextLLK"], w["nextLLK"], tie_eps)
     assert okb.all(), f"BEST.GUESS differs in {int((~okb).sum())} cells"
     assert okn.all(), f"NEXT.GUESS differs in {int((~okn).sum())} cells"
+    report["excuses_used"] = used
+    report["cells_needing_an_excuse"] = int((((g["sBest"] != w["sBest"]) | (g["sNext"] != w["sNext"])) |
+                                             ~(same_best & same_next) | ~raw_same).sum())
     return report
 
 
@@ -172,8 +182,12 @@ def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7, want_full=None):
         ok_idx = (lo >= 0) & (hi * (hi + 1) // 2 + lo < want_full.shape[1])
         named = want_full[np.arange(got.size), np.where(ok_idx, hi * (hi + 1) // 2 + lo, 0)]
         next_tie = ok_idx & (np.abs(named - want["dblNextLLK"]) < tie_eps)
+    differs = np.zeros(got.shape, dtype=bool)
     for f in FMX_INT_FIELDS:
         excused = tie | (next_tie if f in ("dNext1", "dNext2") else False)
         bad = (got[f] != want[f]) & ~excused
         assert not bad.any(), f"{f} differs in {int(bad.sum())} cells"
-    return {"cells": int(got.size), "max_abs_ll_diff": worst, "ties": int(tie.sum())}
+        differs |= got[f] != want[f]
+    # "ties": cells whose oracle numbers tie (an excuse was AVAILABLE); "cells_needing_an_excuse": where one was USED
+    return {"cells": int(got.size), "max_abs_ll_diff": worst, "ties": int(tie.sum()),
+            "cells_needing_an_excuse": int(differs.sum())}

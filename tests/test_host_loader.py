@@ -373,3 +373,55 @@ def test_vcf_sample_subset_is_numbered_in_sorted_id_order(exe, tmp_path):
     r = subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", str(tmp_path / "x.bin"), "--vcf", vcf, "--field", "GT",
                         "--sm", "nobody"], capture_output=True, text=True)
     assert r.returncode != 0 and "Cannot find sample ID nobody" in r.stderr
+
+
+def test_plp_rules_against_hand_derived_rows(exe, tmp_path):
+    """The CEL / PLP rules of load_from_plp derived by hand from sc_drop_seq.cpp:335-380, independent of tests/pyplp.py:
+    a base is kept if bq >= minBQ and then capped (:361-363); every kept base is its own UMI named sprintf("%x", numi++)
+    with ONE counter over the whole file (:364), and an entry is a std::map keyed by that string, so its reads come out in
+    the LEXICOGRAPHIC order of the hex names ("0" < "1" < "10" < "11" < "2" ... "9" < "a" ... "f"); dropped bases do not
+    consume a name; cell_uniq_reads counts kept bases, cell_totl_reads too -- unless the CEL row's NUM.UMIwSNP and NUM.SNP
+    agree with what was loaded, in which case it is overwritten by the CEL row's NUM.READ (:375-380)."""
+    import gzip
+
+    prefix = str(tmp_path / "h")
+    with gzip.open(prefix + ".cel.gz", "wt") as f:
+        f.write("#DROPLET_ID\tBARCODE\tNUM.READ\tNUM.UMI\tNUM.UMIwSNP\tNUM.SNP\n")
+        f.write("0\tAAA-1\t50\t40\t18\t2\n")  # 17 + 1 kept bases at 2 markers: consistent -> totl := 50
+        f.write("1\tCCC-1\t30\t20\t5\t1\n")   # 3 kept bases, the row says 5 -> totl stays the kept count
+        f.write("2\tGGG-1\t10\t8\t2\t1\n")    # consistent -> totl := 10
+    with gzip.open(prefix + ".var.gz", "wt") as f:
+        f.write("#SNP_ID\tCHROM\tPOS\tREF\tALT\tAF\n0\t1\t1000\tA\tG\t0.25000\n1\t1\t1010\tA\tG\t0.50000\n")
+    # droplet 0 / marker 0: 18 bases, the fourth below --min-BQ 13 (dropped, takes no name), so 17 kept bases named
+    # 0..9, a..f, 10; quality of kept base n: 14 + n (--cap-BQ 60 keeps them distinct); alleles 0/1 alternating, one '2'
+    al0, bq0, kept = "", "", 0
+    for i in range(18):
+        if i == 3:
+            al0 += "1"
+            bq0 += chr(33 + 5)
+            continue
+        al0 += "2" if kept == 6 else str(kept & 1)
+        bq0 += chr(33 + 14 + kept)
+        kept += 1
+    assert kept == 17
+    with gzip.open(prefix + ".plp.gz", "wt") as f:
+        f.write("#DROPLET_ID\tSNP_ID\tALLELES\tBASEQS\n")
+        f.write(f"0\t0\t{al0}\t{bq0}\n")                            # names 0 .. 10 (hex)
+        f.write("1\t0\t101\t" + chr(33 + 20) + chr(33 + 70) + chr(33 + 13) + "\n")  # names 11, 12, 13; 70 capped to 60
+        f.write("0\t1\t1\t" + chr(33 + 33) + "\n")                  # name 14
+        f.write("2\t1\t00\t" + chr(33 + 13) + chr(33 + 12) + "\n")  # name 15; the second base is below min-BQ
+    got = dump(exe, prefix, str(tmp_path / "d.bin"), "--min-BQ", "13", "--cap-BQ", "60")
+    assert got["C"] == 3 and got["S"] == 2 and got["bcs"] == ["AAA-1", "CCC-1", "GGG-1"]
+    assert got["cell_ptr"].tolist() == [0, 2, 3, 4] and got["entry_snp"].tolist() == [0, 1, 0, 1]
+    assert got["entry_rptr"].tolist() == [0, 17, 18, 21, 22]
+
+    def code(n):  # kept base n of droplet 0 / marker 0
+        return 0xFF if n == 6 else ((n & 1) << 7) | (14 + n)
+
+    lex = sorted(range(17), key=lambda n: "%x" % n)  # 0, 1, 16, 2, 3, ..., 9, 10 (a), ..., 15 (f)
+    assert lex[:4] == [0, 1, 16, 2] and lex[-1] == 15
+    want = [code(n) for n in lex] + [(1 << 7) | 33] + [(1 << 7) | 20, 60, (1 << 7) | 13] + [13]
+    assert got["reads"].tolist() == want
+    assert got["cell_uniq_reads"].tolist() == [18, 3, 1]
+    # GGG-1: the CEL row promises 2 kept bases, one was loaded -> no overwrite either
+    assert got["cell_totl_reads"].tolist() == [50, 3, 1]
