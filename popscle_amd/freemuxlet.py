@@ -121,6 +121,24 @@ def load_rank(eng, p, c_range, s_range):
     return eng.fmx_prepare(p.af)
 
 
+def load_rank_from_files(eng, exe, plp_prefix, rank, world, scratch, extra=()):
+    """load_rank() from a dsc-pileup data set on disk: the C++ loader (`popscle-amd dump-plp --rank r --world N`) keeps
+    only this rank's two slabs while it parses the .plp.gz -- the whole pileup is never held by a rank, on the host or
+    on the device.  Returns (scores of the own cells, the slab dictionary)."""
+    import subprocess
+
+    from . import plpio
+
+    r = subprocess.run([exe, "dump-plp", "--plp", plp_prefix, "--out", scratch, "--rank", str(rank), "--world", str(world),
+                        *extra], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-2000:])
+    d = plpio.read_slab_dump(scratch)
+    eng.set_pileup(d["S"], *d["rows"])
+    eng.fmx_set_column_slab(d["C"], d["c0"], d["s0"], d["s1"], *d["cols"])
+    return eng.fmx_prepare(d["af"]), d
+
+
 def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early_stop=True, exchange=None,
            exchange_tensor=engine_exchange_tensor, log=None, per=None, timings=None, sync=None, stream_ctx=None):
     """EM loop of cmd_cram_freemux2.cpp:373-605 on a prepared engine.  One rank: a plain engine holding the whole

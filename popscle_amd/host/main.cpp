@@ -686,6 +686,8 @@ int cmd_dump_plp(int argc, char** argv) {
   a.add_double("min-callrate", &vr.vfilt.minCallRate);
   a.add_multi_string("sm", &smIDs);
   a.add_string("sm-list", &smList);
+  a.add_int("rank", &cf.lo.rank);    // one rank's two slabs of a sharded run (LoadOptions): the file then holds the row
+  a.add_int("world", &cf.lo.world);  // slab in place of the pileup and the column slab behind it
   a.parse(argc, argv);
   if (cf.plpPrefix.empty() || cf.outPrefix.empty()) fatal("Missing required option(s) : --plp, --out");
   Pileup p;
@@ -702,6 +704,29 @@ int cmd_dump_plp(int argc, char** argv) {
   }
   FILE* f = fopen(cf.outPrefix.c_str(), "wb");
   if (!f) fatal("Cannot open %s for writing", cf.outPrefix.c_str());
+  if (p.slabbed) {  // --rank / --world: magic "MUXGLSLB", int64 C, S, c0, c1, s0, s1, nnz_r, R_r, nnz_c, R_c; the row slab's
+                    // cell_ptr[c1-c0+1], entry_snp, entry_rptr, reads; the column slab's cell_ptr[C+1], ...; af[S]; the
+                    // two read counts [C]
+    const int64_t hdr[10] = {p.C(), p.S(), p.slab_c0, p.slab_c1, p.slab_s0, p.slab_s1, p.nnz(), (int64_t)p.reads.size(),
+                             (int64_t)p.col_entry_snp.size(), (int64_t)p.col_reads.size()};
+    fwrite("MUXGLSLB", 1, 8, f);
+    fwrite(hdr, sizeof(int64_t), 10, f);
+    fwrite(p.cell_ptr.data(), sizeof(int64_t), p.cell_ptr.size(), f);
+    fwrite(p.entry_snp.data(), sizeof(int32_t), p.entry_snp.size(), f);
+    fwrite(p.entry_rptr.data(), sizeof(int64_t), p.entry_rptr.size(), f);
+    fwrite(p.reads.data(), 1, p.reads.size(), f);
+    fwrite(p.col_cell_ptr.data(), sizeof(int64_t), p.col_cell_ptr.size(), f);
+    fwrite(p.col_entry_snp.data(), sizeof(int32_t), p.col_entry_snp.size(), f);
+    fwrite(p.col_entry_rptr.data(), sizeof(int64_t), p.col_entry_rptr.size(), f);
+    fwrite(p.col_reads.data(), 1, p.col_reads.size(), f);
+    std::vector<double> af((size_t)p.S());
+    for (int64_t s = 0; s < p.S(); ++s) af[(size_t)s] = p.snps[(size_t)s].af;
+    fwrite(af.data(), sizeof(double), af.size(), f);
+    fwrite(p.cell_totl_reads.data(), sizeof(int32_t), p.cell_totl_reads.size(), f);
+    fwrite(p.cell_uniq_reads.data(), sizeof(int32_t), p.cell_uniq_reads.size(), f);
+    fclose(f);
+    return 0;
+  }
   const int64_t hdr[5] = {p.C(), p.S(), p.nnz(), (int64_t)p.reads.size(), p.nv};
   fwrite("MUXGLPLP", 1, 8, f);
   fwrite(hdr, sizeof(int64_t), 5, f);

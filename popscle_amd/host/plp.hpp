@@ -42,6 +42,15 @@ struct Pileup {
   std::vector<std::string> sample_ids;
   std::vector<double> gp;       // [S][nv][3]
   std::vector<uint8_t> has_gp;  // [S]
+  // Slabs of one rank of a sharded run (LoadOptions::world > 1): the packed arrays above then hold the ROW slab -- the
+  // cells [slab_c0, slab_c1) of the file with every marker, renumbered from 0 (bcs and the two read counts still span
+  // all C cells; the counts are filled for the slab's cells) -- and col_* the COLUMN slab: every cell, the entries with
+  // slab_s0 <= marker < slab_s1, marker ids unchanged (the arguments of muxgl_fmx_set_column_slab).
+  bool slabbed = false;
+  int64_t slab_c0 = 0, slab_c1 = 0, slab_s0 = 0, slab_s1 = 0;
+  std::vector<int64_t> col_cell_ptr, col_entry_rptr;
+  std::vector<int32_t> col_entry_snp;
+  std::vector<uint8_t> col_reads;
   int64_t C() const { return (int64_t)bcs.size(); }
   int64_t S() const { return (int64_t)snps.size(); }
   int64_t nnz() const { return (int64_t)entry_snp.size(); }
@@ -55,6 +64,11 @@ struct LoadOptions {
   std::string field = "GP";                     // --field
   double genoErrorOffset = 0.10, genoErrorCoeffR2 = 0.0;
   std::string r2info = "R2";
+  // One rank of a sharded run: keep only this rank's two slabs of the pileup -- equal slices of ceil(n / world) cells
+  // and markers (popscle_amd/shard.py: equal_ranges; the reference's own way to cut a job is by droplets at file level,
+  // --group-list, README.md:168).  The .plp.gz rows of other cells AND other markers are tokenised and counted, not kept:
+  // memory, ordering and packing are 2 / world of the whole.
+  int32_t rank = 0, world = 1;
 };
 
 inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, VcfReader* pvr, Pileup& out) {
@@ -224,6 +238,16 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
     po.capBQ = opt.capBQ > 127 ? 127 : opt.capBQ;
     po.S = (int32_t)S;
     po.index_bcs = &index_bcs;
+    if (opt.world > 1) {
+      if (opt.rank < 0 || opt.rank >= opt.world) fatal("--rank must be in [0, --world)");
+      const int64_t pc = C > 0 ? (C + opt.world - 1) / opt.world : 0, ps = S > 0 ? (S + opt.world - 1) / opt.world : 0;
+      out.slabbed = true;
+      out.slab_c0 = std::min<int64_t>(opt.rank * pc, C);
+      out.slab_c1 = std::min<int64_t>((opt.rank + 1) * pc, C);
+      out.slab_s0 = std::min<int64_t>(opt.rank * ps, S);
+      out.slab_s1 = std::min<int64_t>((opt.rank + 1) * ps, S);
+      po.c0 = (int32_t)out.slab_c0, po.c1 = (int32_t)out.slab_c1, po.s0 = (int32_t)out.slab_s0, po.s1 = (int32_t)out.slab_s1;
+    }
     const uint64_t numi = parse_plp_gz(prefix, po, rds, &sorted);
     tm.lap("plp inflate+parse");
     for (const PlpRead& r : rds) {
@@ -235,6 +259,47 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
   // order: cell, SNP, then the reference's std::map<std::string> order of the "%x" UMI strings
   tm.lap("plp counts");
   std::vector<int64_t> cell_rd0;  // first read of every cell in the ordered list
+  if (out.slabbed) {  // the kept rows go to the row slab (cells renumbered), to the column slab, or to both
+    PlpReadVec rows, cols;
+    size_t nr = 0, nc = 0;
+    for (const PlpRead& r : rds) {
+      nr += r.cell >= out.slab_c0 && r.cell < out.slab_c1;
+      nc += r.snp >= out.slab_s0 && r.snp < out.slab_s1;
+    }
+    rows.resize(nr);
+    cols.resize(nc);
+    nr = nc = 0;
+    for (const PlpRead& r : rds) {
+      if (r.snp >= out.slab_s0 && r.snp < out.slab_s1) cols[nc++] = r;
+      if (r.cell >= out.slab_c0 && r.cell < out.slab_c1) {
+        rows[nr] = r;
+        rows[nr++].cell -= (int32_t)out.slab_c0;
+      }
+    }
+    PlpReadVec().swap(rds);
+    plp_order_by_cell(cols, C, sorted, cell_rd0);
+    plp_pack(cols, C, cell_rd0, out.col_cell_ptr, out.col_entry_snp, out.col_entry_rptr, out.col_reads);
+    PlpReadVec().swap(cols);
+    const int64_t Cr = out.slab_c1 - out.slab_c0;
+    plp_order_by_cell(rows, Cr, sorted, cell_rd0);
+    tm.lap("plp order (two slabs)");
+    plp_pack(rows, Cr, cell_rd0, out.cell_ptr, out.entry_snp, out.entry_rptr, out.reads);
+    tm.lap("plp pack");
+    for (int64_t c = 0; c < C; ++c) {  // read counts: the slab's cells only
+      const bool mine = c >= out.slab_c0 && c < out.slab_c1;
+      if (!mine) {
+        out.cell_totl_reads[(size_t)c] = out.cell_uniq_reads[(size_t)c] = 0;
+        continue;
+      }
+      const int64_t lc = c - out.slab_c0, nent = out.cell_ptr[(size_t)lc + 1] - out.cell_ptr[(size_t)lc];
+      int32_t kept = 0;
+      for (int64_t e = out.cell_ptr[(size_t)lc]; e < out.cell_ptr[(size_t)lc + 1]; ++e)
+        kept += (int32_t)(out.entry_rptr[(size_t)e + 1] - out.entry_rptr[(size_t)e]);
+      out.cell_totl_reads[(size_t)c] = out.cell_uniq_reads[(size_t)c] = kept;
+      if (kept == tmp_uniq[(size_t)c] && tmp_nsnp[(size_t)c] == (int32_t)nent) out.cell_totl_reads[(size_t)c] = tmp_totl[(size_t)c];
+    }
+    return;
+  }
   plp_order_by_cell(rds, C, sorted, cell_rd0);
   tm.lap("plp order");
   plp_pack(rds, C, cell_rd0, out.cell_ptr, out.entry_snp, out.entry_rptr, out.reads);

@@ -79,6 +79,10 @@ class PlpReadVec {
 struct PlpParseOptions {
   int32_t minBQ = 13, capBQ = 20, S = 0;
   const std::vector<int32_t>* index_bcs = nullptr;  // DROPLET_ID -> cell id, -1 = filtered
+  // slab filter (one rank of a sharded run): only the rows of cells [c0, c1) or markers [s0, s1) are kept; the bases of
+  // the other rows are still COUNTED, because the name of a kept base -- and with it the order of the reads inside an
+  // entry -- is its number among all kept bases of the file (sc_drop_seq.cpp:364)
+  int32_t c0 = 0, c1 = INT32_MAX, s0 = 0, s1 = INT32_MAX;
 };
 
 // strcmp(sprintf("%x", a), sprintf("%x", b)) < 0 without the strings: left-align the hex digits; if one string is a
@@ -106,6 +110,7 @@ inline int32_t atoi_tok(const char* b, const char* e) {  // atoi on a token: opt
 struct Slice {
   const char *b = nullptr, *e = nullptr;
   std::vector<PlpRead> rds;  // numi local to the slice
+  uint32_t nkept = 0;        // kept bases of the slice, those of rows outside the slab filter included
   int64_t lines = 0;         // rows consumed (incl. the one that failed / the blank one)
   bool blank = false;        // a line without fields was met: the file ends there
   bool sorted = true;        // (cell, snp) non-decreasing inside the slice
@@ -113,6 +118,7 @@ struct Slice {
   void reset() {
     b = e = nullptr;
     rds.clear();
+    nkept = 0;
     lines = 0;
     blank = false;
     sorted = true;
@@ -123,7 +129,7 @@ struct Slice {
 inline void parse_slice(Slice& sl, const PlpParseOptions& po, const char* prefix) {
   const std::vector<int32_t>& index_bcs = *po.index_bcs;
   const char* p = sl.b;
-  uint32_t numi = 0;
+  uint32_t& numi = sl.nkept;
   int64_t lastkey = -1;
   char msg[512];
   while (p < sl.e) {
@@ -174,6 +180,10 @@ inline void parse_slice(Slice& sl, const PlpParseOptions& po, const char* prefix
       snprintf(msg, sizeof(msg), "Length are different between %.*s and %.*s", (int)(fe[2] - fb[2]), pa, (int)l, pq);
       sl.err = msg;
       return;
+    }
+    if (!((ibc >= po.c0 && ibc < po.c1) || (snp >= po.s0 && snp < po.s1))) {  // outside the slabs: count, do not keep
+      for (int32_t i = 0; i < l; ++i) numi += (int)(char)(pq[i] - (char)33) >= po.minBQ;
+      continue;
     }
     const int64_t key = ((int64_t)ibc << 32) | (uint32_t)snp;
     if (key < lastkey) sl.sorted = false;
@@ -482,13 +492,16 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
     // append in file order
     std::vector<size_t> off((size_t)want + 1, rds.size());
     {  // copy the slices' reads to their places (numi made global), in parallel
-      for (size_t i = 0; i < (size_t)want; ++i) off[i + 1] = off[i] + sl[i].rds.size();
+      std::vector<uint64_t> nbase((size_t)want + 1, numi);  // kept bases of the file in front of each slice
+      for (size_t i = 0; i < (size_t)want; ++i) {
+        off[i + 1] = off[i] + sl[i].rds.size();
+        nbase[i + 1] = nbase[i] + sl[i].nkept;
+      }
       rds.resize(off.back());
-      const uint64_t base0 = numi - off[0];
       parallel_for(want, nth, [&](int64_t i) {
         const std::vector<PlpRead>& src = sl[(size_t)i].rds;
         PlpRead* d = rds.data() + off[(size_t)i];
-        const uint32_t base = (uint32_t)(base0 + off[(size_t)i]);
+        const uint32_t base = (uint32_t)nbase[(size_t)i];
         for (size_t k = 0; k < src.size(); ++k) {
           d[k] = src[k];
           d[k].numi += base;
@@ -502,8 +515,8 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
         const int64_t last = ((int64_t)s.rds.back().cell << 32) | (uint32_t)s.rds.back().snp;
         if (!s.sorted || first < lastkey) file_sorted = false;
         lastkey = last;
-        numi += s.rds.size();
       }
+      numi += s.nkept;
       if (!s.err.empty()) {
         std::string m = s.err;
         const size_t k = m.find("%lld");

@@ -132,3 +132,28 @@ def read_dump(path: str):
     out["bcs"] = [s.decode() for s in strs[:int(C)]]
     out["sample_ids"] = [s.decode() for s in strs[int(C):int(C) + int(nv)]]
     return out
+
+
+def read_slab_dump(path: str):
+    """Parse the file `popscle-amd dump-plp --rank r --world N` writes: one rank's row slab (its cells, every marker,
+    cells renumbered from 0) and column slab (every cell, its markers) of a sharded run, cut by the loader itself."""
+    buf = open(path, "rb").read()
+    assert buf[:8] == b"MUXGLSLB"
+    off = 8
+    C, S, c0, c1, s0, s1, nnz_r, R_r, nnz_c, R_c = (int(x) for x in np.frombuffer(buf, dtype=np.int64, count=10, offset=off))
+    off += 80
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(buf, dtype=dtype, count=int(n), offset=off).copy()
+        off += a.nbytes
+        return a
+
+    out = dict(C=C, S=S, c0=c0, c1=c1, s0=s0, s1=s1)
+    out["rows"] = (take(np.int64, c1 - c0 + 1), take(np.int32, nnz_r), take(np.int64, nnz_r + 1), take(np.uint8, R_r))
+    out["cols"] = (take(np.int64, C + 1), take(np.int32, nnz_c), take(np.int64, nnz_c + 1), take(np.uint8, R_c))
+    out["af"] = take(np.float64, S)
+    out["cell_totl_reads"] = take(np.int32, C)
+    out["cell_uniq_reads"] = take(np.int32, C)
+    assert off == len(buf)
+    return out

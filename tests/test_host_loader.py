@@ -425,3 +425,33 @@ def test_plp_rules_against_hand_derived_rows(exe, tmp_path):
     assert got["cell_uniq_reads"].tolist() == [18, 3, 1]
     # GGG-1: the CEL row promises 2 kept bases, one was loaded -> no overwrite either
     assert got["cell_totl_reads"].tolist() == [50, 3, 1]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_loader_cuts_a_ranks_slabs_at_file_level(exe, tmp_path, world):
+    """`dump-plp --rank r --world N`: the loader keeps only the rank's row slab (its cells) and column slab (its markers)
+    while it parses -- and they are exactly the cuts shard.take_cells / take_snps make of the whole pileup, read order
+    inside the entries included (the name of a kept base counts the bases of ALL rows, kept or not)."""
+    from popscle_amd import shard
+
+    p, prefix = make_files(tmp_path, C=23, S=70, deep=True)
+    whole = dump(exe, prefix, str(tmp_path / "whole.bin"), "--min-BQ", "5", "--cap-BQ", "33")
+    C, S = whole["C"], whole["S"]
+    q = synth.Pileup(C, S, whole["cell_ptr"], whole["entry_snp"], whole["entry_rptr"], whole["reads"], whole["af"])
+    (c_ranges, _), (s_ranges, _) = shard.equal_ranges(C, world), shard.equal_ranges(S, world)
+    for r in range(world):
+        out = str(tmp_path / f"slab{r}.bin")
+        sub = subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", out, "--rank", str(r), "--world", str(world),
+                              "--min-BQ", "5", "--cap-BQ", "33"], capture_output=True, text=True)
+        assert sub.returncode == 0, sub.stderr
+        d = plpio.read_slab_dump(out)
+        assert (d["c0"], d["c1"]) == c_ranges[r] and (d["s0"], d["s1"]) == s_ranges[r] and d["C"] == C and d["S"] == S
+        rows = shard.take_cells(q, *c_ranges[r])
+        for a, b in zip(d["rows"], (rows.cell_ptr, rows.entry_snp, rows.entry_rptr, rows.reads)):
+            assert np.array_equal(a, b)
+        for a, b in zip(d["cols"], shard.take_snps(q, *s_ranges[r])):
+            assert np.array_equal(a, b)
+        c0, c1 = c_ranges[r]
+        assert np.array_equal(d["cell_uniq_reads"][c0:c1], whole["cell_uniq_reads"][c0:c1])
+        assert np.array_equal(d["cell_totl_reads"][c0:c1], whole["cell_totl_reads"][c0:c1])
+        assert np.array_equal(d["af"], whole["af"])
