@@ -196,3 +196,58 @@ def test_group_create_errors():
         muxgl.Engine([0, 99])
     with pytest.raises(ValueError):
         muxgl.Engine([0] * 17)
+
+
+def test_slab_ranks_loaded_from_files_match_single_handle(tmp_path):
+    """The ranks' slabs cut by the C++ loader while it parses the .plp.gz (popscle-amd dump-plp --rank r --world N,
+    freemuxlet.load_rank_from_files): three EM iterations equal the one-handle run on the pileup loaded whole."""
+    import os
+
+    from popscle_amd import plpio
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "popscle_amd", "bin", "popscle-amd")
+    if not os.path.exists(exe):
+        pytest.skip("popscle-amd not built")
+    K, world = 5, 3
+    src = synth.make_pileup(150, 1500, K, seed=77, mean_entries=200, min_entries=20, reads_lambda=1.0, with_gp=False)
+    prefix = str(tmp_path / "plp")
+    plpio.write_plp(prefix, src, seed=5)
+    whole = plpio.read_dump(_dump(exe, prefix, str(tmp_path / "whole.bin")))
+    p = synth.Pileup(whole["C"], whole["S"], whole["cell_ptr"], whole["entry_snp"], whole["entry_rptr"], whole["reads"],
+                     whole["af"], truth=src.truth)
+    clust0 = start_clusters(p, K)
+    scores, ref, ref_gls, ref_cnt = single_run(p, K, clust0)
+    (c_ranges, _), (s_ranges, _) = freemuxlet.plan_ranges(p.C, p.S, world)
+    engs = []
+    for r in range(world):
+        e = muxgl.Engine(0)
+        got, d = freemuxlet.load_rank_from_files(e, exe, prefix, r, world, str(tmp_path / f"slab{r}.bin"))
+        b, en = c_ranges[r]
+        assert (d["c0"], d["c1"]) == (b, en)
+        for g, w in zip(got, scores):
+            assert np.array_equal(g, w[b:en])
+        e.fmx_set_clusters(K, clust0)
+        engs.append(e)
+    for it in range(3):
+        for e in engs:
+            e.fmx_iter_gp(0.5, 0.1)
+        slab_allgather(engs, muxgl.BUF_CGP, s_ranges, K * 3 * 8)
+        for e in engs:
+            e.fmx_iter_estep(0.5, 0.1)
+        fetched = [e.fmx_iter_fetch() for e in engs]
+        slab_allgather(engs, muxgl.BUF_CLUST, c_ranges, 4)
+        for e in engs:
+            e.fmx_iter_mstep()
+        cells = np.concatenate([f[0] for f in fetched])
+        assert cells.tobytes() == ref[it][0].tobytes(), f"iteration {it}"
+        assert tuple(np.sum([f[1] for f in fetched], axis=0)) == tuple(ref[it][1])
+    for e in engs:
+        e.close()
+
+
+def _dump(exe, prefix, out):
+    import subprocess
+
+    r = subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
