@@ -14,7 +14,12 @@
 #include "../../include/muxgl.h"
 
 constexpr int MUXGL_ROW_CH = 128;   // entries per chunk of the row kernels (16-lane slots)
-constexpr int MUXGL_QUAD_CH = 128;  // entries per chunk of the quad kernel (4-lane slots)
+constexpr int MUXGL_QUAD_CH = 128;  // entries per chunk of the freemuxlet quad E-step (4-lane slots)
+constexpr int MUXGL_OCT_CH = 192;   // entries per chunk of the demuxlet oct kernel (8-lane slots).  Measured at configs[1]
+                                    // (sweep + finish, ms): 96: 0.270 + 0.107, 128: 0.258 + 0.083, 160: 0.243 + 0.074,
+                                    // 192: 0.252 + 0.068, 224: 0.250 + 0.066, 256: 0.253 + 0.067, 320: 0.281 + 0.066 --
+                                    // longer chunks are fewer partial products for the finish kernel, shorter ones more
+                                    // work units to balance.  A constant: a cell's cut must not depend on its neighbours.
 
 // per-entry record of the quad kernel: everything phase 1 needs for an entry with <= 4 reads in ONE 16-byte load
 struct quad_entry {

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64)
   const int64_t i = (int64_t)blockIdx.x * (64 / G) + lane / G;
   const bool cell_ok = i < C;
   const int64_t ic = cell_ok ? i : 0;
-  demux_call_group<G>(lane, cell_ok, cell_ok ? (int32_t)(cell_ptr[i + 1] - cell_ptr[i]) : 0, nv, nAlpha, al.a,
+  demux_call_group<G>(lane, cell_ok, cell_ok ? (int32_t)(cell_ptr[i + 1] - cell_ptr[i]) : 0, nv, nAlpha, al,
                       doublet_prior, ll + (size_t)ic * nv * nv * nAlpha, out + ic);
 }
 
@@ -90,14 +90,13 @@ __global__ void __launch_bounds__(64)
       }
     }
   }
-  demux_call_finish<64>(j, true, nsnps, nv, nAlpha, al.a, doublet_prior, sng, dbl, sterm, rowmax, racc, out + i);
+  demux_call_finish<64>(j, true, nsnps, nv, nAlpha, al, doublet_prior, sng, dbl, sterm, rowmax, racc, out + i);
 }
 
 }  // namespace
 
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
-  call_alpha al;
-  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+  const call_alpha al = make_call_alpha(p, h->V);
   hipLaunchKernelGGL(demux_call_wave_kernel, dim3((unsigned)h->C), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
                      p->n_alpha, al, p->doublet_prior, h->d_llw, h->d_dcells);
   HIPCHK(h, hipGetLastError());
@@ -105,8 +104,7 @@ int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 }
 
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p) {
-  call_alpha al;
-  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+  const call_alpha al = make_call_alpha(p, h->V);
   if (h->V <= 16) {
     const unsigned blocks = (unsigned)((h->C + 3) / 4);
     hipLaunchKernelGGL(demux_callg_kernel<16>, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr,

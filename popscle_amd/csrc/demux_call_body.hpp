@@ -7,26 +7,61 @@
 
 namespace muxgl_call {
 
+// the alpha grid and the three log priors of cmd_cram_demuxlet.cpp:793-795, which depend on the run's parameters only:
+// taken on the host (glibc's log, the reference's own) instead of once per lane
 struct call_alpha {
   double a[MUXGL_MAX_ALPHA];
+  double log_single_prior, log_doublet_prior1, log_doublet_prior2;
 };
+inline call_alpha make_call_alpha(const muxgl_demux_params* p, int nv) {
+  call_alpha al;
+  for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+  const double dp = p->doublet_prior, nA = p->n_alpha;
+  al.log_single_prior = log((1.0 - dp) / nv);
+  al.log_doublet_prior1 = log(dp / nv / (nv - 1.) / (nA - 1.));
+  al.log_doublet_prior2 = log(dp / nv / (nv - 1.) / (nA - 1.) * 2);
+  return al;
+}
+
+// exp(x) for x <= 0, as the evidence sums use it (terms relative to their maximum): n = rint(x log2 e),
+// r = x - n ln 2 in two pieces, a degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18) and ldexp -- about 20
+// instructions against the library exp's 250 (it has no special cases to serve here); within 2 ulp.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  if (x < -708.0) return 0.0;
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
 
 struct top2 {
   double bv, nv;  // best / next value
   int32_t bp, np; // scan positions (-1: none); position encodes the hypothesis
 };
 
-// reference update rule for one more element at a later position
+// reference update rule for one more element at a later position (selects, no branches: the scans are lock-step loops
+// over sixteen lanes' rows, and a divergent branch per element serialises them)
 __device__ __forceinline__ void top2_push(top2& t, double v, int32_t pos) {
-  if (t.bv < v) {
-    t.nv = t.bv;
-    t.np = t.bp;
-    t.bv = v;
-    t.bp = pos;
-  } else if (t.nv < v) {
-    t.nv = v;
-    t.np = pos;
-  }
+  const bool b = t.bv < v;
+  const bool n = !b && t.nv < v;
+  t.nv = b ? t.bv : (n ? v : t.nv);
+  t.np = b ? t.bp : (n ? pos : t.np);
+  t.bv = b ? v : t.bv;
+  t.bp = b ? pos : t.bp;
 }
 
 // key order: value descending, then position ascending; "none" entries (pos < 0) carry -1e300 and never win
@@ -39,28 +74,16 @@ __device__ __forceinline__ bool key_before(double va, int32_t pa, double vb, int
 }
 
 __device__ __forceinline__ top2 top2_merge(const top2& a, const top2& b) {
+  // the best of the two lists, then the better of (the winner's runner-up, the loser's best) -- as selects
+  const bool ab = key_before(a.bv, a.bp, b.bv, b.bp);
+  const double wv = ab ? a.bv : b.bv, wn = ab ? a.nv : b.nv, lv = ab ? b.bv : a.bv;
+  const int32_t wp = ab ? a.bp : b.bp, wnp = ab ? a.np : b.np, lp = ab ? b.bp : a.bp;
+  const bool keep = key_before(wn, wnp, lv, lp);
   top2 r;
-  if (key_before(a.bv, a.bp, b.bv, b.bp)) {
-    r.bv = a.bv;
-    r.bp = a.bp;
-    if (key_before(a.nv, a.np, b.bv, b.bp)) {
-      r.nv = a.nv;
-      r.np = a.np;
-    } else {
-      r.nv = b.bv;
-      r.np = b.bp;
-    }
-  } else {
-    r.bv = b.bv;
-    r.bp = b.bp;
-    if (key_before(b.nv, b.np, a.bv, a.bp)) {
-      r.nv = b.nv;
-      r.np = b.np;
-    } else {
-      r.nv = a.bv;
-      r.np = a.bp;
-    }
-  }
+  r.bv = wv;
+  r.bp = wp;
+  r.nv = keep ? wn : lv;
+  r.np = keep ? wnp : lp;
   return r;
 }
 
@@ -91,14 +114,15 @@ __device__ __forceinline__ void top2_insert(top2& t, double v, int32_t pos) {
 // it -- 1 for a lane with one row) over the G lanes of the cell and makes the decision.
 template <int G>
 __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
-                                                  const double* gridAlpha, double doublet_prior, top2 sng, top2 dbl,
+                                                  const call_alpha& al, double doublet_prior, top2 sng, top2 dbl,
                                                   double sterm, double rowmax, double racc, muxgl_demux_cell* out,
                                                   double sacc = 1.0) {
   const int j = lane & (G - 1);
   const double NEG_INF = -__builtin_huge_val();
-  const double log_single_prior = log((1.0 - doublet_prior) / nv);
-  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
-  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
+  const double* gridAlpha = al.a;
+  const double log_single_prior = al.log_single_prior;
+  const double log_doublet_prior1 = al.log_doublet_prior1;
+  const double log_doublet_prior2 = al.log_doublet_prior2;
   // merge the G rows: top-2 lists, maxima, then the scaled sums
   double M = rowmax, Ms = sterm;
 #pragma unroll
@@ -108,8 +132,8 @@ __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_
     M = fmax(M, __shfl_xor(M, m, 64));
     Ms = fmax(Ms, __shfl_xor(Ms, m, 64));
   }
-  double S = (racc > 0.0) ? racc * exp(rowmax - M) : 0.0;
-  double Ss = (sterm > NEG_INF) ? sacc * exp(sterm - Ms) : 0.0;
+  double S = (racc > 0.0) ? racc * exp_nonpos(rowmax - M) : 0.0;
+  double Ss = (sterm > NEG_INF) ? sacc * exp_nonpos(sterm - Ms) : 0.0;
 #pragma unroll
   for (int m = 1; m < G; m <<= 1) {
     S += __shfl_xor(S, m, 64);
@@ -218,14 +242,21 @@ __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_
 // lane = lane id in the wave; lanes [base, base+G) with base = lane & ~(G-1) work on one cell.  ll_cell points at that
 // cell's [nv][nv][nAlpha] hypotheses (global or LDS); lane base+0 writes *out when cell_ok.
 template <int G>
+// (ld: distance of two rows in doubles, nv * nAlpha unless the caller pads its tile -- the lanes of a group read the same
+//  column of their rows at the same time, and rows a multiple of 64 dwords apart all sit in one LDS bank)
 __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
-                                                 const double* gridAlpha, double doublet_prior, const double* ll_cell,
-                                                 muxgl_demux_cell* out) {
+                                                 const call_alpha& al, double doublet_prior, const double* ll_cell,
+                                                 muxgl_demux_cell* out, int ld = 0) {
+  if (ld == 0) ld = nv * nAlpha;
+#ifndef CALL_EXP
+#define CALL_EXP 0  // (timing experiments: 1 no scans, 2 no evidence pass, 4 no merge / decision)
+#endif
   const int j = lane & (G - 1);
-  const bool live = cell_ok && j < nv;
-  const double log_single_prior = log((1.0 - doublet_prior) / nv);
-  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
-  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
+  const bool live = cell_ok && j < nv && !(CALL_EXP & 1);
+  const double* gridAlpha = al.a;
+  const double log_single_prior = al.log_single_prior;
+  const double log_doublet_prior1 = al.log_doublet_prior1;
+  const double log_doublet_prior2 = al.log_doublet_prior2;
 
   top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
   const double NEG_INF = -__builtin_huge_val();
@@ -235,7 +266,7 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
     // (top2_push) applies across them as it does inside a row
     // pass 1: scans, and the largest evidence term of the lane's rows
     for (int jr = j; jr < nv; jr += G) {
-      const double* row = ll_cell + (size_t)jr * nv * nAlpha;
+      const double* row = ll_cell + (size_t)jr * ld;
       const double s = row[0];  // llksAB[j][0][0]
       top2_push(sng, s, jr);
       const double st = s + log_single_prior;
@@ -255,28 +286,31 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
       }
     }
     // pass 2: the evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
-    if (rowmax > NEG_INF) {
+    if (rowmax > NEG_INF && !(CALL_EXP & 2)) {
       for (int jr = j; jr < nv; jr += G) {
-        const double* row = ll_cell + (size_t)jr * nv * nAlpha;
+        const double* row = ll_cell + (size_t)jr * ld;
         const double st = row[0] + log_single_prior;
-        racc += exp(st - rowmax);
-        sacc += exp(st - sterm);
+        racc += exp_nonpos(st - rowmax);
+        sacc += exp_nonpos(st - sterm);
         for (int k = 0; k < nv; ++k) {
           if (k == jr) continue;
           for (int n = 1; n < nAlpha; ++n) {
             const double v = row[k * nAlpha + n];
             if (gridAlpha[n] == 0.5) {
-              if (k < jr) racc += exp(v + log_doublet_prior2 - rowmax);
+              if (k < jr) racc += exp_nonpos(v + log_doublet_prior2 - rowmax);
             } else {
-              racc += exp(v + log_doublet_prior1 - rowmax);
+              racc += exp_nonpos(v + log_doublet_prior1 - rowmax);
             }
           }
         }
       }
     }
   }
-  demux_call_finish<G>(lane, cell_ok, nsnps, nv, nAlpha, gridAlpha, doublet_prior, sng, dbl, sterm, rowmax, racc, out,
-                       sacc);
+  if (CALL_EXP & 4) {
+    if (j == 0 && cell_ok) out->sumLLK = racc + sacc + sng.bv + dbl.bv + rowmax + sterm;
+    return;
+  }
+  demux_call_finish<G>(lane, cell_ok, nsnps, nv, nAlpha, al, doublet_prior, sng, dbl, sterm, rowmax, racc, out, sacc);
 }
 
 }  // namespace muxgl_call

@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(256)
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_chunks) return;
   const int nl = chunk_nlin[w], len = chunks[w].len;
-  const uint64_t bg = (uint64_t)(len - nl), bl = (uint64_t)nl;  // <= 128 each
-  key[w] = ((uint64_t)(w / bucket) << 40) | ((255u - bg) << 30) | ((255u - bl) << 20) | (uint64_t)(w % bucket);
+  const uint64_t bg = (uint64_t)min(len - nl, 1023), bl = (uint64_t)min(nl, 1023);
+  key[w] = ((uint64_t)(w / bucket) << 40) | ((1023u - bg) << 30) | ((1023u - bl) << 20) | (uint64_t)(w % bucket);
   iota[w] = w;
 }
 
@@ -784,12 +784,14 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
                             const int32_t* __restrict__ cell_chunks, const double* __restrict__ part_m,
                             const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
                             muxgl_call::call_alpha al, double doublet_prior, muxgl_demux_cell* __restrict__ out) {
-  __shared__ double llt[QF_CELLS][16 * 16 * 2];
+  constexpr int LD = 33;  // row stride of the tiles in doubles: odd, so that the sixteen lanes of a cell's call, which read
+                          // the same column of their rows at once, meet sixteen LDS banks (32 would be one)
+  __shared__ double llt[QF_CELLS][16 * LD];
   __shared__ __align__(16) muxgl_demux_cell rec[QF_CELLS];
   static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
   const int64_t cbase = (int64_t)blockIdx.x * QF_CELLS;
   const int tid = threadIdx.x;
-  for (int t = tid; t < QF_CELLS * 512; t += 64 * QF_CELLS) (&llt[0][0])[t] = 0.0;
+  for (int t = tid; t < QF_CELLS * 16 * LD; t += 64 * QF_CELLS) (&llt[0][0])[t] = 0.0;
   __syncthreads();
   for (int w = tid; w < QF_CELLS * O_NHYP; w += 64 * QF_CELLS) {
     const int lc = w / O_NHYP, idx = w - lc * O_NHYP;
@@ -800,10 +802,10 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
     double v;
     if (c0 != c1 && oct_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, pmap, V, j, k, v)) {
       if (idx < 16) {
-        llt[lc][(j * V + k) * 2 + 0] = v;
+        llt[lc][j * LD + k * 2 + 0] = v;
       } else {
-        llt[lc][(j * V + k) * 2 + 1] = v;
-        llt[lc][(k * V + j) * 2 + 1] = v;
+        llt[lc][j * LD + k * 2 + 1] = v;
+        llt[lc][k * LD + j * 2 + 1] = v;
       }
     }
   }
@@ -812,8 +814,8 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
     const int lc = tid >> 4;
     const int64_t c = cbase + lc;
     const bool ok = c < C;
-    muxgl_call::demux_call_group<16>(tid, ok, ok ? (int32_t)(cell_ptr[c + 1] - cell_ptr[c]) : 0, V, 2, al.a,
-                                     doublet_prior, llt[lc], &rec[lc]);
+    muxgl_call::demux_call_group<16>(tid, ok, ok ? (int32_t)(cell_ptr[c + 1] - cell_ptr[c]) : 0, V, 2, al,
+                                     doublet_prior, llt[lc], &rec[lc], LD);
   }
   __syncthreads();
   constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
@@ -939,11 +941,14 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     hipLaunchKernelGGL(demux_oct_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);
   } else {  // reduce + call fused, records written to the pinned host buffer
-    muxgl_call::call_alpha al;
-    for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+    const muxgl_call::call_alpha al = muxgl_call::make_call_alpha(p, h->V);
     hipLaunchKernelGGL(demux_oct_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(64 * QF_CELLS), 0,
                        h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
+#ifdef FIN_DEV
+                       p->doublet_prior, h->d_dcells);  // (timing experiment: records stay on the device)
+#else
                        p->doublet_prior, h->h_dcells);
+#endif
     h->records_on_host = true;
   }
   HIPCHK(h, hipGetLastError());

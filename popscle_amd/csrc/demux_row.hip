@@ -314,7 +314,9 @@ void demux_row_free(muxgl_handle* h) {
 // builds the chunk tables of every cell from the host copy of the CSR arrays (called by muxgl_set_pileup)
 int demux_row_plan(muxgl_handle* h) {
   if (demux_row_build(h, &h->row, 0, h->C, MUXGL_ROW_CH)) return 1;
-  return demux_row_build(h, &h->qrow, 0, h->C, MUXGL_QUAD_CH);
+  int qch = MUXGL_OCT_CH;
+  if (const char* ev = getenv("MUXGL_OCT_CH")) qch = atoi(ev) >= 16 ? atoi(ev) / 4 * 4 : qch;  // (tuning)
+  return demux_row_build(h, &h->qrow, 0, h->C, qch);
 }
 
 // chunk tables of the cells [cb, ce): built on the device (plan_kernels.hip) from the device copy of the CSR arrays

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   if (tid < 64)
-    muxgl_call::demux_call_group<64>(tid, true, (int32_t)(cell_ptr[c + 1] - cell_ptr[c]), V, 2, al.a, doublet_prior, llt,
+    muxgl_call::demux_call_group<64>(tid, true, (int32_t)(cell_ptr[c + 1] - cell_ptr[c]), V, 2, al, doublet_prior, llt,
                                      &rec);
   __syncthreads();
   constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
@@ -318,8 +318,7 @@ int demux_rowx_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     hipLaunchKernelGGL(demux_rowx_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_tmap, h->V, p->n_alpha, h->d_ll);
   } else {  // reduce + call fused, records written to the pinned host buffer
-    muxgl_call::call_alpha ca;
-    for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) ca.a[i] = (i < p->n_alpha) ? p->alpha[i] : 0.0;
+    const muxgl_call::call_alpha ca = muxgl_call::make_call_alpha(p, h->V);
     hipLaunchKernelGGL(demux_rowx_finish_kernel, dim3((unsigned)h->C), dim3(256), 0, h->stream, h->d_cell_ptr,
                        st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_tmap, h->V, ca, p->doublet_prior,
                        h->h_dcells);

@@ -1103,7 +1103,12 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   tic(h, MUXGL_T_FMX_ESTEP);
   muxgl_row_state* st = h->frow ? h->frow : h->row;
   int qrc = -1;
-  if (nc > 0) qrc = fmx_quad_estep_launch(h, h->fqrow ? h->fqrow : h->qrow, c0, nc);  // K <= 16: quad tiling
+  // (the chunk tables of the quad E-step are its own: demuxlet's oct kernel cuts cells into longer chunks, and a sharded
+  //  run must cut a cell exactly as the whole-pileup run does)
+  if (nc > 0 && K <= 16 && !h->fqrow && h->qrow && !(h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL)) &&
+      demux_row_build(h, &h->fqrow, 0, h->C, MUXGL_QUAD_CH))
+    return 1;
+  if (nc > 0) qrc = fmx_quad_estep_launch(h, h->fqrow, c0, nc);  // K <= 16: quad tiling
   if (nc > 0 && qrc < 0) qrc = fmx_rowx_estep_launch(h, st, c0, nc);  // 16 < K <= 24: row kernel + broadcast extras
   if (nc > 0 && qrc < 0) qrc = fmx_row2_estep_launch(h, st, c0, nc);  // 16 < K <= 32: two clusters per lane
   if (nc > 0 && qrc < 0) qrc = fmx_wave_estep_launch(h, c0, nc);  // 32 < K: one wave per cell (part) and block
