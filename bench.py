@@ -112,7 +112,7 @@ def demux_sweep_kernel(V, alphas):
 
 def fmx_estep_kernel(K):
     if K <= 16:
-        return "fmx_estep_quad_kernel"
+        return "fmx_estep_oct_kernel"
     if K <= 24:
         return "fmx_estep_rowx_kernel"
     if K <= 32:

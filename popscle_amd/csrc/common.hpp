@@ -14,7 +14,8 @@
 #include "../../include/muxgl.h"
 
 constexpr int MUXGL_ROW_CH = 128;   // entries per chunk of the row kernels (16-lane slots)
-constexpr int MUXGL_QUAD_CH = 128;  // entries per chunk of the freemuxlet quad E-step (4-lane slots)
+constexpr int MUXGL_QUAD_CH = 192;  // entries per chunk of the freemuxlet oct E-step (configs[3], E-step in ms: 128: 1.63,
+                                    // 160: 1.58, 192: 1.50, 256: 1.49)
 constexpr int MUXGL_OCT_CH = 192;   // entries per chunk of the demuxlet oct kernel (8-lane slots).  Measured at configs[1]
                                     // (sweep + finish, ms): 96: 0.270 + 0.107, 128: 0.258 + 0.083, 160: 0.243 + 0.074,
                                     // 192: 0.252 + 0.068, 224: 0.250 + 0.066, 256: 0.253 + 0.067, 320: 0.281 + 0.066 --
@@ -58,10 +59,12 @@ struct muxgl_row_state {
   int32_t* d_quad_order = nullptr;      // ... and the launch order of the chunks (sorted by trip count within buckets)
   // freemuxlet quad E-step (fmx_quad.hip, built on first use after muxgl_fmx_prepare): per chunk, its linear entries
   // as {c0, c1, snp} records in front, then the SNP ids and six likelihoods of the others
-  struct fmx_lrec* d_fq_lrec = nullptr;
-  int32_t* d_fq_gsnp = nullptr;
-  double* d_fq_gl6 = nullptr;
   int32_t* d_fq_nlin = nullptr;
+  int32_t *d_fo_lsteps = nullptr, *d_fo_gsteps = nullptr;  // steps of every unit's two loops (fmx_oct.hip)
+  int64_t *d_fo_lptr = nullptr, *d_fo_gptr = nullptr;      // first record of every unit in the step-major tables below
+  uint32_t *d_fo_loff = nullptr, *d_fo_goff = nullptr;     // row offsets of the linear / other entries
+  double2* d_fo_lc = nullptr;                              // (c0, c1) of the linear entries
+  double* d_fo_ggl = nullptr;                              // six likelihoods of the other entries
   int32_t* d_fq_order = nullptr;        // launch order of the chunks, as d_quad_order
   int32_t* d_part_e = nullptr;          // per-chunk partial exponents (quad kernel)
   size_t part_cap = 0, part_e_cap = 0;
@@ -384,7 +387,7 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not 
 int demux_row2_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable (demux_row2.hip)
 int demux_rowx_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable (demux_rowx.hip)
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
-int fmx_quad_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
+int fmx_oct_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int fmx_rowx_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int fmx_row2_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);

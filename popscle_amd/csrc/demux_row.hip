@@ -295,9 +295,14 @@ void demux_row_release(muxgl_row_state** pst) {
   dev_free(&st->d_orec);
   dev_free(&st->d_unit_ptr);
   dev_free(&st->d_quad_order);
-  dev_free(&st->d_fq_lrec);
-  dev_free(&st->d_fq_gsnp);
-  dev_free(&st->d_fq_gl6);
+  dev_free(&st->d_fo_lsteps);
+  dev_free(&st->d_fo_gsteps);
+  dev_free(&st->d_fo_lptr);
+  dev_free(&st->d_fo_gptr);
+  dev_free(&st->d_fo_loff);
+  dev_free(&st->d_fo_goff);
+  dev_free(&st->d_fo_lc);
+  dev_free(&st->d_fo_ggl);
   dev_free(&st->d_fq_nlin);
   dev_free(&st->d_fq_order);
   delete st;

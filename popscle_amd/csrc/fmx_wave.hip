@@ -516,9 +516,14 @@ int64_t fmx_wave_fll_rows(const muxgl_handle* h) {
 void fmx_wave_streams_release(muxgl_handle* h) {
   for (muxgl_row_state* st : {h->qrow, h->fqrow})  // the quad E-step's partitioned copies are made of the same data
     if (st) {
-      dev_free(&st->d_fq_lrec);
-      dev_free(&st->d_fq_gsnp);
-      dev_free(&st->d_fq_gl6);
+      dev_free(&st->d_fo_lsteps);
+      dev_free(&st->d_fo_gsteps);
+      dev_free(&st->d_fo_lptr);
+      dev_free(&st->d_fo_gptr);
+      dev_free(&st->d_fo_loff);
+      dev_free(&st->d_fo_goff);
+      dev_free(&st->d_fo_lc);
+      dev_free(&st->d_fo_ggl);
       dev_free(&st->d_fq_nlin);
       dev_free(&st->d_fq_order);
     }

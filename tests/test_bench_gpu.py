@@ -57,7 +57,7 @@ def test_single_gpu_line():
     assert fx["scaling"] == "strong" and fx["steps"] == 20 and fx["n_gpus"] == 1 and fx["config"]["clusters"] == 16
     assert fx["config"]["cells"] == 50000 and fx["config"]["snps"] == 100000
     assert abs(fx["value"] - 50000 * 136 / (fx["ms_per_step"] * 1e-3)) / fx["value"] < 1e-9
-    assert fx["kernel_ms_rank0_last_iteration"]["estep"] > 0 and fx["roofline"]["kernel"] == "fmx_estep_quad_kernel"
+    assert fx["kernel_ms_rank0_last_iteration"]["estep"] > 0 and fx["roofline"]["kernel"] == "fmx_estep_oct_kernel"
     assert fx["roofline"]["frac"] is not None and 0 < fx["roofline"]["frac"] <= 1.0
     # the roofline prices the sweep kernel alone, inside the E-step bracket
     km = fx["kernel_ms_rank0_last_iteration"]

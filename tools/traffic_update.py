@@ -27,7 +27,7 @@ from popscle_amd.build import source_hash  # noqa: E402
 FAMILY = {  # config -> (kernels of the dominant phase, a kernel that runs exactly once per step)
     1: (r"^demux_oct_kernel", r"^demux_oct_finish_kernel"),
     2: (r"^demux_wave(_multi)?_kernel", r"^demux_call_wave_kernel"),
-    3: (r"^fmx_estep_quad_kernel", r"^fmx_call_kernel"),
+    3: (r"^fmx_estep_oct_kernel", r"^fmx_call_kernel"),
     4: (r"^fmx_estep_wave_kernel", r"^fmx_call_kernel"),
 }
 
