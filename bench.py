@@ -99,8 +99,6 @@ def demux_sweep_kernel(V, alphas):
         return "demux_oct_kernel"
     if V <= 16 and sum(1 for a in alphas[1:] if a != 0.5) <= 5 and sum(1 for a in alphas[1:] if a == 0.5) <= 1:
         return "demux_row_kernel"
-    if V <= 24 and tuple(alphas) == (0.0, 0.5):
-        return "demux_rowx_kernel"
     if V <= 32 and len(alphas) == 2 and alphas[1] == 0.5 and alphas[0] != 0.5:
         return "demux_row2_kernel"
     if V <= 32:
@@ -113,8 +111,6 @@ def demux_sweep_kernel(V, alphas):
 def fmx_estep_kernel(K):
     if K <= 16:
         return "fmx_estep_oct_kernel"
-    if K <= 24:
-        return "fmx_estep_rowx_kernel"
     if K <= 32:
         return "fmx_estep_row2_kernel"
     return "fmx_estep_wave_kernel"

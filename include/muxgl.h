@@ -43,9 +43,9 @@ extern "C" {
 enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 
 /* muxgl_config.flags */
-#define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row/quad kernels (lets tests cover the general tile sweep) */
-#define MUXGL_FLAG_FORCE_ROW_KERNEL 2  /* never take the default-grid quad kernel nor, at 17..24 samples / clusters, the
-                                          broadcast-extras kernels (lets tests cover the row kernels behind them) */
+#define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row/oct kernels (lets tests cover the general tile sweep) */
+#define MUXGL_FLAG_FORCE_ROW_KERNEL 2  /* never take the default-grid oct kernels (V, K <= 16: lets tests cover the row
+                                          kernels behind them) */
 #define MUXGL_FLAG_FORCE_WAVE_KERNEL 4 /* take the wave kernels for V <= 16 too, and the rings of 32 instead of the
                                           two-per-lane row kernels at 17..32 samples / clusters (test coverage) */
 #define MUXGL_FLAG_FORCE_BATCHED_GREEDY 8 /* (no effect since the batched greedy-init kernels became the default for K <= 64;
@@ -58,7 +58,7 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
                                       against that stream (popscle_amd/freemuxlet.py) */
 #define MUXGL_FLAG_NO_LINEAR_ENTRIES 64 /* sweep every entry through the general three-term form, also those whose
                                           likelihoods are linear in the genotypes (one usable read) and would take the
-                                          one-moment form of the quad (V, K <= 16) and wave (V, K > 32) kernels
+                                          one-moment form of the oct (V, K <= 16) and wave (V, K > 32) kernels
                                           (lets tests compare the two) */
 
 typedef struct muxgl_handle muxgl_handle;

@@ -385,10 +385,8 @@ void demux_row_free(muxgl_handle* h);
 int demux_row_build(muxgl_handle* h, muxgl_row_state** st, int64_t c0, int64_t c1, int ch);
 int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 int demux_row2_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable (demux_row2.hip)
-int demux_rowx_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable (demux_rowx.hip)
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int fmx_oct_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
-int fmx_rowx_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int fmx_row2_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64_t nc);  // -1: not applicable
 int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr);
 int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable

@@ -526,14 +526,13 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   int rc = -1;
   if (h->V <= 16) {
     if (demux_ensure_ll(h, p)) return 1;
-    rc = demux_oct_launch(h, p);               // the reference's default grid {0, 0.5}: quad kernel
-    if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the quad path's finish kernel
+    rc = demux_oct_launch(h, p);               // the reference's default grid {0, 0.5}: oct kernel
+    if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into the oct path's finish kernel
     if (rc < 0) rc = demux_row_launch(h, p);    // other grids: row kernel
   }
   if (h->V > 16 && h->V <= 32 && !(h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_WAVE_KERNEL))) {
     if (h->want_full_ll && demux_ensure_ll(h, p)) return 1;  // (without the tensor the call is made in LDS)
-    rc = demux_rowx_launch(h, p);                // grid {0, 0.5} at 17..24 samples: row kernel + broadcast extras
-    if (rc < 0) rc = demux_row2_launch(h, p);    // {a0, 0.5} up to 32 samples: row kernel with two samples per lane
+    rc = demux_row2_launch(h, p);    // {a0, 0.5} up to 32 samples: row kernel with two samples per lane
     if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into its finish kernel
   }
   if (rc < 0) rc = demux_wave_launch(h, p);  // one wave per cell and 64 x 64 block of the pair matrix, lane = sample

@@ -1117,7 +1117,6 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
       demux_row_build(h, &h->fqrow, 0, h->C, fmx_oct_chunk()))
     return 1;
   if (nc > 0) qrc = fmx_oct_estep_launch(h, h->fqrow, c0, nc);  // K <= 16: eight lanes per entry
-  if (nc > 0 && qrc < 0) qrc = fmx_rowx_estep_launch(h, st, c0, nc);  // 16 < K <= 24: row kernel + broadcast extras
   if (nc > 0 && qrc < 0) qrc = fmx_row2_estep_launch(h, st, c0, nc);  // 16 < K <= 32: two clusters per lane
   if (nc > 0 && qrc < 0) qrc = fmx_wave_estep_launch(h, c0, nc);  // 32 < K: one wave per cell (part) and block
   if (qrc > 0) return 1;

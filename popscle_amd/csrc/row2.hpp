@@ -1,6 +1,5 @@
-// row2.hpp -- what the row kernels for 17..32 samples / clusters (demux_row2.hip, fmx_row2.hip, demux_rowx.hip,
-// fmx_rowx.hip) share: rotations of a 16-lane DPP row by a constant, the lane map that goes with them, and the
-// accumulator layouts.
+// row2.hpp -- what the row kernels for 17..32 samples / clusters (demux_row2.hip, fmx_row2.hip) share: rotations of a
+// 16-lane DPP row by a constant, the lane map that goes with them, and the accumulator layout.
 #pragma once
 #include "common.hpp"
 
@@ -44,38 +43,6 @@ __device__ __forceinline__ bool row2_pair_of(int a, int j, const int32_t* __rest
     const int ka = kmap[t * 16 + j];
     if (t == 8 && j < ka) return false;
     x = j + 16 * (combo >> 1), y = ka + 16 * (combo & 1);
-  }
-  return true;
-}
-
-// ---- row kernel + broadcast extras (demux_rowx.hip, fmx_rowx.hip): units 0..15 in the lanes, NB <= 8 more in LDS ----
-constexpr int ROWX_MAX_NB = 8;
-
-// accumulators of lane j: 0 singlet j; t = 1..8: (j, kmap[t][j]); 9 + m: (j, 16 + m), m < NB; and for lanes j < NB:
-// 9 + NB: singlet 16 + j; 9 + NB + d: (16 + j, 16 + (j + d) mod NB), d = 1 .. NB/2
-__host__ __device__ constexpr int rowx_nacc(int NB) { return 10 + NB + NB / 2; }
-
-// the hypothesis (x, y) accumulator `a` of lane j stands for (singlets: y = -1); false where nobody or another lane
-// is the writer
-__device__ __forceinline__ bool rowx_pair_of(int a, int j, int NB, const int32_t* __restrict__ kmap, int& x, int& y) {
-  if (a == 0) {
-    x = j, y = -1;
-  } else if (a <= 8) {
-    const int ka = kmap[a * 16 + j];
-    if (a == 8 && j < ka) return false;  // rotation 8 visits every unordered pair of lanes twice
-    x = j, y = ka;
-  } else if (a < 9 + NB) {
-    x = j, y = 16 + (a - 9);
-  } else {
-    if (j >= NB) return false;
-    const int d = a - (9 + NB);
-    if (d == 0) {
-      x = 16 + j, y = -1;
-    } else {
-      const int pm = (j + d) % NB;
-      if (2 * d == NB && j > pm) return false;  // the half-way offset of an even ring: visited from both ends
-      x = 16 + j, y = 16 + pm;
-    }
   }
   return true;
 }

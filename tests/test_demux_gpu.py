@@ -58,11 +58,11 @@ def test_golden(eng, name):
     (1, (0.0, 0.5), 20, 500, 100),                # nv-1 == 0: infinite doublet prior, no doublet hypotheses
     (5, (0.0,), 40, 800, 150),                    # nAlpha == 1 (reference quirk: division by nAlpha-1 == 0)
     (7, (0.0, 0.3), 60, 1500, 200),               # no symmetric alpha at all
-    (17, (0.0, 0.5), 30, 3000, 400),              # row kernel + one broadcast sample (demux_rowx.hip); 'row': two samples
+    (17, (0.0, 0.5), 30, 3000, 400),              # two samples per lane (demux_row2.hip)
                                                   # per lane (demux_row2.hip); 'wave': ring of 32, one alpha
     (18, (0.0, 0.5), 24, 3000, 400),              #   two broadcast samples: the even ring's half-way offset
     (21, (0.0, 0.5), 24, 3000, 700),              #   five (odd ring), several chunks per cell
-    (24, (0.0, 0.5), 24, 3000, 400),              #   eight: the last shape of demux_rowx.hip
+    (24, (0.0, 0.5), 24, 3000, 400),              #   (was the last shape of the broadcast-extras kernel)
     (32, (0.0, 0.5), 24, 4000, 700),              #   every lane with two live samples, several chunks per cell
     (25, (0.2, 0.5), 24, 3000, 300),              #   singlet slot at a non-zero alpha
     (24, GRID6, 24, 4000, 500),                   #   five doublet alphas: a launch of 2 + 2 and one of 1 + 0

@@ -114,7 +114,7 @@ def test_golden(eng):
     (18, 40, 2000, 300, 2),    #   ring of 32, 'pair': pair kernel); even / odd rings among the extra clusters
     (20, 100, 2500, 400, 2),
     (21, 40, 2500, 700, 2),
-    (24, 40, 2500, 400, 2),    #   the last shape of fmx_rowx.hip
+    (24, 40, 2500, 400, 2),    #   (was the last shape of the broadcast-extras kernel)
     (27, 40, 2500, 400, 2),    # 24 < K <= 32: two clusters per lane
     (32, 50, 3000, 2600, 2),   #   full ring, cells in several parts
     (64, 40, 4000, 500, 2),    # config-5 shape, few cells
