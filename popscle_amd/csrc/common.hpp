@@ -115,6 +115,9 @@ struct muxgl_handle {
   fmx_grec* d_lin_rec = nullptr;    // [n_lin_rec] {entry, snp} of the linear entries, in entry order
   fmx_grec* d_gen_rec = nullptr;    // [nnz - n_lin_rec] the others
   int64_t n_lin_rec = -1;
+  uint2* d_ring_rec = nullptr;      // demux_ring.hip: {snp, table row} of the linear entries, in stream order
+  double* d_ring_lut = nullptr;     // ... and the table of (A, Bl, Bm) rows of the current launch
+  int64_t ring_rec_n = -1;
   uint32_t* d_flin = nullptr;       // [ceil(nnz/32)] freemuxlet: additionally, no clamp fired (checked on the values)
   // The wave E-step's two streams (fmx_wave.hip, built on first use): a cell's linear entries as 24-byte records
   // {c0, c1, snp} and its other entries as {entry, snp}, both in entry order; d_flin_rank[w] = linear entries before
@@ -375,10 +378,19 @@ struct wave_item {
 struct wave_cut {
   int64_t cell, first, count;  // overflow slabs [first, first + count)
 };
+struct ring_sel {          // one launch of demux_ring.hip
+  int32_t n[4];            // alpha indices of the non-symmetric slots
+  int32_t nsym;            // ... of the symmetric slot (0: none)
+  int32_t with_singlet;    // the launch also fills llw[c][block][0][0][lane]
+  int32_t jbase, blk, nblk2;  // first sample of the diagonal block, its slab, slabs per cell
+};
 
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, double* d_lpg = nullptr);
+int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
+                          const double* gm, int na, const ring_sel& sel, double* llw);
+void demux_ring_release(muxgl_handle* h);
 int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);

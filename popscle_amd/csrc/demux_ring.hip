@@ -1,0 +1,364 @@
+// demux_ring.hip -- the linear entries of the demuxlet pair sweep for more than 32 samples (demux_wave.hip's diagonal
+// blocks: samples 64 X .. 64 X + 63 against themselves).
+//
+// Reference being replaced: cmd_cram_demuxlet.cpp:733-747 for the entries with at most one usable read, whose
+// likelihoods are pG[l][m] = A + Bl*l + Bm*m (cmd_cram_demuxlet.cpp:673,685 for a single factor; see the notes on
+// EM_LINEAR in demux_wave.hip).  A pair hypothesis of such an entry is s_j s_k (A + Bl rho_j + Bm rho_k): one FMA and the
+// product update per (pair, alpha).  At 64 samples and the north_star's six alphas that is 18 208 hypotheses per entry:
+// the sweep is bound by FP64 issue, so every vector instruction that is not one of those two counts.  The kernels this
+// file replaced spent 55 of 183 vector instructions per (wave, entry) around the sweep: every wave fetched the marker's
+// row and the entry's (A, Bl, Bm) table row for itself through a register pipeline two entries deep, wrote a ring of its
+// own, and the symmetric alpha walked all entries again in a launch of its own.  Here:
+//   * workgroup = work unit (a cell, or a part of a long one: wave_item), four waves; wave w owns the rotation steps
+//     16 w + 1 .. 16 w + 16 of up to four non-symmetric alphas AND the distances 8 w + 1 .. 8 w + 8 of the symmetric one
+//     (alpha = 0.5 meets every unordered pair within 32 steps): 72 product accumulators per lane, all five pair alphas of
+//     the north_star grid in ONE walk;
+//   * the marker rows (s, rho per sample: wave_gm_kernel) are STAGED: the entries of a unit are taken in batches of
+//     eight; each wave fetches two rows of the next batch (one 16-byte load per lane and row) while the current batch is
+//     swept and leaves them in LDS -- rho twice over, so that the staged row IS the ring all four waves read their
+//     partners from at immediate offsets (demux_wave.hip: the ring), the sums s, and the factor of the singlet slot
+//     (j, 0, n = 0), which the loader forms once.  One fetch per row and workgroup with a whole batch (~5 k cycles) of
+//     cover, and per wave and entry nothing but two LDS reads and the lane's A + Bl rho_j per alpha;
+//   * (A, Bl, Bm) come from a table of 130 rows indexed by (allele, base quality) of the entry's one read (row 128: no
+//     usable read; row 129: a marker without genotypes, or padding -- factors of exactly 1), read through the scalar
+//     cache: 8 bytes of record {snp, row} per entry instead of 24 bytes per entry and alpha;
+//   * products as mantissa * 2^exponent, renormalised every 24 entries (each factor is >= 1e-10 / (1 + 1e-10), so 24 of
+//     them cannot underflow); half of the exponents live in registers, half in LDS; the product of the lane's own sums
+//     (wave 1) and the singlet slot (wave 0) are kept by one wave each.
+// Results go to the wave layout llw[cell][block][alpha][step][lane] of demux_wave.hip, whose EM_GENERAL launches add the
+// other entries on top.
+#include "common.hpp"
+#include "demux_entry.hpp"
+
+namespace {
+
+constexpr int RL_B = 8;       // entries per staged batch
+constexpr int RL_ROW = 256;   // doubles per staged entry: rho of the 64 lanes twice over (the ring), s, singlet factors
+constexpr int RL_LUTW = 24;   // doubles per table row: (A, Bl, Bm) of six slots, padded to 192 bytes
+constexpr int RL_NLUT = 130;  // rows: allele << 6 | quality; 128 = no usable read; 129 = neutral
+constexpr int RL_PAD = 32;    // records readable behind the end of the stream
+constexpr int RL_RENORM = 3;  // batches between renormalisations
+
+struct ring_alpha {
+  double a[6];  // slot 0: alpha[0] (singlets), 1..4: the launch's non-symmetric alphas, 5: the symmetric one
+};
+
+// table row r, slot s: the likelihoods of a one-read entry as the per-entry kernel computes them (row_entry_pg), read off
+// as A = pG[0][0], Bl = pG[1][0] - pG[0][0], Bm = pG[0][1] - pG[0][0]
+__global__ void __launch_bounds__(64) ring_lut_kernel(ring_alpha al, const double* __restrict__ lut, double* __restrict__ out) {
+  const int r = blockIdx.x, s = threadIdx.x;
+  if (s >= 6) return;
+  double* o = out + (size_t)r * RL_LUTW + s * 3;
+  if (r == RL_NLUT - 1) {
+    o[0] = 1.0, o[1] = 0.0, o[2] = 0.0;
+    return;
+  }
+  double pG[9];
+  const uint32_t byte = (uint32_t)(((r >> 6) & 1) << 7) | (uint32_t)(r & 63);
+  row_entry_pg<1>(nullptr, 0, r < 128 ? 1 : 0, byte, &al.a[s], lut, pG);
+  o[0] = pG[0];
+  o[1] = pG[3] - pG[0];
+  o[2] = pG[1] - pG[0];
+}
+
+// the linear entries' records in stream order: {snp, byte offset of the table row}
+__global__ void __launch_bounds__(256)
+    ring_rec_kernel(int64_t n_lin, const fmx_grec* __restrict__ rec_lin, const int64_t* __restrict__ entry_rptr,
+                    const uint8_t* __restrict__ reads, const uint8_t* __restrict__ has_gp, uint2* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_lin + RL_PAD) return;
+  uint32_t snp = 0, row = RL_NLUT - 1;
+  if (r < n_lin) {
+    const fmx_grec x = rec_lin[r];
+    snp = (uint32_t)x.snp;
+    if (has_gp[x.snp]) {
+      row = 128;
+      for (int64_t q = entry_rptr[x.e]; q < entry_rptr[x.e + 1]; ++q) {
+        const uint8_t b = reads[q];
+        if (b == MUXGL_READ_OTHER) continue;
+        row = ((uint32_t)(b >> 7) << 6) | (uint32_t)(b & 0x3f);  // (the class holds qualities <= 60 only: lin_kernel)
+        break;
+      }
+    }
+  }
+  out[r] = uint2{snp, row * (uint32_t)(RL_LUTW * 8)};
+}
+
+template <int NA, bool SYM>
+__global__ void __launch_bounds__(256, 2)
+    demux_ring_lin_kernel(const wave_item* __restrict__ items, int64_t n_items, const uint32_t* __restrict__ lin,
+                          const int64_t* __restrict__ lin_rank, const uint2* __restrict__ rrec,
+                          const double* __restrict__ lutg, const double* __restrict__ gm, int V, int nAlpha, ring_sel sel,
+                          double* __restrict__ ll) {
+  constexpr int NS = NA > 0 ? 16 : 0, NSY = SYM ? 8 : 0, NACC = NA * NS + NSY;
+  constexpr int NXV = NACC / 2, NXL = NACC - NXV;         // exponents in registers / in LDS
+  constexpr int GN = NS / 4, GS = NSY / 4, GT = GN + GS;  // groups of four ring reads per entry
+  constexpr int NA1 = NA > 0 ? NA : 1;
+  static_assert(GT % 2 == 0 && GT > 0, "the read buffers alternate per group");
+  __shared__ double stage[2][RL_B][RL_ROW];
+  __shared__ int32_t exs_all[4][NXL][64];
+  if ((int64_t)blockIdx.x >= n_items) return;
+  const wave_item it = items[blockIdx.x];
+  if (it.e0 == it.e1) return;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = threadIdx.x & 63;  // (w: known to be wave-uniform)
+  const bool live = sel.jbase + j < V;
+  int32_t (*exs)[64] = exs_all[w];
+  int64_t i0, i1;
+  wave_stream_range<EM_LINEAR>(lin, lin_rank, it.e0, it.e1, i0, i1);
+  const int64_t n = i1 - i0;
+  const int nb = (int)((n + RL_B - 1) / RL_B);
+  const uint2* rr = rrec + i0;
+  const double* grow = gm + (size_t)(live ? sel.jbase + j : V - 1) * 2;
+
+  double acc[NACC], accX = 1.0;  // accX: wave 0 the singlet slot, wave 1 the product of the lane's own sums s
+  int32_t ex[NXV], exX = 0;
+#pragma unroll
+  for (int t = 0; t < NACC; ++t) {
+    acc[t] = 1.0;
+    if (t < NXV) ex[t] = 0;
+    else exs[t - NXV][j] = 0;
+  }
+
+  // LDS byte addresses inside a staged row: own rho at [j]; second own value: the singlet factor [192 + j] (wave 0) or the
+  // sum s [128 + j]; ring reads of the non-symmetric steps relative to [j + 64 - 16 w - 16], of the symmetric distances
+  // relative to [j + 64 - 8 w - 8]
+  const uint32_t base0 = (uint32_t)(uintptr_t)&stage[0][0][0];
+  constexpr uint32_t ROWB = RL_ROW * 8, BUFB = RL_B * ROWB;
+  const uint32_t ownoff = (uint32_t)j * 8u, own2off = (uint32_t)((w == 0 ? 192 : 128) + j) * 8u;
+  const uint32_t rboff = (uint32_t)(j + 64 - 16 * w - 16) * 8u, rsoff = (uint32_t)(j + 64 - 8 * w - 8) * 8u;
+
+  // ---- loader: rows of the entries w and w + 4 of a batch
+  uint32_t rcs[RL_B], rcl[RL_B], rns[RL_B], rnl[RL_B];  // records of the current / next batch: snp, table row offset
+  auto load_recs = [&](uint32_t (&rs_)[RL_B], uint32_t (&rl_)[RL_B], int b) {  // (records behind the unit's end exist -- RL_PAD)
+    const uint32_t* p = (const uint32_t*)(rr + (int64_t)b * RL_B);
+#pragma unroll
+    for (int k = 0; k < RL_B; ++k) {
+      const bool in = (int64_t)b * RL_B + k < n;
+      rs_[k] = in ? p[2 * k] : 0u;
+      rl_[k] = in ? p[2 * k + 1] : (uint32_t)((RL_NLUT - 1) * RL_LUTW * 8);
+    }
+  };
+  double2 g2[2], h2[2];  // (s, rho) of the lane's sample / of sample 0, whose moments every singlet carries (:806,828)
+  double q0[2][3];       // (A, Bl, Bm) of alpha[0] for the two entries
+  auto load_rows = [&](const uint32_t (&rs_)[RL_B], const uint32_t (&rl_)[RL_B]) {
+    const uint32_t sa = w == 0 ? rs_[0] : (w == 1 ? rs_[1] : (w == 2 ? rs_[2] : rs_[3]));
+    const uint32_t sb = w == 0 ? rs_[4] : (w == 1 ? rs_[5] : (w == 2 ? rs_[6] : rs_[7]));
+    const uint32_t la = w == 0 ? rl_[0] : (w == 1 ? rl_[1] : (w == 2 ? rl_[2] : rl_[3]));
+    const uint32_t lb = w == 0 ? rl_[4] : (w == 1 ? rl_[5] : (w == 2 ? rl_[6] : rl_[7]));
+    g2[0] = *(const double2*)(grow + (size_t)sa * V * 2);
+    g2[1] = *(const double2*)(grow + (size_t)sb * V * 2);
+    h2[0] = *(const double2*)(gm + (size_t)sa * V * 2);
+    h2[1] = *(const double2*)(gm + (size_t)sb * V * 2);
+    const double* La = (const double*)((const char*)lutg + la);
+    const double* Lb = (const double*)((const char*)lutg + lb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q0[0][i] = La[i], q0[1][i] = Lb[i];
+  };
+  auto store_rows = [&](int buf, int b) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = w + 4 * q;
+      const bool ok = live && (int64_t)b * RL_B + k < n;
+      const double s = ok ? g2[q].x : 1.0, rho = ok ? g2[q].y : 0.0;
+      // sum_m h[m] sum_l g[l] (A + Bl l + Bm m) of alpha[0] = s_h s_g (A + Bl rho_g + Bm rho_h)
+      const double sv = ok ? (s * h2[q].x) * fma(q0[q][2], h2[q].y, fma(q0[q][1], rho, q0[q][0])) : 1.0;
+      double* row = &stage[buf][k][0];
+      row[j] = rho;
+      row[j + 64] = rho;
+      row[128 + j] = s;
+      row[192 + j] = sv;
+    }
+  };
+
+  unsigned pfv = 0, pfx = 0;  // touches of the record stream (see dw_walk in demux_wave.hip)
+  load_recs(rcs, rcl, 0);
+  load_rows(rcs, rcl);
+  store_rows(0, 0);
+  __syncthreads();
+
+  double rd[2][4], ow[2][2];             // ring values of a group; own (rho, second value) of an entry
+  double lA[2][6], lB[2][6], lM[2][6];   // table row of an entry, by slot (see ring_alpha)
+  double u0[NA1], u0s = 0.0;             // the lane's A + Bl rho_j per alpha
+  auto load_lut = [&](auto pc, uint32_t off) {
+    constexpr int p = decltype(pc)::value;
+    const double* L = (const double*)((const char*)lutg + off);
+#pragma unroll
+    for (int s = 1; s < 6; ++s) {
+      const bool used = s <= 4 ? s - 1 < NA : SYM;
+      if (used) lA[p][s] = L[s * 3], lB[p][s] = L[s * 3 + 1], lM[p][s] = L[s * 3 + 2];
+    }
+  };
+  load_lut(std::integral_constant<int, 0>{}, rcl[0]);
+
+  int cnt = 0;
+  for (int b = 0; b < nb; ++b) {
+    const uint32_t bb = base0 + (uint32_t)(b & 1) * BUFB;
+    const uint32_t own = bb + ownoff, own2 = bb + own2off, rb = bb + rboff, rs = bb + rsoff;
+    load_recs(rns, rnl, b + 1);
+    pfx ^= pfv;
+    {
+      const int64_t ta = (int64_t)(b + 4) * RL_B;
+      pfv = ((const unsigned*)(rr + (ta < n ? ta : 0)))[j & 15];
+    }
+    load_rows(rns, rnl);
+
+    // ---- the batch: 8 entries x GT groups of four ring reads as one flat pipeline, a group ahead of its use
+    auto issue = [&](auto kc, auto gc) {
+      constexpr int k = decltype(kc)::value, g = decltype(gc)::value;
+      if constexpr (g == 0) {
+        ow[k & 1][0] = wave_ring_rd<k * ROWB>(own);
+        ow[k & 1][1] = wave_ring_rd<k * ROWB>(own2);
+      }
+      wave_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (g < GN) rd[g & 1][i] = wave_ring_rd<k * ROWB + (15 - (4 * g + i)) * 8>(rb);
+        else rd[g & 1][i] = wave_ring_rd<k * ROWB + (7 - (4 * (g - GN) + i)) * 8>(rs);
+      });
+    };
+    issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    wave_for<0, RL_B>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, p = k & 1;
+      wave_for<0, GT>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr bool last = g + 1 == GT;
+        constexpr bool more = !last || k + 1 < RL_B;
+        if constexpr (!last) issue(kc, std::integral_constant<int, g + 1>{});
+        else if constexpr (k + 1 < RL_B) issue(std::integral_constant<int, k + 1>{}, std::integral_constant<int, 0>{});
+        constexpr int ahead = more ? (last ? 6 : 4) : 0;  // younger reads: they may stay in flight
+        if constexpr (g == 0) {
+          asm volatile("s_waitcnt lgkmcnt(%6)"
+                       : "+v"(rd[0][0]), "+v"(rd[0][1]), "+v"(rd[0][2]), "+v"(rd[0][3]), "+v"(ow[p][0]), "+v"(ow[p][1])
+                       : "n"(ahead));
+          // the entry's factors of the lane
+          const double rho = ow[p][0];
+#pragma unroll
+          for (int a = 0; a < NA; ++a) u0[a] = fma(lB[p][a + 1], rho, lA[p][a + 1]);
+          if (SYM) u0s = fma(lB[p][5], rho, lA[p][5]);
+          if (w < 2) accX *= ow[p][1];
+          // table row of the next entry
+          if constexpr (k + 1 < RL_B) load_lut(std::integral_constant<int, 1 - p>{}, rcl[k + 1]);
+          else load_lut(std::integral_constant<int, 1 - p>{}, rnl[0]);
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(%4)"
+                       : "+v"(rd[g & 1][0]), "+v"(rd[g & 1][1]), "+v"(rd[g & 1][2]), "+v"(rd[g & 1][3])
+                       : "n"(ahead));
+        }
+        wave_for<0, 4>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr (g < GN) {
+            constexpr int t = 4 * g + i;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(lM[p][a + 1], rd[g & 1][i], u0[a]);
+          } else {
+            constexpr int t = 4 * (g - GN) + i;
+            acc[NA * NS + t] *= fma(lM[p][5], rd[g & 1][i], u0s);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all the sums first
+      });
+    });
+
+    if (++cnt == RL_RENORM) {
+      cnt = 0;
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) {
+        if (t < NXV) {
+          prodacc_renorm(acc[t], ex[t]);
+        } else {
+          int ee;
+          acc[t] = frexp(acc[t], &ee);
+          exs[t - NXV][j] += ee;
+        }
+      }
+      prodacc_renorm(accX, exX);
+    }
+    store_rows((b + 1) & 1, b + 1);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RL_B; ++k) rcs[k] = rns[k], rcl[k] = rnl[k];
+  }
+  pfx ^= pfv;
+  asm volatile("" ::"v"(pfx));
+
+  // ---- results: the wave layout llw[c][block][n][step t][lane j], lane j at step t holds (j, k = j - t - 1 mod 64); the
+  //      logarithm of the product of the partner's sums comes out of the ring like the partner's rho did
+  double* out = ll + ((size_t)it.slab * sel.nblk2 + sel.blk) * nAlpha * 4096;
+  const double lx = prodacc_log(accX, exX);
+  if (w == 1) stage[0][0][j] = lx, stage[0][0][j + 64] = lx;
+  __syncthreads();
+  const double logW = stage[0][0][j];
+  const uint32_t rb = base0 + rboff, rs = base0 + rsoff;
+  wave_for<0, NS>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (16 * w + t >= 63) return;
+    double lw = wave_ring_rd<(15 - t) * 8>(rb);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
+    lw += logW;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      constexpr int x = 0;
+      (void)x;
+      const int xi = a * NS + t;
+      const int32_t e = xi < NXV ? ex[xi < NXV ? xi : 0] : exs[xi < NXV ? 0 : xi - NXV][j];
+      out[((size_t)sel.n[a] * 64 + 16 * w + t) * 64 + j] = prodacc_log(acc[xi], e) + lw;
+    }
+  });
+  wave_for<0, NSY>([&](auto tc) {
+    constexpr int t = decltype(tc)::value, xi = NA * NS + t;
+    double lw = wave_ring_rd<(7 - t) * 8>(rs);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
+    const int tt = 8 * w + t, kk = (j - tt - 1) & 63;
+    const int32_t e = xi < NXV ? ex[xi < NXV ? xi : 0] : exs[xi < NXV ? 0 : xi - NXV][j];
+    const double v = prodacc_log(acc[xi], e) + lw + logW;
+    if (tt < 31 || j > kk) {  // distance 32 meets every unordered pair from both ends: one writer
+      out[((size_t)sel.nsym * 64 + tt) * 64 + j] = v;
+      out[((size_t)sel.nsym * 64 + (62 - tt)) * 64 + kk] = v;
+    }
+  });
+  if (w == 0 && sel.with_singlet) out[j] = lx;  // llw[c][0][0][j]
+}
+
+template <int NA, bool SYM>
+void ring_launch(muxgl_handle* h, const wave_item* items, int64_t n_items, const double* lut, const double* gm, int A,
+                 const ring_sel& sel, double* llw) {
+  hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items, h->d_lin,
+                     h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, llw);
+}
+
+}  // namespace
+
+void demux_ring_release(muxgl_handle* h) {
+  dev_free(&h->d_ring_rec);
+  dev_free(&h->d_ring_lut);
+  h->ring_rec_n = -1;
+}
+
+// One launch: the linear entries of every work unit for up to four non-symmetric alphas (sel.n[0 .. na)) and, with
+// sel.nsym > 0, the symmetric one.  gm: wave_gm_kernel's moments.  Needs h->d_lin_rank / d_lin_rec (plan_build_bit_streams).
+int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
+                          const double* gm, int na, const ring_sel& sel, double* llw) {
+  if (h->ring_rec_n != h->n_lin_rec || !h->d_ring_rec) {  // per pileup and genotype set (rows of markers without genotypes)
+    if (dev_alloc(h, &h->d_ring_rec, (size_t)h->n_lin_rec + RL_PAD)) return 1;
+    const int64_t nr = h->n_lin_rec + RL_PAD;
+    hipLaunchKernelGGL(ring_rec_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, h->stream, h->n_lin_rec, h->d_lin_rec,
+                       h->d_entry_rptr, h->d_reads, h->d_has_gp, h->d_ring_rec);
+    HIPCHK(h, hipGetLastError());
+    h->ring_rec_n = h->n_lin_rec;
+  }
+  if (!h->d_ring_lut && dev_alloc(h, &h->d_ring_lut, (size_t)RL_NLUT * RL_LUTW)) return 1;
+  ring_alpha al;
+  al.a[0] = p->alpha[0];
+  for (int a = 0; a < 4; ++a) al.a[1 + a] = a < na ? p->alpha[sel.n[a]] : p->alpha[0];
+  al.a[5] = sel.nsym > 0 ? p->alpha[sel.nsym] : p->alpha[0];
+  hipLaunchKernelGGL(ring_lut_kernel, dim3(RL_NLUT), dim3(64), 0, h->stream, al, h->d_lut, h->d_ring_lut);
+  const bool sym = sel.nsym > 0;
+#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, llw)
+  if (na == 4) sym ? RING(4, true) : RING(4, false);
+  else if (na == 2) sym ? RING(2, true) : RING(2, false);
+  else if (na == 1) sym ? RING(1, true) : RING(1, false);
+  else if (na == 0 && sym) RING(0, true);
+  else MUXGL_FAIL(h, "demux_ring_lin_launch: %d alphas", na);
+#undef RING
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}

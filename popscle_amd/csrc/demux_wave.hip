@@ -920,25 +920,23 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 #define MULTI_K(NA, NS, WS, CR, EMODE)                                                                                        \
   hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64 * (64 / NS)), 0, h->stream, KARGS, \
                      sel, wb, h->d_llw)
-#define MULTI_LAUNCH(NA, NS, WS, CR)         \
-  do {                                       \
-    if (use_lin && !(CR)) {                  \
-      MULTI_K(NA, NS, WS, false, EM_LINEAR); \
+#define MULTI_LAUNCH(NA, NS, WS, CR)          \
+  do {                                        \
+    if (use_lin && !(CR)) {                   \
       MULTI_K(NA, NS, WS, false, EM_GENERAL); \
-    } else {                                 \
-      MULTI_K(NA, NS, WS, CR, EM_ALL);       \
-    }                                        \
+    } else {                                  \
+      MULTI_K(NA, NS, WS, CR, EM_ALL);        \
+    }                                         \
   } while (0)
 #define WAVE_K(NS, WS, CR, EMODE) \
   hipLaunchKernelGGL((demux_wave_kernel<NS, WS, CR, EMODE>), dim3(blocks), dim3(64), 0, h->stream, KARGS, n, wb, h->d_llw)
-#define WAVE_LAUNCH(NS, WS, CR)           \
-  do {                                    \
-    if (use_lin && !(CR)) {               \
-      WAVE_K(NS, WS, false, EM_LINEAR);   \
-      WAVE_K(NS, WS, false, EM_GENERAL);  \
-    } else {                              \
-      WAVE_K(NS, WS, CR, EM_ALL);         \
-    }                                     \
+#define WAVE_LAUNCH(NS, WS, CR)          \
+  do {                                   \
+    if (use_lin && !(CR)) {              \
+      WAVE_K(NS, WS, false, EM_GENERAL); \
+    } else {                             \
+      WAVE_K(NS, WS, CR, EM_ALL);        \
+    }                                    \
   } while (0)
   if (V <= 32) {  // ring of 32: 16 rotation steps, up to four alphas per launch, see demux_wave32_kernel
     std::vector<int> all;
@@ -981,8 +979,23 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       const wave_blk wb = {64 * X, 64 * X, X * nblk + X, nblk2};
       bool first = true;
       size_t done = 0;
+      // the linear entries of the launch's alphas first (demux_ring.hip; the symmetric alpha rides with the first of
+      // these launches), then the others on top
+      uint32_t sym_left = symmask;
+      auto ring = [&](int na, const int* idx, int nsym) -> int {
+        if (!use_lin) return 0;
+        ring_sel rs{};
+        for (int a = 0; a < na; ++a) rs.n[a] = idx[a];
+        if (nsym == 0 && sym_left) nsym = __builtin_ctz(sym_left);
+        if (nsym) sym_left &= ~(1u << nsym);
+        rs.nsym = nsym;
+        rs.with_singlet = first ? 1 : 0;
+        rs.jbase = 64 * X, rs.blk = wb.blk, rs.nblk2 = nblk2;
+        return demux_ring_lin_launch(h, p, st->d_items, st->n_items, st->d_gm, na, rs, h->d_llw);
+      };
       while (plain.size() - done >= 4) {
         wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};
+        if (ring(4, &plain[done], 0)) return 1;
         if (first) MULTI_LAUNCH(4, 16, true, false);  // (all four step ranges: a wave each)
         else MULTI_LAUNCH(4, 16, false, false);
         HIPCHK(h, hipGetLastError());
@@ -991,6 +1004,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       }
       while (plain.size() - done >= 2) {
         wave_sel sel = {{plain[done], plain[done + 1], 0, 0}};
+        if (ring(2, &plain[done], 0)) return 1;
         if (first) MULTI_LAUNCH(2, 32, true, false);
         else MULTI_LAUNCH(2, 32, false, false);
         HIPCHK(h, hipGetLastError());
@@ -1000,6 +1014,8 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       for (int n = 1; n < A; ++n) {
         const bool sym = (p->alpha[n] == 0.5);
         if (!sym && !(done < plain.size() && plain[done] == n)) continue;  // already covered by a multi-alpha launch
+        if (sym && ((sym_left >> n) & 1u) && ring(0, nullptr, n)) return 1;  // (not yet taken along)
+        if (!sym && ring(1, &plain[done], 0)) return 1;
         if (sym && first) WAVE_LAUNCH(32, true, false);
         else if (sym) WAVE_LAUNCH(32, false, false);
         else if (first) WAVE_LAUNCH(63, true, false);

@@ -313,6 +313,7 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
   dev_free(&h->d_gpq);
   dev_free(&h->d_gp0s);
   dev_free(&h->d_gmq);
+  demux_ring_release(h);  // (its records name the neutral table row for markers without genotypes)
   if (h->qrow) {  // the oct kernel's partitioned records carry has_gp (quad_lrec::code): rebuilt on the next run
     dev_free(&h->qrow->d_qent_lin);
     dev_free(&h->qrow->d_chunk_nlin);

@@ -217,6 +217,7 @@ void plan_lin_streams_release(muxgl_handle* h) {
   dev_free(&h->d_lin_rec);
   dev_free(&h->d_gen_rec);
   h->n_lin_rec = -1;
+  demux_ring_release(h);
 }
 
 int plan_build_lin(muxgl_handle* h) {
