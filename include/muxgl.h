@@ -60,6 +60,9 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
                                           likelihoods are linear in the genotypes (one usable read) and would take the
                                           one-moment form of the oct (V, K <= 16) and wave (V, K > 32) kernels
                                           (lets tests compare the two) */
+#define MUXGL_FLAG_MSTEP_LDS_STATES 128 /* freemuxlet M-step for K <= 64 with one lane per marker and the cluster states
+                                           in LDS (fmx_mstep_snp_kernel) instead of one lane per (marker, cluster) chain
+                                           over the marker's list as a stream (lets tests compare the two) */
 
 typedef struct muxgl_handle muxgl_handle;
 

@@ -171,6 +171,8 @@ struct muxgl_handle {
   int32_t* d_ccnt = nullptr;      // [K][S][3]
   double* d_cgp = nullptr;        // [S][K][3] cluster genotype posteriors for the E-step
   int32_t* d_clust = nullptr;     // [C] current singlet cluster or -1
+  uint8_t* d_clust8 = nullptr;    // the same as bytes (255: none), rewritten by every M-step (fmx_mstep.hip)
+  int64_t clust8_n = -1;
   muxgl_fmx_cell* d_fcells = nullptr;
   muxgl_fmx_cell* h_fcells = nullptr;  // pinned
   double* d_fll = nullptr;        // [C][K(K+1)/2]
@@ -435,6 +437,7 @@ int fmx_cluster_counts_device(muxgl_handle* m);  // m->d_ccnt := read counts of 
 int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_mstep(muxgl_handle* h);
+int fmx_mstep_stream_launch(muxgl_handle* h);  // K <= 64 (fmx_mstep.hip); -1: not applicable
 
 // device groups (muxgl_group.hip): every entry point of the C-ABI forwards here when h->group is set
 int group_create(const muxgl_config* cfg, muxgl_handle** out, std::string* err);

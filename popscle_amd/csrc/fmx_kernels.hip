@@ -803,6 +803,10 @@ static int fmx_mstep_launch(muxgl_handle* h) {
   while (P * 16 < h->K) P *= 2;
   const int KL = (h->K + P - 1) / P;
   const size_t lds = (size_t)64 * (KL * 6 + 1) * sizeof(double);
+  if (!(h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_MSTEP_LDS_STATES))) {  // lane = chain, the list as a stream
+    const int rc = fmx_mstep_stream_launch(h);
+    if (rc >= 0) return rc;
+  }
   if (P <= 16 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // lane(s) per SNP, cluster states in LDS
     const int64_t ns = h->fs1 - h->fs0;
     const int per = 64 / P;

@@ -266,6 +266,8 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_ccnt);
   dev_free(&h->d_cgp);
   dev_free(&h->d_clust);
+  dev_free(&h->d_clust8);
+  h->clust8_n = -1;
   dev_free(&h->d_fcells);
   dev_free(&h->d_fll);
   dev_free(&h->d_fstat);

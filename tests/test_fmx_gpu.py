@@ -287,3 +287,32 @@ def test_greedy_init_near_ties(geng, C, S, K, me):
     got = geng.fmx_greedy_init(K, scores)
     flips = np.flatnonzero(got != want)
     assert flips.size == 0, f"{flips.size} of {C} assignments differ from the oracle, first at cells {flips[:5]}"
+
+
+@pytest.mark.parametrize("K,C,S,me", [(3, 2500, 60, 30), (16, 3000, 50, 25), (20, 2500, 40, 20), (32, 4000, 64, 30),
+                                      (40, 3000, 48, 24), (64, 6000, 70, 40), (16, 64, 40, 30)])
+def test_mstep_stream_vs_lds_states_and_oracle(K, C, S, me):
+    """Ordered clamped M-step (sc_drop_seq.h:77-101 driven by cmd_cram_freemux2.cpp:586-597) on markers covered by
+    hundreds to thousands of cells -- lists of many batches per chain, clusters of very different sizes, unassigned
+    cells: the stream kernel (lane = (marker, cluster) chain, fmx_mstep.hip) and the kernel with the states in LDS
+    (MUXGL_FLAG_MSTEP_LDS_STATES) agree bit for bit, and with the oracle's cluster pileups to rounding."""
+    p = synth.make_pileup(C, S, min(K, 8), seed=900 + K + C, mean_entries=me, min_entries=5, with_gp=False)
+    rng = np.random.default_rng(K * 1000 + C)
+    w = rng.dirichlet(np.full(K, 0.6))  # unbalanced clusters: some chains much longer than a batch, some empty
+    clust = rng.choice(K, size=p.C, p=w).astype(np.int32)
+    clust[rng.random(p.C) < 0.07] = -1
+    e = ob.fmx_entry_pileup(p)
+    want = ob.fmx_build_cluster_pileup(p, e, K, clust)
+    got = []
+    for flags in (0, muxgl.FLAG_MSTEP_LDS_STATES):
+        with muxgl.Engine(0, flags) as en:
+            en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+            en.fmx_prepare(p.af)
+            en.fmx_set_clusters(K, clust)
+            g, c = en.fmx_cluster_pileup()
+            assert np.array_equal(c, np.stack([want["nreads"], want["nref"], want["nalt"]], axis=-1))
+            assert np.allclose(g, want["gls"], rtol=1e-11, atol=1e-300)
+            en.fmx_iterate(0.5, 0.1)  # the M-step behind a re-assignment
+            g2, _ = en.fmx_cluster_pileup()
+            got.append((g, g2))
+    assert got[0][0].tobytes() == got[1][0].tobytes() and got[0][1].tobytes() == got[1][1].tobytes()
