@@ -124,9 +124,13 @@ def pmc_record(config):
         d = json.load(open(tfile))
     except Exception:
         return None, "no profiles/traffic.json"
-    if d.get("source_hash") != source_hash():
-        return None, f"profiles/traffic.json is stale (measured on sources {d.get('source_hash')}, git {d.get('git_head')})"
-    return d.get(f"config{config}"), d.get("measured_with", "")
+    rec = d.get(f"config{config}")
+    if not rec:
+        return None, f"profiles/traffic.json has no config{config}"
+    if rec.get("source_hash") != source_hash(config):  # fingerprint of the files this config's kernel family is built from
+        return None, (f"profiles/traffic.json config{config} is stale (measured on sources {rec.get('source_hash')}, "
+                      f"git {rec.get('git_head')})")
+    return rec, d.get("measured_with", "")
 
 
 def roofline(kernel, kern_s, abytes, ref_flops, issued_model_flops, config, scale=1.0):

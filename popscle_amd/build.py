@@ -23,15 +23,29 @@ if __name__ == "__main__":
     print(build_lib())
 
 
-def source_hash() -> str:
-    """fingerprint of the kernel sources (csrc/*.hip, *.hpp, include/muxgl.h): stamps measurements that are only valid
-    for the code they were taken on (profiles/traffic.json); works on the GPU box, where there is no .git"""
+# sources the dominant kernel family of a BASELINE config is built from (kernels, the headers they include, the plan
+# kernels that cut their work): counters in profiles/traffic.json are stamped per config with a fingerprint of these
+FAMILY_SOURCES = {
+    1: ["demux_oct.hip", "oct_tiling.hpp", "demux_entry.hpp", "demux_call_body.hpp", "common.hpp", "plan_kernels.hip"],
+    2: ["demux_wave.hip", "demux_ring.hip", "demux_kernels.hip", "demux_entry.hpp", "common.hpp", "plan_kernels.hip"],
+    3: ["fmx_oct.hip", "oct_tiling.hpp", "fmx_kernels.hip", "common.hpp", "plan_kernels.hip"],
+    4: ["fmx_wave.hip", "fmx_kernels.hip", "common.hpp", "plan_kernels.hip"],
+}
+
+
+def source_hash(config: int | None = None) -> str:
+    """fingerprint of the kernel sources (all of csrc/*.hip, *.hpp and include/muxgl.h, or the files of one config's
+    dominant kernel family): stamps measurements that are only valid for the code they were taken on
+    (profiles/traffic.json); works on the GPU box, where there is no .git"""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
-    files.append(os.path.join(os.path.dirname(HERE), "include", "muxgl.h"))
+    if config is None:
+        files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+        files.append(os.path.join(os.path.dirname(HERE), "include", "muxgl.h"))
+    else:
+        files = [os.path.join(CSRC, f) for f in FAMILY_SOURCES[config]]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

@@ -84,11 +84,7 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const 
                                                               const uint8_t* __restrict__ reads,
                                                               const double* __restrict__ lut_g, int nAlpha,
                                                               alpha_args al, double* __restrict__ pg,
-                                                              const uint32_t* __restrict__ lin,
-                                                              const int64_t* __restrict__ lin_rank,
-                                                              const int32_t* __restrict__ entry_snp,
-                                                              const uint8_t* __restrict__ has_gp,
-                                                              double* __restrict__ lpg) {
+                                                              const uint32_t* __restrict__ lin, int skip_lin) {
   __shared__ double lut[384];
   __shared__ double stage[4][64 * 9 + 1];  // one alpha of a wave's 64 entries at a time (+1: odd stride, no bank conflicts)
   for (int i = threadIdx.x; i < 384; i += 256) lut[i] = lut_g[i];
@@ -107,27 +103,10 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const 
       row_entry_pg<NA>(reads, r0, r1, first4, al.a, lut, pG);
     }
     const int ne = (int)((nnz - eb < 64) ? (nnz - eb) : 64);
-    // lpg != NULL (the wave kernels at V <= 64): an entry with one usable read gets its row of the stream-ordered table
-    // of (A, Bl, Bm) per alpha (demux_wave.hip: wave_lpg_kernel) instead of its 72 bytes per alpha here -- (1, 0, 0) for
-    // a marker without genotypes, whose factors are exactly 1
+    // skip_lin (the wave kernels at V <= 64): nobody reads the row of an entry with one usable read -- the ring kernel
+    // takes its (A, Bl, Bm) from a table by allele and quality (demux_ring.hip) -- so it is not written
     uint64_t linmask = 0;
-    if (lpg) {
-      const bool isl = e < nnz && ((lin[e >> 5] >> (e & 31)) & 1u);
-      linmask = __ballot(isl);
-      if (isl) {
-        const int64_t r = lin_rank[e >> 5] + __popc(lin[e >> 5] & ((1u << (e & 31)) - 1u));
-        const bool gen = has_gp[entry_snp[e]] != 0;
-        double* o = lpg + (size_t)r * nAlpha * 3;
-#pragma unroll
-        for (int n = 0; n < NA; ++n) {
-          if (n >= nAlpha) break;
-          const double q0 = pG[n * 9];
-          o[n * 3] = gen ? q0 : 1.0;
-          o[n * 3 + 1] = gen ? pG[n * 9 + 3] - q0 : 0.0;
-          o[n * 3 + 2] = gen ? pG[n * 9 + 1] - q0 : 0.0;
-        }
-      }
-    }
+    if (skip_lin) linmask = __ballot(e < nnz && ((lin[e >> 5] >> (e & 31)) & 1u));
 #pragma unroll
     for (int n = 0; n < NA; ++n) {
       if (n >= nAlpha) break;
@@ -419,13 +398,12 @@ int launch_sweep(muxgl_handle* h, const muxgl_demux_params* p, uint32_t symmask,
 }
 
 template <int NA>
-int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg, double* d_lpg) {
+int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg, bool skip_lin) {
   int64_t blocks = (h->nnz + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(demux_entry_pg_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->nnz,
-                     h->d_entry_rptr, h->d_reads, h->d_lut, p->n_alpha, al, d_pg, h->d_lin, h->d_lin_rank, h->d_entry_snp,
-                     h->d_has_gp, d_lpg);
+                     h->d_entry_rptr, h->d_reads, h->d_lut, p->n_alpha, al, d_pg, h->d_lin, skip_lin ? 1 : 0);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -566,12 +544,12 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   return 0;
 }
 
-// d_lpg != NULL: the linear entries' rows go to that table (stream order) and are left out of d_pg
-int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, double* d_lpg) {
+// skip_lin: the rows of the linear entries (h->d_lin) are left out of d_pg
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool skip_lin) {
   const int A = p->n_alpha;
   alpha_args al;
   for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : p->alpha[0];
-#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg, d_lpg)
+#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg, skip_lin)
   DISPATCH_NA(A, CALL_PG);
 #undef CALL_PG
 }

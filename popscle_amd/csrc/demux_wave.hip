@@ -12,9 +12,9 @@
 //     u[m] = sum_l g_j[l] * pG[alpha][l][m]; the entry's nine pG values are wave-uniform and are fetched through the
 //     scalar cache into SGPRs, so they cost no vector instruction and no LDS traffic;
 //   * at rotation step t lane j faces sample (j - t) mod 64; the partner's values are read from a copy of the 64 values
-//     in LDS (the "ring", see dw_sweep_lin; round 1 rotated them with DPP moves, which cost as much issue time as the
+//     in LDS (the "ring", see dw_sweep_gen; round 1 rotated them with DPP moves, which cost as much issue time as the
 //     arithmetic they fed): 3 FMA + 1 multiply per hypothesis, or 1 FMA + 1 multiply for the entries with one usable
-//     read (EM_LINEAR below);
+//     read (demux_ring.hip);
 //   * 64 accumulators per lane: alpha = 0.5 (symmetric in (j,k): 32 steps) and a lone alpha (63 steps) get a launch of
 //     their own, other alphas go four (or two) at a time, the rotation steps cut into ranges of 16 (32) that are the
 //     waves of one workgroup (demux_wave_multi_kernel: the ring reads are shared by the alphas); the singlet slot
@@ -42,23 +42,6 @@ __global__ void __launch_bounds__(256)
   for (int i = 0; i < width; ++i) pg[(size_t)e * width + i] = 1.0;
 }
 
-// The linear entries' table in stream order: lpg[r][n] = (A, Bl, Bm) with pG[l][m] = A + Bl*l + Bm*m for the r-th linear
-// entry of the pileup (plan_build_bit_streams) and alpha n -- 24 bytes per (entry, alpha) instead of 72, and rows a wave
-// reads one after the other.
-__global__ void __launch_bounds__(256)
-    wave_lpg_kernel(int64_t n_lin, int A, const fmx_grec* __restrict__ rec_lin, const double* __restrict__ pg,
-                    double* __restrict__ lpg) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (linear entry, alpha)
-  if (i >= n_lin * A) return;
-  const int64_t r = i / A;
-  const int n = (int)(i - r * A);
-  const double* q = pg + ((size_t)rec_lin[r].e * A + n) * 9;
-  const double q0 = q[0];
-  lpg[i * 3] = q0;
-  lpg[i * 3 + 1] = q[3] - q0;
-  lpg[i * 3 + 2] = q[1] - q0;
-}
-
 // The moments of every genotype triple the linear entries use: gm[marker][sample] = (s, rho), s = g0 + g1 + g2,
 // rho = (g1 + 2 g2) / s (0 for an all-zero triple, whose hypotheses are 0 through s).
 __global__ void __launch_bounds__(256) wave_gm_kernel(int64_t n, const double* __restrict__ gp, double* __restrict__ gm) {
@@ -80,14 +63,10 @@ __device__ __forceinline__ double dpp_wror1(double x) {
 #ifndef DW_DEPTH
 #define DW_DEPTH 3  // entries the walk runs ahead (ring slots of the software pipeline)
 #endif
-#ifndef DW_TOUCH_AHEAD
-#define DW_TOUCH_AHEAD 8  // ... of the linear entries' table, which is in stream order
-#endif
 #ifndef DW_TOUCH
 #define DW_TOUCH 1  // touch the likelihood rows D - 1 entries ahead (see dw_walk)
 #endif
-#define DW_G_LIN 4  // ring reads per group of the linear / general sweep
-#define DW_G_GEN 2
+#define DW_G_GEN 2  // ring reads (of three values) per group of the sweep
 
 // The ring.  Rotation t + 1 of a launch that starts at offset s0 brings lane j the value of lane (j - s0 - t - 1) mod 64
 // (one lane further with CROSS).  The 64 values are kept twice over in LDS, ring[i] = ring[i + 64] = value of lane i, so
@@ -95,37 +74,6 @@ __device__ __forceinline__ double dpp_wror1(double x) {
 // rotation of a double is two vector moves, as much issue time as the FMA it feeds; the LDS read travels on the other
 // pipe (ds_read_b64: 2 LDS cycles per wave).  Reads are issued a group ahead of their use.
 // groups [GB, GE) of the sweep (a sweep is cut in two so that work for the next entry can be placed in its middle)
-template <int NA, int NS, int CR, int GB, int GE>
-__device__ __forceinline__ void dw_sweep_lin(uint32_t rb, const double (&u0)[NA], const double (&u1)[NA], double (&acc)[NA * NS]) {
-  constexpr int G = DW_G_LIN;
-  static_assert(G == 4, "the wait below names four values");
-  double rd[2][G];
-  auto issue = [&](auto gc) {
-    constexpr int g = decltype(gc)::value;
-    wave_for<0, G>([&](auto ic) {
-      constexpr int k = decltype(ic)::value, t = g * G + k;
-      if constexpr (t < NS) rd[g & 1][k] = wave_ring_rd<(NS - 1 - t + CR) * 8>(rb);
-      else rd[g & 1][k] = 0.0;
-    });
-  };
-  if constexpr (GB < GE) issue(std::integral_constant<int, GB>{});
-  wave_for<GB, GE>([&](auto gc) {
-    constexpr int g = decltype(gc)::value;
-    constexpr int left = NS - (g + 1) * G;
-    constexpr int ahead = g + 1 < GE ? (left < G ? left : G) : 0;  // younger reads: they may stay in flight
-    if constexpr (g + 1 < GE) issue(std::integral_constant<int, g + 1>{});
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rd[g & 1][0]), "+v"(rd[g & 1][1]), "+v"(rd[g & 1][2]), "+v"(rd[g & 1][3]) : "n"(ahead));
-    wave_for<0, G>([&](auto ic) {
-      constexpr int k = decltype(ic)::value, t = g * G + k;
-      if constexpr (t < NS) {
-#pragma unroll
-        for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(u1[a], rd[g & 1][k], u0[a]);
-      }
-    });
-    __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all the sums first
-  });
-}
-
 template <int NA, int NS, int CR, int GB, int GE>
 __device__ __forceinline__ void dw_sweep_gen(uint32_t rb, const double (&u)[NA][3], double (&acc)[NA * NS]) {
   constexpr int G = DW_G_GEN;
@@ -175,25 +123,16 @@ struct wave_blk {
   int32_t blk, nblk2;    // slab of this launch, slabs per cell
 };
 
-// Entries with at most one usable read (bit set in `lin`, plan_kernels.hip).  A single factor pR*(1-p) + pA*p with
-// p = l/2 + (m-l)*alpha/2 (cmd_cram_demuxlet.cpp:673,685) is LINEAR in the two genotypes, and so is everything the tail
-// (:703-725) makes of it: pG[l][m] = A + Bl*l + Bm*m.  Then
-//     sum_{l,m} g_j[l] g_k[m] pG[l][m] = A s_j s_k + Bl E_j s_k + Bm s_j E_k = s_j s_k (A + Bl rho_j + Bm rho_k),
-// s = sum_l g[l],  E = g[1] + 2 g[2],  rho = E / s (wave_gm_kernel keeps (s, rho) per marker and sample: 16 bytes
-// instead of the triple's 24).  The factor s_j s_k does not depend on alpha or on the pairing of the other entries:
-// every lane keeps the product of its own s over the cell's linear entries (one multiply per entry) and a hypothesis
-// gets log(prod s_j) + log(prod s_k) at the end.  What is left per hypothesis is an FMA of the partner's rho with a
-// wave-uniform number (Bm) and a number of the lane (A + Bl rho_j), and the product update: ONE partner value per step
-// instead of three, two vector instructions per hypothesis instead of four.  Three quarters of the entries of a
-// typical pileup are such entries.  (A, Bl, Bm are read off the table: pG[0][0], pG[1][0] - pG[0][0], pG[0][1] - pG[0][0],
-// wave_lpg_kernel.)
-// Two sweep bodies in one kernel do not fit the register file next to 64 accumulators per lane, so the two kinds of
-// entries get a launch each -- EM_LINEAR walks the flagged entries of a cell and writes, EM_GENERAL walks the others and
-// ADDS its log-likelihoods to what is there -- EM_ALL is the single launch without the distinction.  The walk is a
-// scalar scan of the bit set, so an entry of the other kind costs a few scalar instructions and no loads.
+// Entries with at most one usable read (bit set in `lin`, plan_kernels.hip) have likelihoods that are LINEAR in the two
+// genotypes, pG[l][m] = A + Bl*l + Bm*m, and take the one-moment form s_j s_k (A + Bl rho_j + Bm rho_k) -- two vector
+// instructions per hypothesis instead of four.  Three quarters of the entries of a typical pileup are such entries.
+// In the diagonal blocks they are swept by a kernel of their own (demux_ring.hip), which WRITES the result slab;
+// the kernels here then walk the others (EM_GENERAL: the clear bits' record stream) and ADD their log-likelihoods to
+// what is there.  EM_ALL is the single launch without the distinction (off-diagonal blocks, 17..32 samples, or
+// MUXGL_FLAG_NO_LINEAR_ENTRIES).  (wave_gm_kernel above makes the (s, rho) rows the ring kernel stages.)
 
-// The walk of one work unit: entries [i0, i1) of a record stream {entry, snp} (STREAM: the linear or the other entries
-// of the cell, plan_build_bit_streams), or the entries i0 .. i1 - 1 themselves.  A cell's entries meet marker rows all
+// The walk of one work unit: entries [i0, i1) of a record stream {entry, snp} (STREAM: the non-linear entries of the
+// cell, plan_build_bit_streams), or the entries i0 .. i1 - 1 themselves.  A cell's entries meet marker rows all
 // over the genotype tensor and the table of likelihoods is 72 bytes per (entry, alpha): every entry is a chain of
 // misses a microsecond long, and with 64 accumulators per lane only two waves share a SIMD.  So the walk runs ahead:
 //   * records D entries ahead (scalar loads), genotype triples D - 1 ahead, in rings of D register slots addressed
@@ -208,21 +147,18 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
                                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, int PG,
                                         const int32_t (&seln)[NA], const double* __restrict__ gp, int V3, int jo, int ko,
                                         bool live, bool live2, int j, int s0, double (*ring)[128], int32_t (*exs)[64],
-                                        double (&acc)[NA * NS], int32_t (&ex)[EXL ? 1 : NA * NS], double& accS, int32_t& exS,
-                                        double& accW, int32_t& exW) {
-  constexpr bool L = EM == EM_LINEAR, STREAM = EM != EM_ALL;
+                                        double (&acc)[NA * NS], int32_t (&ex)[EXL ? 1 : NA * NS], double& accS, int32_t& exS) {
+  static_assert(EM == EM_ALL || EM == EM_GENERAL, "the linear entries' walk lives in demux_ring.hip");
+  constexpr bool STREAM = EM != EM_ALL;
   constexpr int D = (CROSS || NA * NS > 32) ? 2 : DW_DEPTH;  // (64 accumulators per lane: two slots is what fits)
   constexpr int HA = (NA + 1) / 2, HB = NA - HA;  // alphas of the first / second batch of likelihoods
-  constexpr int QN = L ? 3 : 9;           // numbers per (entry, alpha): A, Bl, Bm of a linear entry (wave_lpg_kernel), or pG
-  constexpr int UN = L ? 1 : 3;           // factors of the lane per alpha (linear: X = A + Bl rho_j; Bm is wave-uniform)
-  constexpr int GN = L ? 2 : 3;           // numbers per (marker, sample): the moments (s, rho) of the triple, or the triple
   constexpr int CR = CROSS ? 1 : 0;
-  constexpr int NG = L ? (NS + DW_G_LIN - 1) / DW_G_LIN : (NS + DW_G_GEN - 1) / DW_G_GEN, NGH = NG / 2;
+  constexpr int NG = (NS + DW_G_GEN - 1) / DW_G_GEN, NGH = NG / 2;
   if (i0 >= i1) return;
   const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - s0 - NS];
   int64_t ide[D];
   int32_t ids[D];
-  double g[D][GN], p[CROSS ? D : 1][3];  // triple of sample jbase + j (and of kbase + j) at the slot's marker
+  double g[D][3], p[CROSS ? D : 1][3];  // triple of sample jbase + j (and of kbase + j) at the slot's marker
   auto load_id = [&](int64_t i, auto sc) {  // clamped: a valid record is read behind the end, and not used
     constexpr int s = decltype(sc)::value;
     const int64_t ic = i < i1 ? i : i1 - 1;
@@ -233,7 +169,7 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
     constexpr int s = decltype(sc)::value;
     const double* row = gp + (size_t)ids[s] * V3 + jo;
 #pragma unroll
-    for (int k = 0; k < GN; ++k) g[s][k] = row[k];
+    for (int k = 0; k < 3; ++k) g[s][k] = row[k];
     if (CROSS) {
       constexpr int sq = CROSS ? s : 0;
       const double* rowp = gp + (size_t)ids[s] * V3 + ko;
@@ -241,60 +177,48 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
     }
   };
   // factors of the current entry, and those of the next entry that are formed in the middle of the sweep
-  double u[NA][UN], un[HA][UN], sv = 1.0, sw = 1.0;
-  double bu[L ? NA : 1], bun[L ? HA : 1];  // linear: Bm of the current entry's alphas / of the next entry's first batch
-  double rv[3] = {1.0, 0.0, 0.0};  // the next entry's ring values (linear: rho in rv[0])
-  double sm = 1.0;                 // linear: the next entry's sum s
-  double qa[HA][QN], qb[HB > 0 ? HB : 1][QN], qs[WITH_SINGLET ? QN : 1], hs[WITH_SINGLET ? GN : 1];
-  // row of the table for the entry in slot s / at stream position idx: the linear entries' table is in stream order
-  auto row_of = [&](auto sc, int64_t idx) {
+  double u[NA][3], un[HA][3], sv = 1.0;
+  double rv[3] = {1.0, 0.0, 0.0};  // the next entry's ring values
+  double qa[HA][9], qb[HB > 0 ? HB : 1][9], qs[WITH_SINGLET ? 9 : 1], hs[WITH_SINGLET ? 3 : 1];
+  auto row_of = [&](auto sc) {  // row of the table for the entry in slot s
     constexpr int s = decltype(sc)::value;
-    if (L) return pg + (size_t)(idx < i1 ? idx : i1 - 1) * PG;
     return pg + (size_t)ide[s] * PG;
   };
-  auto load_a = [&](auto sc, int64_t idx) {
-    const double* row = row_of(sc, idx);
+  auto load_a = [&](auto sc) {
+    const double* row = row_of(sc);
 #pragma unroll
     for (int a = 0; a < HA; ++a) {
-      const double* q = row + (size_t)seln[a] * QN;
+      const double* q = row + (size_t)seln[a] * 9;
 #pragma unroll
-      for (int k = 0; k < QN; ++k) qa[a][k] = q[k];
+      for (int k = 0; k < 9; ++k) qa[a][k] = q[k];
     }
   };
-  auto load_b = [&](auto sc, int64_t idx) {
+  auto load_b = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
-    const double* row = row_of(sc, idx);
+    const double* row = row_of(sc);
 #pragma unroll
     for (int a = 0; a < HB; ++a) {
-      const double* q = row + (size_t)seln[HA + a] * QN;
+      const double* q = row + (size_t)seln[HA + a] * 9;
 #pragma unroll
-      for (int k = 0; k < QN; ++k) qb[a][k] = q[k];
+      for (int k = 0; k < 9; ++k) qb[a][k] = q[k];
     }
     if (WITH_SINGLET) {
       const double* h = gp + (size_t)ids[s] * V3;  // sample 0's triple multiplies every singlet (:806,828)
 #pragma unroll
-      for (int k = 0; k < QN; ++k) qs[k] = row[k];
+      for (int k = 0; k < 9; ++k) qs[k] = row[k];
 #pragma unroll
-      for (int k = 0; k < GN; ++k) hs[k] = h[k];
+      for (int k = 0; k < 3; ++k) hs[k] = h[k];
     }
   };
-  auto factor = [&](double (&uu)[UN], const double (&q)[QN], double g0, double g1, double g2) {
-    if constexpr (L) {  // q = (A, Bl, Bm); g1 = rho_j
-      uu[0] = fma(q[1], g1, q[0]);
-    } else {
-      uu[0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
-      uu[1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
-      uu[2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
-    }
+  auto factor = [&](double (&uu)[3], const double (&q)[9], double g0, double g1, double g2) {
+    uu[0] = fma(g2, q[6], fma(g1, q[3], g0 * q[0]));
+    uu[1] = fma(g2, q[7], fma(g1, q[4], g0 * q[1]));
+    uu[2] = fma(g2, q[8], fma(g1, q[5], g0 * q[2]));
   };
-  auto comp_a = [&](auto sc) {  // first batch: the moments / ring values and the factors of alphas 0 .. HA-1
+  auto comp_a = [&](auto sc) {  // first batch: the ring values and the factors of alphas 0 .. HA-1
     constexpr int s = decltype(sc)::value, sq = CROSS ? s : 0;
-    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = (!L && live) ? g[s][GN - 1] : 0.0;
-    if constexpr (L) {
-      sm = g0, rv[0] = g1;
-#pragma unroll
-      for (int a = 0; a < HA; ++a) bun[a] = qa[a][2];
-    } else if constexpr (CROSS) {
+    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = live ? g[s][2] : 0.0;
+    if constexpr (CROSS) {
       rv[0] = live2 ? p[sq][0] : 1.0, rv[1] = live2 ? p[sq][1] : 0.0, rv[2] = live2 ? p[sq][2] : 0.0;
     } else {
       rv[0] = g0, rv[1] = g1, rv[2] = g2;
@@ -304,55 +228,42 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   };
   auto comp_b = [&](auto sc) {  // behind the sweep: the current entry's factors are free to be overwritten
     constexpr int s = decltype(sc)::value;
-    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = (!L && live) ? g[s][GN - 1] : 0.0;
+    const double g0 = live ? g[s][0] : 1.0, g1 = live ? g[s][1] : 0.0, g2 = live ? g[s][2] : 0.0;
 #pragma unroll
     for (int a = 0; a < HA; ++a)
 #pragma unroll
-      for (int k = 0; k < UN; ++k) u[a][k] = un[a][k];
-    if constexpr (L) {
-      sw = sm;
-#pragma unroll
-      for (int a = 0; a < HA; ++a) bu[a] = bun[a];
-#pragma unroll
-      for (int a = 0; a < HB; ++a) bu[HA + a] = qb[a][2];
-    }
+      for (int k = 0; k < 3; ++k) u[a][k] = un[a][k];
 #pragma unroll
     for (int a = 0; a < HB; ++a) factor(u[HA + a], qb[a], g0, g1, g2);
     if (WITH_SINGLET) {
-      if constexpr (L) {  // sum_m h[m] sum_l g[l] (A + Bl l + Bm m) of alpha[0] = s_h s_g (A + Bl rho_g + Bm rho_h)
-        sv = (sm * hs[0]) * fma(qs[2], hs[1], fma(qs[1], g1, qs[0]));
-      } else {
-        const double v0 = fma(g2, qs[6], fma(g1, qs[3], g0 * qs[0]));
-        const double v1 = fma(g2, qs[7], fma(g1, qs[4], g0 * qs[1]));
-        const double v2 = fma(g2, qs[8], fma(g1, qs[5], g0 * qs[2]));
-        sv = fma(hs[2], v2, fma(hs[1], v1, hs[0] * v0));
-      }
+      const double v0 = fma(g2, qs[6], fma(g1, qs[3], g0 * qs[0]));
+      const double v1 = fma(g2, qs[7], fma(g1, qs[4], g0 * qs[1]));
+      const double v2 = fma(g2, qs[8], fma(g1, qs[5], g0 * qs[2]));
+      sv = fma(hs[2], v2, fma(hs[1], v1, hs[0] * v0));
     }
   };
   auto ring_put = [&]() {
     ring[0][j] = rv[0], ring[0][j + 64] = rv[0];
-    if (!L) {
-      ring[1][j] = rv[1], ring[1][j + 64] = rv[1];
-      ring[2][j] = rv[2], ring[2][j + 64] = rv[2];
-    }
+    ring[1][j] = rv[1], ring[1][j + 64] = rv[1];
+    ring[2][j] = rv[2], ring[2][j + 64] = rv[2];
   };
   // The table of likelihoods is read through the scalar cache one entry ahead -- not enough for a first touch of its
   // lines, which come from HBM.  So the row of the entry whose record has just arrived (D - 1 entries ahead) is touched
   // with one vector load, 8 bytes per lane; the value is folded into a word nobody reads (its consumer sits D steps
   // later, where the load has long landed) so that the compiler keeps and counts the load.
   unsigned long long pfv[D], pfx = 0;
-  auto touch = [&](auto sc, int64_t idx) {  // linear entries: the table is in stream order, any distance ahead will do
+  auto touch = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
     pfx ^= pfv[s];
-    pfv[s] = ((const unsigned long long*)row_of(sc, idx + (L ? DW_TOUCH_AHEAD - (D - 1) : 0)))[j < PG ? j : PG - 1];
+    pfv[s] = ((const unsigned long long*)row_of(sc))[j < PG ? j : PG - 1];
   };
   wave_for<0, D>([&](auto sc) { pfv[decltype(sc)::value] = 0; });
   wave_for<0, D>([&](auto sc) { load_id(i0 + decltype(sc)::value, sc); });
   wave_for<0, D - 1>([&](auto sc) { load_gp(sc); });
   {
     using S0 = std::integral_constant<int, 0>;
-    load_a(S0{}, i0);
-    load_b(S0{}, i0);
+    load_a(S0{});
+    load_b(S0{});
     comp_a(S0{});
     comp_b(S0{});
     ring_put();
@@ -365,25 +276,14 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
       const int64_t i = ib + s;
       if (i >= i1) return;  // (the factors formed for the entry behind the last one are not used)
       load_gp(std::integral_constant<int, sp>{});  // entry i + D - 1: its record was read a step ago
-      if (DW_TOUCH) touch(std::integral_constant<int, sp>{}, i + D - 1);
-      load_a(S1{}, i + 1);
+      if (DW_TOUCH) touch(std::integral_constant<int, sp>{});
+      load_a(S1{});
       load_id(i + D, sc);
       if (WITH_SINGLET) accS *= sv;
-      if (L) accW *= sw;
-      if constexpr (L) {
-        double u0[NA], u1[NA];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) u0[a] = u[a][0], u1[a] = bu[a];
-        dw_sweep_lin<NA, NS, CR, 0, NGH>(rb, u0, u1, acc);
-        comp_a(S1{});
-        load_b(S1{}, i + 1);
-        dw_sweep_lin<NA, NS, CR, NGH, NG>(rb, u0, u1, acc);
-      } else {
-        dw_sweep_gen<NA, NS, CR, 0, NGH>(rb, u, acc);
-        comp_a(S1{});
-        load_b(S1{}, i + 1);
-        dw_sweep_gen<NA, NS, CR, NGH, NG>(rb, u, acc);
-      }
+      dw_sweep_gen<NA, NS, CR, 0, NGH>(rb, u, acc);
+      comp_a(S1{});
+      load_b(S1{});
+      dw_sweep_gen<NA, NS, CR, NGH, NG>(rb, u, acc);
       comp_b(S1{});
       ring_put();  // behind the sweep's reads: the LDS serves one wave's requests in order
       if (++cnt == 16) {  // every factor is >= 1.1e-11: sixteen of them cannot underflow
@@ -399,7 +299,6 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
           }
         }
         if (WITH_SINGLET) prodacc_renorm(accS, exS);
-        if (L) prodacc_renorm(accW, exW);
       }
     });
   }
@@ -414,9 +313,9 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
 template <int NSHIFT, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL>
 __global__ void __launch_bounds__(64, 2)
     demux_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
-                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const double* __restrict__ lpg,
-                      const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank, const fmx_grec* __restrict__ rec_lin,
-                      const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp, const double* __restrict__ gm,
+                      const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
+                      const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank,
+                      const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp,
                       const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel, wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
@@ -425,19 +324,16 @@ __global__ void __launch_bounds__(64, 2)
   const int j = threadIdx.x;
   const bool live = wb.jbase + j < V;
   const bool live2 = wb.kbase + j < V;
-  constexpr int GW = EM == EM_LINEAR ? 2 : 3;  // numbers per (marker, sample): moments (s, rho) for linear entries, else the triple
-  const double* gsrc = EM == EM_LINEAR ? gm : gp;
-  const int V3 = V * GW;
-  const double* tab = EM == EM_LINEAR ? lpg : pg;  // the table the walk reads, and its row width
-  const int TW = nAlpha * (EM == EM_LINEAR ? 3 : 9);
-  const int jo = (live ? wb.jbase + j : V - 1) * GW, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
+  const int V3 = V * 3;
+  const int TW = nAlpha * 9;  // row width of the table the walk reads
+  const int jo = (live ? wb.jbase + j : V - 1) * 3, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
 
   constexpr bool EXL = NSHIFT > 32;  // 63 / 64 accumulators per lane: their exponents live in LDS
-  __shared__ double ring[3][128];    // the partner values of the current entry, see dw_sweep_lin
+  __shared__ double ring[3][128];    // the partner values of the current entry, see dw_sweep_gen
   __shared__ int32_t exs[EXL ? NSHIFT : 1][64];
   const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - NSHIFT];
-  double acc[NSHIFT], accS = 1.0, accW = 1.0;  // accW: product of the own sums s over the linear entries (EM_LINEAR)
-  int32_t ex[EXL ? 1 : NSHIFT], exS = 0, exW = 0;
+  double acc[NSHIFT], accS = 1.0;
+  int32_t ex[EXL ? 1 : NSHIFT], exS = 0;
 #pragma unroll
   for (int t = 0; t < NSHIFT; ++t) {
     acc[t] = 1.0;
@@ -447,28 +343,18 @@ __global__ void __launch_bounds__(64, 2)
   int64_t i0 = it.e0, i1 = it.e1;
   if constexpr (EM != EM_ALL) wave_stream_range<EM>(lin, lin_rank, it.e0, it.e1, i0, i1);
   const int32_t seln[1] = {n_sel};
-  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gsrc, V3, jo,
-                                                   ko, live, live2, j, 0, ring, exs, acc, ex, accS, exS, accW, exW);
+  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, rec_gen, entry_snp, pg, TW, seln, gp, V3, jo, ko, live, live2, j, 0, ring,
+                                                   exs, acc, ex, accS, exS);
 
   // Results go to the wave layout llw[c][n][step t][lane j] (coalesced; the partner of (t, j) is re-derived by the
   // readers with the same rotation): lane j, step t holds the hypothesis (j, k = j - t - 1 mod 64).  Alpha = 0.5 fills
   // the mirrored half too: the pair met at step t by lane j is met at step 62 - t by lane k.
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;
   int kk = j;
-  double logW = 0.0;
-  if constexpr (EM == EM_LINEAR) {  // log prod s of every lane into the ring: the partner's comes out like its values did
-    logW = prodacc_log(accW, exW);
-    ring[0][j] = logW, ring[0][j + 64] = logW;
-  }
   wave_for<0, NSHIFT>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     kk = __builtin_amdgcn_mov_dpp(kk, 0x13C, 0xF, 0xF, false);
     double v = prodacc_log(acc[t], EXL ? exs[t][j] : ex[EXL ? 0 : t]);
-    if constexpr (EM == EM_LINEAR) {
-      double lw = wave_ring_rd<(NSHIFT - 1 - t) * 8>(rb);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
-      v += lw + logW;  // both samples' sums
-    }
     if (n_sel > 0) {
       if (NSHIFT >= 63) {
         double* o = out + ((size_t)n_sel * 64 + t) * 64 + j;
@@ -500,10 +386,8 @@ template <int NA, int NS, bool WITH_SINGLET, bool CROSS = false, int EM = EM_ALL
 __global__ void __launch_bounds__(64 * (64 / NS), 2)
     demux_wave_multi_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
                             const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
-                            const double* __restrict__ lpg, const uint32_t* __restrict__ lin,
-                            const int64_t* __restrict__ lin_rank,
-                            const fmx_grec* __restrict__ rec_lin, const fmx_grec* __restrict__ rec_gen,
-                            const double* __restrict__ gp, const double* __restrict__ gm,
+                            const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank,
+                            const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp,
                             const uint8_t* __restrict__ has_gp, int V, int nAlpha, wave_sel sel, wave_blk wb, double* __restrict__ ll) {
   // One workgroup per work unit, one WAVE per range of NS rotation steps (s0 = 0, NS, 2 NS, ...).  The waves are
   // independent -- own accumulators, own ring and exponents in LDS, no barrier -- but they walk the same entries at the
@@ -518,21 +402,18 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
   const int s0 = w * NS;
   const bool live = wb.jbase + j < V;
   const bool live2 = wb.kbase + j < V;
-  constexpr int GW = EM == EM_LINEAR ? 2 : 3;  // numbers per (marker, sample): moments (s, rho) for linear entries, else the triple
-  const double* gsrc = EM == EM_LINEAR ? gm : gp;
-  const int V3 = V * GW;
-  const double* tab = EM == EM_LINEAR ? lpg : pg;  // the table the walk reads, and its row width
-  const int TW = nAlpha * (EM == EM_LINEAR ? 3 : 9);
-  const int jo = (live ? wb.jbase + j : V - 1) * GW, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
+  const int V3 = V * 3;
+  const int TW = nAlpha * 9;  // row width of the table the walk reads
+  const int jo = (live ? wb.jbase + j : V - 1) * 3, ko = (live2 ? wb.kbase + j : V - 1) * 3;  // (no sample: any valid row)
 
   // 64 accumulators per lane; their integer exponents live in LDS (touched once per 16 entries), 16 KB per wave
   __shared__ int32_t exs_all[NW][NA * NS][64];
-  __shared__ double ring_all[NW][3][128];  // the partner values of the current entry, see dw_sweep_lin
+  __shared__ double ring_all[NW][3][128];  // the partner values of the current entry, see dw_sweep_gen
   int32_t (*exs)[64] = exs_all[w];
   double (*ring)[128] = ring_all[w];
   const uint32_t rb = (uint32_t)(uintptr_t)&ring[0][j + 64 - s0 - NS];
-  double acc[NA * NS], accS = 1.0, accW = 1.0;  // accW: product of the own sums s over the linear entries (EM_LINEAR)
-  int32_t ex[1] = {0}, exS = 0, exW = 0;
+  double acc[NA * NS], accS = 1.0;
+  int32_t ex[1] = {0}, exS = 0;
 #pragma unroll
   for (int t = 0; t < NA * NS; ++t) {
     acc[t] = 1.0;
@@ -544,31 +425,20 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
 #pragma unroll
   for (int a = 0; a < NA; ++a) seln[a] = sel.n[a];
   if (WITH_SINGLET && w == 0)  // the singlet slot rides along with the first step range only
-    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gsrc, V3, jo,
-                                                   ko, live, live2, j, s0, ring, exs, acc, ex, accS, exS, accW, exW);
+    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, rec_gen, entry_snp, pg, TW, seln, gp, V3, jo, ko, live, live2, j, s0, ring,
+                                                   exs, acc, ex, accS, exS);
   else
-    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, EM == EM_LINEAR ? rec_lin : rec_gen, entry_snp, tab, TW, seln, gsrc, V3, jo, ko, live,
-                                            live2, j, s0, ring, exs, acc, ex, accS, exS, accW, exW);
+    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, rec_gen, entry_snp, pg, TW, seln, gp, V3, jo, ko, live, live2, j, s0, ring, exs,
+                                            acc, ex, accS, exS);
 
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;  // wave layout, see demux_wave_kernel
-  double logW = 0.0;
-  if constexpr (EM == EM_LINEAR) {  // log prod s of every lane into the ring: the partner's comes out like its values did
-    logW = prodacc_log(accW, exW);
-    ring[0][j] = logW, ring[0][j + 64] = logW;
-  }
   wave_for<0, NS>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     if (s0 + t >= (CROSS ? 64 : 63)) return;
-    double lw = 0.0;
-    if constexpr (EM == EM_LINEAR) {
-      lw = wave_ring_rd<(NS - 1 - t) * 8>(rb);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
-      lw += logW;  // both samples' sums
-    }
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
       double* o = out + ((size_t)sel.n[a] * 64 + s0 + t) * 64 + j;
-      double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]) + lw;
+      double v = prodacc_log(acc[a * NS + t], exs[a * NS + t][j]);
       if (EM == EM_GENERAL) v += *o;  // on top of the linear entries' launch
       *o = v;
     }
@@ -594,10 +464,9 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
 template <int NA, bool WITH_SINGLET, bool ALLSYM = false>
 __global__ void __launch_bounds__(64, 2)
     demux_wave32_kernel(const wave_item* __restrict__ items, int64_t n_items, const int64_t* __restrict__ cell_ptr,
-                        const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, const double* __restrict__,
+                        const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                         const uint32_t* __restrict__ /*lin: the rings of 32 keep the single launch*/,
-                        const int64_t* __restrict__, const fmx_grec* __restrict__, const fmx_grec* __restrict__,
-                        const double* __restrict__ gp, const double* __restrict__ /*gm*/,
+                        const int64_t* __restrict__, const fmx_grec* __restrict__, const double* __restrict__ gp,
                         const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
   constexpr int NS = ALLSYM ? 8 : 16;
@@ -757,10 +626,9 @@ struct muxgl_wave_state {
   wave_cut* d_cuts = nullptr;    // cells cut into several units
   int64_t n_items = 0, n_cuts = 0, n_over = 0;
   double* d_pg = nullptr;      // [nnz][A][9]
-  double* d_lpg = nullptr;     // [n_lin][A][3], see wave_lpg_kernel
   double* d_gm = nullptr;      // [S][V][2], see wave_gm_kernel
   size_t gm_cap = 0;
-  size_t pg_cap = 0, lpg_cap = 0;
+  size_t pg_cap = 0;
 };
 
 namespace {
@@ -806,7 +674,6 @@ void demux_wave_free(muxgl_handle* h) {
   dev_free(&st->d_items);
   dev_free(&st->d_cuts);
   dev_free(&st->d_pg);
-  dev_free(&st->d_lpg);
   dev_free(&st->d_gm);
   delete st;
   h->wave = nullptr;
@@ -872,29 +739,23 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (dev_alloc(h, &h->d_llw, llw_need)) return 1;
     h->llw_cap = llw_need;
   }
-  // linear entries (one usable read) in a launch of their own with the one-moment form, the others on top: see EM_LINEAR
+  // linear entries (one usable read) in a launch of their own with the one-moment form, the others on top: see the notes above dw_walk
   const bool use_lin = V > 32 && h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
   if (use_lin && h->n_lin_rec < 0 &&
       plan_build_bit_streams(h, h->d_lin, &h->d_lin_rank, &h->d_lin_rec, &h->d_gen_rec, &h->n_lin_rec))
     return 1;
   if (use_lin) {
-    const size_t need_l = (size_t)h->n_lin_rec * A * 3;
-    if (need_l > st->lpg_cap || !st->d_lpg) {
-      if (dev_alloc(h, &st->d_lpg, need_l)) return 1;
-      st->lpg_cap = need_l;
-    }
     const size_t need_g = (size_t)h->S * V * 2;
     if (need_g > st->gm_cap || !st->d_gm) {
       if (dev_alloc(h, &st->d_gm, need_g)) return 1;
       st->gm_cap = need_g;
     }
   }
-  // one block of the pair matrix (V <= 64): nobody reads the linear entries' rows of the nine-value table, the kernel that
-  // computes the likelihoods writes their (A, Bl, Bm) rows instead; beyond, the off-diagonal blocks walk every entry
-  // through the nine-value table and the rows are made from it afterwards
-  const bool fused_lpg = use_lin && nblk == 1;
+  // one block of the pair matrix (V <= 64): nobody reads the linear entries' rows of the nine-value table (the ring kernel
+  // takes their (A, Bl, Bm) from a table by allele and quality), so they are not written; beyond, the off-diagonal blocks
+  // walk every entry through the table
   tic(h, MUXGL_T_DEMUX_SWEEP);
-  if (demux_entry_pg_launch(h, p, st->d_pg, fused_lpg ? st->d_lpg : nullptr)) return 1;
+  if (demux_entry_pg_launch(h, p, st->d_pg, use_lin && nblk == 1)) return 1;
   if (h->nnz)
     hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
                        A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
@@ -908,14 +769,9 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   if (use_lin) {
     const int64_t ng = h->S * (int64_t)V;
     if (ng) hipLaunchKernelGGL(wave_gm_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, h->stream, ng, h->d_gp, st->d_gm);
-    const int64_t n = h->n_lin_rec * (int64_t)A;
-    if (n && !fused_lpg)
-      hipLaunchKernelGGL(wave_lpg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->n_lin_rec, A, h->d_lin_rec,
-                         st->d_pg, st->d_lpg);
   }
 #define KARGS                                                                                                    \
-  st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, st->d_lpg, h->d_lin, h->d_lin_rank, h->d_lin_rec, \
-      h->d_gen_rec, h->d_gp, st->d_gm,                                                                                    \
+  st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_lin, h->d_lin_rank, h->d_gen_rec, h->d_gp, \
       h->d_has_gp, V, A
 #define MULTI_K(NA, NS, WS, CR, EMODE)                                                                                        \
   hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64 * (64 / NS)), 0, h->stream, KARGS, \

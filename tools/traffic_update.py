@@ -26,7 +26,8 @@ from popscle_amd.build import source_hash  # noqa: E402
 
 FAMILY = {  # config -> (kernels of the dominant phase, a kernel that runs exactly once per step)
     1: (r"^demux_oct_kernel", r"^demux_oct_finish_kernel"),
-    2: (r"^demux_wave(_multi)?_kernel", r"^demux_call_wave_kernel"),
+    2: (r"^(demux_(wave|ring_lin|entry_pg)|wave_(neutral_pg|gm|combine|lpg)_kernel|ring_lut_kernel)",  # MUXGL_T_DEMUX_SWEEP
+        r"^demux_call_wave_kernel"),
     3: (r"^fmx_estep_oct_kernel", r"^fmx_call_kernel"),
     4: (r"^fmx_estep_wave_kernel", r"^fmx_call_kernel"),
 }
@@ -69,13 +70,20 @@ def main():
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         head = None
-    doc = {"source_hash": source_hash(), "git_head": head, "measured_with": a.note,
+    try:
+        doc = json.load(open(a.out))  # configs that are not named keep their records (and their own fingerprints)
+    except Exception:
+        doc = {}
+    doc.pop("source_hash", None)
+    doc.pop("git_head", None)
+    doc.update({"measured_with": a.note,
            "what": "counters of the dominant kernel family per step (rocprofv3 --pmc, one counter set per run); "
                    "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (FETCH x2 on gfx950, "
-                   "MI355X_MICROARCH.md); fma/mul/add_f64 and valu are wave-level instruction counts"}
+                   "MI355X_MICROARCH.md); fma/mul/add_f64 and valu are wave-level instruction counts; every config record "
+                   "carries the fingerprint of the sources of its kernel family (popscle_amd.build.FAMILY_SOURCES)"})
     for cfg, pre in zip(a.config, a.prefix):
         fam, anchor = FAMILY[cfg]
-        rec = {"kernels": fam}
+        rec = {"kernels": fam, "source_hash": source_hash(cfg), "git_head": head}
         fe = per_step(pre + "_fetch", fam, anchor, ["FETCH_SIZE"])
         wr = per_step(pre + "_write", fam, anchor, ["WRITE_SIZE"])
         f64 = per_step(pre + "_f64", fam, anchor, ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"])
