@@ -127,7 +127,7 @@ def pmc_record(config):
     rec = d.get(f"config{config}")
     if not rec:
         return None, f"profiles/traffic.json has no config{config}"
-    if rec.get("source_hash") != source_hash(config):  # fingerprint of the files this config's kernel family is built from
+    if rec.get("source_hash") != source_hash(config):  # fingerprint of the machine code of this config's kernel family
         return None, (f"profiles/traffic.json config{config} is stale (measured on sources {rec.get('source_hash')}, "
                       f"git {rec.get('git_head')})")
     return rec, d.get("measured_with", "")
@@ -435,7 +435,7 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
                 "entries_per_gpu": int(p.nnz), "lls_per_cell": lls_per_cell, "parallelism": f"cells sharded x{ctx.world}",
             },
             "entries_per_s": total_entries / step_s, "cells_per_s": total_cells / step_s,
-            # quad path: "reduce" is the fused finish kernel (chunk reduction + call + records written to pinned host
+            # oct path: "reduce" is the fused finish kernel (chunk reduction + call + records written to pinned host
             # memory), "call" and "d2h" are then 0; other paths run them as separate launches
             "kernel_ms": {"sweep": float(kern_ms[muxgl.T_DEMUX_SWEEP]), "reduce": float(kern_ms[muxgl.T_DEMUX_REDUCE]),
                           "call": float(kern_ms[muxgl.T_DEMUX_CALL]), "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},

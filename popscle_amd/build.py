@@ -23,29 +23,67 @@ if __name__ == "__main__":
     print(build_lib())
 
 
-# sources the dominant kernel family of a BASELINE config is built from (kernels, the headers they include, the plan
-# kernels that cut their work): counters in profiles/traffic.json are stamped per config with a fingerprint of these
-FAMILY_SOURCES = {
-    1: ["demux_oct.hip", "oct_tiling.hpp", "demux_entry.hpp", "demux_call_body.hpp", "common.hpp", "plan_kernels.hip"],
-    2: ["demux_wave.hip", "demux_ring.hip", "demux_kernels.hip", "demux_entry.hpp", "common.hpp", "plan_kernels.hip"],
-    3: ["fmx_oct.hip", "oct_tiling.hpp", "fmx_kernels.hip", "common.hpp", "plan_kernels.hip"],
-    4: ["fmx_wave.hip", "fmx_kernels.hip", "common.hpp", "plan_kernels.hip"],
+# translation units that hold the device code behind a BASELINE config's dominant kernel family (its kernels, the plan
+# kernels that cut their work, the kernels that prepare their inputs): the counters in profiles/traffic.json are stamped
+# per config with a fingerprint of the gfx950 MACHINE CODE of these units, so host-side edits, comments and declarations
+# do not invalidate a measurement, and any change of the instructions does
+FAMILY_UNITS = {
+    1: ["demux_oct", "plan_kernels"],
+    2: ["demux_wave", "demux_ring", "demux_kernels", "plan_kernels"],
+    3: ["fmx_oct", "fmx_kernels", "plan_kernels"],
+    4: ["fmx_wave", "fmx_kernels", "plan_kernels"],
 }
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+HASH_CACHE = os.path.join(HERE, "lib", "code_hashes.json")
 
 
-def source_hash(config: int | None = None) -> str:
-    """fingerprint of the kernel sources (all of csrc/*.hip, *.hpp and include/muxgl.h, or the files of one config's
-    dominant kernel family): stamps measurements that are only valid for the code they were taken on
-    (profiles/traffic.json); works on the GPU box, where there is no .git"""
+def _unit_code_hash(unit: str) -> str:
+    """sha256 of the .text and .rodata sections of the gfx950 code object embedded in popscle_amd/lib/<unit>.o"""
+    import hashlib
+    import tempfile
+
+    obj = os.path.join(HERE, "lib", unit + ".o")
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "u.fatbin"), os.path.join(td, "u.co")
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--type=o", "--unbundle",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co],
+                       check=True, capture_output=True)
+        h = hashlib.sha256()
+        for sec in (".text", ".rodata"):
+            out = os.path.join(td, "sec.bin")
+            subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "-O", "binary", "--only-section=" + sec, co, out], check=True)
+            h.update(sec.encode())
+            h.update(open(out, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def source_hash(config: int | None = None) -> str | None:
+    """config given: fingerprint of the machine code of that config's kernel family (FAMILY_UNITS), cached in
+    popscle_amd/lib/code_hashes.json next to the objects it was taken from (the cache travels with the built library;
+    it is recomputed when an object file is newer).  None when it cannot be determined (no objects, no LLVM tools).
+    No config: fingerprint of all kernel SOURCES (csrc/*.hip, *.hpp, include/muxgl.h)."""
     import glob
     import hashlib
+    import json
 
+    if config is not None:
+        units = FAMILY_UNITS[config]
+        objs = [os.path.join(HERE, "lib", u + ".o") for u in units]
+        try:
+            newest = max(os.path.getmtime(o) for o in objs)
+            cache = {}
+            if os.path.exists(HASH_CACHE) and os.path.getmtime(HASH_CACHE) >= newest:
+                cache = json.load(open(HASH_CACHE))
+            if any(u not in cache for u in units):
+                cache = {u: _unit_code_hash(u) for us in FAMILY_UNITS.values() for u in us}
+                json.dump(cache, open(HASH_CACHE, "w"), indent=1)
+        except Exception:
+            return None
+        return hashlib.sha256("".join(u + cache[u] for u in units).encode()).hexdigest()[:16]
     h = hashlib.sha256()
-    if config is None:
-        files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
-        files.append(os.path.join(os.path.dirname(HERE), "include", "muxgl.h"))
-    else:
-        files = [os.path.join(CSRC, f) for f in FAMILY_SOURCES[config]]
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "muxgl.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

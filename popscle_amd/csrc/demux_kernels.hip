@@ -77,36 +77,42 @@ struct alpha_args {
   double a[MUXGL_MAX_ALPHA];
 };
 
-// standalone per-entry kernel: only used by muxgl_demux_get_entry_pg (parity of a4/a5); the product path fuses
-// the same entry_pg<> into the sweep below.
+// The table of per-entry likelihoods pG[row][alpha][9] (a4/a5) for the wave / tile kernels and muxgl_demux_get_entry_pg.
+// rec == NULL: row = entry, every entry.  rec != NULL (the wave kernels at V <= 64): row = position in the record stream
+// of the NON-linear entries (plan_build_bit_streams) -- nobody reads the likelihoods of an entry with one usable read,
+// the ring kernel takes its (A, Bl, Bm) from a table by allele and quality (demux_ring.hip) -- so a quarter of the
+// entries are computed and the table is a quarter of the size, in the order the waves read it; the rows of markers
+// without genotypes are all ones there (neutral: demux_wave.hip).
 template <int NA>
-__global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const int64_t* __restrict__ entry_rptr,
+__global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nrows, const int64_t* __restrict__ entry_rptr,
                                                               const uint8_t* __restrict__ reads,
                                                               const double* __restrict__ lut_g, int nAlpha,
                                                               alpha_args al, double* __restrict__ pg,
-                                                              const uint32_t* __restrict__ lin, int skip_lin) {
+                                                              const fmx_grec* __restrict__ rec,
+                                                              const uint8_t* __restrict__ has_gp) {
   __shared__ double lut[384];
   __shared__ double stage[4][64 * 9 + 1];  // one alpha of a wave's 64 entries at a time (+1: odd stride, no bank conflicts)
   for (int i = threadIdx.x; i < 384; i += 256) lut[i] = lut_g[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int W = nAlpha * 9;  // doubles per entry in the table
-  // lane <-> entry for the arithmetic; the table rows of a wave's 64 entries are contiguous, so they are written by
+  const int W = nAlpha * 9;  // doubles per row of the table
+  // lane <-> row for the arithmetic; the table rows of a wave's 64 entries are contiguous, so they are written by
   // consecutive lanes through LDS instead of 64 streams W doubles apart
-  for (int64_t eb = ((int64_t)blockIdx.x * 4 + w) * 64; eb < nnz; eb += (int64_t)gridDim.x * 256) {
-    const int64_t e = eb + lane;
+  for (int64_t eb = ((int64_t)blockIdx.x * 4 + w) * 64; eb < nrows; eb += (int64_t)gridDim.x * 256) {
+    const int64_t r = eb + lane;
     double pG[NA * 9];
-    if (e < nnz) {  // the row kernel's formulation (demux_entry.hpp); slots beyond nAlpha repeat alpha[0]
+    if (r < nrows) {  // the row kernel's formulation (demux_entry.hpp); slots beyond nAlpha repeat alpha[0]
+      const int64_t e = rec ? rec[r].e : r;
       const int64_t r0 = entry_rptr[e], r1 = entry_rptr[e + 1];
       uint32_t first4 = 0;
       for (int64_t k = 0; k < 4 && r0 + k < r1; ++k) first4 |= (uint32_t)reads[r0 + k] << (8 * (int)k);
       row_entry_pg<NA>(reads, r0, r1, first4, al.a, lut, pG);
+      if (rec && !has_gp[rec[r].snp]) {
+#pragma unroll
+        for (int i = 0; i < NA * 9; ++i) pG[i] = 1.0;
+      }
     }
-    const int ne = (int)((nnz - eb < 64) ? (nnz - eb) : 64);
-    // skip_lin (the wave kernels at V <= 64): nobody reads the row of an entry with one usable read -- the ring kernel
-    // takes its (A, Bl, Bm) from a table by allele and quality (demux_ring.hip) -- so it is not written
-    uint64_t linmask = 0;
-    if (skip_lin) linmask = __ballot(e < nnz && ((lin[e >> 5] >> (e & 31)) & 1u));
+    const int ne = (int)((nrows - eb < 64) ? (nrows - eb) : 64);
 #pragma unroll
     for (int n = 0; n < NA; ++n) {
       if (n >= nAlpha) break;
@@ -115,7 +121,7 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nnz, const 
       // (a wave's LDS traffic is in order: no barrier between the phases)
       for (int x = lane; x < ne * 9; x += 64) {
         const int le = x / 9, i = x - le * 9;
-        if (!((linmask >> le) & 1ull)) pg[(size_t)(eb + le) * W + n * 9 + i] = stage[w][x];
+        pg[(size_t)(eb + le) * W + n * 9 + i] = stage[w][x];
       }
     }
   }
@@ -398,12 +404,14 @@ int launch_sweep(muxgl_handle* h, const muxgl_demux_params* p, uint32_t symmask,
 }
 
 template <int NA>
-int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg, bool skip_lin) {
-  int64_t blocks = (h->nnz + 255) / 256;
+int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg, bool gen_stream) {
+  const int64_t nrows = gen_stream ? h->nnz - h->n_lin_rec : h->nnz;
+  int64_t blocks = (nrows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(demux_entry_pg_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->nnz,
-                     h->d_entry_rptr, h->d_reads, h->d_lut, p->n_alpha, al, d_pg, h->d_lin, skip_lin ? 1 : 0);
+  hipLaunchKernelGGL(demux_entry_pg_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, h->stream, nrows, h->d_entry_rptr,
+                     h->d_reads, h->d_lut, p->n_alpha, al, d_pg, gen_stream ? h->d_gen_rec : (const fmx_grec*)nullptr,
+                     h->d_has_gp);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -544,12 +552,12 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   return 0;
 }
 
-// skip_lin: the rows of the linear entries (h->d_lin) are left out of d_pg
-int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool skip_lin) {
+// gen_stream: one row per NON-linear entry, in the order of h->d_gen_rec (needs plan_build_bit_streams)
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream) {
   const int A = p->n_alpha;
   alpha_args al;
   for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : p->alpha[0];
-#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg, skip_lin)
+#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg, gen_stream)
   DISPATCH_NA(A, CALL_PG);
 #undef CALL_PG
 }

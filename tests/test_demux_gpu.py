@@ -19,10 +19,10 @@ GRID6 = (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)
 
 @pytest.fixture(scope="module", params=["default", "row", "wave", "tile"])
 def eng(request):
-    """all sweep implementations: 'default' = normal dispatch (quad kernel for V <= 16 with the grid {0,0.5}, row kernel
-    for other grids at V <= 16; default grid beyond: row kernel + broadcast extras up to 24 samples, two samples per
-    lane up to 32; wave kernels otherwise), 'row' = quad and broadcast-extras kernels disabled, 'wave' = the wave
-    kernels for every shape they take, 'tile' = the general tile sweep forced"""
+    """all sweep implementations: 'default' = normal dispatch (oct kernel for V <= 16 with the grid {0,0.5}, row kernel
+    for other grids at V <= 16; default grid beyond: two samples per lane up to 32; ring + wave kernels otherwise),
+    'row' = oct kernel disabled, 'wave' = the wave kernels for every shape they take, 'tile' = the general tile sweep
+    forced"""
     flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "wave": muxgl.FLAG_FORCE_WAVE_KERNEL,
              "tile": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
     e = muxgl.Engine(0, flags)
@@ -120,7 +120,7 @@ def test_deep_pileups_per_entry(eng, V):
 
 @pytest.mark.parametrize("V", [8, 16, 17, 19, 22, 24, 27, 32, 48])
 def test_records_do_not_depend_on_the_tensor_request(eng, V):
-    """the quad and two-per-lane row paths make the call in LDS when the LL tensor is not asked for: same records,
+    """the oct and two-per-lane row paths make the call in LDS when the LL tensor is not asked for: same records,
     bit for bit, as the reduce + call kernels behind the tensor"""
     p = synth.make_pileup(70, 3000, V, seed=4000 + V, mean_entries=500, min_entries=5, missing_gp_frac=0.05)
     alphas = (0.0, 0.5)

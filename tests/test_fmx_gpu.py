@@ -19,8 +19,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.fixture(scope="module", params=["default", "row", "wave", "pair"])
 def eng(request):
-    """'default' = normal dispatch (quad E-step for K <= 16, row E-step + broadcast clusters up to 24, two clusters per
-    lane up to 32, wave kernels above), 'row' = quad and broadcast kernels disabled (row E-step, two clusters per lane),
+    """'default' = normal dispatch (oct E-step for K <= 16, two clusters per lane up to 32, wave kernels above), 'row' = the
+    oct kernel disabled (row E-step, two clusters per lane),
     'wave' = the ring-of-32 wave E-step for 16 < K <= 32, 'pair' = the general pair kernel and the (SNP, cluster)-
     parallel M-step forced for every K"""
     flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "wave": muxgl.FLAG_FORCE_WAVE_KERNEL,

@@ -259,9 +259,9 @@ def test_linear_entry_forms_agree_with_the_general_ones():
     assert parity.compare_fmx(a, ocells)["max_abs_ll_diff"] < 1e-7
 
 
-def test_linear_entry_loops_of_the_quad_kernels_agree_with_the_general_ones():
-    """The quad kernels (V, K <= 16) sweep a chunk's entries with one usable read in a loop of their own (moments of the
-    triples, demux_quad.hip / fmx_quad.hip); MUXGL_FLAG_NO_LINEAR_ENTRIES keeps every entry in the nine-term loop.  Mixed
+def test_linear_entry_loops_of_the_oct_kernels_agree_with_the_general_ones():
+    """The oct kernels (V, K <= 16) sweep a chunk's entries with one usable read in a loop of their own (moments of the
+    triples, demux_oct.hip / fmx_oct.hip); MUXGL_FLAG_NO_LINEAR_ENTRIES keeps every entry in the nine-term loop.  Mixed
     chunks (reads_lambda = 0.6), alleles other than 0/1 among the reads, several chunks per cell, markers without
     genotypes."""
     V, alphas = 16, (0.0, 0.5)
