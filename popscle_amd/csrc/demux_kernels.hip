@@ -77,12 +77,12 @@ struct alpha_args {
   double a[MUXGL_MAX_ALPHA];
 };
 
-// The table of per-entry likelihoods pG[row][alpha][9] (a4/a5) for the wave / tile kernels and muxgl_demux_get_entry_pg.
-// rec == NULL: row = entry, every entry.  rec != NULL (the wave kernels at V <= 64): row = position in the record stream
-// of the NON-linear entries (plan_build_bit_streams) -- nobody reads the likelihoods of an entry with one usable read,
-// the ring kernel takes its (A, Bl, Bm) from a table by allele and quality (demux_ring.hip) -- so a quarter of the
-// entries are computed and the table is a quarter of the size, in the order the waves read it; the rows of markers
-// without genotypes are all ones there (neutral: demux_wave.hip).
+// The table of per-entry likelihoods pG[entry][alpha][9] (a4/a5) for the wave / tile kernels and muxgl_demux_get_entry_pg.
+// rec == NULL: every entry, lane <-> entry.  rec != NULL (the wave kernels at V <= 64): lane <-> record of the stream of the
+// NON-linear entries (plan_build_bit_streams) -- nobody reads the likelihoods of an entry with one usable read, the ring
+// kernel takes its (A, Bl, Bm) from a table by allele and quality (demux_ring.hip) -- so a quarter of the entries are
+// computed; their rows (still indexed by entry) are written by the lane itself, and the rows of markers without
+// genotypes are all ones (neutral: demux_wave.hip).
 template <int NA>
 __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nrows, const int64_t* __restrict__ entry_rptr,
                                                               const uint8_t* __restrict__ reads,
@@ -113,6 +113,21 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nrows, cons
       }
     }
     const int ne = (int)((nrows - eb < 64) ? (nrows - eb) : 64);
+    if (rec) {  // rows of a wave's records are far apart: every lane writes its own 72 * nAlpha bytes
+      if (r < nrows) {
+        double* o = pg + (size_t)rec[r].e * W;
+        if ((W & 1) == 0) {  // rows are 16-byte aligned
+#pragma unroll
+          for (int x = 0; x < NA * 9 / 2; ++x)
+            if (2 * x < W) reinterpret_cast<double2*>(o)[x] = double2{pG[2 * x], pG[2 * x + 1]};
+        } else {
+#pragma unroll
+          for (int x = 0; x < NA * 9; ++x)
+            if (x < W) o[x] = pG[x];
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int n = 0; n < NA; ++n) {
       if (n >= nAlpha) break;

@@ -145,8 +145,7 @@ struct wave_blk {
 template <int NA, int NS, bool WITH_SINGLET, bool CROSS, int EM, bool EXL>
 __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* __restrict__ rec,
                                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg, int PG,
-                                        bool pg_by_stream, const int32_t (&seln)[NA], const double* __restrict__ gp, int V3,
-                                        int jo, int ko,
+                                        const int32_t (&seln)[NA], const double* __restrict__ gp, int V3, int jo, int ko,
                                         bool live, bool live2, int j, int s0, double (*ring)[128], int32_t (*exs)[64],
                                         double (&acc)[NA * NS], int32_t (&ex)[EXL ? 1 : NA * NS], double& accS, int32_t& exS) {
   static_assert(EM == EM_ALL || EM == EM_GENERAL, "the linear entries' walk lives in demux_ring.hip");
@@ -163,8 +162,7 @@ __device__ __forceinline__ void dw_walk(int64_t i0, int64_t i1, const fmx_grec* 
   auto load_id = [&](int64_t i, auto sc) {  // clamped: a valid record is read behind the end, and not used
     constexpr int s = decltype(sc)::value;
     const int64_t ic = i < i1 ? i : i1 - 1;
-    // (ide: the row of the table -- the entry, or with a table in stream order the position in the stream)
-    if (STREAM) ide[s] = pg_by_stream ? ic : rec[ic].e, ids[s] = rec[ic].snp;
+    if (STREAM) ide[s] = rec[ic].e, ids[s] = rec[ic].snp;
     else ide[s] = ic, ids[s] = entry_snp[ic];
   };
   auto load_gp = [&](auto sc) {
@@ -318,8 +316,7 @@ __global__ void __launch_bounds__(64, 2)
                       const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                       const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank,
                       const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp,
-                      const uint8_t* __restrict__ has_gp, int pg_by_stream, int V, int nAlpha, int n_sel, wave_blk wb,
-                      double* __restrict__ ll) {
+                      const uint8_t* __restrict__ has_gp, int V, int nAlpha, int n_sel, wave_blk wb, double* __restrict__ ll) {
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
   const int64_t c = it.slab;  // slab index: the cell id, or an overflow slab
@@ -346,8 +343,8 @@ __global__ void __launch_bounds__(64, 2)
   int64_t i0 = it.e0, i1 = it.e1;
   if constexpr (EM != EM_ALL) wave_stream_range<EM>(lin, lin_rank, it.e0, it.e1, i0, i1);
   const int32_t seln[1] = {n_sel};
-  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, rec_gen, entry_snp, pg, TW, pg_by_stream != 0, seln, gp, V3, jo, ko, live,
-                                                   live2, j, 0, ring, exs, acc, ex, accS, exS);
+  dw_walk<1, NSHIFT, WITH_SINGLET, CROSS, EM, EXL>(i0, i1, rec_gen, entry_snp, pg, TW, seln, gp, V3, jo, ko, live, live2, j, 0, ring,
+                                                   exs, acc, ex, accS, exS);
 
   // Results go to the wave layout llw[c][n][step t][lane j] (coalesced; the partner of (t, j) is re-derived by the
   // readers with the same rotation): lane j, step t holds the hypothesis (j, k = j - t - 1 mod 64).  Alpha = 0.5 fills
@@ -391,8 +388,7 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
                             const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                             const uint32_t* __restrict__ lin, const int64_t* __restrict__ lin_rank,
                             const fmx_grec* __restrict__ rec_gen, const double* __restrict__ gp,
-                            const uint8_t* __restrict__ has_gp, int pg_by_stream, int V, int nAlpha, wave_sel sel, wave_blk wb,
-                            double* __restrict__ ll) {
+                            const uint8_t* __restrict__ has_gp, int V, int nAlpha, wave_sel sel, wave_blk wb, double* __restrict__ ll) {
   // One workgroup per work unit, one WAVE per range of NS rotation steps (s0 = 0, NS, 2 NS, ...).  The waves are
   // independent -- own accumulators, own ring and exponents in LDS, no barrier -- but they walk the same entries at the
   // same pace on one CU, so the marker rows and likelihood tables the first of them pulls from HBM are cache hits for
@@ -429,11 +425,11 @@ __global__ void __launch_bounds__(64 * (64 / NS), 2)
 #pragma unroll
   for (int a = 0; a < NA; ++a) seln[a] = sel.n[a];
   if (WITH_SINGLET && w == 0)  // the singlet slot rides along with the first step range only
-    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, rec_gen, entry_snp, pg, TW, pg_by_stream != 0, seln, gp, V3, jo, ko, live,
-                                                   live2, j, s0, ring, exs, acc, ex, accS, exS);
+    dw_walk<NA, NS, WITH_SINGLET, CROSS, EM, true>(i0, i1, rec_gen, entry_snp, pg, TW, seln, gp, V3, jo, ko, live, live2, j, s0, ring,
+                                                   exs, acc, ex, accS, exS);
   else
-    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, rec_gen, entry_snp, pg, TW, pg_by_stream != 0, seln, gp, V3, jo, ko, live, live2,
-                                            j, s0, ring, exs, acc, ex, accS, exS);
+    dw_walk<NA, NS, false, CROSS, EM, true>(i0, i1, rec_gen, entry_snp, pg, TW, seln, gp, V3, jo, ko, live, live2, j, s0, ring, exs,
+                                            acc, ex, accS, exS);
 
   double* out = ll + ((size_t)c * wb.nblk2 + wb.blk) * nAlpha * 4096;  // wave layout, see demux_wave_kernel
   wave_for<0, NS>([&](auto tc) {
@@ -471,7 +467,7 @@ __global__ void __launch_bounds__(64, 2)
                         const int32_t* __restrict__ entry_snp, const double* __restrict__ pg,
                         const uint32_t* __restrict__ /*lin: the rings of 32 keep the single launch*/,
                         const int64_t* __restrict__, const fmx_grec* __restrict__, const double* __restrict__ gp,
-                        const uint8_t* __restrict__ has_gp, int /*pg_by_stream*/, int V, int nAlpha,
+                        const uint8_t* __restrict__ has_gp, int V, int nAlpha,
                         wave_sel sel, uint32_t symmask, double* __restrict__ ll) {
   constexpr int NS = ALLSYM ? 8 : 16;
   if ((int64_t)blockIdx.x >= n_items) return;
@@ -731,16 +727,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   muxgl_wave_state* st = h->wave;
   const int A = p->n_alpha, V = h->V;
   const int nblk = (V + 63) / 64, nblk2 = nblk * nblk;  // 64 x 64 blocks of the pair matrix
-  // linear entries (one usable read) in a launch of their own with the one-moment form, the others on top: see the notes above dw_walk
-  const bool use_lin = V > 32 && h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
-  if (use_lin && h->n_lin_rec < 0 &&
-      plan_build_bit_streams(h, h->d_lin, &h->d_lin_rank, &h->d_lin_rec, &h->d_gen_rec, &h->n_lin_rec))
-    return 1;
-  // one block of the pair matrix (V <= 64): nobody reads the likelihoods of the linear entries (the ring kernel takes their
-  // (A, Bl, Bm) from a table by allele and quality), so the table has one row per NON-linear entry, in the order of their
-  // record stream; beyond, the off-diagonal blocks walk every entry through a table by entry
-  const bool pg_stream = use_lin && nblk == 1;
-  const size_t need = (size_t)(pg_stream ? h->nnz - h->n_lin_rec : h->nnz) * A * 9;
+  const size_t need = (size_t)h->nnz * A * 9;
   const size_t llw_need = (size_t)(h->C + st->n_over) * nblk2 * A * 4096;
   // pG table, result slabs and (V > 64) the tensor the call kernel reads must fit comfortably: else the tile sweep
   if (((double)need + (double)llw_need + (nblk > 1 ? (double)h->C * V * V * A : 0.0)) * 8.0 > 230e9) return -1;
@@ -752,6 +739,11 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (dev_alloc(h, &h->d_llw, llw_need)) return 1;
     h->llw_cap = llw_need;
   }
+  // linear entries (one usable read) in a launch of their own with the one-moment form, the others on top: see the notes above dw_walk
+  const bool use_lin = V > 32 && h->d_lin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
+  if (use_lin && h->n_lin_rec < 0 &&
+      plan_build_bit_streams(h, h->d_lin, &h->d_lin_rank, &h->d_lin_rec, &h->d_gen_rec, &h->n_lin_rec))
+    return 1;
   if (use_lin) {
     const size_t need_g = (size_t)h->S * V * 2;
     if (need_g > st->gm_cap || !st->d_gm) {
@@ -759,9 +751,14 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       st->gm_cap = need_g;
     }
   }
+  // one block of the pair matrix (V <= 64): nobody reads the rows of the linear entries (the ring kernel takes their
+  // (A, Bl, Bm) from a table by allele and quality), so only the rows of the others are computed (lane <-> record of their
+  // stream) -- the table stays indexed by entry: in the order of the stream (tried: a quarter of the memory) the
+  // sweep that reads it was 5 ms slower at configs[2].  Beyond 64 samples the off-diagonal blocks walk every entry.
+  const bool gen_only = use_lin && nblk == 1;
   tic(h, MUXGL_T_DEMUX_SWEEP);
-  if (demux_entry_pg_launch(h, p, st->d_pg, pg_stream)) return 1;
-  if (h->nnz && !pg_stream)
+  if (demux_entry_pg_launch(h, p, st->d_pg, gen_only)) return 1;
+  if (h->nnz && !gen_only)  // (gen_only: the kernel writes the neutral rows itself)
     hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
                        A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
   const unsigned blocks = (unsigned)st->n_items;
@@ -777,7 +774,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
 #define KARGS                                                                                                    \
   st->d_items, st->n_items, h->d_cell_ptr, h->d_entry_snp, st->d_pg, h->d_lin, h->d_lin_rank, h->d_gen_rec, h->d_gp, \
-      h->d_has_gp, pg_stream ? 1 : 0, V, A
+      h->d_has_gp, V, A
 #define MULTI_K(NA, NS, WS, CR, EMODE)                                                                                        \
   hipLaunchKernelGGL((demux_wave_multi_kernel<NA, NS, WS, CR, EMODE>), dim3(blocks), dim3(64 * (64 / NS)), 0, h->stream, KARGS, \
                      sel, wb, h->d_llw)
