@@ -186,7 +186,9 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
  * construction (each assignment changes the cluster pileups the next cell is scored against): the cells are sorted on
  * the host; the device then decides them in batches of 32, each batch as a fixpoint of the sequential rule (guess from
  * the state at the start of the batch, replay of the predecessors' merges at shared SNPs, iterate until no guess changes:
- * the fixpoint IS the sequential result), or, beyond 64 clusters, with one persistent workgroup walking the cells in
+ * the fixpoint is the sequential result in exact arithmetic; in floating point the scores are start product x
+ * term(replayed)/term(start) rather than the product over the replayed state, so a near tie within a few ulp could
+ * resolve differently from the reference's loop -- not seen on any test, including 12 000 near-tie cells), or, beyond 64 clusters, with one persistent workgroup walking the cells in
  * order (fmx_greedy.hip).  One device, whole pileup: not available on a device group or a slabbed handle.
  * clust_out[C] receives the cluster id, or -1 for cells skipped by frac_init_clust / singlet_score_thres. */
 int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,

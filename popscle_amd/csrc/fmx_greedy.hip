@@ -274,9 +274,13 @@ __global__ void __launch_bounds__(GT)
 //      start state of (c, SNP) -- in cell order, with the reference's merge() -- and leave term(replayed) / term(start);
 //   3. greedy_decide_kernel (one workgroup): scores = start products x the ratios, per cell the first maximum; where a
 //      guess changes, the ratios of the hot entries behind that cell are recomputed and the scores taken again, until
-//      nothing changes.  By induction over i the fixpoint IS the sequential result (cell 0 of the batch has no
-//      predecessor, so it is final after the first pass; cell i is final once cells < i are); it is reached after
-//      one or two passes except while the first clusters are being seeded;
+//      nothing changes.  By induction over i the fixpoint is the sequential result (cell 0 of the batch has no
+//      predecessor, so it is final after the first pass; cell i is final once cells < i are) -- in exact arithmetic:
+//      the scores here are start product x term(replayed)/term(start), not the product over the replayed state, so they
+//      match the sequential rule up to rounding and a near tie within a few ulp could pick another cluster than the
+//      reference's loop (strict '>' keeps the first maximum); tests/test_fmx_gpu.py::test_greedy_init_near_ties holds
+//      12 000 low-margin cells against the serial kernel and the oracle.  It is reached after one or two passes except
+//      while the first clusters are being seeded;
 //   4. greedy_apply_kernel (whole chip): the batch's merges into the (cluster, SNP) states, one thread per chain of
 //      entries at the same SNP walking it in cell order (the order matters only inside a chain: merge() clamps).
 // No state is written while a batch is being decided, so the "snapshot" is simply the table itself.
