@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(GT)
 //      the scores here are start product x term(replayed)/term(start), not the product over the replayed state, so they
 //      match the sequential rule up to rounding and a near tie within a few ulp could pick another cluster than the
 //      reference's loop (strict '>' keeps the first maximum); tests/test_fmx_gpu.py::test_greedy_init_near_ties holds
-//      12 000 low-margin cells against the serial kernel and the oracle.  It is reached after one or two passes except
+//      12 000 low-margin cells against the serial kernel and the CPU restatement.  It is reached after one or two passes except
 //      while the first clusters are being seeded;
 //   4. greedy_apply_kernel (whole chip): the batch's merges into the (cluster, SNP) states, one thread per chain of
 //      entries at the same SNP walking it in cell order (the order matters only inside a chain: merge() clamps).
