@@ -17,6 +17,8 @@
 // and merges those rows into its state.  The merges of a round are K independent chains on full wave instructions;
 // a batch costs as many rounds as its most frequent cluster has elements.  The arithmetic of a merge is the one of
 // fmx_mstep_snp_kernel, operation for operation, so the two kernels agree bit for bit (tests/test_fmx_gpu.py).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -176,7 +178,8 @@ int mstep_go(muxgl_handle* h, int64_t ns) {
   // the table next to the waves' staging areas within the 160 KB of a CU
   constexpr size_t stat = (size_t)MS_W * NG * (6 * G * NB * sizeof(double) + (G + 1) * sizeof(typename mask_of<G * NB>::type));
   const size_t dyn = (size_t)((C + 15) / 16 * 16);
-  if (stat + dyn <= 160 * 1024) {
+  static const bool no_tab = getenv("MUXGL_MSTEP_NO_TABLE") != nullptr;  // (tests: the variant for many cells on few)
+  if (stat + dyn <= 160 * 1024 && !no_tab) {
     auto kern = fmx_mstep_stream_kernel<G, NB, MS_W, true>;
     HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const int64_t per = (int64_t)NG * MS_W;

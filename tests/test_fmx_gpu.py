@@ -316,3 +316,36 @@ def test_mstep_stream_vs_lds_states_and_oracle(K, C, S, me):
             g2, _ = en.fmx_cluster_pileup()
             got.append((g, g2))
     assert got[0][0].tobytes() == got[1][0].tobytes() and got[0][1].tobytes() == got[1][1].tobytes()
+
+
+def test_mstep_stream_without_the_lds_table(tmp_path):
+    """Beyond ~60 k cells the assignments do not fit next to the staging areas in LDS and the stream M-step gathers them
+    from global memory (one wave per workgroup): forced here on small inputs through MUXGL_MSTEP_NO_TABLE in a process
+    of its own (the library reads the variable once), bit-identical to the kernel with the states in LDS."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from popscle_amd import muxgl, synth
+for K, C, S, me in [(5, 2000, 40, 20), (16, 3000, 50, 25), (24, 2500, 40, 20), (48, 3000, 48, 24)]:
+    p = synth.make_pileup(C, S, min(K, 8), seed=77 + K, mean_entries=me, min_entries=5, with_gp=False)
+    rng = np.random.default_rng(K)
+    clust = rng.choice(K, size=p.C, p=rng.dirichlet(np.full(K, 0.6))).astype(np.int32)
+    clust[rng.random(p.C) < 0.07] = -1
+    out = []
+    for flags in (0, muxgl.FLAG_MSTEP_LDS_STATES):
+        with muxgl.Engine(0, flags) as en:
+            en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+            en.fmx_prepare(p.af)
+            en.fmx_set_clusters(K, clust)
+            g, c = en.fmx_cluster_pileup()
+            en.fmx_iterate(0.5, 0.1)
+            g2, _ = en.fmx_cluster_pileup()
+            out.append(g.tobytes() + g2.tobytes())
+    assert out[0] == out[1], K
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MUXGL_MSTEP_NO_TABLE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
