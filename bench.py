@@ -544,6 +544,8 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
                                                "estep_sweep": float(kern[muxgl.T_FMX_ESTEP_SWEEP]),
                                                "call": float(kern[muxgl.T_FMX_CALL]), "mstep": float(kern[muxgl.T_FMX_MSTEP])},
             "last_iteration": {"nsingle": hist[-1][0], "namb": hist[-1][1], "nchanged": hist[-1][2]},
+            # device-event times of the two exchanges per iteration on rank 0 (RCCL only): DESIGN.md 4.3's scaling model
+            "exchange_ms_rank0": tm.get("exchange_ms"),
             "roofline": roofline(fmx_estep_kernel(K), est_s, fmx_bytes_per_entry(K) * my_entries,
                                  fmx_flops_per_entry(K) * my_entries, fmx_issued_flops_model(K) * my_entries, config,
                                  scale=my_entries),

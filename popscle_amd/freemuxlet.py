@@ -161,6 +161,16 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
         stat_host = torch.zeros(4, dtype=torch.int32).pin_memory()
         stat_ready = torch.cuda.Event()
     history = []
+    # device-ordered exchanges are timed with events on the engine's stream (the collective's own stream is ordered
+    # against it on both sides): what the scaling model of DESIGN.md 4.3 is compared with
+    marks = [] if (ordered and timings is not None) else None
+
+    def mark():
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+
     if sync:
         sync()
     t_loop = time.perf_counter()
@@ -168,11 +178,15 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
         for it in range(max_iter):
             eng.fmx_iter_gp(doublet_prior, geno_error)
             if multi:
+                mark()
                 ex.allgather_equal(t_cgp, per_s)
+                mark()
             eng.fmx_iter_estep(doublet_prior, geno_error)
             if multi:
+                mark()
                 ex.allgather_equal(t_clust, per_c)
                 ex.allreduce_sum(t_stat)
+                mark()
             if ordered:  # counters on their way to the host; the M-step is enqueued before anybody waits for them
                 stat_host.copy_(t_stat, non_blocking=True)
                 stat_ready.record()
@@ -196,6 +210,12 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
     t_end = time.perf_counter()
     if timings is not None:  # `sync` (a barrier) makes these comparable across ranks
         timings.update(setup_s=t_loop - t_start, loop_s=t_end - t_loop, iterations=len(history))
+        if marks:
+            torch.cuda.synchronize()
+            gp = [marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 4)]
+            cl = [marks[i + 2].elapsed_time(marks[i + 3]) for i in range(0, len(marks), 4)]
+            timings.update(exchange_ms={"cluster_gp_allgather": sum(gp) / len(gp),
+                                        "assignments_allgather_and_counters": sum(cl) / len(cl)})
     cells, _ = eng.fmx_iter_fetch()  # the rank's own cells
     c0 = eng.cell_base
     parts = ex.gather_objects((c0, c0 + len(cells), cells.tobytes()))

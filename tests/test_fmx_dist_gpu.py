@@ -61,6 +61,8 @@ def test_single_rank_over_rccl(tmp_path):
     run([sys.executable, PROBE, "--gpus", "1", "--dump", one] + SHAPE)
     j = run([sys.executable, PROBE, "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--dump", rccl] + SHAPE)
     assert j["config"]["backend"] == "nccl" and j["n_gpus"] == 1
+    ex = j["exchange_ms_rank0"]  # the exchanges are timed with device events (what DESIGN 4.3's model is compared with)
+    assert ex and ex["cluster_gp_allgather"] >= 0.0 and ex["assignments_allgather_and_counters"] >= 0.0
     a, b = np.load(one), np.load(rccl)
     assert np.array_equal(a["hist"], b["hist"])
     assert a["cells"].tobytes() == b["cells"].tobytes()
