@@ -39,6 +39,10 @@ namespace {
 #ifndef FMX_EXP_LDS
 #define FMX_EXP_LDS 1
 #endif
+// the pair sums of the general entries around the lane's smallest u (see PIV in fw_walk_gen); 0: the three-term sums
+#ifndef FMX_PIVOT
+#define FMX_PIVOT 1
+#endif
 
 __device__ __forceinline__ double fw_wror1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -123,6 +127,16 @@ __device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_gr
   };
   double u0 = 0, u1 = 0, u2 = 0, sing = 1.0;
   double c0r = 1.0, c1r = 0, c2r = 0;  // what the ring carries for the current entry
+  // PIV (diagonal blocks): the pair sum  sum_m P_k[m] u[m]  of a lane is taken around the lane's SMALLEST u,
+  //     u_p + P_k[a] (u_a - u_p) + P_k[b] (u_b - u_p),   {a, b} = {0, 1, 2} \ {p},
+  // which uses sum_m P_k[m] = 1 (the posteriors are normalised in FP64 by the kernel that writes them: 1 to within 2 ulp,
+  // the assumption the linear form makes too).  Every term is >= 0, so nothing cancels whatever the entry looks like
+  // (relative deviation from the three-term sum <= ~4e-16), and a hypothesis costs two FMAs and the product update
+  // instead of three and one.  Which two of the partner's three numbers a lane needs depends on the lane: they are read
+  // from the ring in LDS through two per-lane base addresses (no DPP rotations in this form), set once per entry.
+  constexpr bool PIV = !CROSS && FMX_PIVOT;
+  double up = 0, da = 0, db = 0;
+  uint32_t ra_a = ring_a, ra_b = ring_a + 1024;
   auto factors = [&](auto sc, double q0, double q1, double q2, double q3, double q4, double q5, double q6, double q7, double q8) {
     constexpr int s = decltype(sc)::value, sq = CROSS ? s : 0;
     const double g0 = live ? gp[s][0] : 1.0, g1 = live ? gp[s][1] : 0.0, g2 = live ? gp[s][2] : 0.0;
@@ -134,6 +148,14 @@ __device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_gr
       c0r = live2 ? gq[sq][0] : 1.0, c1r = live2 ? gq[sq][1] : 0.0, c2r = live2 ? gq[sq][2] : 0.0;
     } else {
       c0r = g0, c1r = g1, c2r = g2;
+    }
+    if constexpr (PIV) {
+      const bool p0 = u0 <= u1 && u0 <= u2, p1 = !p0 && u1 <= u2;  // pivot 0 / 1 / (else) 2
+      up = p0 ? u0 : (p1 ? u1 : u2);
+      da = (p0 ? u1 : u0) - up;  // a = 1 with pivot 0, else 0
+      db = ((p0 || p1) ? u2 : u1) - up;  // b = 2 with pivot 0 or 1, else 1
+      ra_a = ring_a + (p0 ? 1024u : 0u);
+      ra_b = ring_a + ((p0 || p1) ? 2048u : 1024u);
     }
     ring[0][j] = c0r, ring[0][j + 64] = c0r;
     ring[1][j] = c1r, ring[1][j + 64] = c1r;
@@ -156,6 +178,39 @@ __device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_gr
       load_id(i + D, sc);
       // sweep of entry i
       if (!CROSS) accS *= sing;  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
+      if constexpr (PIV) {
+        constexpr int G = 4;  // pairs of ring reads per group; the reads of group g + 1 are in flight while group g is consumed
+        constexpr int NG = (NS + G - 1) / G;
+        double rd[2][G][2];
+        auto issue = [&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          wave_for<0, G>([&](auto ic) {
+            constexpr int k = decltype(ic)::value, t = g * G + k;  // rotation t + 1
+            if constexpr (t < NS) {
+              rd[g & 1][k][0] = wave_ring_rd<(64 - (t + 1)) * 8>(ra_a);
+              rd[g & 1][k][1] = wave_ring_rd<(64 - (t + 1)) * 8>(ra_b);
+            } else {
+              rd[g & 1][k][0] = rd[g & 1][k][1] = 0.0;
+            }
+          });
+        };
+        issue(std::integral_constant<int, 0>{});
+        wave_for<0, NG>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int left = NS - (g + 1) * G;
+          constexpr int ahead = g + 1 < NG ? 2 * (left < G ? left : G) : 0;  // younger reads: they may stay in flight
+          if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+          asm volatile("s_waitcnt lgkmcnt(%8)"
+                       : "+v"(rd[g & 1][0][0]), "+v"(rd[g & 1][0][1]), "+v"(rd[g & 1][1][0]), "+v"(rd[g & 1][1][1]),
+                         "+v"(rd[g & 1][2][0]), "+v"(rd[g & 1][2][1]), "+v"(rd[g & 1][3][0]), "+v"(rd[g & 1][3][1])
+                       : "n"(ahead));
+          wave_for<0, G>([&](auto ic) {
+            constexpr int k = decltype(ic)::value, t = g * G + k;
+            if constexpr (t < NS) acc[t] *= fma(rd[g & 1][k][1], db, fma(rd[g & 1][k][0], da, up));  // :440-446 as a product
+          });
+          __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from forming all the sums first
+        });
+      } else {
       constexpr int G = CROSS ? 1 : 2;  // ring reads per group; the reads of group g + 1 are in flight while group g is consumed
       constexpr int NG = (NS - TD + G - 1) / G;
       double r0 = c0r, r1 = c1r, r2 = c2r;
@@ -211,6 +266,7 @@ __device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_gr
           r2 = fw_wror1(r2);
           acc[decltype(dc)::value] *= fma(r2, u2, fma(r1, u1, r0 * u0));
         });
+      }
       }
       // factors of the next entry and its ring (behind the sweep's reads: the LDS serves one wave's requests in order)
       factors(std::integral_constant<int, s1>{}, q0, q1, q2, q3, q4, q5, q6, q7, q8);
