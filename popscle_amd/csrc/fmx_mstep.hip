@@ -179,7 +179,9 @@ int mstep_go(muxgl_handle* h, int64_t ns) {
   constexpr size_t stat = (size_t)MS_W * NG * (6 * G * NB * sizeof(double) + (G + 1) * sizeof(typename mask_of<G * NB>::type));
   const size_t dyn = (size_t)((C + 15) / 16 * 16);
   static const bool no_tab = getenv("MUXGL_MSTEP_NO_TABLE") != nullptr;  // (tests: the variant for many cells on few)
-  if (stat + dyn <= 160 * 1024 && !no_tab) {
+  // (measured: with the table 0.54 vs 0.59 ms at configs[3], K = 16; at K = 64 and 50 k cells 2.87 vs 2.55 ms -- one
+  // 16-wave workgroup per CU loses more than the gather costs -- so the table is for the 16-lane groups only)
+  if (G == 16 && stat + dyn <= 160 * 1024 && !no_tab) {
     auto kern = fmx_mstep_stream_kernel<G, NB, MS_W, true>;
     HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const int64_t per = (int64_t)NG * MS_W;
