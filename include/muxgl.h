@@ -46,8 +46,9 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 #define MUXGL_FLAG_FORCE_TILE_SWEEP 1 /* never take the V<=16 row/oct kernels (lets tests cover the general tile sweep) */
 #define MUXGL_FLAG_FORCE_ROW_KERNEL 2  /* never take the default-grid oct kernels (V, K <= 16: lets tests cover the row
                                           kernels behind them) */
-#define MUXGL_FLAG_FORCE_WAVE_KERNEL 4 /* take the wave kernels for V <= 16 too, and the rings of 32 instead of the
-                                          two-per-lane row kernels at 17..32 samples / clusters (test coverage) */
+#define MUXGL_FLAG_FORCE_WAVE_KERNEL 4 /* demuxlet: take the wave kernels for V <= 16 too, and the ring of 32 instead of the
+                                          two-per-lane row kernel at 17..32 samples; freemuxlet: never take the
+                                          two-per-lane row kernel at 17..32 clusters (test coverage) */
 #define MUXGL_FLAG_FORCE_BATCHED_GREEDY 8 /* (no effect since the batched greedy-init kernels became the default for K <= 64;
                                              MUXGL_FLAG_FORCE_TILE_SWEEP selects the serial kernel) */
 #define MUXGL_FLAG_DEMUX_ONLY 16   /* device group: the caller will only run demuxlet, so muxgl_set_pileup need not cut

@@ -1,4 +1,4 @@
-// fmx_wave.hip -- freemuxlet E-step (cmd_cram_freemux2.cpp:383-456) for 16 < K <= 255 clusters: one wave per cell, one
+// fmx_wave.hip -- freemuxlet E-step (cmd_cram_freemux2.cpp:383-456) for 32 < K <= 255 clusters: one wave per cell, one
 // lane per cluster, the design of demux_wave.hip with the entry's nine genotype-pair likelihoods in the role of pG.
 //
 //   * lane j keeps cluster j's genotype posterior gp_j (three doubles from the per-iteration tensor cgp[S][K][3], loaded
@@ -465,86 +465,6 @@ __global__ void __launch_bounds__(256) fw_ce_kernel(int64_t n, const double* __r
   if (i < n) cE[i] = fma(2.0, cgp[3 * i + 2], cgp[3 * i + 1]);
 }
 
-// 16 < K <= 32: the wave as a ring of 32.  Both 32-lane halves hold the same 32 posteriors (lane j and j + 32: cluster
-// j & 31), so wave_ror:1 rotates the ring inside each half; lane j of the upper half works for cluster (j + 8) & 31, i.e.
-// it sees the ring eight positions further on.  The pair likelihood is symmetric, so the ring offsets 1..16 are all the
-// unordered pairs: the lower half meets offsets 1..8, the upper half 9..16 -- eight steps instead of 32 (offset 16 meets
-// a pair from both sides: one writer).
-__global__ void __launch_bounds__(64, 4)
-    fmx_estep_wave32_kernel(const wave_item* __restrict__ items, int64_t n_items, int64_t c0, int64_t c1,
-                            const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
-                            const double* __restrict__ cgp, int K, double* __restrict__ fll) {
-  constexpr int NS = 8;
-  if ((int64_t)blockIdx.x >= n_items) return;
-  const wave_item it = items[blockIdx.x];
-  if (it.cell < c0 || it.cell >= c1) return;
-  const int64_t c = it.slab;
-  const int64_t e0 = it.e0, e1 = it.e1;
-  const int j = threadIdx.x;
-  const int half = j >> 5, sj = j & 31;  // ring position
-  const int so = (sj + 8 * half) & 31;   // the cluster this lane works for
-  const bool live = so < K, rlive = sj < K;
-  const int K3 = K * 3;
-  const int npairs = K * (K + 1) / 2;
-
-  double acc[NS], accS = 1.0;
-  int32_t ex[NS], exS = 0;
-#pragma unroll
-  for (int t = 0; t < NS; ++t) {
-    acc[t] = 1.0;
-    ex[t] = 0;
-  }
-  double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;  // own posterior (cluster so)
-  double nr0 = 1.0, nr1 = 0.0, nr2 = 0.0;  // ring posterior (cluster sj)
-  if (e0 < e1) {
-    const double* row = cgp + (size_t)entry_snp[e0] * K3;
-    if (live) ng0 = row[so * 3], ng1 = row[so * 3 + 1], ng2 = row[so * 3 + 2];
-    if (rlive) nr0 = row[sj * 3], nr1 = row[sj * 3 + 1], nr2 = row[sj * 3 + 2];
-  }
-  int cnt = 0;
-  for (int64_t e = e0; e < e1; ++e) {
-    const double g0 = ng0, g1 = ng1, g2 = ng2;
-    double r0 = nr0, r1 = nr1, r2 = nr2;
-    ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    nr0 = 1.0, nr1 = 0.0, nr2 = 0.0;
-    if (e + 1 < e1) {
-      const double* row = cgp + (size_t)entry_snp[e + 1] * K3;
-      if (live) ng0 = row[so * 3], ng1 = row[so * 3 + 1], ng2 = row[so * 3 + 2];
-      if (rlive) nr0 = row[sj * 3], nr1 = row[sj * 3 + 1], nr2 = row[sj * 3 + 2];
-    }
-    const double* q = egls + (size_t)e * 9;  // wave-uniform: glis[g1*3+g2]
-    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
-    accS *= fma(g2, q8, fma(g1, q4, g0 * q0));  // singlet: sum_g glis[g][g] * gp_j[g] (:448-452)
-    const double u0 = fma(g2, q6, fma(g1, q3, g0 * q0));
-    const double u1 = fma(g2, q7, fma(g1, q4, g0 * q1));
-    const double u2 = fma(g2, q8, fma(g1, q5, g0 * q2));
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      r0 = fw_wror1(r0);
-      r1 = fw_wror1(r1);
-      r2 = fw_wror1(r2);
-      acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));  // :440-446 as a product
-    }
-    if (++cnt == 16) {  // a factor is >= ~1e-13 (clamped likelihoods, mixed posteriors): sixteen cannot underflow
-      cnt = 0;
-#pragma unroll
-      for (int t = 0; t < NS; ++t) prodacc_renorm(acc[t], ex[t]);
-      prodacc_renorm(accS, exS);
-    }
-  }
-
-  double* out = fll + (size_t)c * npairs;
-#pragma unroll
-  for (int t = 0; t < NS; ++t) {
-    const int k = (sj - t - 1) & 31;  // wave_ror:1 brings lane j the value of lane j - 1: here inside the ring of 32
-    if (!live || k >= K || k == so) continue;
-    if (half == 1 && t == NS - 1 && so < k) continue;  // ring offset 16: both ends meet the pair
-    const int hi = so > k ? so : k, lo = so > k ? k : so;
-    out[hi * (hi + 1) / 2 + lo] = prodacc_log(acc[t], ex[t]);
-  }
-  if (half == 0 && live) out[so * (so + 1) / 2 + so] = prodacc_log(accS, exS);
-}
-
 // rows of the parts of a cut cell added, in entry order, into the cell's row of fll
 __global__ void __launch_bounds__(256)
     fmx_wave_combine_kernel(const wave_cut* __restrict__ cuts, int64_t c0, int64_t c1, int npairs, double* __restrict__ fll) {
@@ -620,13 +540,13 @@ static int fmx_wave_streams_build(muxgl_handle* h) {
 
 // returns -1 when this path does not apply, 0 ok, 1 error
 int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
-  if (h->K <= 16 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;
+  if (h->K <= 32 || (h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) return -1;  // (up to 32 clusters: fmx_row2.hip, fmx_oct.hip)
   const wave_item* items;
   const wave_cut* cuts;
   int64_t n_items, n_cuts, n_over;
   if (demux_wave_items(h, &items, &n_items, &cuts, &n_cuts, &n_over) || n_items == 0) return -1;
   const int nblk = (h->K + 63) / 64;
-  const bool use_lin = h->K > 32 && h->d_flin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);  // linear-entry stream
+  const bool use_lin = h->d_flin && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);  // linear-entry stream
   if (use_lin) {
     if (fmx_wave_streams_build(h)) return 1;
     const int64_t n = h->S * (int64_t)h->K;
@@ -637,10 +557,7 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
     if (n) hipLaunchKernelGGL(fw_ce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, h->d_cgp, h->d_cE);
   }
   tic(h, MUXGL_T_FMX_ESTEP_SWEEP);
-  if (h->K <= 32)
-    hipLaunchKernelGGL(fmx_estep_wave32_kernel, dim3((unsigned)n_items), dim3(64), 0, h->stream, items, n_items, c0,
-                       c0 + nc, h->d_entry_snp, h->d_egls, h->d_cgp, h->K, h->d_fll);
-  for (int X = 0; X < (h->K <= 32 ? 0 : nblk); ++X) {
+  for (int X = 0; X < nblk; ++X) {
 #define FW_ARGS(XB, YB) \
   items, n_items, c0, c0 + nc, h->d_entry_snp, h->d_egls, h->d_flin, h->d_flin_rank, h->d_lrec, h->d_grec, h->d_cgp, h->d_cE, h->K, \
       64 * (XB), 64 * (YB), h->d_fll

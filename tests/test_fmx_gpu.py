@@ -21,7 +21,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 def eng(request):
     """'default' = normal dispatch (oct E-step for K <= 16, two clusters per lane up to 32, wave kernels above), 'row' = the
     oct kernel disabled (row E-step, two clusters per lane),
-    'wave' = the ring-of-32 wave E-step for 16 < K <= 32, 'pair' = the general pair kernel and the (SNP, cluster)-
+    'wave' = no two-per-lane kernel for 16 < K <= 32 (those shapes then take the pair kernel), 'pair' = the general pair kernel and the (SNP, cluster)-
     parallel M-step forced for every K"""
     flags = {"default": 0, "row": muxgl.FLAG_FORCE_ROW_KERNEL, "wave": muxgl.FLAG_FORCE_WAVE_KERNEL,
              "pair": muxgl.FLAG_FORCE_TILE_SWEEP}[request.param]
