@@ -283,6 +283,10 @@ void* muxgl_stream(const muxgl_handle* h);
 /* ---- measurement --------------------------------------------------------------------------------------------- */
 /* ms[MUXGL_T_COUNT]: hipEvent durations of the kernels of the most recent run/iterate call (0 where not run) */
 int muxgl_get_timing(const muxgl_handle* h, float* ms);
+/* ms_sum[MUXGL_T_COUNT]: the same durations summed over the run/iterate calls since the last reset, and the number of
+ * those calls (either pointer may be NULL); reset != 0 clears both afterwards.  For loops that time many calls without
+ * a fetch per call.  One-device handles. */
+int muxgl_get_timing_sum(muxgl_handle* h, double* ms_sum, int64_t* calls, int32_t reset);
 
 #ifdef __cplusplus
 }

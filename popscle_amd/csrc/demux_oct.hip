@@ -935,8 +935,7 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
                        h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }
-  toc(h, MUXGL_T_DEMUX_SWEEP);
-  tic(h, MUXGL_T_DEMUX_REDUCE);
+  toc_tic(h, MUXGL_T_DEMUX_SWEEP, MUXGL_T_DEMUX_REDUCE);
   if (h->want_full_ll) {
     hipLaunchKernelGGL(demux_oct_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);

@@ -464,4 +464,16 @@ int muxgl_get_timing(const muxgl_handle* h, float* ms) {
   return 0;
 }
 
+int muxgl_get_timing_sum(muxgl_handle* h, double* ms_sum, int64_t* calls, int32_t reset) {
+  if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_get_timing_sum");
+  if (ms_sum) memcpy(ms_sum, h->ms_sum, sizeof(double) * MUXGL_T_COUNT);
+  if (calls) *calls = h->ms_calls;
+  if (reset) {
+    memset(h->ms_sum, 0, sizeof(h->ms_sum));
+    h->ms_calls = 0;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -105,6 +105,7 @@ SYMBOLS = {
     "muxgl_memcpy_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64]),
     "muxgl_stream": (_VP, [_VP]),
     "muxgl_get_timing": (C.c_int, [_VP, _VP]),
+    "muxgl_get_timing_sum": (C.c_int, [_VP, _VP, _VP, C.c_int32]),
 }
 
 _lib = None
@@ -383,6 +384,13 @@ class Engine:
         return gls, cnt
 
     # ---- measurement
+    def timing_sum(self, reset=False):
+        """(kernel times summed over the run / iterate calls since the last reset, ms; number of those calls)"""
+        ms = np.zeros(T_COUNT, dtype=np.float64)
+        n = C.c_int64(0)
+        self._check(self.lib.muxgl_get_timing_sum(self.h, _ptr(ms), C.byref(n), 1 if reset else 0))
+        return ms, int(n.value)
+
     def timing(self, out=None):
         """kernel times of the last run / iterate call, ms (out: a float32[T_COUNT] array to fill instead of a new one)"""
         ms = np.zeros(T_COUNT, dtype=np.float32) if out is None else out
