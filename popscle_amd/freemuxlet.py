@@ -176,6 +176,15 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
     t_loop = time.perf_counter()
     with (stream_ctx() if stream_ctx else contextlib.nullcontext()):
         for it in range(max_iter):
+            if not multi:  # one handle, whole pileup: the three phases as ONE call (no host round trip between them)
+                _, stats = eng.fmx_iterate(doublet_prior, geno_error, want_cells=False)
+                history.append(stats)
+                if log:
+                    log(f"iter {it + 1}: {stats[0]} singlets, {eng.C_total - stats[0] - stats[1]} doublets, "
+                        f"{stats[1]} ambiguous, {stats[2]} changed")
+                if stats[2] == 0 and early_stop:  # :601-604
+                    break
+                continue
             eng.fmx_iter_gp(doublet_prior, geno_error)
             if multi:
                 mark()
