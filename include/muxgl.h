@@ -61,6 +61,9 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
                                           likelihoods are linear in the genotypes (one usable read) and would take the
                                           one-moment form of the oct (V, K <= 16) and wave (V, K > 32) kernels
                                           (lets tests compare the two) */
+#define MUXGL_FLAG_NO_PIVOT_SUMS 256 /* freemuxlet E-step beyond 32 clusters: the pair sums of the non-linear entries as the
+                                        three-term sums instead of around the lane's smallest term (lets tests compare the
+                                        two forms) */
 #define MUXGL_FLAG_MSTEP_LDS_STATES 128 /* freemuxlet M-step for K <= 64 with one lane per marker and the cluster states
                                            in LDS (fmx_mstep_snp_kernel) instead of one lane per (marker, cluster) chain
                                            over the marker's list as a stream (lets tests compare the two) */

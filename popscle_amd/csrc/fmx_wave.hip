@@ -92,7 +92,7 @@ __device__ __forceinline__ void fw_renorm(double (&acc)[NS], int32_t (&ex)[EXL ?
 }
 
 // the general sweep over entries [i0, i1) of the stream grec (STREAM), or over the entries i0 .. i1 - 1 themselves
-template <bool CROSS, bool STREAM, int NS, bool EXL>
+template <bool CROSS, bool STREAM, int NS, bool EXL, bool PIVOT = true>
 __device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_grec* __restrict__ grec,
                                             const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
                                             const double* __restrict__ cgp, int K3, int jo, int ko, bool live, bool live2, int j,
@@ -134,7 +134,7 @@ __device__ __forceinline__ void fw_walk_gen(int64_t i0, int64_t i1, const fmx_gr
   // (relative deviation from the three-term sum <= ~4e-16), and a hypothesis costs two FMAs and the product update
   // instead of three and one.  Which two of the partner's three numbers a lane needs depends on the lane: they are read
   // from the ring in LDS through two per-lane base addresses (no DPP rotations in this form), set once per entry.
-  constexpr bool PIV = !CROSS && FMX_PIVOT;
+  constexpr bool PIV = !CROSS && PIVOT && FMX_PIVOT;
   double up = 0, da = 0, db = 0;
   uint32_t ra_a = ring_a, ra_b = ring_a + 1024;
   auto factors = [&](auto sc, double q0, double q1, double q2, double q3, double q4, double q5, double q6, double q7, double q8) {
@@ -367,7 +367,7 @@ __device__ __forceinline__ void fw_walk_lin(int64_t l0, int64_t l1, const fmx_lr
   }
 }
 
-template <bool CROSS, bool LIN>
+template <bool CROSS, bool LIN, bool PIVOT = true>
 __global__ void __launch_bounds__(64, CROSS ? 2 : 3)
     fmx_estep_wave_kernel(const wave_item* __restrict__ items, int64_t n_items, int64_t c0, int64_t c1,
                           const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
@@ -409,10 +409,10 @@ __global__ void __launch_bounds__(64, CROSS ? 2 : 3)
     };
     const int64_t l0 = rank(it.e0), l1 = rank(it.e1);
     fw_walk_lin<NS, EXL>(l0, l1, lrec, cE, K, sjc, live, j, ring, exs, acc, ex, accS, exS, cnt);
-    fw_walk_gen<false, true, NS, EXL>(it.e0 - l0, it.e1 - l1, grec, entry_snp, egls, cgp, K * 3, sjc * 3, 0, live, false, j,
+    fw_walk_gen<false, true, NS, EXL, PIVOT>(it.e0 - l0, it.e1 - l1, grec, entry_snp, egls, cgp, K * 3, sjc * 3, 0, live, false, j,
                                       ring, exs, acc, ex, accS, exS, cnt);
   } else {
-    fw_walk_gen<CROSS, false, NS, EXL>(it.e0, it.e1, grec, entry_snp, egls, cgp, K * 3, sjc * 3, skc * 3, live, live2, j,
+    fw_walk_gen<CROSS, false, NS, EXL, PIVOT>(it.e0, it.e1, grec, entry_snp, egls, cgp, K * 3, sjc * 3, skc * 3, live, live2, j,
                                        ring, exs, acc, ex, accS, exS, cnt);
   }
 
@@ -561,10 +561,13 @@ int fmx_wave_estep_launch(muxgl_handle* h, int64_t c0, int64_t nc) {
 #define FW_ARGS(XB, YB) \
   items, n_items, c0, c0 + nc, h->d_entry_snp, h->d_egls, h->d_flin, h->d_flin_rank, h->d_lrec, h->d_grec, h->d_cgp, h->d_cE, h->K, \
       64 * (XB), 64 * (YB), h->d_fll
-    if (use_lin) hipLaunchKernelGGL((fmx_estep_wave_kernel<false, true>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
-    else hipLaunchKernelGGL((fmx_estep_wave_kernel<false, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
+    const bool piv = !(h->flags & MUXGL_FLAG_NO_PIVOT_SUMS);  // (the three-term sums: lets tests compare the two forms)
+    if (use_lin && piv) hipLaunchKernelGGL((fmx_estep_wave_kernel<false, true, true>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
+    else if (use_lin) hipLaunchKernelGGL((fmx_estep_wave_kernel<false, true, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
+    else if (piv) hipLaunchKernelGGL((fmx_estep_wave_kernel<false, false, true>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
+    else hipLaunchKernelGGL((fmx_estep_wave_kernel<false, false, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, X));
     for (int Y = 0; Y < X; ++Y)  // (off-diagonal blocks hold 64 accumulators per lane: no room for a second sweep body)
-      hipLaunchKernelGGL((fmx_estep_wave_kernel<true, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, Y));
+      hipLaunchKernelGGL((fmx_estep_wave_kernel<true, false, false>), dim3((unsigned)n_items), dim3(64), 0, h->stream, FW_ARGS(X, Y));
 #undef FW_ARGS
   }
   toc(h, MUXGL_T_FMX_ESTEP_SWEEP);

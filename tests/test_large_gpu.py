@@ -259,6 +259,36 @@ def test_linear_entry_forms_agree_with_the_general_ones():
     assert parity.compare_fmx(a, ocells)["max_abs_ll_diff"] < 1e-7
 
 
+def test_pivoted_pair_sums_agree_with_the_three_term_sums():
+    """freemuxlet E-step beyond 32 clusters: the pair sums of the non-linear entries taken around the lane's smallest
+    term (fmx_wave.hip, PIV) against the three-term sums (MUXGL_FLAG_NO_PIVOT_SUMS) and the oracle: same counters and
+    assignments, LL tensors within 1e-9 -- on shallow cells and on deep entries with reads of both alleles, where a pivot
+    fixed per entry would cancel."""
+    for K, C, S, me, lam in [(40, 60, 4000, 600, 0.3), (64, 40, 3000, 500, 30.0), (70, 24, 4000, 900, 4.0)]:
+        p = synth.make_pileup(C, S, 8, seed=1234 + K, mean_entries=me, min_entries=30, reads_lambda=lam, max_bq=40, cap_bq=40,
+                              with_gp=False)
+        e = ob.fmx_entry_pileup(p)
+        llk0, llk2, _, _ = ob.fmx_cell_scores(p, e)
+        clust = ob.fmx_greedy_init(p, e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
+        cplp = ob.fmx_build_cluster_pileup(p, e, K, clust)
+        cells = ob.fmx_init_cells(clust)
+        want = ob.fmx_iterate(p, e, K, cplp, cells, 0.5, 0.1, full_ll=True)
+        got = []
+        for flags in (0, muxgl.FLAG_NO_PIVOT_SUMS):
+            with muxgl.Engine(0, flags) as eng:
+                eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+                eng.fmx_prepare(p.af)
+                eng.fmx_set_clusters(K, clust)
+                gc, gs, gf = eng.fmx_iterate(0.5, 0.1, want_full_ll=True)
+                assert tuple(gs) == tuple(want[:3])
+                d = np.abs(gf - want[3])
+                assert np.max(d[np.isfinite(d)], initial=0.0) < 1e-9
+                got.append((gc, gf))
+        assert np.array_equal(got[0][0]["clust"], got[1][0]["clust"]) and np.array_equal(got[0][0]["type"], got[1][0]["type"])
+        d = np.abs(got[0][1] - got[1][1])
+        assert np.max(d[np.isfinite(d)], initial=0.0) < 1e-9
+
+
 def test_linear_entry_loops_of_the_oct_kernels_agree_with_the_general_ones():
     """The oct kernels (V, K <= 16) sweep a chunk's entries with one usable read in a loop of their own (moments of the
     triples, demux_oct.hip / fmx_oct.hip); MUXGL_FLAG_NO_LINEAR_ENTRIES keeps every entry in the nine-term loop.  Mixed
