@@ -16,6 +16,8 @@
 
 #include "../../include/muxgl.h"
 #include "plp_fast.hpp"
+#include <thread>
+
 #include "vcf.hpp"
 
 namespace pa {
@@ -167,56 +169,6 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
       s.ref = t.str_field_at(3)[0];
       s.alt = t.str_field_at(4)[0];
       s.af = t.double_field_at(5);
-      bool with_gp = false;
-      if (pvr) {
-        bool found = false, passed = false;  // sc_drop_seq.cpp:258-327
-        while (!(found || passed)) {
-          if (pvr->eof) {
-            passed = true;
-          } else if (pvr->rid > s.rid) {
-            passed = true;
-          } else if (pvr->rid == s.rid) {
-            if (pvr->pos > s.pos) {
-              passed = true;
-            } else if (pvr->pos == s.pos) {
-              const char vref = pvr->alleles[0].empty() ? '.' : pvr->alleles[0][0];
-              const char valt = pvr->alleles.size() > 1 && !pvr->alleles[1].empty() ? pvr->alleles[1][0] : '.';
-              if (vref != s.ref || valt != s.alt) passed = true;
-              else found = true;
-            }
-          }
-          if (passed) break;
-          if (found) {
-            if (!pvr->parse_posteriors(opt.field))
-              fatal("Cannot parse posterior probability at %s:%d", pvr->chrom_name(pvr->rid), pvr->pos);
-            std::vector<double> gps((size_t)nv * 3);
-            double avgGPs[3] = {1e-10, 1e-10, 1e-10};
-            for (int32_t i = 0; i < nv * 3; ++i) avgGPs[i % 3] += (gps[(size_t)i] = pvr->gps[(size_t)i]);
-            const double sumGP = avgGPs[0] + avgGPs[1] + avgGPs[2];
-            avgGPs[0] /= sumGP;
-            avgGPs[1] /= sumGP;
-            avgGPs[2] /= sumGP;
-            double err = opt.genoErrorOffset;
-            if (opt.genoErrorCoeffR2 > 0) {
-              float r2 = 0;
-              if (!pvr->info_float(opt.r2info, &r2))
-                fatal("Cannot extract %s (1 float value) from INFO field at %s:%d. Cannot use --geno-error-coeff",
-                      opt.r2info.c_str(), chr, s.pos);
-              err += (1 - opt.genoErrorOffset) * (1 - r2) * opt.genoErrorCoeffR2;
-            }
-            if (err > 0.999) err = 0.999;
-            if (err < 0) err = 0;
-            if (err > 0)
-              for (int32_t i = 0; i < nv * 3; ++i) gps[(size_t)i] = (1 - err) * gps[(size_t)i] + err * avgGPs[i % 3];
-            out.gp.insert(out.gp.end(), gps.begin(), gps.end());
-            with_gp = true;
-            break;
-          }
-          pvr->read();
-        }
-        if (!with_gp) out.gp.insert(out.gp.end(), (size_t)nv * 3, 0.0);
-        out.has_gp.push_back(with_gp ? 1 : 0);
-      }
       out.snps.push_back(s);
       if ((int)out.snps.size() + 1 != t.nlines)
         fatal("Expected SNP nID = %d but observed %zu", t.nlines - 1, out.snps.size() - 1);
@@ -224,8 +176,73 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
     notice("Finished loading %zu variants..", out.snps.size());
   }
   const int64_t S = out.S();
+  // The VCF merge-join (sc_drop_seq.cpp:258-327) walks the markers in file order next to the VCF cursor and touches
+  // nothing the .plp.gz stage reads or writes (a marker without genotypes stays in the pileup, gps == NULL): it runs on
+  // a thread of its own while the pileup is inflated and parsed -- at the north_star's size the VCF's 200 k x 64
+  // genotypes were 1.2 s of a 4.7 s run, all of it in front of the big file.
+  std::thread vcf_thread;
+  if (pvr) {
+    out.gp.reserve((size_t)S * nv * 3);
+    out.has_gp.reserve((size_t)S);
+    vcf_thread = std::thread([&out, pvr, &opt, nv, S]() {
+      for (int64_t si = 0; si < S; ++si) {
+        const SnpInfo& s = out.snps[(size_t)si];
+        const char* chr = out.rid2chr[(size_t)s.rid].c_str();
+        bool with_gp = false;
+        {
+          bool found = false, passed = false;  // sc_drop_seq.cpp:258-327
+          while (!(found || passed)) {
+            if (pvr->eof) {
+              passed = true;
+            } else if (pvr->rid > s.rid) {
+              passed = true;
+            } else if (pvr->rid == s.rid) {
+              if (pvr->pos > s.pos) {
+                passed = true;
+              } else if (pvr->pos == s.pos) {
+                const char vref = pvr->alleles[0].empty() ? '.' : pvr->alleles[0][0];
+                const char valt = pvr->alleles.size() > 1 && !pvr->alleles[1].empty() ? pvr->alleles[1][0] : '.';
+                if (vref != s.ref || valt != s.alt) passed = true;
+                else found = true;
+              }
+            }
+            if (passed) break;
+            if (found) {
+              if (!pvr->parse_posteriors(opt.field))
+                fatal("Cannot parse posterior probability at %s:%d", pvr->chrom_name(pvr->rid), pvr->pos);
+              std::vector<double> gps((size_t)nv * 3);
+              double avgGPs[3] = {1e-10, 1e-10, 1e-10};
+              for (int32_t i = 0; i < nv * 3; ++i) avgGPs[i % 3] += (gps[(size_t)i] = pvr->gps[(size_t)i]);
+              const double sumGP = avgGPs[0] + avgGPs[1] + avgGPs[2];
+              avgGPs[0] /= sumGP;
+              avgGPs[1] /= sumGP;
+              avgGPs[2] /= sumGP;
+              double err = opt.genoErrorOffset;
+              if (opt.genoErrorCoeffR2 > 0) {
+                float r2 = 0;
+                if (!pvr->info_float(opt.r2info, &r2))
+                  fatal("Cannot extract %s (1 float value) from INFO field at %s:%d. Cannot use --geno-error-coeff",
+                        opt.r2info.c_str(), chr, s.pos);
+                err += (1 - opt.genoErrorOffset) * (1 - r2) * opt.genoErrorCoeffR2;
+              }
+              if (err > 0.999) err = 0.999;
+              if (err < 0) err = 0;
+              if (err > 0)
+                for (int32_t i = 0; i < nv * 3; ++i) gps[(size_t)i] = (1 - err) * gps[(size_t)i] + err * avgGPs[i % 3];
+              out.gp.insert(out.gp.end(), gps.begin(), gps.end());
+              with_gp = true;
+              break;
+            }
+            pvr->read();
+          }
+          if (!with_gp) out.gp.insert(out.gp.end(), (size_t)nv * 3, 0.0);
+          out.has_gp.push_back(with_gp ? 1 : 0);
+        }
+      }
+    });
+  }
 
-  tm.lap("cel+var(+vcf)");
+  tm.lap("cel+var");
   // ---- .plp.gz: the big file.  One thread inflates, the others parse line-aligned slices of each inflated block
   // (plp_fast.hpp); rows come back in file order with the global kept-base counter that names each read's UMI.
   PlpReadVec rds;
@@ -298,12 +315,17 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
       out.cell_totl_reads[(size_t)c] = out.cell_uniq_reads[(size_t)c] = kept;
       if (kept == tmp_uniq[(size_t)c] && tmp_nsnp[(size_t)c] == (int32_t)nent) out.cell_totl_reads[(size_t)c] = tmp_totl[(size_t)c];
     }
+    if (vcf_thread.joinable()) vcf_thread.join();
     return;
   }
   plp_order_by_cell(rds, C, sorted, cell_rd0);
   tm.lap("plp order");
   plp_pack(rds, C, cell_rd0, out.cell_ptr, out.entry_snp, out.entry_rptr, out.reads);
   tm.lap("plp pack");
+  if (vcf_thread.joinable()) {
+    vcf_thread.join();
+    tm.lap("vcf merge-join (waited for)");
+  }
   // sanity check on the observed counts (:375-380)
   for (int64_t c = 0; c < C; ++c) {
     const int64_t nent = out.cell_ptr[(size_t)c + 1] - out.cell_ptr[(size_t)c];
