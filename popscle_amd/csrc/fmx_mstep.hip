@@ -170,6 +170,9 @@ __global__ void __launch_bounds__(64 * W)
 #ifndef MS_W
 #define MS_W 16  // waves per workgroup with the table in LDS
 #endif
+#ifndef MS_WG
+#define MS_WG 4  // ... without it (7.3 ms against 7.8 ms with one at configs[4])
+#endif
 
 template <int G, int NB>
 int mstep_go(muxgl_handle* h, int64_t ns) {
@@ -188,9 +191,10 @@ int mstep_go(muxgl_handle* h, int64_t ns) {
     hipLaunchKernelGGL(kern, dim3((unsigned)((ns + per - 1) / per)), dim3(64 * MS_W), dyn, h->stream, h->S, h->fs0, h->fs1,
                        h->K, C, h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls);
   } else {
-    auto kern = fmx_mstep_stream_kernel<G, NB, 1, false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((ns + NG - 1) / NG)), dim3(64), 0, h->stream, h->S, h->fs0, h->fs1, h->K, C,
-                       h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls);
+    auto kern = fmx_mstep_stream_kernel<G, NB, MS_WG, false>;  // MS_WG independent waves per workgroup
+    const int64_t per = (int64_t)NG * MS_WG;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((ns + per - 1) / per)), dim3(64 * MS_WG), 0, h->stream, h->S, h->fs0, h->fs1, h->K,
+                       C, h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls);
   }
   HIPCHK(h, hipGetLastError());
   return 0;
