@@ -349,3 +349,13 @@ print("ok")
     env = dict(os.environ, MUXGL_MSTEP_NO_TABLE="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("K,C,S,me", [(1, 40, 3, 3), (2, 50, 2, 2), (33, 30, 700, 120), (16, 20, 1, 1)])
+def test_em_edge_shapes(K, C, S, me):
+    """one cluster, fewer markers than a wave holds, a ring with 31 idle lanes, a single marker; every second run starts with
+    all cells unassigned (every chain of the M-step empty) -- default dispatch against the oracle"""
+    p = synth.make_pileup(C, S, min(K, 4), seed=4000 + K + S, mean_entries=me, min_entries=1, with_gp=False)
+    with muxgl.Engine(0) as en:
+        run_em(en, p, K, 2)
+        run_em(en, p, K, 2, clust=np.full(p.C, -1, dtype=np.int32))
