@@ -316,6 +316,18 @@ void oracle_plp_merge(oracle_plp* d, const oracle_plp* o) {
   for (int i = 0; i < 9; ++i) d->gls[i] /= tmp;
 }
 
+/* nchains chains of merges, each from a default-constructed pileup (std::map::operator[] at
+ * cmd_cram_freemux2.cpp:277-288), elements ptr[i] .. ptr[i+1]-1 in that order; used to pin oracle_plp_merge to the
+ * reference's own header-inline merge() (oracle/merge_ref.cpp) */
+void oracle_plp_merge_chains(int64_t nchains, const int64_t* ptr, const oracle_plp* elems, oracle_plp* out) {
+  for (int64_t i = 0; i < nchains; ++i) {
+    oracle_plp d;
+    plp_default(&d);
+    for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) oracle_plp_merge(&d, &elems[e]);
+    out[i] = d;
+  }
+}
+
 /* sc_drop_seq.cpp:452-509 with alpha = 0.5 (the only value freemux2 passes, cmd_cram_freemux2.cpp:135) */
 void oracle_fmx_entry_pileup(int64_t nnz, const int64_t* entry_rptr, const uint8_t* reads, oracle_plp* out) {
   lut_init();

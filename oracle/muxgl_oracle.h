@@ -92,6 +92,9 @@ void oracle_fmx_entry_pileup(int64_t nnz, const int64_t* entry_rptr, const uint8
 /* snp_droplet_pileup::merge, sc_drop_seq.h:77-101 */
 void oracle_plp_merge(oracle_plp* dst, const oracle_plp* src);
 
+/* chains of merges from default-constructed pileups; elements ptr[i] .. ptr[i+1]-1 of chain i in order */
+void oracle_plp_merge_chains(int64_t nchains, const int64_t* ptr, const oracle_plp* elems, oracle_plp* out);
+
 /* freemuxlet b2: per-cell llk0/llk2, nSNPs, nReads, cmd_cram_freemux2.cpp:117-160 */
 void oracle_fmx_cell_scores(int64_t C, const int64_t* cell_ptr, const int32_t* entry_snp, const oracle_plp* eplp,
                             const double* af, double* llk0, double* llk2, int32_t* nsnps, int32_t* nreads);

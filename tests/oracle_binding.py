@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libmuxgl_oracle.so")
 REF_PHRED_SO = os.path.join(ORACLE_DIR, "_ref", "libphred_ref.so")
+REF_MERGE_SO = os.path.join(ORACLE_DIR, "_ref", "libmerge_ref.so")
 
 DEMUX_CELL = np.dtype(
     [(n, np.int32) for n in ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA",
@@ -108,6 +109,54 @@ def fmx_entry_pileup(plp):
 def plp_merge(dst, src):
     """dst, src: PLP scalars (arrays of shape (1,))"""
     lib().oracle_plp_merge(_p(dst), _p(src))
+
+
+def plp_merge_chains(ptr, elems):
+    """final states of chains of merges from default-constructed pileups (elements ptr[i]..ptr[i+1]-1 in order)"""
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    elems = np.ascontiguousarray(elems, dtype=PLP)
+    out = np.zeros(ptr.size - 1, dtype=PLP)
+    lib().oracle_plp_merge_chains(C.c_int64(ptr.size - 1), _p(ptr), _p(elems), _p(out))
+    return out
+
+
+_ref_merge = None
+
+
+def ref_merge_lib():
+    """oracle/_ref/libmerge_ref.so: the reference's own header-inline snp_droplet_pileup::merge (sc_drop_seq.h:77-101)
+    and sc_drop_comp_t (:187-198) behind extern "C" wrappers (oracle/merge_ref.cpp)"""
+    global _ref_merge
+    if _ref_merge is None:
+        _ref_merge = C.CDLL(REF_MERGE_SO)
+        _ref_merge.merge_ref_sizeof_plp.restype = C.c_int
+        _ref_merge.merge_ref_comp.restype = C.c_int
+        assert _ref_merge.merge_ref_sizeof_plp() == PLP.itemsize
+    return _ref_merge
+
+
+def ref_plp_merge(dst, src):
+    ref_merge_lib().merge_ref_merge(_p(dst), _p(src))
+
+
+def ref_plp_merge_chains(ptr, elems):
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    elems = np.ascontiguousarray(elems, dtype=PLP)
+    out = np.zeros(ptr.size - 1, dtype=PLP)
+    ref_merge_lib().merge_ref_chains(C.c_int64(ptr.size - 1), _p(ptr), _p(elems), _p(out))
+    return out
+
+
+def ref_fmx_sort(scores):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    order = np.zeros(scores.size, dtype=np.int32)
+    ref_merge_lib().merge_ref_sort(C.c_int64(scores.size), _p(scores), _p(order))
+    return order
+
+
+def ref_comp(scores, lhs, rhs):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    return bool(ref_merge_lib().merge_ref_comp(C.c_int64(scores.size), _p(scores), C.c_int32(lhs), C.c_int32(rhs)))
 
 
 def fmx_cell_scores(plp, eplp):

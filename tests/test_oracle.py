@@ -164,6 +164,87 @@ def test_plp_merge_vs_pyref_and_order_dependence():
     assert rev["nreads"][0] == dst["nreads"][0] and not np.array_equal(rev["gls"], dst["gls"])
 
 
+needs_ref_merge = pytest.mark.skipif(not os.path.exists(ob.REF_MERGE_SO),
+                                     reason="oracle/_ref/libmerge_ref.so not built (needs /root/reference at build time)")
+
+
+def _random_chain_elements(rng, n, deep_frac=0.3):
+    """entry pileups as calculate_snp_droplet_pileup leaves them (normalised, clamped at 1e-6), from random reads:
+    shallow ones (1 + Poisson(0.3) reads, BQ 13..20 after the cap) and deep / high-quality ones whose merges make
+    the clamp fire for most genotype pairs"""
+    nreads = 1 + rng.poisson(0.3, n)
+    deep = rng.random(n) < deep_frac
+    nreads[deep] = rng.integers(2, 9, int(deep.sum()))
+    rptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nreads, out=rptr[1:])
+    R = int(rptr[-1])
+    allele = (rng.random(R) < 0.5).astype(np.uint8)
+    # chains that agree (one allele throughout) push the opposite homozygote below the clamp quickly
+    bq = rng.integers(13, 21, R).astype(np.uint8)
+    hq = np.repeat(deep, nreads)
+    bq[hq] = rng.integers(20, 41, int(hq.sum())).astype(np.uint8)
+    reads = ((allele << 7) | bq).astype(np.uint8)
+    reads[rng.random(R) < 0.005] = 0xFF
+    out = np.zeros(n, dtype=ob.PLP)
+    ob.lib().oracle_fmx_entry_pileup(ob.C.c_int64(n), ob._p(rptr), ob._p(reads), ob._p(out))
+    return out
+
+
+@needs_ref_merge
+def test_plp_merge_matches_reference_header_bit_for_bit():
+    """oracle_plp_merge against the reference's own snp_droplet_pileup::merge (sc_drop_seq.h:77-101, compiled from the
+    unmodified header): 120 000 random chains, bit for bit, with the clamp firing in most of them"""
+    rng = np.random.default_rng(20240904)
+    nch = 120_000
+    length = np.minimum(1 + rng.geometric(0.25, nch), 40)
+    length[:2000] = rng.integers(30, 200, 2000)       # long chains: clamp + renormalise many times over
+    ptr = np.zeros(nch + 1, dtype=np.int64)
+    np.cumsum(length, out=ptr[1:])
+    elems = _random_chain_elements(rng, int(ptr[-1]))
+    # a third of the chains concordant: every element carries the same allele pattern as the chain's first
+    conc = np.flatnonzero(rng.random(nch) < 0.33)
+    for c in conc[:20000]:
+        elems[ptr[c]:ptr[c + 1]] = elems[ptr[c]]
+    got = ob.plp_merge_chains(ptr, elems)
+    want = ob.ref_plp_merge_chains(ptr, elems)
+    assert np.array_equal(got["gls"].view(np.uint64), want["gls"].view(np.uint64))
+    for f in ("nreads", "nref", "nalt"):
+        assert np.array_equal(got[f], want[f])
+    # the clamp did fire: final states sitting exactly on the renormalised floor
+    floor_hits = (want["gls"] < 1.0000001e-6).any(axis=1).mean()
+    assert floor_hits > 0.3, floor_hits
+    # and the single-merge entry point, from arbitrary (not default) states
+    d0 = want[:5000].copy()
+    d1 = d0.copy()
+    for i in range(5000):
+        ob.plp_merge(d0[i:i + 1], elems[i:i + 1])
+        ob.ref_plp_merge(d1[i:i + 1], elems[i:i + 1])
+    assert np.array_equal(d0["gls"].view(np.uint64), d1["gls"].view(np.uint64))
+
+
+@needs_ref_merge
+def test_fmx_sort_matches_std_sort_with_reference_comparator():
+    """oracle_fmx_sort against std::sort under the reference's sc_drop_comp_t (sc_drop_seq.h:187-198,
+    cmd_cram_freemux2.cpp:184-189) on tie-heavy scores; the comparator is a strict total order on distinct ids, so the
+    result does not depend on the sort algorithm"""
+    rng = np.random.default_rng(5)
+    for n, levels in [(1, 1), (2, 1), (17, 3), (1000, 7), (50_000, 40), (200_000, 1000), (30_000, 10**9)]:
+        scores = rng.integers(0, levels, n).astype(np.float64) * 0.25 - 3.0
+        if n > 100:
+            scores[rng.integers(0, n, 20)] = 0.0
+            scores[rng.integers(0, n, 5)] = -0.0
+        assert np.array_equal(ob.fmx_sort(scores), ob.ref_fmx_sort(scores))
+    s = np.array([1.0, 3.0, 3.0, -2.0, 1.0, 0.0, -0.0])
+    assert ob.ref_fmx_sort(s).tolist() == ob.fmx_sort(s).tolist() == [2, 1, 4, 0, 6, 5, 3]
+    assert ob.ref_comp(s, 2, 1) and not ob.ref_comp(s, 1, 2) and ob.ref_comp(s, 1, 0) and not ob.ref_comp(s, 3, 0)
+    assert ob.ref_comp(s, 6, 5) and not ob.ref_comp(s, 5, 6)      # 0.0 - (-0.0) == 0: tie, id descending
+    # two infinite scores of one sign: cmp = inf - inf = NaN is "!= 0" and "not > 0" either way round, i.e. the
+    # comparator stops being a strict weak order and the result would depend on the sort algorithm.  Scores are
+    # differences of sums of logs of likelihoods >= 1e-6 (sc_drop_seq.cpp:498-506), so this cannot occur on the path.
+    t = np.array([-np.inf, -np.inf])
+    assert not ob.ref_comp(t, 0, 1) and not ob.ref_comp(t, 1, 0)
+
+
 def test_fmx_sort_comparator():
     scores = np.array([1.0, 3.0, 3.0, -2.0, 1.0])
     assert ob.fmx_sort(scores).tolist() == [2, 1, 4, 0, 3]  # score desc, ties id desc
