@@ -286,9 +286,11 @@ void* muxgl_stream(const muxgl_handle* h);
 /* ---- measurement --------------------------------------------------------------------------------------------- */
 /* ms[MUXGL_T_COUNT]: hipEvent durations of the kernels of the most recent run/iterate call (0 where not run) */
 int muxgl_get_timing(const muxgl_handle* h, float* ms);
-/* ms_sum[MUXGL_T_COUNT]: the same durations summed over the run/iterate calls since the last reset, and the number of
- * those calls (either pointer may be NULL); reset != 0 clears both afterwards.  For loops that time many calls without
- * a fetch per call.  One-device handles. */
+/* ms_sum[MUXGL_T_COUNT]: the same durations summed since the last reset -- every event bracket is added exactly once,
+ * whichever entry point collects it -- and `calls`, the number of collecting calls: one per muxgl_demux_run /
+ * muxgl_fmx_iterate, and with the phased API one per phase that reads its brackets back (iter_gp, iter_estep,
+ * iter_mstep; under MUXGL_FLAG_ASYNC_PHASES only an iter_fetch that drains the stream).  Either pointer may be NULL;
+ * reset != 0 clears both afterwards.  For loops that time many calls without a fetch per call.  One-device handles. */
 int muxgl_get_timing_sum(muxgl_handle* h, double* ms_sum, int64_t* calls, int32_t reset);
 
 #ifdef __cplusplus

@@ -285,12 +285,19 @@ static inline void clear_timing(muxgl_handle* h) {
     h->ms[i] = 0.f;
   }
 }
+// Reads the brackets recorded since the last call: a slot is summed ONCE per bracket (its `used` mark is cleared here,
+// so the phased API, which collects after every phase, does not add the earlier phases' times again) and only when
+// the elapsed-time query succeeds; ms[] keeps the last value of every slot until clear_timing.  ms_calls counts the
+// collecting calls (include/muxgl.h says which entry points those are).
 static inline void collect_timing(muxgl_handle* h) {
   for (int i = 0; i < MUXGL_T_COUNT; ++i) {
     if (h->ev_used[i]) {
+      h->ev_used[i] = false;
       float t = 0.f;
-      if (hipEventElapsedTime(&t, h->ev[h->ev_start[i]], h->ev[2 * i + 1]) == hipSuccess) h->ms[i] = t;
-      h->ms_sum[i] += (double)h->ms[i];
+      if (hipEventElapsedTime(&t, h->ev[h->ev_start[i]], h->ev[2 * i + 1]) == hipSuccess) {
+        h->ms[i] = t;
+        h->ms_sum[i] += (double)t;
+      }
     }
   }
   ++h->ms_calls;

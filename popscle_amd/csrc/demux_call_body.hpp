@@ -26,8 +26,11 @@ inline call_alpha make_call_alpha(const muxgl_demux_params* p, int nv) {
 // exp(x) for x <= 0, as the evidence sums use it (terms relative to their maximum): n = rint(x log2 e),
 // r = x - n ln 2 in two pieces, a degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18) and ldexp -- about 20
 // instructions against the library exp's 250 (it has no special cases to serve here); within 2 ulp.
+// Domain: x <= 0 by construction (callers subtract the maximum); a NaN (-inf minus -inf when every term is -inf)
+// is passed through as the library exp would, anything below -708 is 0, and a positive x is treated as 0.
 __device__ __forceinline__ double exp_nonpos(double x) {
-  if (x < -708.0) return 0.0;
+  if (!(x >= -708.0)) return x != x ? x : 0.0;
+  x = fmin(x, 0.0);
   const double n = rint(x * 1.4426950408889634074);
   double r = fma(-n, 6.93147180369123816490e-01, x);
   r = fma(-n, 1.90821492927058770002e-10, r);

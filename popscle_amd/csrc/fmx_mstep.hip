@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(64 * W)
   // and is never read)
   __shared__ double rows_all[W][NG][6][BS];
   __shared__ mask_t masks_all[W][NG][G + 1];
-  extern __shared__ uint8_t tab[];
+  extern __shared__ __align__(16) uint8_t tab[];  // filled and read through uint32_t*
+  static_assert((sizeof(rows_all) + sizeof(masks_all)) % 16 == 0, "the byte table behind the static LDS must stay 16-byte aligned");
   if (TAB) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(clust8);  // (the byte array is padded to a multiple of 16)
     uint32_t* dst = reinterpret_cast<uint32_t*>(tab);

@@ -16,6 +16,7 @@
 
 #include "../../include/muxgl.h"
 #include "plp_fast.hpp"
+#include <exception>
 #include <thread>
 
 #include "vcf.hpp"
@@ -180,11 +181,26 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
   // nothing the .plp.gz stage reads or writes (a marker without genotypes stays in the pileup, gps == NULL): it runs on
   // a thread of its own while the pileup is inflated and parsed -- at the north_star's size the VCF's 200 k x 64
   // genotypes were 1.2 s of a 4.7 s run, all of it in front of the big file.
-  std::thread vcf_thread;
+  // fatal() throws: an error inside the thread is parked and rethrown on the caller's thread after the join, and the
+  // guard joins on every way out of this function (unwinding past a joinable std::thread is std::terminate).
+  struct VcfJoin {
+    std::thread t;
+    std::exception_ptr err;
+    void join() {
+      if (t.joinable()) t.join();
+    }
+    void finish() {
+      join();
+      if (err) std::rethrow_exception(err);
+    }
+    ~VcfJoin() { join(); }
+  } vj;
+  if (opt.world > 1 && (opt.rank < 0 || opt.rank >= opt.world)) fatal("--rank must be in [0, --world)");
   if (pvr) {
     out.gp.reserve((size_t)S * nv * 3);
     out.has_gp.reserve((size_t)S);
-    vcf_thread = std::thread([&out, pvr, &opt, nv, S]() {
+    vj.t = std::thread([&out, &vj, pvr, &opt, nv, S]() {
+     try {
       for (int64_t si = 0; si < S; ++si) {
         const SnpInfo& s = out.snps[(size_t)si];
         const char* chr = out.rid2chr[(size_t)s.rid].c_str();
@@ -239,10 +255,16 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
           out.has_gp.push_back(with_gp ? 1 : 0);
         }
       }
+     } catch (...) {
+      vj.err = std::current_exception();
+     }
     });
   }
 
   tm.lap("cel+var");
+  // the reference meets a VCF error while it reads the .var.gz, i.e. before it opens the .plp.gz: when both stages
+  // fail, the VCF's error is the one reported
+  auto plp_stage = [&]() {
   // ---- .plp.gz: the big file.  One thread inflates, the others parse line-aligned slices of each inflated block
   // (plp_fast.hpp); rows come back in file order with the global kept-base counter that names each read's UMI.
   PlpReadVec rds;
@@ -256,7 +278,6 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
     po.S = (int32_t)S;
     po.index_bcs = &index_bcs;
     if (opt.world > 1) {
-      if (opt.rank < 0 || opt.rank >= opt.world) fatal("--rank must be in [0, --world)");
       const int64_t pc = C > 0 ? (C + opt.world - 1) / opt.world : 0, ps = S > 0 ? (S + opt.world - 1) / opt.world : 0;
       out.slabbed = true;
       out.slab_c0 = std::min<int64_t>(opt.rank * pc, C);
@@ -315,15 +336,15 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
       out.cell_totl_reads[(size_t)c] = out.cell_uniq_reads[(size_t)c] = kept;
       if (kept == tmp_uniq[(size_t)c] && tmp_nsnp[(size_t)c] == (int32_t)nent) out.cell_totl_reads[(size_t)c] = tmp_totl[(size_t)c];
     }
-    if (vcf_thread.joinable()) vcf_thread.join();
+    vj.finish();
     return;
   }
   plp_order_by_cell(rds, C, sorted, cell_rd0);
   tm.lap("plp order");
   plp_pack(rds, C, cell_rd0, out.cell_ptr, out.entry_snp, out.entry_rptr, out.reads);
   tm.lap("plp pack");
-  if (vcf_thread.joinable()) {
-    vcf_thread.join();
+  if (vj.t.joinable()) {
+    vj.finish();
     tm.lap("vcf merge-join (waited for)");
   }
   // sanity check on the observed counts (:375-380)
@@ -331,6 +352,14 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
     const int64_t nent = out.cell_ptr[(size_t)c + 1] - out.cell_ptr[(size_t)c];
     if (out.cell_uniq_reads[(size_t)c] == tmp_uniq[(size_t)c] && tmp_nsnp[(size_t)c] == (int32_t)nent)
       out.cell_totl_reads[(size_t)c] = tmp_totl[(size_t)c];
+  }
+  };
+  try {
+    plp_stage();
+  } catch (...) {
+    vj.join();
+    if (vj.err) std::rethrow_exception(vj.err);
+    throw;
   }
 }
 

@@ -455,3 +455,28 @@ def test_loader_cuts_a_ranks_slabs_at_file_level(exe, tmp_path, world):
         assert np.array_equal(d["cell_uniq_reads"][c0:c1], whole["cell_uniq_reads"][c0:c1])
         assert np.array_equal(d["cell_totl_reads"][c0:c1], whole["cell_totl_reads"][c0:c1])
         assert np.array_equal(d["af"], whole["af"])
+
+
+def test_errors_next_to_the_vcf_thread_exit_cleanly(exe, tmp_path):
+    """The VCF merge-join runs on a thread of its own (plp.hpp); fatal() throws.  A user error inside that thread, or on
+    the main thread while that thread is alive, must end in `FATAL ERROR` + exit status 1 through main()'s handler,
+    not in std::terminate (SIGABRT)."""
+    p, prefix = make_files(tmp_path, C=10, S=80, V=4, seed=11, deep=False)
+    vcf = str(tmp_path / "g.vcf.gz")
+    plpio.write_vcf(vcf, p, p.truth["G"].astype(np.int64), field="GT")
+
+    def run(*extra):
+        return subprocess.run([exe, "dump-plp", "--plp", prefix, "--out", str(tmp_path / "x.bin"), "--vcf", vcf, *extra],
+                              capture_output=True, text=True)
+
+    r = run("--field", "GP")  # the file carries GT only: raised inside the thread
+    assert r.returncode == 1 and "Cannot parse posterior probability" in r.stderr, (r.returncode, r.stderr)
+    r = run("--field", "GT", "--geno-error-coeff", "0.5", "--r2-info", "NOPE")  # missing INFO field: inside the thread
+    assert r.returncode == 1 and "Cannot extract NOPE" in r.stderr, (r.returncode, r.stderr)
+    r = run("--field", "GT", "--rank", "5", "--world", "2")  # checked before the thread starts
+    assert r.returncode == 1 and "--rank must be in" in r.stderr, (r.returncode, r.stderr)
+    rewrite_plp(prefix, lambda rows: rows[:11] + ["3\t5\t01"] + rows[11:])  # main-thread error, thread alive
+    r = run("--field", "GT")
+    assert r.returncode == 1 and "has 3 fields" in r.stderr, (r.returncode, r.stderr)
+    r = run("--field", "GP")  # both stages fail: the VCF's error is the one the reference would meet first
+    assert r.returncode == 1 and "Cannot parse posterior probability" in r.stderr, (r.returncode, r.stderr)

@@ -7,6 +7,8 @@ cd "$(dirname "$0")/../popscle_amd/csrc"
 mkdir -p ../lib/var
 base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -Wall -Wno-unused-function -I../../include $flags -c $src -o ../lib/var/${base}_$tag.o
-objs=$(ls ../lib/*.o | grep -v "/${base}.o")
+# link exactly the Makefile's SRCS (stale objects of removed units may sit in ../lib), all of them up to date
+make -s
+objs=$(make -s -pn | sed -n 's/^SRCS = //p' | head -1 | tr ' ' '\n' | sed 's/\.hip$//' | grep -vx "${base}" | sed 's#^#../lib/#; s#$#.o#')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/var/libmuxgl_$tag.so $objs ../lib/var/${base}_$tag.o
 echo built ../lib/var/libmuxgl_$tag.so
