@@ -84,18 +84,40 @@ __global__ void __launch_bounds__(256)
   out[r] = uint2{snp, row * (uint32_t)(RL_LUTW * 8)};
 }
 
-template <int NA, bool SYM>
+// GEN: the same workgroup then walks the unit's OTHER entries (the clear bits' record stream, pG rows from the table of
+// demux_entry_pg_kernel) with the same accumulators -- three FMAs and the product update per hypothesis
+// (cmd_cram_demuxlet.cpp:738-746) -- so that a unit's hypotheses are written ONCE, as one log per hypothesis of all its
+// entries.  (Round 3 walked them in launches of their own, demux_wave.hip's EM_GENERAL, which read the slab written
+// here and wrote it again, per alpha set.)  The general walk is staged like the linear one, in batches of two entries:
+// of the four waves, two prepare each entry of the NEXT batch -- wave 2 e the ring of triples, the singlet factor and
+// the lane's u[m] = sum_l g_j[l] pG[n][l][m] for alpha[0] and the launch's first two alphas, wave 2 e + 1 the u of the
+// other two and of the symmetric one -- and leave them in LDS; the sweeping waves read their u (15 numbers per lane,
+// formed once per workgroup instead of once per wave) and the partners' triples from there and carry no scalar
+// operands at all.
+// (tells the compiler that the three values, requested by opaque ds_read statements, are defined from here on)
+__device__ __forceinline__ void ring_landed(double (&v)[3]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
+
+template <int NA, bool SYM, bool GEN>
 __global__ void __launch_bounds__(256, 2)
     demux_ring_lin_kernel(const wave_item* __restrict__ items, int64_t n_items, const uint32_t* __restrict__ lin,
                           const int64_t* __restrict__ lin_rank, const uint2* __restrict__ rrec,
                           const double* __restrict__ lutg, const double* __restrict__ gm, int V, int nAlpha, ring_sel sel,
-                          double* __restrict__ ll) {
+                          const fmx_grec* __restrict__ gen_rec, const double* __restrict__ gp,
+                          const double* __restrict__ pgt, double* __restrict__ ll) {
   constexpr int NS = NA > 0 ? 16 : 0, NSY = SYM ? 8 : 0, NACC = NA * NS + NSY;
-  constexpr int NXV = NACC / 2, NXL = NACC - NXV;         // exponents in registers / in LDS
+  constexpr int NXL = NACC / 2, NXV = NACC - NXL;  // exponents in LDS / in registers (GEN: 36 KB + the 44 KB stage = 80 KB per workgroup)
   constexpr int GN = NS / 4, GS = NSY / 4, GT = GN + GS;  // groups of four ring reads per entry
   constexpr int NA1 = NA > 0 ? NA : 1;
   static_assert(GT % 2 == 0 && GT > 0, "the read buffers alternate per group");
-  __shared__ double stage[2][RL_B][RL_ROW];
+  constexpr int RG_B = 2;        // general entries per staged batch
+#ifndef RING_GEN_G
+#define RING_GEN_G 1
+#endif
+  constexpr int RG_G = RING_GEN_G;  // rotation steps per group of ring reads in the general walk
+  constexpr int RG_ROW = 1408;   // doubles per staged general entry: ring[3][128], singlet factor[64], u[5][3][64]
+  constexpr int STAGE_N = (GEN && 2 * RG_B * RG_ROW > 2 * RL_B * RL_ROW) ? 2 * RG_B * RG_ROW : 2 * RL_B * RL_ROW;
+  __shared__ double stage_all[STAGE_N];
+  double (*stage)[RL_B][RL_ROW] = reinterpret_cast<double (*)[RL_B][RL_ROW]>(stage_all);
   __shared__ int32_t exs_all[4][NXL][64];
   if ((int64_t)blockIdx.x >= n_items) return;
   const wave_item it = items[blockIdx.x];
@@ -280,6 +302,187 @@ __global__ void __launch_bounds__(256, 2)
   pfx ^= pfv;
   asm volatile("" ::"v"(pfx));
 
+  // ---- the unit's other entries (GEN) ----
+  if constexpr (GEN) {
+    int64_t gi0, gi1;
+    wave_stream_range<EM_GENERAL>(lin, lin_rank, it.e0, it.e1, gi0, gi1);
+    const int64_t ng = gi1 - gi0;
+    if (ng > 0) {  // (workgroup-uniform)
+      const fmx_grec* gr = gen_rec + gi0;
+      const int nbg = (int)((ng + RG_B - 1) / RG_B);
+      const int V3 = V * 3, PG = nAlpha * 9;
+      const int jo = (live ? sel.jbase + j : V - 1) * 3;
+      constexpr uint32_t ROWGB = RG_ROW * 8, BUFGB = RG_B * ROWGB;
+      // loader role of this wave: entry le of a batch; half 0: ring, singlet factor, u of alpha[0]'s slot and of the
+      // launch's alphas 0 and 1 (table rows n0 .. n2); half 1: u of alphas 2, 3 and of the symmetric one
+      const int le = w >> 1, lh = w & 1;
+      const int n0 = lh == 0 ? 0 : sel.n[2], n1 = lh == 0 ? sel.n[0] : sel.n[3], n2 = lh == 0 ? sel.n[1] : sel.nsym;
+      double gl[3], hs[3], q[3][9];
+      bool gin = false;
+      auto gload = [&](int b) {
+        const int64_t i = (int64_t)b * RG_B + le;
+        gin = i < ng;
+        const fmx_grec r = gr[gin ? i : ng - 1];  // (a valid record behind the end; its values are not used)
+        const double* row = gp + (size_t)r.snp * V3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gl[k] = row[jo + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hs[k] = row[k];  // sample 0's triple multiplies every singlet (:806,828)
+        const double* t = pgt + (size_t)r.e * PG;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) q[0][k] = t[n0 * 9 + k], q[1][k] = t[n1 * 9 + k], q[2][k] = t[n2 * 9 + k];
+      };
+      auto gstore = [&](int buf) {
+        double* base = stage_all + (size_t)(buf * RG_B + le) * RG_ROW;
+        const bool ok = live && gin;
+        const double g0 = ok ? gl[0] : 1.0, g1 = ok ? gl[1] : 0.0, g2 = ok ? gl[2] : 0.0;
+        double uu[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) uu[a][m] = fma(g2, q[a][6 + m], fma(g1, q[a][3 + m], g0 * q[a][m]));
+        if (!gin) {  // an entry behind the end of the stream: every factor exactly 1
+#pragma unroll
+          for (int a = 0; a < 3; ++a) uu[a][0] = 1.0, uu[a][1] = 0.0, uu[a][2] = 0.0;
+        }
+        double* u = base + 448;
+        if (lh == 0) {
+          base[j] = g0, base[j + 64] = g0;
+          base[128 + j] = g1, base[192 + j] = g1;
+          base[256 + j] = g2, base[320 + j] = g2;
+          base[384 + j] = gin ? fma(hs[2], uu[0][2], fma(hs[1], uu[0][1], hs[0] * uu[0][0])) : 1.0;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) u[(0 * 3 + m) * 64 + j] = uu[1][m], u[(1 * 3 + m) * 64 + j] = uu[2][m];
+        } else {
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            u[(2 * 3 + m) * 64 + j] = uu[0][m], u[(3 * 3 + m) * 64 + j] = uu[1][m], u[(4 * 3 + m) * 64 + j] = uu[2][m];
+        }
+      };
+      {  // the linear walk may have left up to 23 factors un-renormalised behind
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+          if (t < NXV) {
+            prodacc_renorm(acc[t], ex[t]);
+          } else {
+            int ee;
+            acc[t] = frexp(acc[t], &ee);
+            exs[t - NXV][j] += ee;
+          }
+        }
+        prodacc_renorm(accX, exX);
+      }
+      __syncthreads();  // (the linear walk's last batch has been read by every wave)
+      gload(0);
+      gstore(0);
+      __syncthreads();
+      const uint32_t gown = base0 + (uint32_t)j * 8u;
+      const uint32_t grb = base0 + (uint32_t)(j + 64 - 16 * w - 16) * 8u, grs = base0 + (uint32_t)(j + 64 - 8 * w - 8) * 8u;
+      int gcnt = 0;
+      for (int b = 0; b < nbg; ++b) {
+        const uint32_t bo = (uint32_t)(b & 1) * BUFGB;
+        gload(b + 1);
+        wave_for<0, RG_B>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          // the lane's factors (and the singlet factor) of entry k
+          double ug[NA1][3], us[3], svk;
+          wave_for<0, NA>([&](auto ac) {
+            constexpr int a = decltype(ac)::value;
+            ug[a][0] = wave_ring_rd<k * ROWGB + (448 + (a * 3 + 0) * 64) * 8>(gown + bo);
+            ug[a][1] = wave_ring_rd<k * ROWGB + (448 + (a * 3 + 1) * 64) * 8>(gown + bo);
+            ug[a][2] = wave_ring_rd<k * ROWGB + (448 + (a * 3 + 2) * 64) * 8>(gown + bo);
+          });
+          if (SYM) {
+            us[0] = wave_ring_rd<k * ROWGB + (448 + 12 * 64) * 8>(gown + bo);
+            us[1] = wave_ring_rd<k * ROWGB + (448 + 13 * 64) * 8>(gown + bo);
+            us[2] = wave_ring_rd<k * ROWGB + (448 + 14 * 64) * 8>(gown + bo);
+          }
+          svk = wave_ring_rd<k * ROWGB + 384 * 8>(gown + bo);
+          // partner triples GS_ steps at a time, a group ahead of their use
+          constexpr int GS_ = RG_G, NGN = NS / GS_, NGS = NSY / GS_, NGT = NGN + NGS;
+          double rd[2][GS_][3];
+          auto issue = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            wave_for<0, GS_>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              if constexpr (g < NGN) {
+                constexpr int off = k * ROWGB + (15 - (GS_ * g + i)) * 8;
+                rd[g & 1][i][0] = wave_ring_rd<off>(grb + bo);
+                rd[g & 1][i][1] = wave_ring_rd<off + 1024>(grb + bo);
+                rd[g & 1][i][2] = wave_ring_rd<off + 2048>(grb + bo);
+              } else {
+                constexpr int off = k * ROWGB + (7 - (GS_ * (g - NGN) + i)) * 8;
+                rd[g & 1][i][0] = wave_ring_rd<off>(grs + bo);
+                rd[g & 1][i][1] = wave_ring_rd<off + 1024>(grs + bo);
+                rd[g & 1][i][2] = wave_ring_rd<off + 2048>(grs + bo);
+              }
+            });
+          };
+          issue(std::integral_constant<int, 0>{});
+          wave_for<0, NGT>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr bool lastg = g + 1 == NGT;
+            if constexpr (!lastg) issue(std::integral_constant<int, g + 1>{});
+            // (the u reads were issued in front of group 0's ring reads: waiting for these waits for them)
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(lastg ? 0 : 3 * GS_) : "memory");
+            wave_for<0, GS_>([&](auto ic) { ring_landed(rd[g & 1][decltype(ic)::value]); });
+            if constexpr (g == 0) {
+              // the lane's factors were requested by opaque statements too: nothing that uses them may be scheduled
+              // in front of the wait above (a "memory" clobber does not order register-only instructions)
+              asm volatile("" : "+v"(svk));
+              wave_for<0, NA>([&](auto ac) { ring_landed(ug[decltype(ac)::value]); });
+              if (SYM) ring_landed(us);
+              if (w == 0) accX *= svk;
+            }
+            wave_for<0, GS_>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              const double r0 = rd[g & 1][i][0], r1 = rd[g & 1][i][1], r2 = rd[g & 1][i][2];
+              if constexpr (g < NGN) {
+                constexpr int t = GS_ * g + i;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, ug[a][2], fma(r1, ug[a][1], r0 * ug[a][0]));  // :738-746
+              } else {
+                constexpr int t = GS_ * (g - NGN) + i;
+                acc[NA * NS + t] *= fma(r2, us[2], fma(r1, us[1], r0 * us[0]));
+              }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+        gcnt += RG_B;
+        if (gcnt >= 16) {  // every factor is >= 1.1e-11: eighteen of them since the last renormalisation cannot underflow
+          gcnt = 0;
+#pragma unroll
+          for (int t = 0; t < NACC; ++t) {
+            if (t < NXV) {
+              prodacc_renorm(acc[t], ex[t]);
+            } else {
+              int ee;
+              acc[t] = frexp(acc[t], &ee);
+              exs[t - NXV][j] += ee;
+            }
+          }
+          prodacc_renorm(accX, exX);
+        }
+        gstore((b + 1) & 1);
+        __syncthreads();
+      }
+      {  // bring the accumulators back to [0.5, 1) for the logarithms below
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+          if (t < NXV) {
+            prodacc_renorm(acc[t], ex[t]);
+          } else {
+            int ee;
+            acc[t] = frexp(acc[t], &ee);
+            exs[t - NXV][j] += ee;
+          }
+        }
+        prodacc_renorm(accX, exX);
+      }
+    }
+  }
+
   // ---- results: the wave layout llw[c][block][n][step t][lane j], lane j at step t holds (j, k = j - t - 1 mod 64); the
   //      logarithm of the product of the partner's sums comes out of the ring like the partner's rho did
   double* out = ll + ((size_t)it.slab * sel.nblk2 + sel.blk) * nAlpha * 4096;
@@ -320,9 +523,13 @@ __global__ void __launch_bounds__(256, 2)
 
 template <int NA, bool SYM>
 void ring_launch(muxgl_handle* h, const wave_item* items, int64_t n_items, const double* lut, const double* gm, int A,
-                 const ring_sel& sel, double* llw) {
-  hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items, h->d_lin,
-                     h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, llw);
+                 const ring_sel& sel, const double* pgt, double* llw) {
+  if (pgt)
+    hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, true>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items,
+                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, llw);
+  else
+    hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, false>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items,
+                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, llw);
 }
 
 }  // namespace
@@ -335,8 +542,10 @@ void demux_ring_release(muxgl_handle* h) {
 
 // One launch: the linear entries of every work unit for up to four non-symmetric alphas (sel.n[0 .. na)) and, with
 // sel.nsym > 0, the symmetric one.  gm: wave_gm_kernel's moments.  Needs h->d_lin_rank / d_lin_rec (plan_build_bit_streams).
+// pgt: the table of per-entry likelihoods [entry][alpha][9] -- the launch then also walks the units' other entries (GEN) and the
+// slab it writes is final; NULL: the linear entries only (the caller adds the others with demux_wave.hip's EM_GENERAL).
 int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
-                          const double* gm, int na, const ring_sel& sel, double* llw) {
+                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt) {
   if (h->ring_rec_n != h->n_lin_rec || !h->d_ring_rec) {  // per pileup and genotype set (rows of markers without genotypes)
     if (dev_alloc(h, &h->d_ring_rec, (size_t)h->n_lin_rec + RL_PAD)) return 1;
     const int64_t nr = h->n_lin_rec + RL_PAD;
@@ -352,7 +561,7 @@ int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wa
   al.a[5] = sel.nsym > 0 ? p->alpha[sel.nsym] : p->alpha[0];
   hipLaunchKernelGGL(ring_lut_kernel, dim3(RL_NLUT), dim3(64), 0, h->stream, al, h->d_lut, h->d_ring_lut);
   const bool sym = sel.nsym > 0;
-#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, llw)
+#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, pgt, llw)
   if (na == 4) sym ? RING(4, true) : RING(4, false);
   else if (na == 2) sym ? RING(2, true) : RING(2, false);
   else if (na == 1) sym ? RING(1, true) : RING(1, false);

@@ -756,6 +756,9 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   // stream) -- the table stays indexed by entry: in the order of the stream (tried: a quarter of the memory) the
   // sweep that reads it was 5 ms slower at configs[2].  Beyond 64 samples the off-diagonal blocks walk every entry.
   const bool gen_only = use_lin && nblk == 1;
+  // the ring kernel walks a unit's other entries too, with the same accumulators: one write of the slab
+  // (MUXGL_FLAG_SPLIT_GENERAL_SWEEP: launches of their own on top of it, as in round 3 -- lets tests compare the two)
+  const bool ring_gen = use_lin && !(h->flags & MUXGL_FLAG_SPLIT_GENERAL_SWEEP);
   tic(h, MUXGL_T_DEMUX_SWEEP);
   if (demux_entry_pg_launch(h, p, st->d_pg, gen_only)) return 1;
   if (h->nnz && !gen_only)  // (gen_only: the kernel writes the neutral rows itself)
@@ -781,7 +784,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 #define MULTI_LAUNCH(NA, NS, WS, CR)          \
   do {                                        \
     if (use_lin && !(CR)) {                   \
-      MULTI_K(NA, NS, WS, false, EM_GENERAL); \
+      if (!ring_gen) MULTI_K(NA, NS, WS, false, EM_GENERAL); \
     } else {                                  \
       MULTI_K(NA, NS, WS, CR, EM_ALL);        \
     }                                         \
@@ -791,7 +794,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 #define WAVE_LAUNCH(NS, WS, CR)          \
   do {                                   \
     if (use_lin && !(CR)) {              \
-      WAVE_K(NS, WS, false, EM_GENERAL); \
+      if (!ring_gen) WAVE_K(NS, WS, false, EM_GENERAL); \
     } else {                             \
       WAVE_K(NS, WS, CR, EM_ALL);        \
     }                                    \
@@ -849,7 +852,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
         rs.nsym = nsym;
         rs.with_singlet = first ? 1 : 0;
         rs.jbase = 64 * X, rs.blk = wb.blk, rs.nblk2 = nblk2;
-        return demux_ring_lin_launch(h, p, st->d_items, st->n_items, st->d_gm, na, rs, h->d_llw);
+        return demux_ring_lin_launch(h, p, st->d_items, st->n_items, st->d_gm, na, rs, h->d_llw, ring_gen ? st->d_pg : nullptr);
       };
       while (plain.size() - done >= 4) {
         wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};

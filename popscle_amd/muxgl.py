@@ -30,6 +30,7 @@ FLAG_ASYNC_PHASES = 32
 FLAG_NO_LINEAR_ENTRIES = 64
 FLAG_MSTEP_LDS_STATES = 128
 FLAG_NO_PIVOT_SUMS = 256
+FLAG_SPLIT_GENERAL_SWEEP = 512
 MAX_DEVICES = 16
 XCHG_PAD = 64
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
