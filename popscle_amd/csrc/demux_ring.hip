@@ -35,9 +35,11 @@ namespace {
 constexpr int RL_B = 8;       // entries per staged batch
 constexpr int RL_ROW = 256;   // doubles per staged entry: rho of the 64 lanes twice over (the ring), s, singlet factors
 constexpr int RL_LUTW = 24;   // doubles per table row: (A, Bl, Bm) of six slots, padded to 192 bytes
+constexpr int RL_BITS = 18;   // ... and, as an int32 in the double behind them, an upper bound of the bits a factor of the row costs
 constexpr int RL_NLUT = 130;  // rows: allele << 6 | quality; 128 = no usable read; 129 = neutral
 constexpr int RL_PAD = 32;    // records readable behind the end of the stream
-constexpr int RL_RENORM = 3;  // batches between renormalisations
+constexpr int RL_RENORM = 3;  // batches between renormalisations of the singlet slot / the product of the lane's sums
+constexpr int RL_BUDGET = 600;  // bits the products may have lost before they are renormalised (a batch costs <= 8 * 35 more)
 
 struct ring_alpha {
   double a[6];  // slot 0: alpha[0] (singlets), 1..4: the launch's non-symmetric alphas, 5: the symmetric one
@@ -47,18 +49,33 @@ struct ring_alpha {
 // as A = pG[0][0], Bl = pG[1][0] - pG[0][0], Bm = pG[0][1] - pG[0][0]
 __global__ void __launch_bounds__(64) ring_lut_kernel(ring_alpha al, const double* __restrict__ lut, double* __restrict__ out) {
   const int r = blockIdx.x, s = threadIdx.x;
-  if (s >= 6) return;
-  double* o = out + (size_t)r * RL_LUTW + s * 3;
-  if (r == RL_NLUT - 1) {
-    o[0] = 1.0, o[1] = 0.0, o[2] = 0.0;
-    return;
+  __shared__ double lo[6];
+  double* o = out + (size_t)r * RL_LUTW + (s < 6 ? s : 0) * 3;
+  if (s < 6) {
+    if (r == RL_NLUT - 1) {
+      o[0] = 1.0, o[1] = 0.0, o[2] = 0.0;
+    } else {
+      double pG[9];
+      const uint32_t byte = (uint32_t)(((r >> 6) & 1) << 7) | (uint32_t)(r & 63);
+      row_entry_pg<1>(nullptr, 0, r < 128 ? 1 : 0, byte, &al.a[s], lut, pG);
+      o[0] = pG[0];
+      o[1] = pG[3] - pG[0];
+      o[2] = pG[1] - pG[0];
+    }
+    // the smallest factor A + Bl rho_j + Bm rho_k an accumulator can meet at this row (rho in [0, 2]: a corner)
+    lo[s] = fmin(fmin(o[0], fma(2.0, o[1], o[0])), fmin(fma(2.0, o[2], o[0]), fma(2.0, o[1] + o[2], o[0])));
   }
-  double pG[9];
-  const uint32_t byte = (uint32_t)(((r >> 6) & 1) << 7) | (uint32_t)(r & 63);
-  row_entry_pg<1>(nullptr, 0, r < 128 ? 1 : 0, byte, &al.a[s], lut, pG);
-  o[0] = pG[0];
-  o[1] = pG[3] - pG[0];
-  o[2] = pG[1] - pG[0];
+  __syncthreads();
+  if (s == 0) {  // RL_BITS: how many bits a product can lose to a factor of this row, at most (0 for the neutral row)
+    double m = lo[0];
+    for (int i = 1; i < 6; ++i) m = fmin(m, lo[i]);
+    int e = 0;
+    if (m < 1.0) {
+      (void)frexp(m > 1e-300 ? m : 1e-300, &e);  // m >= 2^(e-1)
+      e = 1 - e;
+    }
+    reinterpret_cast<int32_t*>(out + (size_t)r * RL_LUTW + RL_BITS)[0] = e > 0 ? e + 1 : 0;
+  }
 }
 
 // the linear entries' records in stream order: {snp, byte offset of the table row}
@@ -212,7 +229,7 @@ __global__ void __launch_bounds__(256, 2)
   };
   load_lut(std::integral_constant<int, 0>{}, rcl[0]);
 
-  int cnt = 0;
+  int cnt = 0, bits = 0;
   for (int b = 0; b < nb; ++b) {
     const uint32_t bb = base0 + (uint32_t)(b & 1) * BUFB;
     const uint32_t own = bb + ownoff, own2 = bb + own2off, rb = bb + rboff, rs = bb + rsoff;
@@ -280,8 +297,21 @@ __global__ void __launch_bounds__(256, 2)
       });
     });
 
+    // Renormalisation when the products may have lost RL_BUDGET bits since the last one, by the rows' own bounds (a
+    // Q20 read costs 9 bits where the worst row costs 34: every dozen batches instead of every third).  The singlet
+    // slot / the product of the lane's sums carry the samples' sums, which no table bounds: every third batch.
+#pragma unroll
+    for (int k = 0; k < RL_B; ++k) bits += *reinterpret_cast<const int32_t*>((const char*)lutg + rcl[k] + RL_BITS * 8);
     if (++cnt == RL_RENORM) {
       cnt = 0;
+      prodacc_renorm(accX, exX);
+    }
+#ifdef RL_FIXED_RENORM
+    if (cnt == 0) {
+#else
+    if (bits > RL_BUDGET) {
+#endif
+      bits = 0;
 #pragma unroll
       for (int t = 0; t < NACC; ++t) {
         if (t < NXV) {
@@ -292,7 +322,6 @@ __global__ void __launch_bounds__(256, 2)
           exs[t - NXV][j] += ee;
         }
       }
-      prodacc_renorm(accX, exX);
     }
     store_rows((b + 1) & 1, b + 1);
     __syncthreads();
@@ -359,26 +388,17 @@ __global__ void __launch_bounds__(256, 2)
             u[(2 * 3 + m) * 64 + j] = uu[0][m], u[(3 * 3 + m) * 64 + j] = uu[1][m], u[(4 * 3 + m) * 64 + j] = uu[2][m];
         }
       };
-      {  // the linear walk may have left up to 23 factors un-renormalised behind
-#pragma unroll
-        for (int t = 0; t < NACC; ++t) {
-          if (t < NXV) {
-            prodacc_renorm(acc[t], ex[t]);
-          } else {
-            int ee;
-            acc[t] = frexp(acc[t], &ee);
-            exs[t - NXV][j] += ee;
-          }
-        }
-        prodacc_renorm(accX, exX);
-      }
       __syncthreads();  // (the linear walk's last batch has been read by every wave)
       gload(0);
       gstore(0);
       __syncthreads();
       const uint32_t gown = base0 + (uint32_t)j * 8u;
       const uint32_t grb = base0 + (uint32_t)(j + 64 - 16 * w - 16) * 8u, grs = base0 + (uint32_t)(j + 64 - 8 * w - 8) * 8u;
-      int gcnt = 0;
+      // Bits since the last renormalisation: the linear walk leaves at most RL_BUDGET + 8 * 35 = 880 behind; a general entry
+      // costs < 37 (every factor >= 1.1e-11): renormalising once more than 870 are counted keeps a product above
+      // 2^-(870 + 2 * 37) -- and above 2^-(880 + 74) in the first batch.  (A renormalisation block of its own in front of
+      // this loop made the compiler spill inside both walks: 246 instead of 215 ms at configs[2].)
+      int gbits = bits;
       for (int b = 0; b < nbg; ++b) {
         const uint32_t bo = (uint32_t)(b & 1) * BUFGB;
         gload(b + 1);
@@ -449,9 +469,9 @@ __global__ void __launch_bounds__(256, 2)
             __builtin_amdgcn_sched_barrier(0);
           });
         });
-        gcnt += RG_B;
-        if (gcnt >= 16) {  // every factor is >= 1.1e-11: eighteen of them since the last renormalisation cannot underflow
-          gcnt = 0;
+        gbits += 37 * RG_B;
+        if (gbits > 870) {
+          gbits = 0;
 #pragma unroll
           for (int t = 0; t < NACC; ++t) {
             if (t < NXV) {
@@ -466,19 +486,6 @@ __global__ void __launch_bounds__(256, 2)
         }
         gstore((b + 1) & 1);
         __syncthreads();
-      }
-      {  // bring the accumulators back to [0.5, 1) for the logarithms below
-#pragma unroll
-        for (int t = 0; t < NACC; ++t) {
-          if (t < NXV) {
-            prodacc_renorm(acc[t], ex[t]);
-          } else {
-            int ee;
-            acc[t] = frexp(acc[t], &ee);
-            exs[t - NXV][j] += ee;
-          }
-        }
-        prodacc_renorm(accX, exX);
       }
     }
   }

@@ -191,3 +191,22 @@ def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7, want_full=None):
     # "ties": cells whose oracle numbers tie (an excuse was AVAILABLE); "cells_needing_an_excuse": where one was USED
     return {"cells": int(got.size), "max_abs_ll_diff": worst, "ties": int(tie.sum()),
             "cells_needing_an_excuse": int(differs.sum())}
+
+
+SUM_FIELDS = ("sumLLK", "sngLLK", "bestPP", "sngPP", "sngOnlyPP")
+
+
+def same_records(a, b, sum_rtol=1e-12):
+    """Two sets of demuxlet records made by different call paths of the library (in the sweep's workgroup / by the call
+    kernel from the result slab): every integer field and every hypothesis log-likelihood identical bit for bit; the
+    evidence sums and the posteriors derived from them are added up in another association and may differ in the last
+    bits (relative to 1, or to the value where that is larger)."""
+    assert a.shape == b.shape
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        if name in SUM_FIELDS:
+            ok = (x == y) | (np.abs(x - y) <= sum_rtol * np.maximum(1.0, np.maximum(np.abs(x), np.abs(y))))
+            assert ok.all(), (name, x[~ok][:3], y[~ok][:3])
+        else:
+            assert np.array_equal(x, y), (name, np.flatnonzero(x != y)[:5])
+    return True

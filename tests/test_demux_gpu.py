@@ -173,6 +173,66 @@ def test_ragged_and_edge_inputs(eng, V):
         assert run_gpu(eng, p, alphas).tobytes() == got.tobytes()  # the call made in LDS (no tensor requested)
 
 
+@pytest.mark.parametrize("V,alphas", [(33, (0.0, 0.5)), (48, GRID6), (64, GRID6), (64, (0.0, 0.3, 0.5)), (40, (0.0, 0.2)),
+                                      (50, (0.0, 0.1, 0.2, 0.3, 0.5)), (64, (0.0, 0.1, 0.2, 0.3, 0.4, 0.6, 0.5))])
+def test_one_sweep_for_all_entries_matches_the_split_sweeps(V, alphas):
+    """Between 33 and 255 samples a workgroup of the ring kernel sweeps ALL entries of its work unit -- the linear ones, then
+    the others, one set of accumulators -- and writes the unit's hypotheses once.  Against round 3's scheme
+    (MUXGL_FLAG_SPLIT_GENERAL_SWEEP: the general entries in launches of their own, added on top of the slab) and against
+    the oracle, with empty cells, cells walked in parts (> 2048 entries), very short cells and markers without genotypes
+    in the batch, for grids that take one ring launch (<= 4 non-symmetric alphas + 0.5) or several."""
+    base = synth.make_pileup(40, 9000, V, seed=5000 + V + len(alphas), mean_entries=700, sigma=1.0, min_entries=1,
+                             max_entries=6000, missing_gp_frac=0.04)
+    base = _truncate_cells(base, {3: 1, 11: 2, 20: 7})
+    p = _with_empty_cells(base, [0, 7, 39])
+    lens = np.diff(p.cell_ptr)
+    assert (lens == 0).sum() == 3 and lens.max() > 2048 and (lens[lens > 0] < 10).sum() >= 3
+    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
+    with muxgl.Engine(0, muxgl.FLAG_SPLIT_GENERAL_SWEEP) as old, muxgl.Engine(0) as new:
+        a, afull = run_gpu(old, p, alphas, full=True)
+        b, bfull = run_gpu(new, p, alphas, full=True)
+        for _ in range(3):
+            assert run_gpu(new, p, alphas).tobytes() == b.tobytes()
+    parity.compare_demux(b, want, alphas, want_full=wfull)
+    parity.compare_demux(a, want, alphas, want_full=wfull)
+    assert parity.compare_full_ll(bfull, wfull, V, alphas) < 1e-7
+    assert b["valid"].tolist() == (lens > 0).astype(int).tolist()
+    # the two sweeps accumulate in different associations (one product over all entries / a sum of two logarithms)
+    m = parity.needed_ll_mask(V, alphas)
+    assert np.max(np.abs(afull[:, m] - bfull[:, m])) < 1e-8
+
+
+def _truncate_cells(p, keep):
+    """the same pileup with cell c cut down to its first keep[c] entries"""
+    lens = np.diff(p.cell_ptr)
+    new_lens = lens.copy()
+    for c, n in keep.items():
+        new_lens[c] = min(n, lens[c])
+    keep_e = np.concatenate([np.arange(l) < n for l, n in zip(lens, new_lens)]) if p.nnz else np.zeros(0, bool)
+    rl = np.diff(p.entry_rptr)
+    keep_r = np.repeat(keep_e, rl)
+    cell_ptr = np.zeros(p.C + 1, dtype=np.int64)
+    np.cumsum(new_lens, out=cell_ptr[1:])
+    entry_rptr = np.zeros(int(keep_e.sum()) + 1, dtype=np.int64)
+    np.cumsum(rl[keep_e], out=entry_rptr[1:])
+    return synth.Pileup(p.C, p.S, cell_ptr, p.entry_snp[keep_e], entry_rptr, p.reads[keep_r], p.af, p.gp, p.has_gp)
+
+
+def _with_empty_cells(p, cells):
+    """the same pileup with the entries of the given cells removed (the cells stay, without entries)"""
+    lens = np.diff(p.cell_ptr)
+    keep_cell = np.ones(p.C, dtype=bool)
+    keep_cell[cells] = False
+    keep_e = np.repeat(keep_cell, lens)
+    rl = np.diff(p.entry_rptr)
+    keep_r = np.repeat(keep_e, rl)
+    cell_ptr = np.zeros(p.C + 1, dtype=np.int64)
+    np.cumsum(np.where(keep_cell, lens, 0), out=cell_ptr[1:])
+    entry_rptr = np.zeros(int(keep_e.sum()) + 1, dtype=np.int64)
+    np.cumsum(rl[keep_e], out=entry_rptr[1:])
+    return synth.Pileup(p.C, p.S, cell_ptr, p.entry_snp[keep_e], entry_rptr, p.reads[keep_r], p.af, p.gp, p.has_gp)
+
+
 def test_zero_cells_and_reuse_of_handle(eng):
     p = synth.make_pileup(10, 300, 3, seed=8, mean_entries=50, min_entries=10)
     empty = synth.Pileup(0, p.S, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(1, np.int64),
