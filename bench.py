@@ -93,6 +93,71 @@ def fmx_issued_flops_model(K):
     return K * (K + 1) / 2 * 6.0 + K * 15.0
 
 
+# ---- the floor: the least work the algorithm AS BUILT must do (DESIGN.md section 6.1 states the same table) -----------
+# SURVEY.md 8d's byte / flop figures count every GP-row gather as HBM bytes and every (j, k, n) slot of the reference's
+# loop nest as work; the kernels keep the GP tensor in cache and evaluate only the hypotheses the reference READS, a
+# linear entry (at most one usable read) at two instructions per hypothesis.  With those figures the fractions exceed 1
+# for configs[1] and [3] (reported as `reference_equiv_*`, without a fraction).  The floor below is what a reader can
+# recompute: FP64 lane-instructions that cannot be avoided without another algorithm, at 4 issue cycles per wave64
+# instruction on 1024 SIMDs at 2.4 GHz, and the bytes that must cross HBM once, at 8 TB/s.
+def linear_fraction(entry_rptr, reads):
+    """share of the entries with at most one usable read (allele 0/1): the class the kernels sweep at 2 instructions
+    per hypothesis (the library also requires the read's quality <= 60, which the synthetic qualities always meet)"""
+    rp = np.asarray(entry_rptr, dtype=np.int64)
+    if rp.size < 2:
+        return 0.0
+    cs = np.concatenate(([0], np.cumsum(np.asarray(reads) != 0xFF, dtype=np.int64)))
+    return float(np.mean((cs[rp[1:]] - cs[rp[:-1]]) <= 1))
+
+
+def demux_hypotheses(V, alphas):
+    """hypotheses the reference reads per entry: V singlets (j, 0, 0) and, per non-first alpha, the V (V - 1) ordered
+    pairs -- an alpha of 0.5 is symmetric in (j, k): evaluated once, mirrored"""
+    nsym = sum(1 for a in alphas[1:] if a == 0.5)
+    nns = len(alphas) - 1 - nsym
+    return V + nns * V * (V - 1) + nsym * V * (V - 1) // 2
+
+
+def demux_floor(V, alphas, nnz, frac_lin, rpe, S, C, kernel_ms):
+    A = len(alphas)
+    H = demux_hypotheses(V, alphas)
+    # linear entry: one FMA (partner's rho times B_m, plus the lane's A + B_l rho_j) and the product update per
+    # hypothesis; the lane's A + B_l rho_j once per sample and alpha.  Other entries: a three-term dot product
+    # (MUL + 2 FMA) and the update; u[m] = sum_l g_j[l] pG[l][m] (9 per sample and alpha); the per-read update of
+    # cmd_cram_demuxlet.cpp:655-700 (9 products per alpha and read)
+    i_lin = 2.0 * H + V * A
+    i_gen = 4.0 * H + 9.0 * V * A + 9.0 * A * rpe
+    lane_instr = nnz * (frac_lin * i_lin + (1.0 - frac_lin) * i_gen)
+    valu_ms = lane_instr / 64.0 * VALU_CYCLES / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+    # every input once: 4 B SNP id + 8 B read offset + the reads per entry, the GP tensor, the 160-byte records
+    byts = nnz * (12.0 + rpe) + S * V * 24.0 + C * 160.0
+    hbm_ms = byts / (HBM_PEAK_GBS * 1e9) * 1e3
+    fl = max(valu_ms, hbm_ms)
+    return {"hypotheses_per_entry": H, "linear_entry_share": frac_lin,
+            "fp64_instr_per_hypothesis": {"linear": 2, "general": 4},
+            "lane_instructions": lane_instr, "valu_ms": valu_ms, "compulsory_bytes": byts, "hbm_ms": hbm_ms,
+            "frac_of_floor": (fl / kernel_ms) if kernel_ms > 0 else None,
+            "note": "floor of the algorithm as built (DESIGN.md 6.1): FP64 issue at 2.4 GHz / compulsory bytes at 8 TB/s"}
+
+
+def fmx_floor(K, nnz, frac_lin, S, kernel_ms):
+    H = K * (K + 1) // 2  # unordered pairs and the K singlets (cmd_cram_freemux2.cpp:440-452)
+    i_lin = 2.0 * H + K            # (c0 + c1 E_j) once per cluster
+    i_gen = 4.0 * H + 9.0 * K      # u[m] = sum_l P_j[l] glis[l][m]
+    lane_instr = nnz * (frac_lin * i_lin + (1.0 - frac_lin) * i_gen)
+    valu_ms = lane_instr / 64.0 * VALU_CYCLES / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+    # a linear entry streams {c0, c1, snp} (24 B), another one its six distinct likelihoods and its SNP id (52 B);
+    # the cluster posteriors once
+    byts = nnz * (frac_lin * 24.0 + (1.0 - frac_lin) * 52.0) + S * K * 24.0
+    hbm_ms = byts / (HBM_PEAK_GBS * 1e9) * 1e3
+    fl = max(valu_ms, hbm_ms)
+    return {"hypotheses_per_entry": H, "linear_entry_share": frac_lin,
+            "fp64_instr_per_hypothesis": {"linear": 2, "general": 4},
+            "lane_instructions": lane_instr, "valu_ms": valu_ms, "compulsory_bytes": byts, "hbm_ms": hbm_ms,
+            "frac_of_floor": (fl / kernel_ms) if kernel_ms > 0 else None,
+            "note": "floor of the E-step as built (DESIGN.md 6.1): FP64 issue at 2.4 GHz / compulsory bytes at 8 TB/s"}
+
+
 def demux_sweep_kernel(V, alphas):
     """the kernel libmuxgl dispatches for this shape (popscle_amd/csrc/demux_kernels.hip: demux_launch)"""
     if V <= 16 and tuple(alphas) == (0.0, 0.5):
@@ -381,6 +446,9 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
     # weak scaling: every rank owns a full config-sized shard of cells (its own seed), GP tensor replicated
     C = max(1, int(round(cfg["C"] * args.scale)))
     seeds = dict(seed=synth.BASE_SEED + config + 1000 * ctx.rank, donor_seed=synth.BASE_SEED + config)
+    reads_lambda = args.reads_lambda if args.reads_lambda is not None else (2.0 if args.dense else None)
+    if reads_lambda is not None:
+        seeds["reads_lambda"] = reads_lambda
     t_gen = time.perf_counter()
     on_device = use_device_synth(args, C * 950.0)
     if on_device:
@@ -389,7 +457,7 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
     else:
         p = synth.make_pileup(C, cfg["S"], V, **seeds)
     gen_s = time.perf_counter() - t_gen
-    eng = muxgl.Engine(ctx.dev)
+    eng = muxgl.Engine(ctx.dev, muxgl.FLAG_NO_LINEAR_ENTRIES if args.no_linear else 0)
     t_h = time.perf_counter()
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.demux_set_gp(p.gp, p.has_gp)
@@ -445,6 +513,22 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
                                  demux_flops_per_entry(V, A, rpe) * p.nnz,
                                  demux_issued_flops_model(V, alphas, rpe) * p.nnz, config, scale=float(p.nnz)),
         }
+        frac_lin = linear_fraction(p.entry_rptr, p.reads)
+        out["roofline"]["floor"] = demux_floor(V, alphas, float(p.nnz), 0.0 if args.no_linear else frac_lin, rpe, cfg["S"],
+                                               C, sweep_s * 1e3)
+        if reads_lambda is not None or args.no_linear:
+            out["sensitivity"] = {"reads_lambda": 0.3 if reads_lambda is None else reads_lambda, "reads_per_entry": rpe,
+                                  "linear_entry_share": frac_lin, "linear_entry_form": not args.no_linear,
+                                  "note": "not the BASELINE workload: the default line's entries carry 1 + Poisson(0.3) reads "
+                                          "(three quarters linear: two FP64 instructions per hypothesis instead of four)"}
+        if ctx.world > 1:  # every rank swept a full config-sized shard of its own: N x the one-GPU value by construction
+            out["scaling_note"] = ("weak scaling: each of the %d ranks owns %d cells (no data-path collective; cells are "
+                                   "independent, cmd_cram_demuxlet.cpp:636-1013); value = sum over ranks / max-rank time"
+                                   % (ctx.world, C))
+            out["per_rank_value"] = out["value"] / ctx.world
+        out["roofline"]["note_8d"] = ("SURVEY 8d's per-entry bytes / flops (reference_equiv_*) exceed the roofs for V <= 16: they count "
+                                      "cache-resident GP-row gathers as HBM bytes and all V*V*A slots of the reference's loop "
+                                      "nest as work; `floor` is the recomputable bound of the algorithm as built")
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline_demux(p, alphas, eng.demux_results_view().copy(), budget_s=cpu_budget_s)
         else:
@@ -472,6 +556,10 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
     if on_device:
         d = synth.make_pileup_device(C, S, K, device=f"cuda:{ctx.dev}", **gen)
         nnz_total, my_entries = d.nnz, float(d.cell_ptr[c_ranges[0][1]] - d.cell_ptr[c_ranges[0][0]])
+        usable = torch.cumsum((d.reads != 0xFF).to(torch.int64), 0)
+        usable = torch.cat([usable.new_zeros(1), usable])
+        frac_lin = float(((usable[d.entry_rptr[1:]] - usable[d.entry_rptr[:-1]]) <= 1).double().mean())
+        del usable
         af, truth_s1 = d.af.cpu().numpy(), d.truth["s1"].cpu().numpy()
         if ctx.dist_on:
             rows = d.take_cells(*c_ranges[ctx.rank])
@@ -483,6 +571,7 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
     else:
         p = synth.make_pileup(C, S, K, **gen)
         nnz_total, my_entries = p.nnz, float(p.cell_ptr[c_ranges[0][1]] - p.cell_ptr[c_ranges[0][0]])
+        frac_lin = linear_fraction(p.entry_rptr, p.reads)
         af, truth_s1 = p.af, p.truth["s1"]
         if ctx.dist_on:
             rows = shard.take_cells(p, *c_ranges[ctx.rank])
@@ -552,6 +641,24 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
                                  fmx_flops_per_entry(K) * my_entries, fmx_issued_flops_model(K) * my_entries, config,
                                  scale=my_entries),
         }
+        out["roofline"]["floor"] = fmx_floor(K, my_entries, frac_lin, S, est_s * 1e3)
+        if ctx.world > 1:
+            # DESIGN.md 4.3's model next to the measurement: this rank's kernels + the two exchanges (xGMI: point to
+            # point, ~70 GB/s usable per link and direction; a small collective ~25 us end to end) + the host's wait
+            N = ctx.world
+            kern_ms = float(kern[muxgl.T_FMX_GP] + kern[muxgl.T_FMX_ESTEP] + kern[muxgl.T_FMX_CALL] + kern[muxgl.T_FMX_MSTEP])
+            slice_b = S * K * 24.0 / N
+            x1_direct, x1_ring = 0.025 + slice_b / 70e9 * 1e3, 0.025 + (N - 1) * slice_b / 70e9 * 1e3
+            x2 = 0.05
+            out["scaling_model"] = {
+                "kernels_ms_rank0_last_iteration": kern_ms,
+                "exchange1_cluster_gp_allgather_ms": {"bytes_total": S * K * 24.0, "every_peer_on_its_own_link": x1_direct,
+                                                      "single_ring": x1_ring},
+                "exchange2_assignments_and_counters_ms": x2, "host_wait_ms": 0.02,
+                "predicted_ms_per_iteration": {"direct": kern_ms + x1_direct + x2 + 0.02, "ring": kern_ms + x1_ring + x2 + 0.02},
+                "measured_ms_per_iteration": elapsed / steps * 1e3,
+                "note": "strong scaling: the same job on every rank count; E-step and scans shard by cells, cluster "
+                        "posteriors and the ordered M-step by SNPs (DESIGN.md 4.3)"}
         if cpu_baseline and ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fmx(p, K, clust0, budget_s=cpu_budget_s)
         else:
@@ -641,6 +748,12 @@ def main():
     ap.add_argument("--clusters", type=int, default=0, help="freemuxlet: override K (tests)")
     ap.add_argument("--mean-entries", type=float, default=800.0)
     ap.add_argument("--dump", default="", help="freemuxlet: write rank 0's final records (tests)")
+    ap.add_argument("--dense", action="store_true",
+                    help="demuxlet sensitivity run: the same shape with 1 + Poisson(2.0) reads per entry (a third of the "
+                         "entries linear instead of three quarters); adds a 'sensitivity' key to the line")
+    ap.add_argument("--reads-lambda", type=float, default=None, help="reads per entry = 1 + Poisson(lambda) (default 0.3)")
+    ap.add_argument("--no-linear", action="store_true",
+                    help="demuxlet: MUXGL_FLAG_NO_LINEAR_ENTRIES -- every entry through the general three-term form")
     args = ap.parse_args()
     if args.config not in synth.CONFIGS:
         raise SystemExit("--config must be 1, 2 (demuxlet) or 3, 4 (freemuxlet)")

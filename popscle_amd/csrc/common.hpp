@@ -67,6 +67,7 @@ struct muxgl_row_state {
   double* d_fo_ggl = nullptr;                              // six likelihoods of the other entries
   int32_t* d_fq_order = nullptr;        // launch order of the chunks, as d_quad_order
   int32_t* d_part_e = nullptr;          // per-chunk partial exponents (quad kernel)
+  int32_t* d_chunk_pos = nullptr;       // position of every chunk in its cell's list: where the oct kernel leaves its partials
   size_t part_cap = 0, part_e_cap = 0;
   int64_t n_chunks = 0;
 };

@@ -20,16 +20,33 @@ namespace {
 
 using namespace muxgl_call;
 
-template <int G>  // lanes per cell: 16 (V <= 16) or 64 (V <= 64)
+// V <= 16: a workgroup of four waves takes four cells -- a wave per cell for the scans (sixteen rows x four ranges of
+// columns), the four decisions side by side in wave 0 (demux_call_decide's note) -- exactly as the oct path's finish
+// kernel does on its tile in LDS: the two paths give the same records bit for bit.
+__global__ void __launch_bounds__(256)
+    demux_call16_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
+                        const double* __restrict__ ll, muxgl_demux_cell* __restrict__ out) {
+  __shared__ call_partial parts[4];
+  const int tid = threadIdx.x, lc = tid >> 6;
+  const int64_t cbase = (int64_t)blockIdx.x * 4, i = cbase + lc;
+  const bool cell_ok = i < C;
+  const call_partial cp = demux_call_scan<16, 4>(tid & 63, cell_ok, nv, nAlpha, al, ll + (size_t)(cell_ok ? i : 0) * nv * nv * nAlpha);
+  if ((tid & 63) == 0) parts[lc] = cp;
+  __syncthreads();
+  if (tid < 4 && cbase + tid < C)
+    demux_call_decide(parts[tid], (int32_t)(cell_ptr[cbase + tid + 1] - cell_ptr[cbase + tid]), nv, nAlpha, al, out + cbase + tid);
+}
+
+// 16 < V: a wave per cell, lane = row
 __global__ void __launch_bounds__(64)
     demux_callg_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
                         double doublet_prior, const double* __restrict__ ll, muxgl_demux_cell* __restrict__ out) {
   const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * (64 / G) + lane / G;
+  const int64_t i = (int64_t)blockIdx.x;
   const bool cell_ok = i < C;
   const int64_t ic = cell_ok ? i : 0;
-  demux_call_group<G>(lane, cell_ok, cell_ok ? (int32_t)(cell_ptr[i + 1] - cell_ptr[i]) : 0, nv, nAlpha, al,
-                      doublet_prior, ll + (size_t)ic * nv * nv * nAlpha, out + ic);
+  demux_call_group<64>(lane, cell_ok, cell_ok ? (int32_t)(cell_ptr[i + 1] - cell_ptr[i]) : 0, nv, nAlpha, al,
+                       doublet_prior, ll + (size_t)ic * nv * nv * nAlpha, out + ic);
 }
 
 // The call on the wave layout llw[c][n][step t][lane j] (demux_wave.hip): lane j owns row j; at step t it faces sample
@@ -105,13 +122,12 @@ int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const call_alpha al = make_call_alpha(p, h->V);
+  const unsigned blocks = (unsigned)h->C;
   if (h->V <= 16) {
-    const unsigned blocks = (unsigned)((h->C + 3) / 4);
-    hipLaunchKernelGGL(demux_callg_kernel<16>, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr,
-                       h->V, p->n_alpha, al, p->doublet_prior, h->d_ll, h->d_dcells);
+    hipLaunchKernelGGL(demux_call16_kernel, dim3((blocks + 3) / 4 ? (blocks + 3) / 4 : 1), dim3(256), 0, h->stream, h->C,
+                       h->d_cell_ptr, h->V, p->n_alpha, al, h->d_ll, h->d_dcells);
   } else {
-    const unsigned blocks = (unsigned)h->C;
-    hipLaunchKernelGGL(demux_callg_kernel<64>, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr,
+    hipLaunchKernelGGL(demux_callg_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr,
                        h->V, p->n_alpha, al, p->doublet_prior, h->d_ll, h->d_dcells);
   }
   HIPCHK(h, hipGetLastError());

@@ -112,21 +112,20 @@ __device__ __forceinline__ void top2_insert(top2& t, double v, int32_t pos) {
   }
 }
 
-// Second half of the call: merges the per-lane row results (top-2 lists, the largest evidence term rowmax of the lane's
-// rows, their evidence sum racc relative to rowmax, the largest singlet term sterm and the singlet sum sacc relative to
-// it -- 1 for a lane with one row) over the G lanes of the cell and makes the decision.
+// A cell's scans after the merge over its lanes: top-two lists, the evidence as (largest term M, sum S of the terms
+// relative to M), the same for the singlet terms alone.
+struct call_partial {
+  top2 sng, dbl;
+  double M, S, Ms, Ss;
+};
+
+// merges the per-lane row results (top-2 lists, the largest evidence term rowmax of the lane's rows, their evidence sum
+// racc relative to rowmax, the largest singlet term sterm and the singlet sum sacc relative to it) over the G lanes of
+// the cell; every lane of the group ends with the cell's partial
 template <int G>
-__device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
-                                                  const call_alpha& al, double doublet_prior, top2 sng, top2 dbl,
-                                                  double sterm, double rowmax, double racc, muxgl_demux_cell* out,
-                                                  double sacc = 1.0) {
-  const int j = lane & (G - 1);
+__device__ __forceinline__ call_partial demux_call_merge(top2 sng, top2 dbl, double sterm, double rowmax, double racc,
+                                                         double sacc) {
   const double NEG_INF = -__builtin_huge_val();
-  const double* gridAlpha = al.a;
-  const double log_single_prior = al.log_single_prior;
-  const double log_doublet_prior1 = al.log_doublet_prior1;
-  const double log_doublet_prior2 = al.log_doublet_prior2;
-  // merge the G rows: top-2 lists, maxima, then the scaled sums
   double M = rowmax, Ms = sterm;
 #pragma unroll
   for (int m = 1; m < G; m <<= 1) {
@@ -142,11 +141,24 @@ __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_
     S += __shfl_xor(S, m, 64);
     Ss += __shfl_xor(Ss, m, 64);
   }
+  return call_partial{sng, dbl, M, S, Ms, Ss};
+}
+
+// Second half of the call, ONE lane per cell: the evidence sums and the decision of cmd_cram_demuxlet.cpp:921-991.  (Its
+// nine exponentials and logarithms are library calls of ~150 instructions each: callers that hold several cells give
+// them to consecutive lanes of one wave instead of to lane 0 of a wave per cell.)
+__device__ __forceinline__ void demux_call_decide(const call_partial& c, int32_t nsnps, int nv, int nAlpha,
+                                                  const call_alpha& al, muxgl_demux_cell* out) {
+  const double* gridAlpha = al.a;
+  const double log_single_prior = al.log_single_prior;
+  const double log_doublet_prior1 = al.log_doublet_prior1;
+  const double log_doublet_prior2 = al.log_doublet_prior2;
+  const top2& sng = c.sng;
+  const top2& dbl = c.dbl;
   // :791 (sic): the reference starts both sums at -1e-300, i.e. with one more term exp(-1e-300)
   double sumLLK = -1e-300, sngLLK = -1e-300;
-  if (S > 0.0) sumLLK = dev_logadd(sumLLK, M + log(S));
-  if (Ss > 0.0) sngLLK = dev_logadd(sngLLK, Ms + log(Ss));
-  if (!cell_ok || j != 0) return;
+  if (c.S > 0.0) sumLLK = dev_logadd(sumLLK, c.M + log(c.S));
+  if (c.Ss > 0.0) sngLLK = dev_logadd(sngLLK, c.Ms + log(c.Ss));
 
   muxgl_demux_cell o;
   memset(&o, 0, sizeof(o));
@@ -240,21 +252,38 @@ __device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_
   *out = o;
 }
 
-
-
-// lane = lane id in the wave; lanes [base, base+G) with base = lane & ~(G-1) work on one cell.  ll_cell points at that
-// cell's [nv][nv][nAlpha] hypotheses (global or LDS); lane base+0 writes *out when cell_ok.
 template <int G>
+__device__ __forceinline__ void demux_call_finish(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
+                                                  const call_alpha& al, double doublet_prior, top2 sng, top2 dbl,
+                                                  double sterm, double rowmax, double racc, muxgl_demux_cell* out,
+                                                  double sacc = 1.0) {
+  const call_partial c = demux_call_merge<G>(sng, dbl, sterm, rowmax, racc, sacc);
+  if (!cell_ok || (lane & (G - 1)) != 0) return;
+  demux_call_decide(c, nsnps, nv, nAlpha, al, out);
+}
+
+
+
+// lane = lane id in the wave; the G * Q lanes [base, base + G Q), base = lane & ~(G Q - 1), work on one cell: lane
+// base + q G + j takes the rows j, j + G, ... and of each row the columns [q KQ, (q + 1) KQ), KQ = ceil(nv / Q) (Q = 1: whole
+// rows).  ll_cell points at that cell's [nv][nv][nAlpha] hypotheses (global or LDS); lane base + 0 writes *out when
+// cell_ok.  (Q = 4 at nv <= 16: a cell's scan is a chain of dependent selects and exponentials per lane; with sixteen
+// lanes per cell and one calling wave per four-cell workgroup the oct path's finish kernel spent 35 of its 69 us in
+// it -- measured by compiling the scans out -- whatever the number of cells.)
+// demux_call_scan: the scans and their merge -- every lane of the group returns the cell's partial; demux_call_group: the
+// scans and the decision by the group's first lane.
+template <int G, int Q = 1>
 // (ld: distance of two rows in doubles, nv * nAlpha unless the caller pads its tile -- the lanes of a group read the same
 //  column of their rows at the same time, and rows a multiple of 64 dwords apart all sit in one LDS bank)
-__device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
-                                                 const call_alpha& al, double doublet_prior, const double* ll_cell,
-                                                 muxgl_demux_cell* out, int ld = 0) {
+__device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, int nv, int nAlpha, const call_alpha& al,
+                                                        const double* ll_cell, int ld = 0) {
   if (ld == 0) ld = nv * nAlpha;
 #ifndef CALL_EXP
 #define CALL_EXP 0  // (timing experiments: 1 no scans, 2 no evidence pass, 4 no merge / decision)
 #endif
   const int j = lane & (G - 1);
+  const int q = (lane / G) & (Q - 1);
+  const int kq = (nv + Q - 1) / Q, k0 = q * kq, k1 = (k0 + kq < nv) ? k0 + kq : nv;
   const bool live = cell_ok && j < nv && !(CALL_EXP & 1);
   const double* gridAlpha = al.a;
   const double log_single_prior = al.log_single_prior;
@@ -266,16 +295,18 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
   double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0, sacc = 0.0;
   if (live) {
     // a lane takes the rows j, j + G, ..: ascending rows are ascending scan positions, so the reference's update rule
-    // (top2_push) applies across them as it does inside a row
+    // (top2_push) applies across them as it does inside a row (and inside a lane's range of columns)
     // pass 1: scans, and the largest evidence term of the lane's rows
     for (int jr = j; jr < nv; jr += G) {
       const double* row = ll_cell + (size_t)jr * ld;
-      const double s = row[0];  // llksAB[j][0][0]
-      top2_push(sng, s, jr);
-      const double st = s + log_single_prior;
-      sterm = fmax(sterm, st);
-      rowmax = fmax(rowmax, st);
-      for (int k = 0; k < nv; ++k) {
+      if (q == 0) {
+        const double s = row[0];  // llksAB[j][0][0]
+        top2_push(sng, s, jr);
+        const double st = s + log_single_prior;
+        sterm = fmax(sterm, st);
+        rowmax = fmax(rowmax, st);
+      }
+      for (int k = k0; k < k1; ++k) {
         if (k == jr) continue;
         for (int n = 1; n < nAlpha; ++n) {
           const double v = row[k * nAlpha + n];
@@ -292,10 +323,12 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
     if (rowmax > NEG_INF && !(CALL_EXP & 2)) {
       for (int jr = j; jr < nv; jr += G) {
         const double* row = ll_cell + (size_t)jr * ld;
-        const double st = row[0] + log_single_prior;
-        racc += exp_nonpos(st - rowmax);
-        sacc += exp_nonpos(st - sterm);
-        for (int k = 0; k < nv; ++k) {
+        if (q == 0) {
+          const double st = row[0] + log_single_prior;
+          racc += exp_nonpos(st - rowmax);
+          sacc += exp_nonpos(st - sterm);
+        }
+        for (int k = k0; k < k1; ++k) {
           if (k == jr) continue;
           for (int n = 1; n < nAlpha; ++n) {
             const double v = row[k * nAlpha + n];
@@ -309,11 +342,16 @@ __device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t
       }
     }
   }
-  if (CALL_EXP & 4) {
-    if (j == 0 && cell_ok) out->sumLLK = racc + sacc + sng.bv + dbl.bv + rowmax + sterm;
-    return;
-  }
-  demux_call_finish<G>(lane, cell_ok, nsnps, nv, nAlpha, al, doublet_prior, sng, dbl, sterm, rowmax, racc, out, sacc);
+  if (CALL_EXP & 4) return call_partial{sng, dbl, rowmax, racc, sterm, sacc};
+  return demux_call_merge<G * Q>(sng, dbl, sterm, rowmax, racc, sacc);
+}
+
+template <int G, int Q = 1>
+__device__ __forceinline__ void demux_call_group(int lane, bool cell_ok, int32_t nsnps, int nv, int nAlpha,
+                                                 const call_alpha& al, double doublet_prior, const double* ll_cell,
+                                                 muxgl_demux_cell* out, int ld = 0) {
+  const call_partial c = demux_call_scan<G, Q>(lane, cell_ok, nv, nAlpha, al, ll_cell, ld);
+  if (cell_ok && (lane & (G * Q - 1)) == 0) demux_call_decide(c, nsnps, nv, nAlpha, al, out);
 }
 
 }  // namespace muxgl_call

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64, 3)
                      const int32_t* __restrict__ order, const uint8_t* __restrict__ reads,
                      const double* __restrict__ gpo, const double* __restrict__ gmo,
                      const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
-                     double* __restrict__ part_m, int32_t* __restrict__ part_e) {
+                     const int32_t* __restrict__ chunk_pos, double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double ablut[O_NLUT * 4];
   __shared__ __align__(16) double pgs[O_SLOTS * O_SLOT_STRIDE];
@@ -234,9 +234,11 @@ __global__ void __launch_bounds__(64, 3)
   const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
   int64_t e0 = 0;
   int len = 0;
+  int32_t qpos = 0;  // where the chunk's partials go: its position in its cell's list
   if (q < n_chunks) {
     e0 = chunks[q].e0;
     len = chunks[q].len;
+    qpos = chunk_pos[q];
   }
   // The chunk's first nl records are its linear entries (oct_partition_kernel; 0 when that form is off): they are swept
   // first, by a loop of their own (below), the others by the nine-term loop.  Trip counts of the wave = the longest
@@ -680,18 +682,16 @@ __global__ void __launch_bounds__(64, 3)
       for (int a = 0; a < ON_ACC; ++a) {
         int e;
         const double m = frexp(acc[a], &e);
-        part_m[((size_t)q * ON_ACC + a) * 8 + p] = m;
-        part_e[((size_t)q * ON_ACC + a) * 8 + p] = exs[a] + e + exa[a];
+        part_m[((size_t)qpos * ON_ACC + a) * 8 + p] = m;
+        part_e[((size_t)qpos * ON_ACC + a) * 8 + p] = exs[a] + e + exa[a];
       }
     }
   }
 }
 
-// Decodes accumulator idx = a*8 + p of the oct kernel into its hypothesis (j, k) and multiplies the chunk partials of
-// one cell in chunk order: ONE log per hypothesis.  Returns false for slots nobody reads (pairs held twice, j/k >= V).
-__device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, const int32_t* __restrict__ cell_chunks,
-                                               const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
-                                               const int32_t* __restrict__ pmap, int V, int& j, int& k, double& v) {
+// Decodes accumulator idx = a*8 + p of the oct kernel into its hypothesis (j, k); false for slots nobody reads (pairs held
+// twice, j/k >= V).
+__device__ __forceinline__ bool oct_decode(int idx, const int32_t* __restrict__ pmap, int V, int& j, int& k) {
   const int a = idx >> 3, p = idx & 7;
   bool publish = true;
   if (a < 2) {
@@ -719,7 +719,20 @@ __device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, 
       publish = p < pf;
     }
   }
-  if (!publish || j >= V || k >= V) return false;
+  return publish && j < V && k < V;
+}
+
+// log(m 2^e), spelled with an explicit fma: the reduce kernel and the finish kernel must give the same bits, and whether
+// "a + b * c" is contracted is the compiler's choice per site
+__device__ __forceinline__ double oct_log(double m, int64_t e) { return fma((double)e, 0.6931471805599453094, log(m)); }
+
+// Multiplies the chunk partials of one cell in chunk order: ONE log per hypothesis.  A chunk's partials sit at the chunk's
+// position ci in its cell's list (the sweep writes them there, oct_chunk_pos_kernel), so a cell's are consecutive and a
+// reader needs no chunk ids.
+__device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, const double* __restrict__ part_m,
+                                               const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
+                                               int& j, int& k, double& v) {
+  if (!oct_decode(idx, pmap, V, j, k)) return false;
   // eight chunks per trip: the sixteen loads are independent and in flight together, the products stay in chunk order
   double m = 1.0;
   int64_t e = 0;
@@ -730,7 +743,7 @@ __device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const bool ok = ci + u < c1;
-      const size_t o = (size_t)cell_chunks[ok ? ci + u : c0] * O_NHYP + idx;
+      const size_t o = (size_t)(ok ? ci + u : c0) * O_NHYP + idx;
       pm[u] = ok ? part_m[o] : 1.0;
       pe[u] = ok ? part_e[o] : 0;
     }
@@ -746,22 +759,29 @@ __device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, 
       e += ee;
     }
   }
-  v = log(m) + (double)e * 0.6931471805599453094;
+  v = oct_log(m, e);
   return true;
+}
+
+// position of every chunk in its cell's list (the inverse of cell_chunks)
+__global__ void __launch_bounds__(256)
+    oct_chunk_pos_kernel(int64_t n_chunks, const int32_t* __restrict__ cell_chunks, int32_t* __restrict__ pos) {
+  const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci < n_chunks) pos[cell_chunks[ci]] = (int32_t)ci;
 }
 
 // writes ll[c][j][k][n] (+ mirror) of one cell to the LL tensor in HBM (needed when the caller asks for the tensor)
 __global__ void __launch_bounds__(192)
-    demux_oct_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
-                            const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
-                            const int32_t* __restrict__ pmap, int V, double* __restrict__ ll) {
+    demux_oct_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const double* __restrict__ part_m,
+                            const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
+                            double* __restrict__ ll) {
   const int64_t c = blockIdx.x;
   const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
   const int idx = threadIdx.x;
   if (c0 == c1 || idx >= O_NHYP) return;
   int j, k;
   double v;
-  if (!oct_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, pmap, V, j, k, v)) return;
+  if (!oct_hypothesis(idx, c0, c1, part_m, part_e, pmap, V, j, k, v)) return;
   double* out = ll + (size_t)c * V * V * 2;
   if (idx < 16) {
     out[((size_t)j * V + k) * 2 + 0] = v;  // singlet: alpha index 0
@@ -781,41 +801,100 @@ __global__ void __launch_bounds__(192)
 constexpr int QF_CELLS = QF_CELLS_N;
 __global__ void __launch_bounds__(64 * QF_CELLS)
     demux_oct_finish_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, const int64_t* __restrict__ cell_chunk_ptr,
-                            const int32_t* __restrict__ cell_chunks, const double* __restrict__ part_m,
-                            const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
+                            const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
+                            const int32_t* __restrict__ pmap, int V,
                             muxgl_call::call_alpha al, double doublet_prior, muxgl_demux_cell* __restrict__ out) {
   constexpr int LD = 33;  // row stride of the tiles in doubles: odd, so that the sixteen lanes of a cell's call, which read
                           // the same column of their rows at once, meet sixteen LDS banks (32 would be one)
   __shared__ double llt[QF_CELLS][16 * LD];
   __shared__ __align__(16) muxgl_demux_cell rec[QF_CELLS];
+  __shared__ int64_t ccp[QF_CELLS + 1];
   static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
   const int64_t cbase = (int64_t)blockIdx.x * QF_CELLS;
   const int tid = threadIdx.x;
+  if (tid <= QF_CELLS) ccp[tid] = cell_chunk_ptr[cbase + tid <= C ? cbase + tid : C];
   for (int t = tid; t < QF_CELLS * 16 * LD; t += 64 * QF_CELLS) (&llt[0][0])[t] = 0.0;
   __syncthreads();
-  for (int w = tid; w < QF_CELLS * O_NHYP; w += 64 * QF_CELLS) {
-    const int lc = w / O_NHYP, idx = w - lc * O_NHYP;
-    const int64_t c = cbase + lc;
-    if (c >= C) break;
-    const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
-    int j, k;
-    double v;
-    if (c0 != c1 && oct_hypothesis(idx, c0, c1, cell_chunks, part_m, part_e, pmap, V, j, k, v)) {
-      if (idx < 16) {
-        llt[lc][j * LD + k * 2 + 0] = v;
-      } else {
-        llt[lc][j * LD + k * 2 + 1] = v;
-        llt[lc][k * LD + j * 2 + 1] = v;
+  // The kernel's time is a chain of dependent latencies (measured: the same 65 us for 5 000 cells as for 10 000), so the
+  // chain is kept short: the chunk ranges of the workgroup's cells come from ONE load (above), a cell's partials are
+  // consecutive (no chunk ids), and a thread's hypotheses -- NH of the workgroup's QF_CELLS x 144 -- are walked TOGETHER,
+  // four chunks a trip: 2 x 4 x NH loads in flight instead of one hypothesis after the other (three dependent trips each).
+  constexpr int NH = (QF_CELLS * O_NHYP + 64 * QF_CELLS - 1) / (64 * QF_CELLS);
+  int hj[NH], hk[NH], hidx[NH], hlc[NH];
+  int64_t h0[NH];
+  int hn[NH];
+  bool hv[NH];
+  double hm[NH];
+  int64_t he[NH];
+  int nmax = 0;
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int w = tid + i * 64 * QF_CELLS;
+    const int lc = w < QF_CELLS * O_NHYP ? w / O_NHYP : 0;
+    hlc[i] = lc;
+    hidx[i] = w - lc * O_NHYP;
+    h0[i] = ccp[lc];
+    hn[i] = (int)(ccp[lc + 1] - ccp[lc]);
+    hv[i] = w < QF_CELLS * O_NHYP && hn[i] > 0 && oct_decode(hidx[i] < O_NHYP ? hidx[i] : 0, pmap, V, hj[i], hk[i]);
+    if (!hv[i]) hn[i] = 0, hidx[i] = 0;
+    hm[i] = 1.0;
+    he[i] = 0;
+    nmax = hn[i] > nmax ? hn[i] : nmax;
+  }
+  int cnt = 0;
+  for (int ci = 0; ci < nmax; ci += 4) {
+    double pm[NH][4];
+    int32_t pe[NH][4];
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = ci + u < hn[i];
+        const size_t o = (ok ? (size_t)(h0[i] + ci + u) * O_NHYP : 0) + hidx[i];  // (a valid address either way)
+        const double vm = part_m[o];
+        const int32_t ve = part_e[o];
+        pm[i][u] = ok ? vm : 1.0;
+        pe[i][u] = ok ? ve : 0;
+      }
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        hm[i] *= pm[i][u];
+        he[i] += pe[i][u];
+      }
+    if (++cnt == 128) {  // mantissas are in [0.5,1): 512 factors cannot underflow (as oct_hypothesis)
+      cnt = 0;
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        int ee;
+        hm[i] = frexp(hm[i], &ee);
+        he[i] += ee;
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    if (!hv[i]) continue;
+    const double v = oct_log(hm[i], he[i]);
+    if (hidx[i] < 16) {
+      llt[hlc[i]][hj[i] * LD + hk[i] * 2 + 0] = v;
+    } else {
+      llt[hlc[i]][hj[i] * LD + hk[i] * 2 + 1] = v;
+      llt[hlc[i]][hk[i] * LD + hj[i] * 2 + 1] = v;
+    }
+  }
   __syncthreads();
-  if (tid < 16 * QF_CELLS) {
-    const int lc = tid >> 4;
+  {  // a wave per cell for the scans (sixteen rows x four ranges of columns); the cells' decisions side by side in wave 0
+    __shared__ muxgl_call::call_partial parts[QF_CELLS];
+    const int lc = tid >> 6;
     const int64_t c = cbase + lc;
-    const bool ok = c < C;
-    muxgl_call::demux_call_group<16>(tid, ok, ok ? (int32_t)(cell_ptr[c + 1] - cell_ptr[c]) : 0, V, 2, al,
-                                     doublet_prior, llt[lc], &rec[lc], LD);
+    const muxgl_call::call_partial cp = muxgl_call::demux_call_scan<16, 4>(tid & 63, c < C, V, 2, al, llt[lc], LD);
+    if ((tid & 63) == 0) parts[lc] = cp;
+    __syncthreads();
+    if (tid < QF_CELLS && cbase + tid < C)
+      muxgl_call::demux_call_decide(parts[tid], (int32_t)(cell_ptr[cbase + tid + 1] - cell_ptr[cbase + tid]), V, 2, al,
+                                    &rec[tid]);
   }
   __syncthreads();
   constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
@@ -878,6 +957,13 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     if (dev_alloc(h, &st->d_part_e, need)) return 1;
     st->part_e_cap = need;
   }
+  if (!st->d_chunk_pos) {  // where a chunk's partials go (oct_hypothesis)
+    if (dev_alloc(h, &st->d_chunk_pos, (size_t)(st->n_chunks ? st->n_chunks : 1))) return 1;
+    if (st->n_chunks)
+      hipLaunchKernelGGL(oct_chunk_pos_kernel, dim3((unsigned)((st->n_chunks + 255) / 256)), dim3(256), 0, h->stream, st->n_chunks,
+                         st->d_cell_chunks, st->d_chunk_pos);
+    HIPCHK(h, hipGetLastError());
+  }
   const bool use_lin = h->d_lin && h->d_gmq && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
   const unsigned blocks = (unsigned)((((st->n_chunks + O_SLOTS - 1) / O_SLOTS) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup and GP tensor: every chunk's linear entries first
@@ -932,17 +1018,17 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
                        use_lin ? st->d_qent_lin : h->d_qent, st->d_orec, st->d_unit_ptr,
                        use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
                        use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
-                       h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_part, st->d_part_e);
+                       h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_chunk_pos, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }
   toc_tic(h, MUXGL_T_DEMUX_SWEEP, MUXGL_T_DEMUX_REDUCE);
   if (h->want_full_ll) {
     hipLaunchKernelGGL(demux_oct_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
-                       st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);
+                       st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);
   } else {  // reduce + call fused, records written to the pinned host buffer
     const muxgl_call::call_alpha al = muxgl_call::make_call_alpha(p, h->V);
     hipLaunchKernelGGL(demux_oct_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(64 * QF_CELLS), 0,
-                       h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_cell_chunks, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
+                       h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
 #ifdef FIN_DEV
                        p->doublet_prior, h->d_dcells);  // (timing experiment: records stay on the device)
 #else

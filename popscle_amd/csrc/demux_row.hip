@@ -290,6 +290,7 @@ void demux_row_release(muxgl_row_state** pst) {
   dev_free(&st->d_tmap);
   dev_free(&st->d_part);
   dev_free(&st->d_part_e);
+  dev_free(&st->d_chunk_pos);
   dev_free(&st->d_qent_lin);
   dev_free(&st->d_chunk_nlin);
   dev_free(&st->d_orec);
@@ -328,6 +329,7 @@ int demux_row_plan(muxgl_handle* h) {
 int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, int64_t cb, int64_t ce, int ch) {
   if (!*pst) *pst = new muxgl_row_state();
   muxgl_row_state* st = *pst;
+  dev_free(&st->d_chunk_pos);  // (derived from the chunk tables: rebuilt on first use)
   if (plan_build_chunks(h, st, cb, ce, ch)) return 1;
   if (!st->d_kmap) {
     if (dev_alloc(h, &st->d_kmap, 256)) return 1;

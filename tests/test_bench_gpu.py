@@ -43,6 +43,12 @@ def test_single_gpu_line():
     assert 0.1 < rf["fp64"]["frac"] < 1.0 and 0.1 < rf["fp64"]["issued_over_reference"] < 1.0
     assert rf["traffic"] is None or (rf["traffic"] > 1e8 and rf["hbm"]["frac"] is not None)
     assert rf["traffic"] == rf["hbm"]["traffic_bytes"]
+    # the recomputable floor of the algorithm as built and the fraction of it the kernel reaches
+    fl = rf["floor"]
+    assert fl["hypotheses_per_entry"] == 136 and 0.6 < fl["linear_entry_share"] < 0.85
+    assert 0 < fl["hbm_ms"] < fl["valu_ms"] < rf["kernel_ms"] and 0.2 < fl["frac_of_floor"] <= 1.0
+    assert abs(fl["frac_of_floor"] - max(fl["valu_ms"], fl["hbm_ms"]) / rf["kernel_ms"]) < 1e-12
+    assert "sensitivity" not in d and "note_8d" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["parity_max_abs_ll_diff"] < 1e-5
@@ -73,6 +79,8 @@ def test_single_gpu_line():
     assert abs(d2["value"] - 100000 * (64 + 64 * 63 * 5) / (d2["ms_per_step"] * 1e-3)) / d2["value"] < 1e-9
     assert d2["ms_per_step"] < 60e3  # the north_star's "< 60 s" with room to spare
     assert 0 < d2["roofline"]["frac"] <= 1.0 and d2["cpu_baseline"]["parity_max_abs_ll_diff"] < 1e-5
+    assert d2["roofline"]["floor"]["hypotheses_per_entry"] == 18208 and 0.3 < d2["roofline"]["floor"]["frac_of_floor"] <= 1.0
+    assert 0.2 < fx["roofline"]["floor"]["frac_of_floor"] <= 1.0 and fx["roofline"]["floor"]["hypotheses_per_entry"] == 136
     # ... and configs[4] (freemuxlet 500 k x 500 k, K = 64)
     f4 = d["freemuxlet_config4"]
     assert "error" not in f4, f4
@@ -96,6 +104,26 @@ def test_two_rank_launch_line():
     assert fx["n_gpus"] == 2 and fx["steps"] == 3 and fx["scaling"] == "strong" and fx["config"]["backend"] == "gloo"
     # whole-job aggregate: both ranks' cells
     assert abs(d["value"] - 2 * 10000 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    # a line of an N > 1 run explains itself: weak scaling with the per-rank rate; the freemuxlet leg carries the
+    # model's prediction next to the measurement and the exchange times
+    assert "weak scaling" in d["scaling_note"] and abs(d["per_rank_value"] * 2 - d["value"]) / d["value"] < 1e-12
+    sm = fx["scaling_model"]
+    assert sm["kernels_ms_rank0_last_iteration"] > 0 and sm["measured_ms_per_iteration"] == fx["ms_per_step"]
+    assert sm["predicted_ms_per_iteration"]["direct"] <= sm["predicted_ms_per_iteration"]["ring"]
+    assert "exchange_ms_rank0" in fx
+
+
+def test_dense_pileup_sensitivity_line():
+    """`--dense`: the same shape with 1 + Poisson(2) reads per entry, and once more without the linear-entry form"""
+    base = [sys.executable, BENCH, "--steps", "30", "--warmup", "5", "--ramp-seconds", "0.2", "--no-legs", "--no-cpu-baseline",
+            "--dense"]
+    a = run(base)
+    b = run(base + ["--no-linear"])
+    for d in (a, b):
+        assert d["sensitivity"]["reads_lambda"] == 2.0 and 2.5 < d["sensitivity"]["reads_per_entry"] < 3.5
+        assert 0.2 < d["sensitivity"]["linear_entry_share"] < 0.5
+    assert a["sensitivity"]["linear_entry_form"] and not b["sensitivity"]["linear_entry_form"]
+    assert b["ms_per_step"] > a["ms_per_step"]  # the linear class still pays on a third of the entries
 
 
 def test_plain_shell_gpus_n_launches_itself():
