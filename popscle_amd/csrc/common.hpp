@@ -418,9 +418,11 @@ struct ring_sel {          // one launch of demux_ring.hip
 
 // kernel launchers implemented in the kernel TUs
 int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
-int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream = false);
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream = false,
+                          bool by_record = false);
 int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
-                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt = nullptr);
+                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt = nullptr,
+                          bool pg_by_record = false);
 void demux_ring_release(muxgl_handle* h);
 int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable

@@ -89,7 +89,9 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nrows, cons
                                                               const double* __restrict__ lut_g, int nAlpha,
                                                               alpha_args al, double* __restrict__ pg,
                                                               const fmx_grec* __restrict__ rec,
-                                                              const uint8_t* __restrict__ has_gp) {
+                                                              const uint8_t* __restrict__ has_gp, int by_record) {
+  // by_record (with rec): row r of the table belongs to record r of the stream -- a quarter of the memory of the
+  // entry-indexed table, written in whole lines, and what the ring kernel's loader reads in the order it walks
   __shared__ double lut[384];
   __shared__ double stage[4][64 * 9 + 1];  // one alpha of a wave's 64 entries at a time (+1: odd stride, no bank conflicts)
   for (int i = threadIdx.x; i < 384; i += 256) lut[i] = lut_g[i];
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(256) demux_entry_pg_kernel(int64_t nrows, cons
       }
     }
     const int ne = (int)((nrows - eb < 64) ? (nrows - eb) : 64);
-    if (rec) {  // rows of a wave's records are far apart: every lane writes its own 72 * nAlpha bytes
+    if (rec && !by_record) {  // rows of a wave's records are far apart: every lane writes its own 72 * nAlpha bytes
       if (r < nrows) {
         double* o = pg + (size_t)rec[r].e * W;
         if ((W & 1) == 0) {  // rows are 16-byte aligned
@@ -419,14 +421,15 @@ int launch_sweep(muxgl_handle* h, const muxgl_demux_params* p, uint32_t symmask,
 }
 
 template <int NA>
-int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg, bool gen_stream) {
+int launch_entry_pg(muxgl_handle* h, const muxgl_demux_params* p, const alpha_args& al, double* d_pg, bool gen_stream,
+                    bool by_record) {
   const int64_t nrows = gen_stream ? h->nnz - h->n_lin_rec : h->nnz;
   int64_t blocks = (nrows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(demux_entry_pg_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, h->stream, nrows, h->d_entry_rptr,
                      h->d_reads, h->d_lut, p->n_alpha, al, d_pg, gen_stream ? h->d_gen_rec : (const fmx_grec*)nullptr,
-                     h->d_has_gp);
+                     h->d_has_gp, gen_stream && by_record ? 1 : 0);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -568,11 +571,12 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
 }
 
 // gen_stream: one row per NON-linear entry, in the order of h->d_gen_rec (needs plan_build_bit_streams)
-int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream) {
+// by_record (with gen_stream): the table is indexed by the record's position in the stream instead of by entry
+int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream, bool by_record) {
   const int A = p->n_alpha;
   alpha_args al;
   for (int i = 0; i < MUXGL_MAX_ALPHA; ++i) al.a[i] = (i < A) ? p->alpha[i] : p->alpha[0];
-#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg, gen_stream)
+#define CALL_PG(N) launch_entry_pg<N>(h, p, al, d_pg, gen_stream, by_record)
   DISPATCH_NA(A, CALL_PG);
 #undef CALL_PG
 }

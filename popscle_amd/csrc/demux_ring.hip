@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, 2)
                           const int64_t* __restrict__ lin_rank, const uint2* __restrict__ rrec,
                           const double* __restrict__ lutg, const double* __restrict__ gm, int V, int nAlpha, ring_sel sel,
                           const fmx_grec* __restrict__ gen_rec, const double* __restrict__ gp,
-                          const double* __restrict__ pgt, double* __restrict__ ll) {
+                          const double* __restrict__ pgt, int pg_by_record, double* __restrict__ ll) {
   constexpr int NS = NA > 0 ? 16 : 0, NSY = SYM ? 8 : 0, NACC = NA * NS + NSY;
   constexpr int NXL = NACC / 2, NXV = NACC - NXL;  // exponents in LDS / in registers (GEN: 36 KB + the 44 KB stage = 80 KB per workgroup)
   constexpr int GN = NS / 4, GS = NSY / 4, GT = GN + GS;  // groups of four ring reads per entry
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256, 2)
         for (int k = 0; k < 3; ++k) gl[k] = row[jo + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) hs[k] = row[k];  // sample 0's triple multiplies every singlet (:806,828)
-        const double* t = pgt + (size_t)r.e * PG;
+        const double* t = pgt + (size_t)(pg_by_record ? gi0 + (gin ? i : ng - 1) : r.e) * PG;  // (rows by record / by entry)
 #pragma unroll
         for (int k = 0; k < 9; ++k) q[0][k] = t[n0 * 9 + k], q[1][k] = t[n1 * 9 + k], q[2][k] = t[n2 * 9 + k];
       };
@@ -530,13 +530,14 @@ __global__ void __launch_bounds__(256, 2)
 
 template <int NA, bool SYM>
 void ring_launch(muxgl_handle* h, const wave_item* items, int64_t n_items, const double* lut, const double* gm, int A,
-                 const ring_sel& sel, const double* pgt, double* llw) {
+                 const ring_sel& sel, const double* pgt, bool pg_by_record, double* llw) {
   if (pgt)
     hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, true>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items,
-                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, llw);
+                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt,
+                       pg_by_record ? 1 : 0, llw);
   else
     hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, false>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items,
-                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, llw);
+                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, 0, llw);
 }
 
 }  // namespace
@@ -552,7 +553,7 @@ void demux_ring_release(muxgl_handle* h) {
 // pgt: the table of per-entry likelihoods [entry][alpha][9] -- the launch then also walks the units' other entries (GEN) and the
 // slab it writes is final; NULL: the linear entries only (the caller adds the others with demux_wave.hip's EM_GENERAL).
 int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
-                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt) {
+                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt, bool pg_by_record) {
   if (h->ring_rec_n != h->n_lin_rec || !h->d_ring_rec) {  // per pileup and genotype set (rows of markers without genotypes)
     if (dev_alloc(h, &h->d_ring_rec, (size_t)h->n_lin_rec + RL_PAD)) return 1;
     const int64_t nr = h->n_lin_rec + RL_PAD;
@@ -568,7 +569,7 @@ int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wa
   al.a[5] = sel.nsym > 0 ? p->alpha[sel.nsym] : p->alpha[0];
   hipLaunchKernelGGL(ring_lut_kernel, dim3(RL_NLUT), dim3(64), 0, h->stream, al, h->d_lut, h->d_ring_lut);
   const bool sym = sel.nsym > 0;
-#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, pgt, llw)
+#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, pgt, pg_by_record, llw)
   if (na == 4) sym ? RING(4, true) : RING(4, false);
   else if (na == 2) sym ? RING(2, true) : RING(2, false);
   else if (na == 1) sym ? RING(1, true) : RING(1, false);

@@ -727,14 +727,10 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   muxgl_wave_state* st = h->wave;
   const int A = p->n_alpha, V = h->V;
   const int nblk = (V + 63) / 64, nblk2 = nblk * nblk;  // 64 x 64 blocks of the pair matrix
-  const size_t need = (size_t)h->nnz * A * 9;
+  size_t need = (size_t)h->nnz * A * 9;
   const size_t llw_need = (size_t)(h->C + st->n_over) * nblk2 * A * 4096;
   // pG table, result slabs and (V > 64) the tensor the call kernel reads must fit comfortably: else the tile sweep
   if (((double)need + (double)llw_need + (nblk > 1 ? (double)h->C * V * V * A : 0.0)) * 8.0 > 230e9) return -1;
-  if (need > st->pg_cap) {
-    if (dev_alloc(h, &st->d_pg, need)) return 1;
-    st->pg_cap = need;
-  }
   if (llw_need > h->llw_cap) {
     if (dev_alloc(h, &h->d_llw, llw_need)) return 1;
     h->llw_cap = llw_need;
@@ -759,8 +755,17 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   // the ring kernel walks a unit's other entries too, with the same accumulators: one write of the slab
   // (MUXGL_FLAG_SPLIT_GENERAL_SWEEP: launches of their own on top of it, as in round 3 -- lets tests compare the two)
   const bool ring_gen = use_lin && !(h->flags & MUXGL_FLAG_SPLIT_GENERAL_SWEEP);
+  // ... and then nobody but its loader reads the table, record by record in the order of the stream: rows by record (a
+  // quarter of the entry-indexed table: 10 GB instead of 41 at configs[2]; allocating those 41 GB was most of a first
+  // call's extra second)
+  const bool pg_by_record = ring_gen && gen_only;
+  if (pg_by_record) need = (size_t)(h->nnz - h->n_lin_rec) * A * 9;
+  if (need > st->pg_cap) {
+    if (dev_alloc(h, &st->d_pg, need ? need : 1)) return 1;
+    st->pg_cap = need;
+  }
   tic(h, MUXGL_T_DEMUX_SWEEP);
-  if (demux_entry_pg_launch(h, p, st->d_pg, gen_only)) return 1;
+  if (demux_entry_pg_launch(h, p, st->d_pg, gen_only, pg_by_record)) return 1;
   if (h->nnz && !gen_only)  // (gen_only: the kernel writes the neutral rows itself)
     hipLaunchKernelGGL(wave_neutral_pg_kernel, dim3((unsigned)((h->nnz + 255) / 256)), dim3(256), 0, h->stream, h->nnz,
                        A * 9, h->d_entry_snp, h->d_has_gp, st->d_pg);
@@ -852,7 +857,8 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
         rs.nsym = nsym;
         rs.with_singlet = first ? 1 : 0;
         rs.jbase = 64 * X, rs.blk = wb.blk, rs.nblk2 = nblk2;
-        return demux_ring_lin_launch(h, p, st->d_items, st->n_items, st->d_gm, na, rs, h->d_llw, ring_gen ? st->d_pg : nullptr);
+        return demux_ring_lin_launch(h, p, st->d_items, st->n_items, st->d_gm, na, rs, h->d_llw, ring_gen ? st->d_pg : nullptr,
+                                     pg_by_record);
       };
       while (plain.size() - done >= 4) {
         wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};

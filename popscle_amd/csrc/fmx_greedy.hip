@@ -284,7 +284,10 @@ __global__ void __launch_bounds__(GT)
 //   4. greedy_apply_kernel (whole chip): the batch's merges into the (cluster, SNP) states, one thread per chain of
 //      entries at the same SNP walking it in cell order (the order matters only inside a chain: merge() clamps).
 // No state is written while a batch is being decided, so the "snapshot" is simply the table itself.
-constexpr int GB = 32;     // cells per batch
+#ifndef MUXGL_GREEDY_GB
+#define MUXGL_GREEDY_GB 32
+#endif
+constexpr int GB = MUXGL_GREEDY_GB;  // cells per batch
 constexpr int GCH = 64;    // entries per workgroup of greedy_dist_kernel
 constexpr int GA_T = 256;
 

@@ -288,14 +288,9 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
     }
     const uint64_t numi = parse_plp_gz(prefix, po, rds, &sorted);
     tm.lap("plp inflate+parse");
-    for (const PlpRead& r : rds) {
-      ++out.cell_totl_reads[(size_t)r.cell];
-      ++out.cell_uniq_reads[(size_t)r.cell];  // every kept base is its own UMI (:361-368)
-    }
     notice("Finished loading %llu UMIs in total..", (unsigned long long)numi);
   }
   // order: cell, SNP, then the reference's std::map<std::string> order of the "%x" UMI strings
-  tm.lap("plp counts");
   std::vector<int64_t> cell_rd0;  // first read of every cell in the ordered list
   if (out.slabbed) {  // the kept rows go to the row slab (cells renumbered), to the column slab, or to both
     PlpReadVec rows, cols;
@@ -340,6 +335,8 @@ inline void load_from_plp(const std::string& prefix, const LoadOptions& opt, Vcf
     return;
   }
   plp_order_by_cell(rds, C, sorted, cell_rd0);
+  for (int64_t c = 0; c < C; ++c)  // kept bases per cell; every kept base is its own UMI (:361-368)
+    out.cell_totl_reads[(size_t)c] = out.cell_uniq_reads[(size_t)c] = (int32_t)(cell_rd0[(size_t)c + 1] - cell_rd0[(size_t)c]);
   tm.lap("plp order");
   plp_pack(rds, C, cell_rd0, out.cell_ptr, out.entry_snp, out.entry_rptr, out.reads);
   tm.lap("plp pack");

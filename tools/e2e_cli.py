@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--cpp-writer", action="store_true",
                     help="write the data set with `popscle-amd synth-plp` (same generator family, BGZF, seconds instead of "
                          "minutes at 10^8 rows)")
+    ap.add_argument("--skip-demuxlet", action="store_true", help="freemuxlet only")
     ap.add_argument("--alpha", action="append", default=[], help="demuxlet --alpha values (default: the command's {0, 0.5})")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
@@ -81,13 +82,15 @@ def main():
         subprocess.run([BIN, "bgzf", "--in", prefix + ".plp.txt", "--out", prefix + ".plp.gz"], check=True)
         os.remove(prefix + ".plp.txt")
         print(f"re-compressed as BGZF: plp.gz {os.path.getsize(prefix + '.plp.gz') / 1e6:.1f} MB")
-    print("demuxlet --field GT:")
-    alphas = [x for v in a.alpha for x in ("--alpha", v)]
-    dt = run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", os.path.join(a.dir, "dmx")] + alphas)
-    print(f"    => {rows / dt / 1e6:.2f} M PLP rows/s end to end")
+    if not a.skip_demuxlet:
+        print("demuxlet --field GT:")
+        alphas = [x for v in a.alpha for x in ("--alpha", v)]
+        dt = run([BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", os.path.join(a.dir, "dmx")] + alphas)
+        print(f"    => {rows / dt / 1e6:.2f} M PLP rows/s end to end")
     if a.freemuxlet:
         print(f"freemuxlet --nsample {a.freemuxlet}:")
-        run([BIN, "freemuxlet", "--plp", prefix, "--nsample", str(a.freemuxlet), "--out", os.path.join(a.dir, "fmx")])
+        dt = run([BIN, "freemuxlet", "--plp", prefix, "--nsample", str(a.freemuxlet), "--out", os.path.join(a.dir, "fmx")])
+        print(f"    => {rows / dt / 1e6:.2f} M PLP rows/s end to end")
     if a.freemuxlet_old:
         print(f"freemuxlet-old --nsample {a.freemuxlet_old}:")
         run([BIN, "freemuxlet-old", "--plp", prefix, "--nsample", str(a.freemuxlet_old), "--out",
