@@ -59,9 +59,34 @@ def main():
     ap.add_argument("--sq")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--smi", default="", help="rocm-smi --json samples taken during the trace pass (profile_bench.sh)")
     a = ap.parse_args()
     stats = load_stats(a.kt) if a.kt else {}
     summary = {"note": a.note, "kernels": {}}
+    clock_note = ""
+    if a.smi and os.path.exists(a.smi):
+        sclk, pw = [], []
+        for ln in open(a.smi):
+            try:
+                d = json.loads(ln)["card0"]
+            except Exception:
+                continue
+            for k, v in d.items():
+                m = re.search(r"\((\d+)Mhz\)", str(v))
+                if "sclk" in k and m:
+                    sclk.append(int(m.group(1)))
+                if "Power" in k:
+                    try:
+                        pw.append(float(str(v).split()[0]))
+                    except Exception:
+                        pass
+        busy = sorted(x for x in sclk if x > 500)
+        if busy:
+            summary["box_clock"] = {"sclk_mhz_median_busy": busy[len(busy) // 2], "sclk_mhz_max": busy[-1], "samples": len(sclk),
+                                    "power_w_max": max(pw) if pw else None}
+            clock_note = (f"Box clock during the trace pass (rocm-smi, {len(sclk)} samples every 0.25 s): shader clock median of the "
+                          f"busy samples {busy[len(busy) // 2]} MHz, max {busy[-1]} MHz" +
+                          (f"; package power max {max(pw):.0f} W" if pw else "") + ".\n\n")
     fetch, meta = load_counters(a.fetch) if a.fetch else ({}, {})
     write, _ = load_counters(a.write) if a.write else ({}, {})
     sq, meta2 = load_counters(a.sq) if a.sq else ({}, {})
@@ -82,8 +107,11 @@ def main():
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(summary, open(a.out + ".json", "w"), indent=1, sort_keys=True)
     with open(a.out + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary: {os.path.basename(a.out)}\n\n{a.note}\n\n")
-        f.write("| kernel | calls | avg us | min us | max us | % | VGPR | AGPR | LDS B | FETCH KB | WRITE KB | HBM MB/launch (fetch x2) |\n")
+        f.write(f"# rocprofv3 summary: {os.path.basename(a.out)}\n\n{a.note}\n\n{clock_note}")
+        f.write("The VGPR column is rocprofv3's `VGPR_Count` field, which on gfx950 reads about half of what the compiler "
+                "allocates per lane (e.g. 84 for the 164 of `demux_oct_kernel`); the compiler's own numbers -- the ones "
+                "occupancy follows -- are asserted in `tests/test_isa.py` and printed by `tools/kres.py`.\n\n")
+        f.write("| kernel | calls | avg us | min us | max us | % | VGPR_Count (rocprofv3) | AGPR | LDS B | FETCH KB | WRITE KB | HBM MB/launch (fetch x2) |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k, e in summary["kernels"].items():
             f.write("| {} | {} | {:.1f} | {:.1f} | {:.1f} | {:.1f} | {} | {} | {} | {} | {} | {} |\n".format(

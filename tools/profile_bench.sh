@@ -20,7 +20,11 @@ pass() {  # tag, counters, bench args
   echo "c$CFG $tag rc=$?"
 }
 SHORT="--steps 3 --warmup 1 --ramp-seconds 0"
+# shader clock and package power while the trace pass runs (rocm-smi every 0.25 s; the summary quotes the busy samples)
+( while true; do rocm-smi --showclocks --showpower --json 2>/dev/null | tr -d '\n'; echo; sleep 0.25; done ) > ${P}_smi.jsonl &
+SMI=$!
 pass kt KT --steps $KT_STEPS --warmup $((KT_STEPS / 10 + 1)) --ramp-seconds 0.3
+kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
 pass fetch "FETCH_SIZE" $SHORT
 pass write "WRITE_SIZE" $SHORT
 pass f64 "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" $SHORT
