@@ -50,7 +50,8 @@ struct muxgl_row_state {
   int64_t* d_cell_chunk_ptr = nullptr;  // [C+1]
   int32_t* d_cell_chunks = nullptr;     // chunk positions of each cell in entry order
   int32_t* d_kmap = nullptr;            // [16][16]: sample held by lane j after t DPP row rotations
-  int32_t* d_tmap = nullptr;            // [2][4]: tile seen by a quad lane after row_ror:4 / row_ror:8
+  int32_t* d_tmap = nullptr;            // [P/2][P]: position seen by a lane of the oct tiling after each rotation (P = tmap_p)
+  int tmap_p = 0;
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
   quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
   int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_oct.hip, built on first use)

@@ -536,7 +536,9 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   if (h->V > 16 && h->V <= 32 && !(h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_WAVE_KERNEL))) {
     if (h->want_full_ll && demux_ensure_ll(h, p)) return 1;  // (without the tensor the call is made in LDS)
-    rc = demux_row2_launch(h, p);    // {a0, 0.5} up to 32 samples: row kernel with two samples per lane
+    rc = demux_oct_launch(h, p);     // the default grid {0, 0.5}: the oct tiling with sixteen lanes per entry
+    if (rc == 0 && h->records_on_host) return 0;
+    if (rc < 0) rc = demux_row2_launch(h, p);  // {a0, 0.5} (or MUXGL_FLAG_FORCE_ROW_KERNEL): row kernel, two samples per lane
     if (rc == 0 && h->records_on_host) return 0;  // reduce and call were fused into its finish kernel
   }
   if (rc < 0) rc = demux_wave_launch(h, p);  // one wave per cell and 64 x 64 block of the pair matrix, lane = sample

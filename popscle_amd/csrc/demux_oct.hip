@@ -47,11 +47,32 @@ namespace {
 #endif
 constexpr int O_NLUT = 129;        // {A, B, 2B} by (allele << 6 | base quality <= 63), and one neutral entry
 constexpr int O_LPAD = 3;          // steps of neutral records behind a unit's longest linear list (the loop reads ahead)
-constexpr int ON_ACC = 18;         // per lane: 2 singlets, 1 in-lane pair, 3 x 4 pairs with the partners at 1..3, 3 at 4
-constexpr int O_SLOTS = 8;         // entry streams (chunks) per wave
-constexpr int O_BATCH = 8;         // entries per slot and phase 1 (64 lanes <-> 8 slots x 8 entries)
-constexpr int O_SLOT_STRIDE = 74;  // doubles: 8 entries x 8 likelihoods + 8 singlet factors + 2 pad (bank spread)
-constexpr int O_NHYP = ON_ACC * 8; // accumulators of a chunk: 144 slots for the 136 hypotheses
+
+// Geometry of the tiling, by the number P of lanes ("positions") an entry occupies: P = 8 for V <= 16 samples (lane p
+// owns samples p and p + 8; two entries share a 16-lane DPP row, interleaved, so row_ror:2t rotates both rings of eight
+// by t), P = 16 for 16 < V <= 32 (round 4: lane p owns samples p and p + 16, an entry IS a DPP row, row_ror:t).
+// Rotations t = 1 .. P/2 - 1 bring the partner's two samples (four pairs each); at t = P/2 lane p faces lane p + P/2
+// and takes (a, b'), both take (a, a') and (b, b') (published once).
+template <int P>
+struct og {
+  static_assert(P == 8 || P == 16, "eight or sixteen lanes per entry");
+  static constexpr int SLOTS = 64 / P;            // entry streams (chunks) per wave
+  static constexpr int BATCH = P;                 // entries per slot and phase 1 (64 lanes <-> SLOTS x P entries)
+  static constexpr int NROT = P / 2 - 1;          // full rotations
+  static constexpr int N_ACC = 3 + 4 * NROT + 3;  // per lane: 2 singlets, the in-lane pair, 4 per rotation, 3 facing (18 / 34)
+  static constexpr int N_HYP = N_ACC * P;         // accumulators of a chunk: 144 slots for 136 hypotheses / 544 for 528
+  static constexpr int SLOT_STRIDE = 9 * P + 2;   // doubles: P entries x 8 likelihoods + P singlet factors + 2 pad (bank spread)
+  static constexpr int ACC_AB = 2;                // (a, b)
+  static constexpr int ACC_F_AB = 3 + 4 * NROT, ACC_F_AA = ACC_F_AB + 1, ACC_F_BB = ACC_F_AB + 2;  // (a, b'), (a, a'), (b, b')
+  __host__ __device__ static constexpr int acc_single(int c) { return c; }  // c = 0: a, 1: b
+  __host__ __device__ static constexpr int acc_rot(int t, int c, int d) { return 3 + (t - 1) * 4 + c * 2 + d; }  // t = 1 .. NROT
+  __host__ __device__ static constexpr int ror(int t) { return 0x120 + (P == 8 ? 2 * t : t); }  // DPP control: rotation by t positions
+  __device__ static __forceinline__ int pos(int lane) { return P == 8 ? (lane >> 1) & 7 : lane & 15; }
+  __device__ static __forceinline__ int slot(int lane) { return P == 8 ? ((lane >> 4) << 1) | (lane & 1) : lane >> 4; }
+  __device__ static __forceinline__ int lane0(int lane) { return P == 8 ? lane & ~14 : lane & ~15; }  // position 0 of the slot
+  static constexpr uint32_t MROW = 32u * P;       // bytes of a marker's row of moments (s, rho) x 2P samples (unit sums: half)
+  static constexpr int TROW = 6 * P;              // doubles of a marker's row of triples
+};
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_rot(double x) {
@@ -60,22 +81,17 @@ __device__ __forceinline__ double dpp_rot(double x) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-constexpr int ROR2 = 0x122, ROR4 = 0x124, ROR6 = 0x126, ROR8 = 0x128;  // row_ror:2t = the ring of eight positions by t
 
-// position (0..7) whose samples a lane sees after row_ror:2t, t = 1..4, measured rather than assumed
-__global__ void oct_pmap_kernel(int32_t* pmap /*[4][8]*/) {
+// position whose samples a lane sees after the rotation by t, t = 1 .. P/2, measured rather than assumed: pmap[P/2][P]
+template <int P>
+__global__ void oct_pmap_kernel(int32_t* pmap) {
   const int lane = threadIdx.x;
-  const int p = (lane >> 1) & 7;
-  const int p1 = __builtin_amdgcn_mov_dpp(p, ROR2, 0xF, 0xF, false);
-  const int p2 = __builtin_amdgcn_mov_dpp(p, ROR4, 0xF, 0xF, false);
-  const int p3 = __builtin_amdgcn_mov_dpp(p, ROR6, 0xF, 0xF, false);
-  const int p4 = __builtin_amdgcn_mov_dpp(p, ROR8, 0xF, 0xF, false);
-  if (lane < 16 && (lane & 1) == 0) {
-    pmap[p] = p1;
-    pmap[8 + p] = p2;
-    pmap[16 + p] = p3;
-    pmap[24 + p] = p4;
-  }
+  const int p = og<P>::pos(lane);
+  wave_for<1, P / 2 + 1>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const int pt = __builtin_amdgcn_mov_dpp(p, og<P>::ror(t), 0xF, 0xF, false);
+    if (og<P>::slot(lane) == 0) pmap[(t - 1) * P + p] = pt;
+  });
 }
 
 // A chunk's entry records with its linear entries (at most one usable read, plan_kernels.hip: lin_kernel) first, both
@@ -130,29 +146,29 @@ __global__ void __launch_bounds__(256)
 // Steps of a unit's linear loop: the longest linear list among its eight chunks, rounded to the loop's unrolling, plus
 // the read-ahead (0 for a unit without linear entries).
 __global__ void __launch_bounds__(256)
-    oct_unit_steps_kernel(int n_units, int n_chunks, const int32_t* __restrict__ order, const int32_t* __restrict__ nlin,
-                          int32_t* __restrict__ steps) {
+    oct_unit_steps_kernel(int n_units, int n_chunks, int slots, const int32_t* __restrict__ order,
+                          const int32_t* __restrict__ nlin, int32_t* __restrict__ steps) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_units) return;
   int m = 0;
-  for (int k = 0; k < O_SLOTS; ++k) {
-    const int w = u * O_SLOTS + k;
+  for (int k = 0; k < slots; ++k) {
+    const int w = u * slots + k;
     if (w < n_chunks) m = max(m, nlin[order[w]]);
   }
   steps[u] = m > 0 ? (m + 2) / 3 * 3 + O_LPAD : 0;
 }
 
-// The linear entries' records in the order the sweep reads them: orec[unit_ptr[u] + i * 8 + slot], one 64-byte line per
-// step of a wave.  {byte offset of the marker's row of moments, byte offset of the entry's {A, B, 2B}}.
+// The linear entries' records in the order the sweep reads them: orec[unit_ptr[u] + i * slots + slot], one 64-byte line
+// (eight slots) or half of one (four) per step of a wave.  {byte offset of the marker's row of moments, byte offset of the entry's {A, B, 2B}}.
 __global__ void __launch_bounds__(256)
     oct_repack_kernel(int n_units, int n_chunks, const row_chunk* __restrict__ chunks, const int32_t* __restrict__ order,
                       const int32_t* __restrict__ nlin, const quad_lrec* __restrict__ lrec,
                       const int32_t* __restrict__ steps, const int64_t* __restrict__ unit_ptr, uint32_t S_dummy,
-                      uint2* __restrict__ orec) {
+                      int slots, uint32_t mrow /* bytes of a marker's row of moments */, uint2* __restrict__ orec) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int u = t / O_SLOTS, slot = t % O_SLOTS;
+  const int u = t / slots, slot = t % slots;
   if (u >= n_units) return;
-  const int w = u * O_SLOTS + slot;
+  const int w = u * slots + slot;
   int64_t e0 = 0;
   int nl = 0;
   if (w < n_chunks) {
@@ -163,21 +179,15 @@ __global__ void __launch_bounds__(256)
   uint2* dst = orec + unit_ptr[u] + slot;
   const int n = steps[u];
   for (int i = 0; i < n; ++i) {
-    uint2 r{S_dummy * 256u, (uint32_t)(O_NLUT - 1) * 32u};
+    uint2 r{S_dummy * mrow, (uint32_t)(O_NLUT - 1) * 32u};
     if (i < nl) {
       const quad_lrec x = lrec[e0 + i];
       const uint32_t idx = x.code == MUXGL_READ_OTHER ? (uint32_t)(O_NLUT - 1) : ((x.code >> 7) << 6) | (x.code & 0x3fu);
-      r = uint2{(uint32_t)x.snp * 256u, idx * 32u};
+      r = uint2{(uint32_t)x.snp * mrow, idx * 32u};
     }
-    dst[(size_t)i * O_SLOTS] = r;
+    dst[(size_t)i * slots] = r;
   }
 }
-
-// accumulator index layout of a lane (own samples a = p, b = p + 8; partner at rotation t: a' = p_t, b' = p_t + 8)
-__host__ __device__ constexpr int o_acc_single(int c) { return c; }              // c = 0: a, 1: b
-constexpr int O_ACC_AB = 2;                                                       // (a, b)
-__host__ __device__ constexpr int o_acc_rot(int t, int c, int d) { return 3 + (t - 1) * 4 + c * 2 + d; }  // t = 1..3
-constexpr int O_ACC_F_AB = 15, O_ACC_F_AA = 16, O_ACC_F_BB = 17;                  // t = 4: (a, b'), (a, a'), (b, b')
 
 // The sweep kernel.  Lane = 16 g + 2 p + h: slot 2 g + h of the wave (one chunk), position p (samples p, p + 8).
 // UNIT_S: every triple of the GP tensor sums to 1 within 4 ulp (muxgl_demux_set_gp checks; hard calls through the
@@ -187,8 +197,8 @@ constexpr int O_ACC_F_AB = 15, O_ACC_F_AA = 16, O_ACC_F_BB = 17;                
 // by <= 8 ulp.  (Rows of triples stay whole: g0 = 1 - g1 - g2 has an absolute error of an ulp of 1, which is a
 // relative error of 1e-4 where a genotype no sample carries has probability 0.1 * 1e-10 / V after the mixing -- tried,
 // and caught by the test with qualities up to 93.)
-template <bool UNIT_S>
-__global__ void __launch_bounds__(64, 3)
+template <int P, bool UNIT_S>
+__global__ void __launch_bounds__(64, P == 8 ? 3 : 2)
     demux_oct_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
                      const uint2* __restrict__ orec, const int64_t* __restrict__ unit_ptr,
                      const int32_t* __restrict__ chunk_nlin,
@@ -198,12 +208,15 @@ __global__ void __launch_bounds__(64, 3)
                      const int32_t* __restrict__ chunk_pos, double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double ablut[O_NLUT * 4];
+  using G = og<P>;
+  constexpr int ON_ACC = G::N_ACC, O_SLOTS = G::SLOTS, O_BATCH = G::BATCH, O_SLOT_STRIDE = G::SLOT_STRIDE;
+  constexpr int O_ACC_AB = G::ACC_AB, O_ACC_F_AB = G::ACC_F_AB, O_ACC_F_AA = G::ACC_F_AA, O_ACC_F_BB = G::ACC_F_BB;
   __shared__ __align__(16) double pgs[O_SLOTS * O_SLOT_STRIDE];
   __shared__ int32_t snps[64], snps_nx[64];
 
   const int lane = threadIdx.x;
-  const int p = (lane >> 1) & 7;                    // position: samples p and p + 8
-  const int slot = ((lane >> 4) << 1) | (lane & 1);  // 8 entry streams per wave
+  const int p = G::pos(lane);    // position: samples p and p + P
+  const int slot = G::slot(lane);  // 64 / P entry streams per wave
   for (int i = lane; i < 384; i += 64) lut[i] = lut_g[i];
   // {A, B, 2B} of a linear entry by the read byte that counts (allele << 6 | base quality; O_NLUT - 1: none): the one
   // factor pR + (pA - pR) p of :673,685 through the tail (q / q_max + 1e-10) / (1 + 1e-10) of :703-725;
@@ -260,7 +273,7 @@ __global__ void __launch_bounds__(64, 3)
   double accH = 1.0;            // nine-term entries: product of sample 0's sums, which every singlet carries (:806)
   int32_t exH = 0;
 
-  auto renorm = [&]() {
+  auto renorm = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < ON_ACC; ++a) prodacc_renorm(acc[a], exs[a]);
     prodacc_renorm(accW[0], exW[0]);
@@ -283,8 +296,8 @@ __global__ void __launch_bounds__(64, 3)
     struct rowl_t {
       double sa, ra, sb, rb;  // (s, rho) of samples p and p + 8
     };
-    auto load_rowl = [&](rowl_t& R, uint32_t row_off) {
-      if (UNIT_S) {  // rows of 16 x rho, (rho_p, rho_p+8) adjacent: [8][2]
+    auto load_rowl = [&](rowl_t& R, uint32_t row_off) __attribute__((always_inline)) {
+      if (UNIT_S) {  // rows of 2P x rho, (rho_p, rho_p+P) adjacent: [P][2]
         const double2 v = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gmo) + (size_t)((row_off >> 1) + p16));
         R.sa = R.sb = 1.0;
         R.ra = v.x;
@@ -292,7 +305,7 @@ __global__ void __launch_bounds__(64, 3)
         return;
       }
       const double2* pc = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(gmo) + (size_t)(row_off + p16));
-      const double2 va = pc[0], vb = pc[8];
+      const double2 va = pc[0], vb = pc[P];
       R.sa = va.x;
       R.ra = va.y;
       R.sb = vb.x;
@@ -305,12 +318,12 @@ __global__ void __launch_bounds__(64, 3)
     struct ab_t {
       double A, B, B2;
     };
-    auto ab_of = [&](const uint2& rc) {
+    auto ab_of = [&](const uint2& rc) __attribute__((always_inline)) {
       const double* t = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ablut) + rc.y);
       const double2 v = *reinterpret_cast<const double2*>(t);
       return ab_t{v.x, v.y, t[2]};
     };
-    auto sweepL = [&](const rowl_t& R, const ab_t& ab) {
+    auto sweepL = [&](const rowl_t& R, const ab_t& ab) __attribute__((always_inline)) {
       const double A = ab.A, B = ab.B, B2 = ab.B2;
       if (OCT_EXP & 128) {  // (experiment) the loads with next to no arithmetic
         accW[0] *= R.sa;
@@ -323,33 +336,20 @@ __global__ void __launch_bounds__(64, 3)
         accW[0] *= R.sa;
         accW[1] *= R.sb;
       }
-      acc[o_acc_single(0)] *= fma(B2, R.ra, A);  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
-      acc[o_acc_single(1)] *= fma(B2, R.rb, A);
+      acc[G::acc_single(0)] *= fma(B2, R.ra, A);  // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
+      acc[G::acc_single(1)] *= fma(B2, R.rb, A);
       const double Xa = fma(B, R.ra, A), Xb = fma(B, R.rb, A);
       acc[O_ACC_AB] *= fma(B, R.rb, Xa);
-      {
-        const double Pa = dpp_rot<ROR2>(R.ra), Pb = dpp_rot<ROR2>(R.rb);
-        acc[o_acc_rot(1, 0, 0)] *= fma(B, Pa, Xa);
-        acc[o_acc_rot(1, 0, 1)] *= fma(B, Pb, Xa);
-        acc[o_acc_rot(1, 1, 0)] *= fma(B, Pa, Xb);
-        acc[o_acc_rot(1, 1, 1)] *= fma(B, Pb, Xb);
-      }
-      {
-        const double Pa = dpp_rot<ROR4>(R.ra), Pb = dpp_rot<ROR4>(R.rb);
-        acc[o_acc_rot(2, 0, 0)] *= fma(B, Pa, Xa);
-        acc[o_acc_rot(2, 0, 1)] *= fma(B, Pb, Xa);
-        acc[o_acc_rot(2, 1, 0)] *= fma(B, Pa, Xb);
-        acc[o_acc_rot(2, 1, 1)] *= fma(B, Pb, Xb);
-      }
-      {
-        const double Pa = dpp_rot<ROR6>(R.ra), Pb = dpp_rot<ROR6>(R.rb);
-        acc[o_acc_rot(3, 0, 0)] *= fma(B, Pa, Xa);
-        acc[o_acc_rot(3, 0, 1)] *= fma(B, Pb, Xa);
-        acc[o_acc_rot(3, 1, 0)] *= fma(B, Pa, Xb);
-        acc[o_acc_rot(3, 1, 1)] *= fma(B, Pb, Xb);
-      }
+      wave_for<1, G::NROT + 1>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const double Pa = dpp_rot<G::ror(t)>(R.ra), Pb = dpp_rot<G::ror(t)>(R.rb);
+        acc[G::acc_rot(t, 0, 0)] *= fma(B, Pa, Xa);
+        acc[G::acc_rot(t, 0, 1)] *= fma(B, Pb, Xa);
+        acc[G::acc_rot(t, 1, 0)] *= fma(B, Pa, Xb);
+        acc[G::acc_rot(t, 1, 1)] *= fma(B, Pb, Xb);
+      });
       {  // the lane facing this one: (a, b') here and (a', b) over there; (a, a') and (b, b') on both sides
-        const double Pa = dpp_rot<ROR8>(R.ra), Pb = dpp_rot<ROR8>(R.rb);
+        const double Pa = dpp_rot<G::ror(P / 2)>(R.ra), Pb = dpp_rot<G::ror(P / 2)>(R.rb);
         acc[O_ACC_F_AB] *= fma(B, Pb, Xa);
         acc[O_ACC_F_AA] *= fma(B, Pa, Xa);
         acc[O_ACC_F_BB] *= fma(B, Pb, Xb);
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(64, 3)
     };
     // entry i: its row in Rc and {A, B, 2B} in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
     auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const ab_t& abc, ab_t& abn, uint2& rc0, const uint2& rc1,
-                    const uint2& rc2) {
+                    const uint2& rc2) __attribute__((always_inline)) {
       if (OCT_EXP & 32) {  // (experiment) no record loads: a cheap pseudo-random record
         rc0.x = (rc0.x * 1664525u + 1013904223u) & 0x00FFFF00u;
       } else {
@@ -396,11 +396,11 @@ __global__ void __launch_bounds__(64, 3)
   // it is used: a predicated load followed by a merge with the defaults makes the compiler wait for the load on the spot)
   if (nb > 0) {
     const int last = len > 0 ? len - 1 : 0;
-    auto fetch_meta = [&](int b) {
+    auto fetch_meta = [&](int b) __attribute__((always_inline)) {
       const int idx = nl + b * O_BATCH + p;
       return qent[e0 + (idx < last ? idx : last)];
     };
-    auto snp_of = [&](const quad_entry& r, int b) { return (nl + b * O_BATCH + p < len) ? r.snp : -1; };
+    auto snp_of = [&](const quad_entry& r, int b) __attribute__((always_inline)) { return (nl + b * O_BATCH + p < len) ? r.snp : -1; };
     quad_entry precA = fetch_meta(0), precB = fetch_meta(1);
     // sum of sample 0's triple at the lane's own entry (negative: marker without genotypes), one batch ahead as well
     double hs_cur = gp0s[precA.snp];
@@ -408,12 +408,12 @@ __global__ void __launch_bounds__(64, 3)
     struct row_t {
       double a[3], b[3];  // triples of samples p and p + 8
     };
-    auto load_row = [&](row_t& R, int32_t s) {
+    auto load_row = [&](row_t& R, int32_t s) __attribute__((always_inline)) {
       // 16-byte pieces of this lane's doubles; a piece of the entry's eight lanes is 128 contiguous bytes.  Rows of
       // padding entries and of markers without genotypes are (1,0,0) -- the dummy row S_dummy resp. the host's fill --
       // which together with read likelihoods of 1 (phase 1) makes every factor of such an entry exactly 1 (:733).
-      const double2* pc = reinterpret_cast<const double2*>(gpo + (size_t)s * 48) + p;
-      const double2 v0 = pc[0], v1 = pc[8], v2 = pc[16];
+      const double2* pc = reinterpret_cast<const double2*>(gpo + (size_t)s * G::TROW) + p;
+      const double2 v0 = pc[0], v1 = pc[P], v2 = pc[2 * P];
       R.a[0] = v0.x;
       R.a[1] = v0.y;
       R.a[2] = v1.x;
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64, 3)
 
     // phase 1 of a batch.  cmd_cram_demuxlet.cpp:655-725 for alpha in {0, 0.5}:
     //      q0[l] = prod_reads (pR + d*l/2),  q1[t] = prod_reads (pR + d*t/4), t = l+m, d = pA - pR
-    auto phase1 = [&](int b) {
+    auto phase1 = [&](int b) __attribute__((always_inline)) {
       const int32_t sa = snp_of(precA, b);
       const int32_t s = (hs_cur >= 0.0) ? sa : -1;  // no genotypes: the entry is skipped (:733)
       const double hs_out = (s >= 0) ? hs_cur : 1.0;       // multiplies every singlet (:806)
@@ -528,21 +528,21 @@ __global__ void __launch_bounds__(64, 3)
       dst[2] = q0[2];
 #pragma unroll
       for (int t = 0; t < 5; ++t) dst[3 + t] = q1[t];
-      pgs[slot * O_SLOT_STRIDE + 64 + p] = hs_out;
-      snps[slot * 8 + p] = (s >= 0) ? s : S_dummy;
+      pgs[slot * O_SLOT_STRIDE + 8 * P + p] = hs_out;
+      snps[slot * P + p] = (s >= 0) ? s : S_dummy;
       const int32_t sn = snp_of(precA, b + 1);
-      snps_nx[slot * 8 + p] = (sn >= 0) ? sn : S_dummy;  // next batch; its no-genotype rows are (1,0,0)
+      snps_nx[slot * P + p] = (sn >= 0) ? sn : S_dummy;  // next batch; its no-genotype rows are (1,0,0)
     };
 
     // phase 2 for entry i of the slot's batch: lane <-> 2 samples
-    auto sweep_entry = [&](const row_t& R, int i) {
+    auto sweep_entry = [&](const row_t& R, int i) __attribute__((always_inline)) {
       const double* qq = pgs + slot * O_SLOT_STRIDE + i * 8;
       const double a0 = qq[0], a1 = qq[1], a2 = qq[2];
       const double b0 = qq[3], b1 = qq[4], b2 = qq[5], b3 = qq[6], b4 = qq[7];
-      if (!UNIT_S) accH *= pgs[slot * O_SLOT_STRIDE + 64 + i];
+      if (!UNIT_S) accH *= pgs[slot * O_SLOT_STRIDE + 8 * P + i];
       // singlet slot llksAB[j][0][0] (:806,828), alpha = 0
-      acc[o_acc_single(0)] *= fma(R.a[2], a2, fma(R.a[1], a1, R.a[0] * a0));
-      acc[o_acc_single(1)] *= fma(R.b[2], a2, fma(R.b[1], a1, R.b[0] * a0));
+      acc[G::acc_single(0)] *= fma(R.a[2], a2, fma(R.a[1], a1, R.a[0] * a0));
+      acc[G::acc_single(1)] *= fma(R.b[2], a2, fma(R.b[1], a1, R.b[0] * a0));
       // u[m] = sum_l g_j[l] * pG[alpha=.5][l][m],  pG[l][m] = b[l+m]
       double ua[3], ub[3];
       ua[0] = fma(R.a[2], b2, fma(R.a[1], b1, R.a[0] * b0));
@@ -553,81 +553,79 @@ __global__ void __launch_bounds__(64, 3)
       ub[2] = fma(R.b[2], b4, fma(R.b[1], b3, R.b[0] * b2));
       auto dot = [](const double* g, const double* u) { return fma(g[2], u[2], fma(g[1], u[1], g[0] * u[0])); };  // :738-746
       acc[O_ACC_AB] *= dot(R.b, ua);
-#define OCT_ROT(T, CTRL)                                                                             \
-  {                                                                                                  \
-    double Pa[3], Pb[3];                                                                             \
-    Pa[0] = dpp_rot<CTRL>(R.a[0]);                                                                   \
-    Pa[1] = dpp_rot<CTRL>(R.a[1]);                                                                   \
-    Pa[2] = dpp_rot<CTRL>(R.a[2]);                                                                   \
-    Pb[0] = dpp_rot<CTRL>(R.b[0]);                                                                   \
-    Pb[1] = dpp_rot<CTRL>(R.b[1]);                                                                   \
-    Pb[2] = dpp_rot<CTRL>(R.b[2]);                                                                   \
-    acc[o_acc_rot(T, 0, 0)] *= dot(Pa, ua);                                                          \
-    acc[o_acc_rot(T, 0, 1)] *= dot(Pb, ua);                                                          \
-    acc[o_acc_rot(T, 1, 0)] *= dot(Pa, ub);                                                          \
-    acc[o_acc_rot(T, 1, 1)] *= dot(Pb, ub);                                                          \
-  }
-      OCT_ROT(1, ROR2)
-      OCT_ROT(2, ROR4)
-      OCT_ROT(3, ROR6)
-#undef OCT_ROT
-      {  // the lane facing this one: (a, b') here and (a', b) over there; (a, a') and (b, b') on both sides
+      wave_for<1, G::NROT + 1>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
         double Pa[3], Pb[3];
-        Pa[0] = dpp_rot<ROR8>(R.a[0]);
-        Pa[1] = dpp_rot<ROR8>(R.a[1]);
-        Pa[2] = dpp_rot<ROR8>(R.a[2]);
-        Pb[0] = dpp_rot<ROR8>(R.b[0]);
-        Pb[1] = dpp_rot<ROR8>(R.b[1]);
-        Pb[2] = dpp_rot<ROR8>(R.b[2]);
+        Pa[0] = dpp_rot<G::ror(t)>(R.a[0]);
+        Pa[1] = dpp_rot<G::ror(t)>(R.a[1]);
+        Pa[2] = dpp_rot<G::ror(t)>(R.a[2]);
+        Pb[0] = dpp_rot<G::ror(t)>(R.b[0]);
+        Pb[1] = dpp_rot<G::ror(t)>(R.b[1]);
+        Pb[2] = dpp_rot<G::ror(t)>(R.b[2]);
+        acc[G::acc_rot(t, 0, 0)] *= dot(Pa, ua);
+        acc[G::acc_rot(t, 0, 1)] *= dot(Pb, ua);
+        acc[G::acc_rot(t, 1, 0)] *= dot(Pa, ub);
+        acc[G::acc_rot(t, 1, 1)] *= dot(Pb, ub);
+      });
+      {  // the lane facing this one: (a, b') here and (a', b) over there; (a, a') and (b, b') on both sides
+        constexpr int CF = G::ror(P / 2);
+        double Pa[3], Pb[3];
+        Pa[0] = dpp_rot<CF>(R.a[0]);
+        Pa[1] = dpp_rot<CF>(R.a[1]);
+        Pa[2] = dpp_rot<CF>(R.a[2]);
+        Pb[0] = dpp_rot<CF>(R.b[0]);
+        Pb[1] = dpp_rot<CF>(R.b[1]);
+        Pb[2] = dpp_rot<CF>(R.b[2]);
         acc[O_ACC_F_AB] *= dot(Pb, ua);
         acc[O_ACC_F_AA] *= dot(Pa, ua);
         acc[O_ACC_F_BB] *= dot(Pb, ub);
       }
     };
 
-    // One batch: phase 1, then its eight entries.  Rows are requested TWO entries ahead into three register sets that
-    // rotate without copies; eight entries against three sets give a period of three batches, which are written out,
-    // each starting one set later.  On entry X holds the row of entry 0, Y of entry 1 (both requested earlier), Z is free.
-    auto batch = [&](int b, row_t& X, row_t& Y, row_t& Z) {
+    // One batch: phase 1, then its P entries.  Rows are requested TWO entries ahead into three register sets that
+    // rotate without copies; P entries against three sets give a period of three batches, which are written out, each
+    // starting P mod 3 sets later.  On entry X holds the row of entry 0, Y of entry 1 (both requested earlier), Z is free.
+    auto batch = [&](int b, row_t& X, row_t& Y, row_t& Z) __attribute__((always_inline)) {
       phase1(b);
       __syncthreads();
-      const int32_t* sn = snps + slot * 8;
-      const int32_t* sx = snps_nx + slot * 8;
-#define OCT_E(LD, SRC, SW, I)                \
-  load_row(LD, SRC);                         \
-  __builtin_amdgcn_sched_barrier(0);         \
-  sweep_entry(SW, I);                        \
-  __builtin_amdgcn_sched_barrier(0);         \
-  if (lim <= I + 1) break;
+      const int32_t* sn = snps + slot * P;
+      const int32_t* sx = snps_nx + slot * P;
       const int lim = (b == nb - 1) ? ngmax - b * O_BATCH : O_BATCH;  // the last batch ends with the longest list
-      do {
-        OCT_E(Z, sn[2], X, 0)
-        OCT_E(X, sn[3], Y, 1)
-        OCT_E(Y, sn[4], Z, 2)
-        OCT_E(Z, sn[5], X, 3)
-        OCT_E(X, sn[6], Y, 4)
-        OCT_E(Y, sn[7], Z, 5)
-        OCT_E(Z, sx[0], X, 6)
-        OCT_E(X, sx[1], Y, 7)
-      } while (false);
-#undef OCT_E
-      if (b & 1) renorm();  // 16 entries per slot since the last renormalisation
+      auto set = [&](auto ic) __attribute__((always_inline)) -> row_t& {
+        constexpr int i = decltype(ic)::value % 3;
+        if constexpr (i == 0) return X;
+        else if constexpr (i == 1) return Y;
+        else return Z;
+      };
+      bool go = true;  // (wave-uniform)
+      wave_for<0, P>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        if (!go) return;
+        load_row(set(std::integral_constant<int, e + 2>{}), e + 2 < P ? sn[e + 2 < P ? e + 2 : 0] : sx[e + 2 - P < 0 ? 0 : e + 2 - P]);
+        __builtin_amdgcn_sched_barrier(0);
+        sweep_entry(set(ec), e);
+        __builtin_amdgcn_sched_barrier(0);
+        if (lim <= e + 1) go = false;
+      });
+      if (P == 16 || (b & 1)) renorm();  // 16 entries per slot since the last renormalisation
       __syncthreads();
     };
-    // (after a batch that started with (X, Y, Z) the next batch's entries 0 and 1 sit in Z and X)
+    // (after a batch that started with (X, Y, Z) the next batch's entries 0 and 1 sit in the sets P mod 3 and P mod 3 + 1)
 
     row_t R0, R1, R2;
-    snps_nx[slot * 8 + p] = (snp_of(precA, 0) >= 0) ? precA.snp : S_dummy;
+    snps_nx[slot * P + p] = (snp_of(precA, 0) >= 0) ? precA.snp : S_dummy;
     __syncthreads();
-    load_row(R0, snps_nx[slot * 8 + 0]);
-    load_row(R1, snps_nx[slot * 8 + 1]);
+    load_row(R0, snps_nx[slot * P + 0]);
+    load_row(R1, snps_nx[slot * P + 1]);
     __syncthreads();
     for (int b = 0; b < nb; b += 3) {
       batch(b, R0, R1, R2);
       if (b + 1 >= nb) break;
-      batch(b + 1, R2, R0, R1);
+      if (P == 8) batch(b + 1, R2, R0, R1);
+      else batch(b + 1, R1, R2, R0);
       if (b + 2 >= nb) break;
-      batch(b + 2, R1, R2, R0);
+      if (P == 8) batch(b + 2, R1, R2, R0);
+      else batch(b + 2, R2, R0, R1);
     }
     renorm();
   }
@@ -639,37 +637,34 @@ __global__ void __launch_bounds__(64, 3)
     int32_t exa[ON_ACC];
     const double wa = accW[0], wb = accW[1];
     const int32_t ea = exW[0], eb = exW[1];
-    const int src0 = lane & ~14;  // position 0 of the same slot
+    const int src0 = G::lane0(lane);  // position 0 of the same slot
     const double W0 = __shfl(wa, src0, 64) * accH;
     const int32_t e0w = __shfl(ea, src0, 64) + exH;
-    acc[o_acc_single(0)] *= wa * W0;
-    exa[o_acc_single(0)] = ea + e0w;
-    acc[o_acc_single(1)] *= wb * W0;
-    exa[o_acc_single(1)] = eb + e0w;
+    acc[G::acc_single(0)] *= wa * W0;
+    exa[G::acc_single(0)] = ea + e0w;
+    acc[G::acc_single(1)] *= wb * W0;
+    exa[G::acc_single(1)] = eb + e0w;
     acc[O_ACC_AB] *= wa * wb;
     exa[O_ACC_AB] = ea + eb;
-#define OCT_FOLD(T, CTRL)                                                          \
-  {                                                                                \
-    const double pa = dpp_rot<CTRL>(wa), pb = dpp_rot<CTRL>(wb);                   \
-    const int32_t qa = __builtin_amdgcn_mov_dpp(ea, CTRL, 0xF, 0xF, false);        \
-    const int32_t qb = __builtin_amdgcn_mov_dpp(eb, CTRL, 0xF, 0xF, false);        \
-    acc[o_acc_rot(T, 0, 0)] *= wa * pa;                                            \
-    exa[o_acc_rot(T, 0, 0)] = ea + qa;                                             \
-    acc[o_acc_rot(T, 0, 1)] *= wa * pb;                                            \
-    exa[o_acc_rot(T, 0, 1)] = ea + qb;                                             \
-    acc[o_acc_rot(T, 1, 0)] *= wb * pa;                                            \
-    exa[o_acc_rot(T, 1, 0)] = eb + qa;                                             \
-    acc[o_acc_rot(T, 1, 1)] *= wb * pb;                                            \
-    exa[o_acc_rot(T, 1, 1)] = eb + qb;                                             \
-  }
-    OCT_FOLD(1, ROR2)
-    OCT_FOLD(2, ROR4)
-    OCT_FOLD(3, ROR6)
-#undef OCT_FOLD
+    wave_for<1, G::NROT + 1>([&](auto tc) {
+      constexpr int T = decltype(tc)::value, CTRL = G::ror(T);
+      const double pa = dpp_rot<CTRL>(wa), pb = dpp_rot<CTRL>(wb);
+      const int32_t qa = __builtin_amdgcn_mov_dpp(ea, CTRL, 0xF, 0xF, false);
+      const int32_t qb = __builtin_amdgcn_mov_dpp(eb, CTRL, 0xF, 0xF, false);
+      acc[G::acc_rot(T, 0, 0)] *= wa * pa;
+      exa[G::acc_rot(T, 0, 0)] = ea + qa;
+      acc[G::acc_rot(T, 0, 1)] *= wa * pb;
+      exa[G::acc_rot(T, 0, 1)] = ea + qb;
+      acc[G::acc_rot(T, 1, 0)] *= wb * pa;
+      exa[G::acc_rot(T, 1, 0)] = eb + qa;
+      acc[G::acc_rot(T, 1, 1)] *= wb * pb;
+      exa[G::acc_rot(T, 1, 1)] = eb + qb;
+    });
     {
-      const double pa = dpp_rot<ROR8>(wa), pb = dpp_rot<ROR8>(wb);
-      const int32_t qa = __builtin_amdgcn_mov_dpp(ea, ROR8, 0xF, 0xF, false);
-      const int32_t qb = __builtin_amdgcn_mov_dpp(eb, ROR8, 0xF, 0xF, false);
+      constexpr int CF = G::ror(P / 2);
+      const double pa = dpp_rot<CF>(wa), pb = dpp_rot<CF>(wb);
+      const int32_t qa = __builtin_amdgcn_mov_dpp(ea, CF, 0xF, 0xF, false);
+      const int32_t qb = __builtin_amdgcn_mov_dpp(eb, CF, 0xF, 0xF, false);
       acc[O_ACC_F_AB] *= wa * pb;
       exa[O_ACC_F_AB] = ea + qb;
       acc[O_ACC_F_AA] *= wa * pa;
@@ -682,40 +677,42 @@ __global__ void __launch_bounds__(64, 3)
       for (int a = 0; a < ON_ACC; ++a) {
         int e;
         const double m = frexp(acc[a], &e);
-        part_m[((size_t)qpos * ON_ACC + a) * 8 + p] = m;
-        part_e[((size_t)qpos * ON_ACC + a) * 8 + p] = exs[a] + e + exa[a];
+        part_m[((size_t)qpos * ON_ACC + a) * P + p] = m;
+        part_e[((size_t)qpos * ON_ACC + a) * P + p] = exs[a] + e + exa[a];
       }
     }
   }
 }
 
-// Decodes accumulator idx = a*8 + p of the oct kernel into its hypothesis (j, k); false for slots nobody reads (pairs held
-// twice, j/k >= V).
+// Decodes accumulator idx = a * P + p into its hypothesis (j, k); false for slots nobody reads (pairs held twice,
+// j / k >= V).
+template <int P>
 __device__ __forceinline__ bool oct_decode(int idx, const int32_t* __restrict__ pmap, int V, int& j, int& k) {
-  const int a = idx >> 3, p = idx & 7;
+  using G = og<P>;
+  const int a = idx / P, p = idx % P;
   bool publish = true;
   if (a < 2) {
-    j = p + 8 * a;
+    j = p + P * a;
     k = 0;
-  } else if (a == O_ACC_AB) {
-    j = p + 8;
+  } else if (a == G::ACC_AB) {
+    j = p + P;
     k = p;
-  } else if (a < 15) {
+  } else if (a < G::ACC_F_AB) {
     const int t = (a - 3) >> 2, c = ((a - 3) >> 1) & 1, d = (a - 3) & 1;
-    j = p + 8 * c;
-    k = pmap[t * 8 + p] + 8 * d;
+    j = p + P * c;
+    k = pmap[t * P + p] + P * d;
   } else {
-    const int pf = pmap[24 + p];
-    if (a == O_ACC_F_AB) {
+    const int pf = pmap[G::NROT * P + p];
+    if (a == G::ACC_F_AB) {
       j = p;
-      k = pf + 8;
-    } else if (a == O_ACC_F_AA) {
+      k = pf + P;
+    } else if (a == G::ACC_F_AA) {
       j = p;
       k = pf;
       publish = p < pf;  // the facing lane holds the same pair
     } else {
-      j = p + 8;
-      k = pf + 8;
+      j = p + P;
+      k = pf + P;
       publish = p < pf;
     }
   }
@@ -729,10 +726,12 @@ __device__ __forceinline__ double oct_log(double m, int64_t e) { return fma((dou
 // Multiplies the chunk partials of one cell in chunk order: ONE log per hypothesis.  A chunk's partials sit at the chunk's
 // position ci in its cell's list (the sweep writes them there, oct_chunk_pos_kernel), so a cell's are consecutive and a
 // reader needs no chunk ids.
+template <int P>
 __device__ __forceinline__ bool oct_hypothesis(int idx, int64_t c0, int64_t c1, const double* __restrict__ part_m,
                                                const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
                                                int& j, int& k, double& v) {
-  if (!oct_decode(idx, pmap, V, j, k)) return false;
+  constexpr int O_NHYP = og<P>::N_HYP;
+  if (!oct_decode<P>(idx, pmap, V, j, k)) return false;
   // eight chunks per trip: the sixteen loads are independent and in flight together, the products stay in chunk order
   double m = 1.0;
   int64_t e = 0;
@@ -771,55 +770,59 @@ __global__ void __launch_bounds__(256)
 }
 
 // writes ll[c][j][k][n] (+ mirror) of one cell to the LL tensor in HBM (needed when the caller asks for the tensor)
+template <int P>
 __global__ void __launch_bounds__(192)
     demux_oct_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const double* __restrict__ part_m,
                             const int32_t* __restrict__ part_e, const int32_t* __restrict__ pmap, int V,
                             double* __restrict__ ll) {
   const int64_t c = blockIdx.x;
   const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
-  const int idx = threadIdx.x;
-  if (c0 == c1 || idx >= O_NHYP) return;
-  int j, k;
-  double v;
-  if (!oct_hypothesis(idx, c0, c1, part_m, part_e, pmap, V, j, k, v)) return;
+  if (c0 == c1) return;
   double* out = ll + (size_t)c * V * V * 2;
-  if (idx < 16) {
-    out[((size_t)j * V + k) * 2 + 0] = v;  // singlet: alpha index 0
-  } else {
-    out[((size_t)j * V + k) * 2 + 1] = v;
-    out[((size_t)k * V + j) * 2 + 1] = v;
+  for (int idx = threadIdx.x; idx < og<P>::N_HYP; idx += 192) {
+    int j, k;
+    double v;
+    if (!oct_hypothesis<P>(idx, c0, c1, part_m, part_e, pmap, V, j, k, v)) continue;
+    if (idx < 2 * P) {
+      out[((size_t)j * V + k) * 2 + 0] = v;  // singlet: alpha index 0
+    } else {
+      out[((size_t)j * V + k) * 2 + 1] = v;
+      out[((size_t)k * V + j) * 2 + 1] = v;
+    }
   }
 }
 
-// The same reduction, but the hypotheses of four cells stay in LDS and the call (demux_call_body.hpp) follows at once,
-// sixteen lanes per cell in wave 0: no LL tensor round trip through HBM, one launch less, and the 160-byte records go
-// straight to the caller's pinned host buffer (16-byte stores of consecutive lanes), which removes the separate
-// device-to-host copy.
+// The same reduction, but the hypotheses of the workgroup's cells (four at P = 8, one at P = 16) stay in LDS and the call
+// (demux_call_body.hpp) follows at once: no LL tensor round trip through HBM, one launch less, and the 160-byte
+// records go straight to the caller's pinned host buffer (16-byte stores of consecutive lanes), which removes the
+// separate device-to-host copy.
 #ifndef QF_CELLS_N
 #define QF_CELLS_N 4
 #endif
-constexpr int QF_CELLS = QF_CELLS_N;
-__global__ void __launch_bounds__(64 * QF_CELLS)
+template <int P>
+__global__ void __launch_bounds__(256)
     demux_oct_finish_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, const int64_t* __restrict__ cell_chunk_ptr,
                             const double* __restrict__ part_m, const int32_t* __restrict__ part_e,
                             const int32_t* __restrict__ pmap, int V,
                             muxgl_call::call_alpha al, double doublet_prior, muxgl_demux_cell* __restrict__ out) {
-  constexpr int LD = 33;  // row stride of the tiles in doubles: odd, so that the sixteen lanes of a cell's call, which read
-                          // the same column of their rows at once, meet sixteen LDS banks (32 would be one)
-  __shared__ double llt[QF_CELLS][16 * LD];
+  constexpr int QF_CELLS = P == 8 ? QF_CELLS_N : 1, THREADS = 256, O_NHYP = og<P>::N_HYP;
+  static_assert(P == 16 || QF_CELLS * 64 == THREADS, "a wave per cell at P = 8");
+  constexpr int LD = 4 * P + 1;  // row stride of the tiles in doubles (2P samples x 2 alphas): odd, so that the lanes of a cell's
+                                 // call, which read the same column of their rows at once, meet different LDS banks
+  __shared__ double llt[QF_CELLS][2 * P * LD];
   __shared__ __align__(16) muxgl_demux_cell rec[QF_CELLS];
   __shared__ int64_t ccp[QF_CELLS + 1];
   static_assert(sizeof(muxgl_demux_cell) % 16 == 0, "records are copied out in 16-byte pieces");
   const int64_t cbase = (int64_t)blockIdx.x * QF_CELLS;
   const int tid = threadIdx.x;
   if (tid <= QF_CELLS) ccp[tid] = cell_chunk_ptr[cbase + tid <= C ? cbase + tid : C];
-  for (int t = tid; t < QF_CELLS * 16 * LD; t += 64 * QF_CELLS) (&llt[0][0])[t] = 0.0;
+  for (int t = tid; t < QF_CELLS * 2 * P * LD; t += THREADS) (&llt[0][0])[t] = 0.0;
   __syncthreads();
   // The kernel's time is a chain of dependent latencies (measured: the same 65 us for 5 000 cells as for 10 000), so the
   // chain is kept short: the chunk ranges of the workgroup's cells come from ONE load (above), a cell's partials are
-  // consecutive (no chunk ids), and a thread's hypotheses -- NH of the workgroup's QF_CELLS x 144 -- are walked TOGETHER,
+  // consecutive (no chunk ids), and a thread's hypotheses -- NH of the workgroup's QF_CELLS x N_HYP -- are walked TOGETHER,
   // four chunks a trip: 2 x 4 x NH loads in flight instead of one hypothesis after the other (three dependent trips each).
-  constexpr int NH = (QF_CELLS * O_NHYP + 64 * QF_CELLS - 1) / (64 * QF_CELLS);
+  constexpr int NH = (QF_CELLS * O_NHYP + THREADS - 1) / THREADS;
   int hj[NH], hk[NH], hidx[NH], hlc[NH];
   int64_t h0[NH];
   int hn[NH];
@@ -829,13 +832,13 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
   int nmax = 0;
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
-    const int w = tid + i * 64 * QF_CELLS;
+    const int w = tid + i * THREADS;
     const int lc = w < QF_CELLS * O_NHYP ? w / O_NHYP : 0;
     hlc[i] = lc;
     hidx[i] = w - lc * O_NHYP;
     h0[i] = ccp[lc];
     hn[i] = (int)(ccp[lc + 1] - ccp[lc]);
-    hv[i] = w < QF_CELLS * O_NHYP && hn[i] > 0 && oct_decode(hidx[i] < O_NHYP ? hidx[i] : 0, pmap, V, hj[i], hk[i]);
+    hv[i] = w < QF_CELLS * O_NHYP && hn[i] > 0 && oct_decode<P>(hidx[i] < O_NHYP ? hidx[i] : 0, pmap, V, hj[i], hk[i]);
     if (!hv[i]) hn[i] = 0, hidx[i] = 0;
     hm[i] = 1.0;
     he[i] = 0;
@@ -877,7 +880,7 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
   for (int i = 0; i < NH; ++i) {
     if (!hv[i]) continue;
     const double v = oct_log(hm[i], he[i]);
-    if (hidx[i] < 16) {
+    if (hidx[i] < 2 * P) {
       llt[hlc[i]][hj[i] * LD + hk[i] * 2 + 0] = v;
     } else {
       llt[hlc[i]][hj[i] * LD + hk[i] * 2 + 1] = v;
@@ -885,7 +888,7 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
     }
   }
   __syncthreads();
-  {  // a wave per cell for the scans (sixteen rows x four ranges of columns); the cells' decisions side by side in wave 0
+  if constexpr (P == 8) {  // a wave per cell for the scans (sixteen rows x four ranges of columns); the cells' decisions side by side
     __shared__ muxgl_call::call_partial parts[QF_CELLS];
     const int lc = tid >> 6;
     const int64_t c = cbase + lc;
@@ -895,6 +898,10 @@ __global__ void __launch_bounds__(64 * QF_CELLS)
     if (tid < QF_CELLS && cbase + tid < C)
       muxgl_call::demux_call_decide(parts[tid], (int32_t)(cell_ptr[cbase + tid + 1] - cell_ptr[cbase + tid]), V, 2, al,
                                     &rec[tid]);
+  } else {  // one cell, wave 0, lane = row: the association of demux_callg_kernel, which makes the call from the tensor
+    if (tid < 64)
+      muxgl_call::demux_call_group<64>(tid, cbase < C, cbase < C ? (int32_t)(cell_ptr[cbase + 1] - cell_ptr[cbase]) : 0, V, 2,
+                                       al, doublet_prior, llt[0], &rec[0], LD);
   }
   __syncthreads();
   constexpr int NQ = (int)(sizeof(muxgl_demux_cell) / 16);
@@ -936,17 +943,16 @@ int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t*
   return 0;
 }
 
-// returns -1 when the path does not apply, 0 ok, 1 error
-int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
-  if (h->V > 16 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
-  if (h->S + 1 >= ((int64_t)1 << 24)) return -1;  // (row offsets of the linear entries' records are 32-bit byte offsets)
-  if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL | MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;
-  if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
+namespace {
+template <int P>
+int oct_launch_t(muxgl_handle* h, const muxgl_demux_params* p) {
+  constexpr int O_SLOTS = og<P>::SLOTS, O_NHYP = og<P>::N_HYP;
   muxgl_row_state* st = h->qrow;
-  if (!st->d_tmap) {  // positions met by the four rotations
-    if (dev_alloc(h, &st->d_tmap, 32)) return 1;
-    hipLaunchKernelGGL(oct_pmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
+  if (!st->d_tmap || st->tmap_p != P) {  // positions met by the rotations
+    if (dev_alloc(h, &st->d_tmap, (size_t)(P / 2) * P)) return 1;
+    hipLaunchKernelGGL(oct_pmap_kernel<P>, dim3(1), dim3(64), 0, h->stream, st->d_tmap);
     HIPCHK(h, hipGetLastError());
+    st->tmap_p = P;
   }
   const size_t need = (size_t)st->n_chunks * O_NHYP;
   if (need > st->part_cap) {
@@ -994,7 +1000,7 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
       return 1;
     }
     hipLaunchKernelGGL(oct_unit_steps_kernel, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, h->stream, n_units,
-                       (int)st->n_chunks, st->d_quad_order, st->d_chunk_nlin, d_steps);
+                       (int)st->n_chunks, O_SLOTS, st->d_quad_order, st->d_chunk_nlin, d_steps);
     hipError_t e = hipMemcpyAsync(steps.data(), d_steps, sizeof(int32_t) * (size_t)n_units, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     for (int u = 0; u < n_units; ++u) uptr[(size_t)u + 1] = uptr[(size_t)u] + (int64_t)steps[(size_t)u] * O_SLOTS;
@@ -1005,7 +1011,7 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
     e = hipMemcpyAsync(st->d_unit_ptr, uptr.data(), sizeof(int64_t) * uptr.size(), hipMemcpyHostToDevice, h->stream);
     hipLaunchKernelGGL(oct_repack_kernel, dim3((unsigned)(((size_t)n_units * O_SLOTS + 255) / 256)), dim3(256), 0, h->stream,
                        n_units, (int)st->n_chunks, st->d_chunks, st->d_quad_order, st->d_chunk_nlin, d_lrec, d_steps,
-                       st->d_unit_ptr, (uint32_t)h->S, st->d_orec);
+                       st->d_unit_ptr, (uint32_t)h->S, O_SLOTS, og<P>::MROW, st->d_orec);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (uptr is a host buffer; d_lrec is freed)
     cleanup();
@@ -1013,7 +1019,8 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   tic(h, MUXGL_T_DEMUX_SWEEP);
   if (blocks) {
-    hipLaunchKernelGGL(h->gp_unit_sums ? demux_oct_kernel<true> : demux_oct_kernel<false>, dim3(blocks), dim3(64), 0,
+    auto kern = h->gp_unit_sums ? demux_oct_kernel<P, true> : demux_oct_kernel<P, false>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0,
                        h->stream, st->d_chunks, (int)st->n_chunks,
                        use_lin ? st->d_qent_lin : h->d_qent, st->d_orec, st->d_unit_ptr,
                        use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
@@ -1023,11 +1030,12 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   }
   toc_tic(h, MUXGL_T_DEMUX_SWEEP, MUXGL_T_DEMUX_REDUCE);
   if (h->want_full_ll) {
-    hipLaunchKernelGGL(demux_oct_reduce_kernel, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
+    hipLaunchKernelGGL(demux_oct_reduce_kernel<P>, dim3((unsigned)h->C), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
                        st->d_part, st->d_part_e, st->d_tmap, h->V, h->d_ll);
   } else {  // reduce + call fused, records written to the pinned host buffer
     const muxgl_call::call_alpha al = muxgl_call::make_call_alpha(p, h->V);
-    hipLaunchKernelGGL(demux_oct_finish_kernel, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(64 * QF_CELLS), 0,
+    constexpr int QF_CELLS = P == 8 ? QF_CELLS_N : 1;
+    hipLaunchKernelGGL(demux_oct_finish_kernel<P>, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(256), 0,
                        h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
 #ifdef FIN_DEV
                        p->doublet_prior, h->d_dcells);  // (timing experiment: records stay on the device)
@@ -1039,4 +1047,16 @@ int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   HIPCHK(h, hipGetLastError());
   toc(h, MUXGL_T_DEMUX_REDUCE);
   return 0;
+}
+}  // namespace
+
+// returns -1 when the path does not apply, 0 ok, 1 error
+int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p) {
+  if (h->V > 32 || !h->qrow || !h->d_gpq || !h->d_qent || h->C == 0) return -1;
+  const int P = h->V <= 16 ? 8 : 16;
+  // (row offsets of the linear entries' records are 32-bit byte offsets)
+  if ((uint64_t)(h->S + 1) * (32u * (unsigned)P) >= ((uint64_t)1 << 32)) return -1;
+  if (h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL | MUXGL_FLAG_FORCE_WAVE_KERNEL)) return -1;
+  if (p->n_alpha != 2 || p->alpha[0] != 0.0 || p->alpha[1] != 0.5) return -1;
+  return P == 8 ? oct_launch_t<8>(h, p) : oct_launch_t<16>(h, p);
 }

@@ -323,7 +323,8 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
     dev_free(&h->qrow->d_unit_ptr);
     dev_free(&h->qrow->d_quad_order);
   }
-  if (V <= 16 && h->S > 0) {
+  if (V <= 32 && h->S > 0) {
+    const int P = V <= 16 ? 8 : 16;  // lanes per entry of the oct tiling (demux_oct.hip): lane p owns samples p and p + P
     // Do all triples sum to 1 within 4 ulp?  (Hard calls through the reference's error mixing do, sc_drop_seq.cpp:287-315;
     // posteriors normalised in float do not.)  The rows of the oct kernel then carry no sums -- see demux_oct.hip.
     bool unit = !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);  // (the flag keeps the general formats: tests compare the two)
@@ -345,16 +346,16 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
     // Samples >= V are padded with (1,0,0), which makes their factors exactly 1.
     // Row S is a dummy marker, (1,0,0) for every sample and sum 1: padding entries and markers without genotypes are
     // pointed at it, so the kernel loads rows unconditionally.
-    std::vector<double> q((size_t)(h->S + 1) * 48), g0((size_t)h->S + 1);
+    std::vector<double> q((size_t)(h->S + 1) * 6 * P), g0((size_t)h->S + 1);
     for (int64_t s = 0; s <= h->S; ++s) {
       const double* row = s < h->S ? gp + (size_t)s * V * 3 : nullptr;
       const bool have = row && has_gp[s];
-      for (int pp = 0; pp < 8; ++pp)
+      for (int pp = 0; pp < P; ++pp)
         for (int c = 0; c < 2; ++c)
           for (int l = 0; l < 3; ++l) {
-            const int j = pp + 8 * c, d = 3 * c + l;
+            const int j = pp + P * c, d = 3 * c + l;
             const double v = (j < V && have) ? row[j * 3 + l] : (l == 0 ? 1.0 : 0.0);  // no genotypes: neutral row
-            q[(size_t)s * 48 + ((size_t)(d / 2) * 8 + pp) * 2 + (d & 1)] = v;
+            q[(size_t)s * 6 * P + ((size_t)(d / 2) * P + pp) * 2 + (d & 1)] = v;
           }
       // a SNP without genotypes (gps == NULL, cmd_cram_demuxlet.cpp:733) is marked by a negative sum
       g0[(size_t)s] = s == h->S ? 1.0 : (have ? (row[0] + row[1]) + row[2] : -1.0);
@@ -362,9 +363,9 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
     // The same rows as moments (s, rho = (g1 + 2 g2) / s) for the entries with one usable read: 16 bytes per sample in
     // sample order ([S + 1][16][2]; lane p reads samples p and p + 8, each a whole line per entry); with unit sums rho
     // alone, (rho_p, rho_p+8) adjacent ([S + 1][8][2]: one line per entry).
-    std::vector<double> gm((size_t)(h->S + 1) * (unit ? 16 : 32));
+    std::vector<double> gm((size_t)(h->S + 1) * (unit ? 2 * P : 4 * P));  // (P = 16: [S + 1][32][2] / [S + 1][16][2])
     for (int64_t s = 0; s <= h->S; ++s)
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < 2 * P; ++j) {
         double sm = 1.0, rho = 0.0;
         if (s < h->S && j < V && has_gp[s]) {
           const double* t = gp + ((size_t)s * V + j) * 3;
@@ -372,10 +373,10 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
           rho = sm > 0.0 ? std::fma(2.0, t[2], t[1]) / sm : 0.0;
         }
         if (unit) {
-          gm[(size_t)s * 16 + (size_t)(j & 7) * 2 + (j >> 3)] = rho;
+          gm[(size_t)s * 2 * P + (size_t)(j % P) * 2 + (j / P)] = rho;
         } else {
-          gm[(size_t)s * 32 + (size_t)j * 2] = sm;
-          gm[(size_t)s * 32 + (size_t)j * 2 + 1] = rho;
+          gm[(size_t)s * 4 * P + (size_t)j * 2] = sm;
+          gm[(size_t)s * 4 * P + (size_t)j * 2 + 1] = rho;
         }
       }
     if (dev_alloc(h, &h->d_gmq, gm.size())) return 1;
