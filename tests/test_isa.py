@@ -60,8 +60,8 @@ def hipcc_version():
 
 
 def test_oct_kernel_resources_and_linear_loop(tmp_path_factory, hipcc_version):
-    ks = kernels(isa(tmp_path_factory, "demux_oct"), "demux_oct_kernelILb")
-    assert len(ks) == 2  # <UNIT_S = true / false>
+    ks = kernels(isa(tmp_path_factory, "demux_oct"), "demux_oct_kernelILi8ELb")
+    assert len(ks) == 2  # eight lanes per entry, <UNIT_S = true / false>
     for name, (body, meta) in ks.items():
         assert meta["num_vgpr"] <= 168 and meta["num_agpr"] == 0, (name, meta)  # three waves per SIMD
         assert meta["private_seg_size"] == 0, "scratch (spills) in the sweep kernel"
@@ -72,12 +72,30 @@ def test_oct_kernel_resources_and_linear_loop(tmp_path_factory, hipcc_version):
         t = lin[0]
         assert "s_waitcnt vmcnt(0)" not in t, "the linear loop drains its loads"
         rows = len(re.findall(r"global_load_dwordx4", t))
-        assert rows == (3 if "ILb1E" in name else 6), rows  # 3 unrolled steps x (1 | 2) row pieces
+        assert rows == (3 if "ELb1E" in name else 6), rows  # 3 unrolled steps x (1 | 2) row pieces
         assert len(re.findall(r"v_mov_b32_dpp", t)) == 3 * 16  # two rho per rotation, four rotations, two dwords each
         fp = len(re.findall(r"v_(fma|mul|fmac|add)_f64", t))
         assert fp <= 3 * 42 + 45, fp  # <= 42 FP64 per step; the renormalisation rides in the same block
-    m = re.search(r"demux_oct_kernelILb1E.*?LDSByteSize: (\d+)", isa(tmp_path_factory, "demux_oct"), re.S)
+    m = re.search(r"demux_oct_kernelILi8ELb1E.*?LDSByteSize: (\d+)", isa(tmp_path_factory, "demux_oct"), re.S)
     assert m and int(m.group(1)) <= 12800
+
+
+def test_oct_kernel_sixteen_lanes_per_entry(tmp_path_factory, hipcc_version):
+    """16 < V <= 32: the same kernel with sixteen lanes per entry (34 accumulators per lane): two waves per SIMD, its
+    lambdas inlined (without always_inline hipcc compiled the batch of sixteen entries as calls through scratch memory),
+    seven full rotations + the facing one per linear step, no drain of the loads in the linear loop"""
+    ks = kernels(isa(tmp_path_factory, "demux_oct"), "demux_oct_kernelILi16ELb")
+    assert len(ks) == 2
+    for name, (body, meta) in ks.items():
+        assert meta["num_vgpr"] <= 256 and meta["num_agpr"] == 0, (name, meta)
+        assert "s_swappc" not in body and "s_setpc" not in body, "a lambda of the sweep was not inlined"
+        assert len(re.findall(r"v_(fma|mul|fmac)_f64", body)) > 5000  # three batch variants x sixteen entries, inline
+        lin = [t for t in blocks(body) if t.count("row_ror:1 ") >= 12 and "ds_read_b128" in t and "ds_write" not in t
+               and "v_frexp_mant" not in t.split("s_cbranch")[0]]
+        assert len(lin) == 1, [len(t) for t in blocks(body)]
+        t = lin[0]
+        assert "s_waitcnt vmcnt(0)" not in t, "the linear loop drains its loads"
+        assert len(re.findall(r"v_mov_b32_dpp", t)) == 3 * 32  # two rho per rotation, eight rotations, two dwords each
 
 
 def test_wave_ring_reads_are_single_b64(tmp_path_factory, hipcc_version):
