@@ -352,6 +352,31 @@ def cpu_baseline_fmx(p, K, clust0, budget_s=10.0):
                       f"(the reference is single-threaded), {dt:.1f} s", "entries_per_s": nnz / dt}
 
 
+def fmx_parity_sample(eng, p, K, cells_now, n=24):
+    """One more EM iteration on the device, untimed, and the oracle's E-step, scans and re-assignment of a sample of the
+    cells against the device's OWN cluster pileups of that moment (as tests/test_large_gpu.py does at configs[4]): the
+    freemuxlet legs' counterpart of the demuxlet legs' parity check.  The oracle is the checker only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import parity
+
+    gls, cnt = eng.fmx_cluster_pileup()  # [K][S][9], [K][S][3]: the state the next E-step starts from
+    nxt, _ = eng.fmx_iterate(0.5, 0.1)
+    pick = np.sort(np.random.default_rng(2).choice(p.C, min(n, p.C), replace=False))
+    sub = p.subset_cells(pick)
+    se = ob.fmx_entry_pileup(sub)
+    cplp = np.zeros((K, p.S), dtype=ob.PLP)
+    cplp["gls"] = gls
+    cplp["nreads"], cplp["nref"], cplp["nalt"] = cnt[..., 0], cnt[..., 1], cnt[..., 2]
+    del gls, cnt
+    clust = np.where(cells_now["type"][pick] == 0, cells_now["clust"][pick], -1).astype(np.int32)
+    ocells = ob.fmx_init_cells(np.ascontiguousarray(clust))
+    ob.fmx_iterate(sub, se, K, cplp, ocells, 0.5, 0.1, nthreads=min(8, usable_cores()))
+    rep = parity.compare_fmx(nxt[pick], ocells)
+    return {"parity_checked_cells": int(rep["cells"]), "parity_max_abs_ll_diff": float(rep["max_abs_ll_diff"]),
+            "parity_excuses_used": rep.get("excuses_used")}
+
+
 # ---- distributed context --------------------------------------------------------------------------------------------
 class Ctx:
     def __init__(self, args):
@@ -661,6 +686,7 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
                         "posteriors and the ordered M-step by SNPs (DESIGN.md 4.3)"}
         if cpu_baseline and ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fmx(p, K, clust0, budget_s=cpu_budget_s)
+            out["cpu_baseline"].update(fmx_parity_sample(eng, p, K, cells))
         else:
             out["cpu_baseline"] = None
         if args.dump:
@@ -749,8 +775,8 @@ def main():
     ap.add_argument("--mean-entries", type=float, default=800.0)
     ap.add_argument("--dump", default="", help="freemuxlet: write rank 0's final records (tests)")
     ap.add_argument("--dense", action="store_true",
-                    help="demuxlet sensitivity run: the same shape with 1 + Poisson(2.0) reads per entry (a third of the "
-                         "entries linear instead of three quarters); adds a 'sensitivity' key to the line")
+                    help="demuxlet sensitivity run: the same shape with 1 + Poisson(2.0) reads per entry (one entry in seven "
+                         "linear instead of three quarters); adds a 'sensitivity' key to the line")
     ap.add_argument("--reads-lambda", type=float, default=None, help="reads per entry = 1 + Poisson(lambda) (default 0.3)")
     ap.add_argument("--no-linear", action="store_true",
                     help="demuxlet: MUXGL_FLAG_NO_LINEAR_ENTRIES -- every entry through the general three-term form")

@@ -144,6 +144,47 @@ def test_config4_full_size_freemuxlet_eight_ranks():
     assert ok.sum() > 0.9 * (~p.truth["is_doublet"]).sum() and (cells["clust"][ok] == p.truth["s1"][ok]).mean() > 0.99
 
 
+def test_config3_full_size_freemuxlet_oracle_sample():
+    """BASELINE configs[3] at FULL size (50 k cells x 100 k SNPs, K = 16, 47.6 M entries; the oct E-step and the stream
+    M-step): three EM iterations from a seeded start; after each, the oracle redoes the E-step, scans and re-assignment of a
+    sample of the cells against the device's own cluster pileups of that iteration, and the ordered clamped merge of a
+    sample of the SNPs over ALL cells."""
+    cfg = synth.CONFIGS[3]
+    K, S, C = cfg["V"], cfg["S"], cfg["C"]
+    p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + 3, with_gp=False)
+    assert p.C == 50_000 and p.nnz > 45_000_000
+    rng = np.random.default_rng(3)
+    clust = np.where(rng.random(C) < 0.9, p.truth["s1"], -1).astype(np.int32)
+    pick = np.sort(rng.choice(C, 32, replace=False))
+    sub = p.subset_cells(pick)
+    se = ob.fmx_entry_pileup(sub)
+    snps = np.sort(rng.choice(S, 200, replace=False))
+    cp, es, er, rd = _masked(p, np.isin(p.entry_snp, snps))
+    q = synth.Pileup(C, S, cp, es, er, rd, p.af)
+    qe = ob.fmx_entry_pileup(q)
+    with muxgl.Engine(0) as e:
+        e.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        e.fmx_prepare(p.af)
+        e.fmx_set_clusters(K, clust)
+        for it in range(3):
+            gls, cnt = e.fmx_cluster_pileup()
+            # the ordered merge over all cells of the sampled SNPs (cmd_cram_freemux2.cpp:277-288 / :590-596)
+            oc = ob.fmx_build_cluster_pileup(q, qe, K, clust)
+            assert np.array_equal(cnt[:, snps], np.stack([oc["nreads"], oc["nref"], oc["nalt"]], axis=-1)[:, snps])
+            assert np.allclose(gls[:, snps], oc["gls"][:, snps], rtol=1e-10, atol=1e-300)
+            cplp = np.zeros((K, S), dtype=ob.PLP)
+            cplp["gls"] = gls
+            cplp["nreads"], cplp["nref"], cplp["nalt"] = cnt[..., 0], cnt[..., 1], cnt[..., 2]
+            cells, stats = e.fmx_iterate(0.5, 0.1)
+            ocells = ob.fmx_init_cells(np.ascontiguousarray(clust[pick]))
+            ob.fmx_iterate(sub, se, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
+            rep = parity.compare_fmx(cells[pick], ocells)
+            assert rep["max_abs_ll_diff"] < 1e-6, (it, rep)
+            clust = np.where(cells["type"] == 0, cells["clust"], -1).astype(np.int32)  # only singlets merge (:590-596)
+    ok = (cells["type"] == 0) & ~p.truth["is_doublet"]
+    assert ok.sum() > 0.9 * (~p.truth["is_doublet"]).sum()
+
+
 def _masked(p, keep):
     """packed arrays of the entries selected by the boolean mask (all cells)"""
     from popscle_amd.synth import _ranges
