@@ -266,133 +266,139 @@ __global__ void __launch_bounds__(GT)
 // is a product over its entries of terms that depend on the state (c, SNP); relative to the state at the START of the
 // batch only the states (w_b, SNP) for SNPs of EARLIER batch cells b < i have changed -- a few per cent of cell i's
 // K x L terms.  The sequential rule  w_i = argmax_c D_i(c | w_0 .. w_{i-1})  is therefore solved as a FIXPOINT:
-//   1. greedy_dist_kernel (whole chip): every batch cell's products against the state at the start of the batch;
-//      greedy_argmax0_kernel: w := argmax of those (the guess that ignores the batch's own merges);
-//   2. greedy_ratio_kernel (whole chip): for every entry of a batch cell whose SNP also occurs in an earlier cell of the
-//      batch (a "hot" entry; its predecessors are a static chain, built once by a sort of (batch, SNP) keys), and every
-//      cluster c some predecessor joined under the current guess: replay those predecessors' merges on top of the
-//      start state of (c, SNP) -- in cell order, with the reference's merge() -- and leave term(replayed) / term(start);
-//   3. greedy_decide_kernel (one workgroup): scores = start products x the ratios, per cell the first maximum; where a
-//      guess changes, the ratios of the hot entries behind that cell are recomputed and the scores taken again, until
-//      nothing changes.  By induction over i the fixpoint is the sequential result (cell 0 of the batch has no
-//      predecessor, so it is final after the first pass; cell i is final once cells < i are) -- in exact arithmetic:
+//   1. start products: every batch cell's products against the state at the start of the batch, and
+//      w := argmax of those (the guess that ignores the batch's own merges);
+//   2. ratios: for every entry of a batch cell whose SNP also occurs in an earlier cell of the batch (a "hot" entry; its
+//      predecessors are a static chain, built once by a sort of (batch, SNP) keys), and every cluster c some predecessor
+//      joined under the current guess: replay those predecessors' merges on top of the start state of (c, SNP) -- in cell
+//      order, with the reference's merge() -- and leave term(replayed) / term(start);
+//   3. scores = start products x the ratios, per cell the first maximum; where a guess changes, 2. and 3. are taken
+//      again, until nothing changes.  By induction over i the fixpoint is the sequential result (cell 0 of the batch has
+//      no predecessor, so it is final after the first pass; cell i is final once cells < i are) -- in exact arithmetic:
 //      the scores here are start product x term(replayed)/term(start), not the product over the replayed state, so they
 //      match the sequential rule up to rounding and a near tie within a few ulp could pick another cluster than the
 //      reference's loop (strict '>' keeps the first maximum); tests/test_fmx_gpu.py::test_greedy_init_near_ties holds
-//      12 000 low-margin cells against the serial kernel and the CPU restatement.  It is reached after one or two passes except
-//      while the first clusters are being seeded;
-//   4. greedy_apply_kernel (whole chip): the batch's merges into the (cluster, SNP) states, one thread per chain of
-//      entries at the same SNP walking it in cell order (the order matters only inside a chain: merge() clamps).
+//      12 000 low-margin cells against the serial kernel and the CPU restatement.  It is reached after one or two passes
+//      except while the first clusters are being seeded;
+//   4. apply: the batch's merges into the (cluster, SNP) states, one thread per chain of entries at the same SNP walking
+//      it in cell order (the order matters only inside a chain: merge() clamps).
 // No state is written while a batch is being decided, so the "snapshot" is simply the table itself.
+//
+// ONE launch walks all batches (greedy_batches_kernel, below): a batch is a chain of small dependent phases, and what it
+// costs is the latency of their dependent trips to memory (~2 us each) -- so everything about a batch that does not
+// depend on the states (which entries, SNPs, allele-frequency weights, likelihoods, chains) sits in tables in processing
+// order, built once, and is fetched BEFORE the grid barrier that the phase waits on.
 #ifndef MUXGL_GREEDY_GB
 #define MUXGL_GREEDY_GB 32
 #endif
 constexpr int GB = MUXGL_GREEDY_GB;  // cells per batch
-constexpr int GCH = 64;    // entries per workgroup of greedy_dist_kernel
-constexpr int GA_T = 256;
+constexpr int GCH = 64;    // entries per chunk of the distance phase
+constexpr int GA_T = 256;  // threads per chunk
+constexpr int BT = 512;    // threads of a workgroup of greedy_batches_kernel (256 VGPRs a thread): two chunks side by side
+constexpr int GSUB = BT / GA_T;
+constexpr int GWAVES = BT / 64;
+constexpr int ICAP = 2048;  // incidences of one cell kept in LDS (more: the rest through the global tables)
 
-__global__ void __launch_bounds__(GA_T)
-    greedy_dist_kernel(int64_t chunk0, const int32_t* __restrict__ chunk_cell, const int64_t* __restrict__ chunk_first,
-                       const int64_t* __restrict__ hdr_e0, const int32_t* __restrict__ hdr_len,
-                       const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
-                       const double* __restrict__ af, int K, int Kp, const double* __restrict__ diag0,
-                       double2* __restrict__ pm, int2* __restrict__ px) {
-  __shared__ int32_t s_snp[GCH];
-  __shared__ __align__(16) double s_w[GCH][4];
-  __shared__ double2 r_m[GA_T];
-  __shared__ int2 r_x[GA_T];
-  const int t = threadIdx.x;
-  const int64_t g = chunk0 + blockIdx.x;
-  const int oi = chunk_cell[g];
-  const int64_t ec = hdr_e0[oi];
-  const int64_t eb = ec + (g - chunk_first[oi]) * GCH, ee = ec + hdr_len[oi];
-  const int n = (int)(ee - eb < GCH ? ee - eb : GCH);
-  if (t < n) {
-    const int64_t e = eb + t;
-    const int32_t snp = entry_snp[e];
-    const double a = af[snp];
-    const double* gl = egls + (size_t)e * 9;
-    s_snp[t] = snp;
-    *reinterpret_cast<double4*>(s_w[t]) =
-        make_double4(gl[0] * ((1.0 - a) * (1.0 - a)), gl[4] * (2.0 * a * (1.0 - a)), gl[8] * (a * a), a);
-  }
-  __syncthreads();
-  const int j = t & (Kp - 1), stripe = t / Kp, nstripes = GA_T / Kp;
-  double m2 = 1.0, m0 = 1.0;
-  int32_t x2 = 0, x0 = 0;
-  if (j < K) {
-    int cnt = 0;
-    for (int i = stripe; i < n; i += nstripes) {
-      const double4 d = *reinterpret_cast<const double4*>(diag0 + ((size_t)s_snp[i] * K + j) * 4);
-      if (d.w == 0.0) continue;  // no such (cluster, SNP) yet
-      const double4 w = *reinterpret_cast<const double4*>(s_w[i]);
-      m2 *= (w.x * d.x + w.y * d.y) + w.z * d.z;
-      m0 *= ((w.x + w.y) + w.z) * d.w;
-      if (++cnt == 4) {
-        cnt = 0;
-        prodacc_renorm(m2, x2);
-        prodacc_renorm(m0, x0);
-      }
-    }
-  }
-  prodacc_renorm(m2, x2);
-  prodacc_renorm(m0, x0);
-  r_m[t] = make_double2(m2, m0);
-  r_x[t] = make_int2(x2, x0);
-  __syncthreads();
-  if (t < Kp) {
-    double a2 = 1.0, a0 = 1.0;
-    int32_t b2 = 0, b0 = 0;
-    for (int sidx = 0; sidx < nstripes; ++sidx) {
-      const double2 m = r_m[sidx * Kp + t];
-      const int2 x = r_x[sidx * Kp + t];
-      a2 *= m.x;
-      a0 *= m.y;
-      b2 += x.x;
-      b0 += x.y;
-      if ((sidx & 7) == 7) {
-        prodacc_renorm(a2, b2);
-        prodacc_renorm(a0, b0);
-      }
-    }
-    prodacc_renorm(a2, b2);
-    prodacc_renorm(a0, b0);
-    pm[(size_t)blockIdx.x * Kp + t] = make_double2(a2, a0);
-    px[(size_t)blockIdx.x * Kp + t] = make_int2(b2, b0);
-  }
-}
+// "position" p = index of an entry in processing order (cells in score order, a cell's entries in SNP order); an
+// "incidence" x = (hot entry, one of its predecessors in the batch), grouped by hot entry, the hot entries by cell.
+struct greedy_tabs {
+  const int64_t* pos_ptr;      // [n + 1] positions of step cell i
+  const int64_t* chunk_first;  // [n + 1] chunks (64 positions of one cell) of step cell i
+  const int64_t* chunk_p0;     // per chunk: first position, entries
+  const int32_t* chunk_n;
+  const int32_t* pos_snp;      // per position: SNP,
+  const double4* pos_w;        //   {gl[0,0] hwe0, gl[1,1] hwe1, gl[2,2] hwe2, allele frequency},
+  const int64_t* pos_e;        //   entry (egls row),
+  const int32_t* pos_cell;     //   step cell,
+  const int32_t* pos_q;        //   index in (batch, SNP) order: the members of its chain are neighbours there,
+  const uchar2* pos_pl;        //   {place in the chain, length of the chain}
+  const uint8_t* srt_cell;     // in (batch, SNP) order: cell inside the batch,
+  const int64_t* srt_e;        //   entry
+  const int64_t* cinc_ptr;     // [n + 1] incidences of step cell i
+  const uchar4* inc_meta;      // per incidence: {cell of the predecessor inside the batch, place in its chain, chain length, -}
+  const int32_t* inc_hp;       //   position of the hot entry
+  const int64_t* inc_e;        //   entry of the predecessor
+  const int32_t* hdr_cell;     // [n] step cell -> cell
+  const double* egls;
+  double* diag;                // [S][K][4] = {g00, g11, g22, B}
+  double* offd;                // [S][K][6]
+  int32_t* ic;                 // per incidence beyond ICAP of its cell: cluster its ratio belongs to (-1: none)
+  double2* rat;                //   {term2, term0}(replayed) / (start)
+  double2* pm;                 // chunk partials of the current batch
+  int2* px;
+  unsigned long long* guess;   // [GB] {batch + 1, first guess} of the batch's cells
+  unsigned long long* passw;   // [GB + 1][GB] {batch + 1, changed << 8 | guess} after each pass of the batch
+  unsigned* cflag;             // per pair of chunks of the batch: batch + 1 once its partials are in memory
+  int32_t* clust;
+  unsigned* bar;               // [0] arrivals, [1] a workgroup gave up
+  int32_t* pass_hist;          // NULL or [GB + 2] (MUXGL_TIMING)
+  uint64_t* ticks;
+  int64_t n;
+  int K, Kp;
+};
 
-// ---- chain tables, built once per run -----------------------------------------------------------------------------------
-// "position" p = index of an entry in processing order (cells in score order, a cell's entries in SNP order).
+// ---- tables, built once per run ---------------------------------------------------------------------------------------
 
-// key (batch, SNP) and payload p of every position; pos_cell[p] = step index of its cell.  One wave per cell.
+// per position: key (batch, SNP) and payload p for the chain sort, SNP, weights, entry, step cell.  One wave per cell.
 __global__ void __launch_bounds__(256)
-    greedy_keys_kernel(int64_t n, const int64_t* __restrict__ hdr_e0, const int64_t* __restrict__ pos_ptr,
-                       const int32_t* __restrict__ entry_snp, uint64_t* __restrict__ key, uint32_t* __restrict__ val,
-                       int32_t* __restrict__ pos_cell) {
+    greedy_pos_kernel(int64_t n, const int64_t* __restrict__ hdr_e0, const int64_t* __restrict__ pos_ptr,
+                      const int32_t* __restrict__ entry_snp, const double* __restrict__ egls, const double* __restrict__ af,
+                      uint64_t* __restrict__ key, uint32_t* __restrict__ val, int32_t* __restrict__ pos_cell,
+                      int32_t* __restrict__ pos_snp, double4* __restrict__ pos_w, int64_t* __restrict__ pos_e) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const int64_t p0 = pos_ptr[i], p1 = pos_ptr[i + 1], e0 = hdr_e0[i];
   for (int64_t p = p0 + (threadIdx.x & 63); p < p1; p += 64) {
-    key[p] = ((uint64_t)(i / GB) << 32) | (uint32_t)entry_snp[e0 + (p - p0)];
+    const int64_t e = e0 + (p - p0);
+    const int32_t snp = entry_snp[e];
+    const double a = af[snp];
+    const double* gl = egls + (size_t)e * 9;
+    key[p] = ((uint64_t)(i / GB) << 32) | (uint32_t)snp;
     val[p] = (uint32_t)p;
     pos_cell[p] = (int32_t)i;
+    pos_snp[p] = snp;
+    pos_e[p] = e;
+    pos_w[p] = make_double4(gl[0] * ((1.0 - a) * (1.0 - a)), gl[4] * (2.0 * a * (1.0 - a)), gl[8] * (a * a), a);
   }
 }
 
-// after the stable sort, equal keys are the entries of one batch at one SNP, in cell order: link them
+// chunks of a cell: 64 consecutive positions
+__global__ void __launch_bounds__(256)
+    greedy_chunks_kernel(int64_t n, const int64_t* __restrict__ pos_ptr, const int64_t* __restrict__ chunk_first,
+                         int64_t* __restrict__ chunk_p0, int32_t* __restrict__ chunk_n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p0 = pos_ptr[i], p1 = pos_ptr[i + 1];
+  int64_t c = chunk_first[i];
+  for (int64_t p = p0; p < p1; p += GCH, ++c) {
+    chunk_p0[c] = p;
+    chunk_n[c] = (int32_t)(p1 - p < GCH ? p1 - p : GCH);
+  }
+}
+
+// after the stable sort, equal keys are the entries of one batch at one SNP, in cell order -- a chain: per position its
+// predecessor, its place in the chain and the chain's length, its index in sorted order; in sorted order (a chain's
+// members side by side) the cell inside the batch and the entry
 __global__ void __launch_bounds__(256)
     greedy_links_kernel(int64_t P, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sval,
-                        int32_t* __restrict__ prev, int32_t* __restrict__ next) {
+                        const int32_t* __restrict__ pos_cell, const int64_t* __restrict__ pos_e, int32_t* __restrict__ prev,
+                        int32_t* __restrict__ pos_q, uchar2* __restrict__ pos_pl, uint8_t* __restrict__ srt_cell,
+                        int64_t* __restrict__ srt_e) {
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < P; q += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t k = skey[q];
     const uint32_t p = sval[q];
-    prev[p] = (q > 0 && skey[q - 1] == k) ? (int32_t)sval[q - 1] : -1;
-    next[p] = (q + 1 < P && skey[q + 1] == k) ? (int32_t)sval[q + 1] : -1;
+    int64_t lo = q, hi = q + 1;
+    while (lo > 0 && skey[lo - 1] == k) --lo;
+    while (hi < P && skey[hi] == k) ++hi;  // (a chain has at most GB members)
+    prev[p] = lo < q ? (int32_t)sval[q - 1] : -1;
+    pos_q[p] = (int32_t)q;
+    pos_pl[p] = make_uchar2((unsigned char)(q - lo), (unsigned char)(hi - lo));
+    srt_cell[q] = (uint8_t)(pos_cell[p] % GB);
+    srt_e[q] = pos_e[p];
   }
 }
 
-// hot entries (positions with a predecessor in their batch) per cell, and the total length of their chains
+// hot entries (positions with a predecessor in their batch) per cell
 __global__ void __launch_bounds__(256)
     greedy_hot_count_kernel(int64_t n, const int64_t* __restrict__ pos_ptr, const int32_t* __restrict__ prev,
                             int64_t* __restrict__ nhot) {
@@ -429,28 +435,35 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// incidences: for hot entry h, its predecessors in cell order -- their position and the step index of their cell
+// incidences: for hot entry h, its predecessors in cell order
 __global__ void __launch_bounds__(256)
     greedy_inc_fill_kernel(int64_t H, const int32_t* __restrict__ hot_pos, const int32_t* __restrict__ prev,
                            const int64_t* __restrict__ hinc_ptr, const int32_t* __restrict__ pos_cell,
-                           int32_t* __restrict__ inc_pos, int32_t* __restrict__ inc_cell, int32_t* __restrict__ inc_hot,
-                           uchar4* __restrict__ inc_meta) {
+                           const int64_t* __restrict__ pos_e, uchar4* __restrict__ inc_meta, int32_t* __restrict__ inc_hp,
+                           int64_t* __restrict__ inc_e) {
   for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < H; h += (int64_t)gridDim.x * blockDim.x) {
     const int64_t xb = hinc_ptr[h], xe = hinc_ptr[h + 1];
-    int32_t q = prev[hot_pos[h]];
+    const int32_t hp = hot_pos[h];
+    int32_t q = prev[hp];
     for (int64_t x = xe - 1; x >= xb; --x) {
-      inc_pos[x] = q;
-      inc_cell[x] = pos_cell[q];
-      inc_hot[x] = (int32_t)h;
-      // what the decide kernel keeps in LDS: cell of the predecessor inside its batch, place in the chain, chain length
       inc_meta[x] = make_uchar4((unsigned char)(pos_cell[q] % GB), (unsigned char)(x - xb), (unsigned char)(xe - xb), 0);
+      inc_hp[x] = hp;
+      inc_e[x] = pos_e[q];
       q = prev[q];
     }
   }
 }
 
+// incidences of step cell i: [cinc_ptr[i], cinc_ptr[i + 1])
+__global__ void __launch_bounds__(256)
+    greedy_cinc_kernel(int64_t n1, const int64_t* __restrict__ hot_ptr, const int64_t* __restrict__ hinc_ptr,
+                       int64_t* __restrict__ cinc_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n1) cinc_ptr[i] = hinc_ptr[hot_ptr[i]];
+}
+
 // sc_drop_seq.h:77-101 on a nine-value state, divisions as reciprocal multiplies (as in the serial kernel)
-__device__ __forceinline__ void greedy_merge9(double (&v)[9], bool present, const double* __restrict__ o) {
+__device__ __forceinline__ void greedy_merge9(double (&v)[9], bool present, const double (&o)[9]) {
   double tmp = 0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
@@ -470,172 +483,234 @@ __device__ __forceinline__ void greedy_merge9(double (&v)[9], bool present, cons
   for (int q = 0; q < 9; ++q) v[q] *= r;
 }
 
-struct greedy_tabs {
-  const int64_t* hdr_e0;
-  const int64_t* pos_ptr;
-  const int32_t* pos_cell;
-  const int32_t* hot_pos;
-  const int64_t* hinc_ptr;
-  const int32_t* inc_pos;
-  const int32_t* inc_cell;
-  const int32_t* inc_hot;
-  const uchar4* inc_meta;  // {cell of the predecessor inside the batch, place in its chain, chain length, -}
-  const int32_t* entry_snp;
-  const double* egls;
-  const double* af;
-  const double* diag;  // [S][K][4] = {g00, g11, g22, B}: the state at the start of the batch
-  const double* offd;  // [S][K][6]
-  int32_t* ic;         // per incidence: cluster this ratio belongs to (-1: none)
-  double2* rat;        // {term2, term0}(replayed) / (start)
-};
-
-// Ratio of incidence x (predecessor x of its hot entry) under the guess w[]: only the LAST predecessor that joined a given
-// cluster carries that cluster's ratio, and it replays every earlier predecessor of the same cluster before itself.
-template <class W>
-__device__ __forceinline__ void greedy_ratio(const greedy_tabs& T, int K, int64_t x, int64_t oi0, W w) {
-  const int32_t h = T.inc_hot[x];
-  const int64_t xb = T.hinc_ptr[h], xe = T.hinc_ptr[h + 1];
-  const int c = w(T.inc_cell[x] - oi0);
-  bool active = c >= 0;
-  for (int64_t y = x + 1; y < xe && active; ++y) active = w(T.inc_cell[y] - oi0) != c;
-  if (!active) {
-    T.ic[x] = -1;
-    return;
-  }
-  const int32_t p = T.hot_pos[h];
-  const int32_t i = T.pos_cell[p];
-  const int64_t e = T.hdr_e0[i] + (p - T.pos_ptr[i]);
-  const int32_t snp = T.entry_snp[e];
-  const double a = T.af[snp];
-  const double h0 = (1.0 - a) * (1.0 - a), h1 = 2.0 * a * (1.0 - a), h2 = a * a;
-  const double* gl = T.egls + (size_t)e * 9;
-  const double wx = gl[0] * h0, wy = gl[4] * h1, wz = gl[8] * h2, A = (wx + wy) + wz;
-  const double2* dg = reinterpret_cast<const double2*>(T.diag + ((size_t)snp * K + c) * 4);
-  const double2* od = reinterpret_cast<const double2*>(T.offd + ((size_t)snp * K + c) * 6);
-  const double2 r0 = dg[0], r1 = dg[1];
-  bool present = r1.y != 0.0;
-  const double o2 = present ? (wx * r0.x + wy * r0.y) + wz * r1.x : 1.0, o0 = present ? A * r1.y : 1.0;
-  double v[9];
-  if (present) {
-    const double2 r2 = od[0], r3 = od[1], r4 = od[2];
-    v[0] = r0.x, v[1] = r2.x, v[2] = r2.y, v[3] = r3.x, v[4] = r0.y, v[5] = r3.y, v[6] = r4.x, v[7] = r4.y, v[8] = r1.x;
-  }
-  for (int64_t y = xb; y <= x; ++y) {
-    const int32_t iq = T.inc_cell[y];
-    if (w(iq - oi0) != c) continue;
-    const int32_t q = T.inc_pos[y];
-    greedy_merge9(v, present, T.egls + (size_t)(T.hdr_e0[iq] + (q - T.pos_ptr[iq])) * 9);
-    present = true;
-  }
-  const double B = (v[0] * h0 + v[4] * h1) + v[8] * h2;
-  T.ic[x] = c;
-  T.rat[x] = make_double2(((wx * v[0] + wy * v[4]) + wz * v[8]) / o2, (A * B) / o0);
+__device__ __forceinline__ void greedy_load9(double (&o)[9], const double* __restrict__ src) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) o[q] = src[q];
 }
 
-// start products of the batch's cells per cluster (chunk partials in entry order) and the first guess: their argmax
-__global__ void __launch_bounds__(1024)
-    greedy_argmax0_kernel(int64_t oi0, int nb, const int64_t* __restrict__ chunk_first, int K, int Kp,
-                          const double2* __restrict__ pm, const int2* __restrict__ px, double2* __restrict__ bm,
-                          int2* __restrict__ bx, int32_t* __restrict__ wguess) {
-  __shared__ double sc[GB * 64];
-  const int t = threadIdx.x;
-  const int64_t cbase = chunk_first[oi0];
-  for (int idx = t; idx < nb * Kp; idx += blockDim.x) {
-    const int b = idx / Kp, jj = idx - b * Kp;
-    const int64_t c0 = chunk_first[oi0 + b] - cbase, c1 = chunk_first[oi0 + b + 1] - cbase;
+// What one workgroup of greedy_batches_kernel writes and another reads later in the same launch (MI355X: eight XCDs with
+// private L2s; a compute unit's L1 is never refreshed by another's stores):
+//   * the states (xwg_ld / xwg_st): plain 16-byte accesses under the grid barrier's agent-scope release / acquire.
+//     Measured alternative, kept as a build knob (-DMUXGL_GREEDY_SC1): 8-byte relaxed agent-scope accesses and a barrier
+//     without fences -- slower (configs[3]: 0.154 s against 0.132 s): every read then goes to memory;
+//   * chunk partials and guesses (sc1_ld / sc1_st): 8-byte relaxed agent-scope accesses (sc1: the store writes through, the
+//     load bypasses L1) handed over point to point -- a tag word stored after the data is drained (chunk partials), or a
+//     word that carries tag and value at once (guesses) -- so that their readers need not wait at a grid barrier.
+__device__ __forceinline__ double sc1_ld(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sc1_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double2 sc1_ld(const double2* p) { return make_double2(sc1_ld(&p->x), sc1_ld(&p->y)); }
+__device__ __forceinline__ double4 sc1_ld(const double4* p) {
+  return make_double4(sc1_ld(&p->x), sc1_ld(&p->y), sc1_ld(&p->z), sc1_ld(&p->w));
+}
+__device__ __forceinline__ int2 sc1_ld(const int2* p) {
+  const unsigned long long u =
+      __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_int2((int)(uint32_t)u, (int)(uint32_t)(u >> 32));
+}
+__device__ __forceinline__ void sc1_st(double2* p, double2 v) { sc1_st(&p->x, v.x), sc1_st(&p->y, v.y); }
+__device__ __forceinline__ void sc1_st(int2* p, int2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(uint32_t)v.x | ((unsigned long long)(uint32_t)v.y << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifdef MUXGL_GREEDY_SC1
+template <class V>
+__device__ __forceinline__ V xwg_ld(const V* p) { return sc1_ld(p); }
+template <class V>
+__device__ __forceinline__ void xwg_st(V* p, V v) { sc1_st(p, v); }
+#else
+template <class V>
+__device__ __forceinline__ V xwg_ld(const V* p) { return *p; }
+template <class V>
+__device__ __forceinline__ void xwg_st(V* p, V v) { *p = v; }
+#endif
+
+// the nine values of state (SNP, cluster) out of the two tables; false: no such state yet
+__device__ __forceinline__ bool greedy_state(const double* diag, const double* offd, size_t row, double (&v)[9], double& B) {
+  const double2* dg = reinterpret_cast<const double2*>(diag + row * 4);
+  const double2* od = reinterpret_cast<const double2*>(offd + row * 6);
+  const double2 r0 = xwg_ld(dg), r1 = xwg_ld(dg + 1);
+  // (the off-diagonal values with the diagonal, not behind the test on it: one trip)
+  const double2 r2 = xwg_ld(od), r3 = xwg_ld(od + 1), r4 = xwg_ld(od + 2);
+  B = r1.y;
+  if (r1.y == 0.0) return false;
+  v[0] = r0.x, v[1] = r2.x, v[2] = r2.y, v[3] = r3.x, v[4] = r0.y, v[5] = r3.y, v[6] = r4.x, v[7] = r4.y, v[8] = r1.x;
+  return true;
+}
+
+__device__ __forceinline__ void greedy_state_store(double* diag, double* offd, size_t row, const double (&v)[9], double B) {
+  double2* dg = reinterpret_cast<double2*>(diag + row * 4);
+  double2* od = reinterpret_cast<double2*>(offd + row * 6);
+#ifdef MUXGL_GREEDY_WT_STATES  // (experiment: write-through stores of the states, so that the barrier's release has less to write back)
+  auto wt = [](double2* q, double2 x) {
+    __hip_atomic_store(&q->x, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&q->y, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  wt(dg, make_double2(v[0], v[4]));
+  wt(dg + 1, make_double2(v[8], B));
+  wt(od, make_double2(v[1], v[2]));
+  wt(od + 1, make_double2(v[3], v[5]));
+  wt(od + 2, make_double2(v[6], v[7]));
+#else
+  xwg_st(dg, make_double2(v[0], v[4]));
+  xwg_st(dg + 1, make_double2(v[8], B));
+  xwg_st(od, make_double2(v[1], v[2]));
+  xwg_st(od + 1, make_double2(v[3], v[5]));
+  xwg_st(od + 2, make_double2(v[6], v[7]));
+#endif
+}
+
+// ---- LDS of a workgroup ------------------------------------------------------------------------------------------------
+struct greedy_dist_lds {  // one 256-thread group working on a PAIR of chunks of the distance phase
+  int32_t n[2];
+  int32_t snp[2][GCH];
+  double w[2][GCH][4];
+  double2 r_m[2][GA_T];
+  int2 r_x[2][GA_T];
+};
+struct greedy_score_lds {  // a workgroup deciding its cell
+  double2 part_m[GWAVES][64];   // per wave: product of its share of the ratios, per cluster
+  int2 part_x[GWAVES][64];
+};
+struct greedy_lds {
+  union {
+    greedy_dist_lds dist[GSUB];
+    greedy_score_lds s;
+  };
+  double2 own_m[64];  // start products of the workgroup's cell
+  int2 own_x[64];
+  double2 rat[ICAP];  // the cell's incidences
+  int32_t ic[ICAP];
+  uchar4 meta[ICAP];
+  int32_t g[GB];      // the guesses
+  unsigned xv[64];    // what greedy_collect gathered
+  int32_t cf[GB + 1]; // chunks of the batch's cells, from the batch's first
+  int ok, any;
+};
+
+// ---- phase 1: products of one chunk per cluster against the states at the start of the batch -----------------------------
+// a group of 256 threads = (cluster, entry stripe) takes two chunks at a time (c, c + 1; `two`: the second exists), so that a
+// thread has eight gathers in flight; each chunk keeps its own products.  t = thread in the group
+__device__ __forceinline__ void greedy_dist_stage(greedy_dist_lds& L, int t, const greedy_tabs& T, int64_t c, bool two) {
+  const int h = t >> 7, tt = t & 127;  // half a group stages a chunk
+  if (h == 0 || two) {
+    const int64_t p = T.chunk_p0[c + h] + tt;
+    const int32_t n = T.chunk_n[c + h];
+    if (tt == 0) L.n[h] = n;
+    if (tt < n) {
+      L.snp[h][tt] = T.pos_snp[p];
+      *reinterpret_cast<double4*>(L.w[h][tt]) = T.pos_w[p];
+    }
+  } else if (tt == 0) {
+    L.n[1] = 0;
+  }
+}
+
+__device__ __forceinline__ void greedy_dist_terms(greedy_dist_lds& L, int t, int K, int Kp, const double* diag0) {
+  const int j = t & (Kp - 1), stripe = t / Kp, nstripes = GA_T / Kp;
+  double m2[2] = {1.0, 1.0}, m0[2] = {1.0, 1.0};
+  int32_t x2[2] = {0, 0}, x0[2] = {0, 0};
+  if (j < K) {
+    int cnt[2] = {0, 0};
+    const int n0 = L.n[0], n1 = L.n[1], nmax = n0 > n1 ? n0 : n1;
+    for (int i0 = stripe; i0 < nmax; i0 += 4 * nstripes) {  // eight gathers in flight; a chunk's terms in entry order
+      double4 d[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * nstripes;
+          d[h][u] = i < (h ? n1 : n0) ? xwg_ld(reinterpret_cast<const double4*>(diag0 + ((size_t)L.snp[h][i] * K + j) * 4))
+                                      : make_double4(0, 0, 0, 0);
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * nstripes;
+          if (i >= (h ? n1 : n0) || d[h][u].w == 0.0) continue;  // no such (cluster, SNP) yet
+          const double4 w = *reinterpret_cast<const double4*>(L.w[h][i]);
+          m2[h] *= (w.x * d[h][u].x + w.y * d[h][u].y) + w.z * d[h][u].z;
+          m0[h] *= ((w.x + w.y) + w.z) * d[h][u].w;
+          if (++cnt[h] == 4) {
+            cnt[h] = 0;
+            prodacc_renorm(m2[h], x2[h]);
+            prodacc_renorm(m0[h], x0[h]);
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    prodacc_renorm(m2[h], x2[h]);
+    prodacc_renorm(m0[h], x0[h]);
+    L.r_m[h][t] = make_double2(m2[h], m0[h]);
+    L.r_x[h][t] = make_int2(x2[h], x0[h]);
+  }
+}
+
+// threads [0, Kp) fold the first chunk's stripes, threads [Kp, 2 Kp) the second's; pm / px: the first chunk's row
+__device__ __forceinline__ void greedy_dist_fold(greedy_dist_lds& L, int t, int Kp, bool two, double2* __restrict__ pm,
+                                                 int2* __restrict__ px) {
+  const int nstripes = GA_T / Kp;
+  const int h = t / Kp, j = t - h * Kp;
+  if (h == 0 || (h == 1 && two)) {
     double a2 = 1.0, a0 = 1.0;
     int32_t b2 = 0, b0 = 0;
-    for (int64_t c = c0; c < c1; ++c) {
-      const double2 m = pm[(size_t)c * Kp + jj];
-      const int2 x = px[(size_t)c * Kp + jj];
+    for (int sidx = 0; sidx < nstripes; ++sidx) {
+      const double2 m = L.r_m[h][sidx * Kp + j];
+      const int2 x = L.r_x[h][sidx * Kp + j];
       a2 *= m.x;
       a0 *= m.y;
       b2 += x.x;
       b0 += x.y;
-      if (((c - c0) & 7) == 7) {
+      if ((sidx & 7) == 7) {
         prodacc_renorm(a2, b2);
         prodacc_renorm(a0, b0);
       }
     }
     prodacc_renorm(a2, b2);
     prodacc_renorm(a0, b0);
-    bm[b * 64 + jj] = make_double2(a2, a0);
-    bx[b * 64 + jj] = make_int2(b2, b0);
-    sc[b * 64 + jj] = prodacc_log(a2, b2) - prodacc_log(a0, b0);
-  }
-  __syncthreads();
-  if (t < nb) {  // first maximum in cluster order (:233-242)
-    int best = 0;
-    double bs = sc[t * 64];
-    for (int c = 1; c < K; ++c)
-      if (sc[t * 64 + c] > bs) {
-        bs = sc[t * 64 + c];
-        best = c;
-      }
-    wguess[t] = best;
+    sc1_st(pm + t, make_double2(a2, a0));  // (row c + 1 follows row c: pm[h Kp + j])
+    sc1_st(px + t, make_int2(b2, b0));
   }
 }
 
-__global__ void __launch_bounds__(256)
-    greedy_ratio_kernel(greedy_tabs T, int K, int64_t oi0, int nb, const int64_t* __restrict__ hot_ptr,
-                        const int32_t* __restrict__ wguess) {
-  const int64_t x0 = T.hinc_ptr[hot_ptr[oi0]], x1 = T.hinc_ptr[hot_ptr[oi0 + nb]];
-  for (int64_t x = x0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < x1; x += (int64_t)gridDim.x * blockDim.x)
-    greedy_ratio(T, K, x, oi0, [&](int b) { return wguess[b]; });
-}
-
-// Scores of one batch cell under the ratios in T.ic / T.rat: the calling wave's lane c holds cluster c.  The cell's
-// incidences are read 256 at a time (lane = incidence, four coalesced requests in flight) and handed round with readlane
-// in their fixed order (entry order, then chain order): lane c multiplies the ratios that belong to cluster c into its
-// product -- one read of every ratio, not one per cluster.  Returns log lk2 - log lk0 of (cell, cluster c).
-__device__ __forceinline__ double greedy_cell_score(const greedy_tabs& T, int K, int c, int b, int64_t oi0,
-                                                    const int64_t* __restrict__ hot_ptr, const double2* __restrict__ bm,
-                                                    const int2* __restrict__ bx) {
+// ---- phase 2 -------------------------------------------------------------------------------------------------------------
+// start products of the workgroup's cell per cluster (chunk partials in entry order): thread jj < Kp = cluster jj; the
+// products stay in LDS for the scores, returns log lk2 - log lk0
+__device__ __forceinline__ double greedy_start_products(greedy_lds& L, int jj, const greedy_tabs& T, int c0, int c1) {
+  const int Kp = T.Kp;
   double a2 = 1.0, a0 = 1.0;
   int32_t b2 = 0, b0 = 0;
-  if (c < K) {
-    const double2 m = bm[b * 64 + c];
-    const int2 xx = bx[b * 64 + c];
-    a2 = m.x, a0 = m.y, b2 = xx.x, b0 = xx.y;
-  }
-  const int64_t y0 = T.hinc_ptr[hot_ptr[oi0 + b]], y1 = T.hinc_ptr[hot_ptr[oi0 + b + 1]];
-  int cnt = 0;
-  for (int64_t yb = y0; yb < y1; yb += 256) {
-    int32_t ci[4];
-    double2 r[4];
+  for (int cc = c0; cc < c1; cc += 16) {  // sixteen partials in flight, multiplied in chunk order
+    double2 m[16];
+    int2 x[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t y = yb + u * 64 + c;
-      ci[u] = (y < y1) ? T.ic[y] : -1;
-    }
+    for (int u = 0; u < 16; ++u)
+      if (cc + u < c1) {
+        m[u] = sc1_ld(T.pm + (size_t)(cc + u) * Kp + jj);
+        x[u] = sc1_ld(T.px + (size_t)(cc + u) * Kp + jj);
+      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t y = yb + u * 64 + c;
-      r[u] = (ci[u] >= 0) ? T.rat[y] : make_double2(1.0, 1.0);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      uint64_t live = __ballot(ci[u] >= 0);
-      while (live) {  // wave-uniform
-        const int k = __builtin_ctzll(live);
-        live &= live - 1;
-        const int ck = __builtin_amdgcn_readlane(ci[u], k);
-        const double rx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r[u].x), k),
-                                           __builtin_amdgcn_readlane(__double2loint(r[u].x), k));
-        const double ry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r[u].y), k),
-                                           __builtin_amdgcn_readlane(__double2loint(r[u].y), k));
-        if (c == ck) {
-          a2 *= rx;
-          a0 *= ry;
-          if (++cnt == 4) {  // a ratio lies within 1e-30 .. 1e30
-            cnt = 0;
-            prodacc_renorm(a2, b2);
-            prodacc_renorm(a0, b0);
-          }
-        }
+    for (int u = 0; u < 16; ++u) {
+      if (cc + u < c1) {
+        a2 *= m[u].x;
+        a0 *= m[u].y;
+        b2 += x[u].x;
+        b0 += x[u].y;
+      }
+      if ((u & 7) == 7 && cc + u < c1) {  // (every eighth chunk from c0)
+        prodacc_renorm(a2, b2);
+        prodacc_renorm(a0, b0);
       }
     }
   }
+  prodacc_renorm(a2, b2);
+  prodacc_renorm(a0, b0);
+  L.own_m[jj] = make_double2(a2, a0);
+  L.own_x[jj] = make_int2(b2, b0);
   return prodacc_log(a2, b2) - prodacc_log(a0, b0);
 }
 
@@ -655,133 +730,433 @@ __device__ __forceinline__ int greedy_wave_argmax(double sc, int c, int K) {
   return best;
 }
 
-// first pass of the fixpoint for every cell of the batch at once (one wave per cell, whole chip): the guess that takes
-// the batch's own merges into account.  In all but a few batches it confirms the first guess and the decision is made.
-__global__ void __launch_bounds__(64)
-    greedy_score_kernel(greedy_tabs T, int K, int64_t oi0, const int64_t* __restrict__ hot_ptr,
-                        const double2* __restrict__ bm, const int2* __restrict__ bx, const int32_t* __restrict__ wguess,
-                        int32_t* __restrict__ wnew /*[GB] guesses, [GB .. 2 GB) changed flags, [2 GB] any*/) {
-  const int b = blockIdx.x, c = threadIdx.x;
-  const double sc = greedy_cell_score(T, K, c, b, oi0, hot_ptr, bm, bx);
-  const int best = greedy_wave_argmax(sc, c, K);
-  if (c == 0) {
-    const int chg = best != wguess[b];
-    wnew[b] = best;
-    wnew[GB + b] = chg;
-    if (chg) atomicOr(wnew + 2 * GB, 1);
+// what an applying thread keeps of "its" position, fetched before the decisions are known
+struct greedy_pos_regs {
+  int32_t snp, q;       // SNP; index in (batch, SNP) order
+  int cell;             // cell inside the batch
+  unsigned place, len;  // place in the chain, length of the chain
+  uint64_t before;      // cells of the (up to eight) members before it, nearest first, a byte each
+  uint64_t behind;      //   ... behind it
+  double af;
+  double gl[9];         // its likelihoods
+  double gl1[9];        // those of the member behind it
+};
+
+// what a thread keeps of "its" incidence (the first ICAP... BT of the cell), fetched before the states are known
+struct greedy_inc_regs {
+  int32_t snp;
+  double4 w;      // of the hot entry
+  double gl[9];   // of the predecessor
+};
+
+// Ratio of incidence x (predecessor x of its hot entry) under the guess L.g[]: only the LAST predecessor that joined a
+// given cluster carries that cluster's ratio, and it replays every earlier predecessor of the same cluster before itself.
+template <class META>
+__device__ __forceinline__ void greedy_ratio(greedy_lds& L, const greedy_tabs& T, int64_t x, int64_t X0, const greedy_inc_regs& R,
+                                             META meta) {
+  const int K = T.K;
+  const uchar4 mx = meta(x);
+  const int64_t xb = x - mx.y, xe = xb + mx.z;
+  const int c = L.g[mx.x];
+  bool active = true;
+  for (int64_t y = x + 1; y < xe && active; ++y) active = L.g[meta(y).x] != c;
+  int32_t icv = -1;
+  double2 rv = make_double2(1.0, 1.0);
+  if (active) {
+    const double a = R.w.w;
+    const double h0 = (1.0 - a) * (1.0 - a), h1 = 2.0 * a * (1.0 - a), h2 = a * a;
+    const double wx = R.w.x, wy = R.w.y, wz = R.w.z, A = (wx + wy) + wz;
+    double v[9], B0;
+    bool present = greedy_state(T.diag, T.offd, (size_t)R.snp * K + c, v, B0);
+    const double o2 = present ? (wx * v[0] + wy * v[4]) + wz * v[8] : 1.0, o0 = present ? A * B0 : 1.0;
+    for (int64_t y = xb; y < x; ++y) {
+      if (L.g[meta(y).x] != c) continue;
+      double o[9];
+      greedy_load9(o, T.egls + (size_t)T.inc_e[y] * 9);
+      greedy_merge9(v, present, o);
+      present = true;
+    }
+    greedy_merge9(v, present, R.gl);
+    const double B = (v[0] * h0 + v[4] * h1) + v[8] * h2;
+    icv = c;
+    rv = make_double2(((wx * v[0] + wy * v[4]) + wz * v[8]) / o2, (A * B) / o0);
+  }
+  const int64_t k = x - X0;
+  if (k < ICAP) {
+    L.ic[k] = icv;
+    L.rat[k] = rv;
+  } else {
+    T.ic[x] = icv;
+    T.rat[x] = rv;
   }
 }
 
-constexpr int BT = 1024;      // threads of greedy_decide_kernel
-constexpr int DI_CAP = 8192;   // incidences of a batch whose chain bytes are kept in LDS (32 KB); denser batches read them from L2
+// Scores of the workgroup's cell under the ratios: wave w takes a contiguous share of the cell's incidences, its lane c
+// holds cluster c and multiplies the ratios that belong to cluster c, in their order, into its partial product -- every
+// lane walks the share and reads (cluster, ratio) at a wave-uniform address (an LDS broadcast); the partials are folded in
+// wave order onto the start products.  Returns the first maximum.
+__device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_tabs& T, int t, int64_t X0, int64_t X1) {
+  const int K = T.K, lane = t & 63, wave = t >> 6;
+  double a2 = 1.0, a0 = 1.0;
+  int32_t b2 = 0, b0 = 0;
+  int cnt = 0;
+  const int nx = (int)(X1 - X0), share = ((nx + GWAVES - 1) / GWAVES + 3) & ~3;  // (a multiple of 4: 16-byte reads of ic)
+  const int k0 = wave * share, k1 = k0 + share < nx ? k0 + share : nx;
+  auto mul = [&](int32_t ci, int k) {
+    if (ci != lane) return;
+    const double2 r = k < ICAP ? L.rat[k] : T.rat[X0 + k];
+    a2 *= r.x;
+    a0 *= r.y;
+    if (++cnt == 4) {  // a ratio lies within 1e-30 .. 1e30
+      cnt = 0;
+      prodacc_renorm(a2, b2);
+      prodacc_renorm(a0, b0);
+    }
+  };
+  for (int k = k0; k < k1; k += 4) {
+    if (k + 4 <= ICAP) {
+      const int4 c4 = *reinterpret_cast<const int4*>(L.ic + k);  // (-1 beyond the cell's last incidence: see the ratios)
+      mul(c4.x, k);
+      mul(c4.y, k + 1);
+      mul(c4.z, k + 2);
+      mul(c4.w, k + 3);
+    } else {
+      for (int u = 0; u < 4 && k + u < k1; ++u) mul(T.ic[X0 + k + u], k + u);
+    }
+  }
+  prodacc_renorm(a2, b2);
+  prodacc_renorm(a0, b0);
+  L.s.part_m[wave][lane] = make_double2(a2, a0);
+  L.s.part_x[wave][lane] = make_int2(b2, b0);
+  __syncthreads();
+  int best = -1;
+  if (wave == 0) {
+    double sc = 0.0;
+    if (lane < K) {
+      double2 m = L.own_m[lane];
+      int2 e = L.own_x[lane];
+      const int nw = share ? (nx + share - 1) / share : 0;
+      for (int w = 0; w < nw; ++w) {
+        const double2 pm = L.s.part_m[w][lane];
+        const int2 px = L.s.part_x[w][lane];
+        m.x *= pm.x;
+        m.y *= pm.y;
+        e.x += px.x;
+        e.y += px.y;
+        prodacc_renorm(m.x, e.x);
+        prodacc_renorm(m.y, e.y);
+      }
+      sc = prodacc_log(m.x, e.x) - prodacc_log(m.y, e.y);
+    }
+    best = greedy_wave_argmax(sc, lane, K);
+  }
+  return best;  // (wave 0)
+}
 
-__global__ void __launch_bounds__(BT)
-    greedy_decide_kernel(greedy_tabs T, int K, int Kp, int64_t oi0, int nb, const int64_t* __restrict__ hot_ptr,
-                         const int32_t* __restrict__ hdr_cell, const double2* __restrict__ bm,
-                         const int2* __restrict__ bx, int32_t* wguess /* greedy_score_kernel's wnew */, int32_t* __restrict__ clust,
-                         int32_t* __restrict__ pass_hist /* NULL or [GB + 2]: batches by number of passes (MUXGL_TIMING) */) {
-  __shared__ double s_sc[GB * 64];
-  __shared__ int32_t s_w[GB];
-  __shared__ int32_t s_chg[GB];  // the guess of this cell changed in the last pass
-  __shared__ int s_any;
-  __shared__ uchar4 s_meta[DI_CAP];
+// ---- point-to-point hand-overs ---------------------------------------------------------------------------------------------
+constexpr unsigned GREEDY_SPIN_LIMIT = 1u << 23;  // polls of ~1 us
+
+// every thread of the workgroup calls; lanes l < n of wave 0 wait until words[l]'s upper half is `tag` and leave the lower
+// halves in L.xv.  false: gave up (bar[1] raised: everyone leaves, the host reports the failure)
+__device__ __forceinline__ bool greedy_collect(greedy_lds& L, const unsigned long long* words, int n, unsigned tag, unsigned* bar) {
   const int t = threadIdx.x;
-  // the first pass was made by greedy_score_kernel: nothing changed -> the guesses are the decision
-  const bool any0 = wguess[2 * GB] != 0;
-  __syncthreads();
-  if (t == 0) wguess[2 * GB] = 0;  // for the next batch's score kernel (stream order)
-  if (!any0) {
-    if (t < nb) clust[hdr_cell[oi0 + t]] = wguess[t];
-    if (pass_hist && t == 0) atomicAdd(pass_hist + 1, 1);
-    return;
-  }
-  if (t < nb) {
-    s_w[t] = wguess[t];
-    s_chg[t] = wguess[GB + t];
-  }
-  const int64_t x0 = T.hinc_ptr[hot_ptr[oi0]], x1 = T.hinc_ptr[hot_ptr[oi0 + nb]];
-  const bool in_lds = x1 - x0 <= DI_CAP;
-  if (in_lds)
-    for (int64_t x = x0 + t; x < x1; x += BT) s_meta[x - x0] = T.inc_meta[x];
-  __syncthreads();
-  for (int pass = 1; pass <= nb; ++pass) {  // cell i of the batch is final after pass i at the latest
-    // ratios of the hot entries that have a predecessor whose guess changed (every incidence of such an entry: which
-    // predecessor carries a cluster's ratio depends on all of them)
-    for (int64_t x = x0 + t; x < x1; x += BT) {
-      bool redo = false;
-      if (in_lds) {
-        const uchar4 m = s_meta[x - x0];
-        const int64_t yb = x - x0 - m.y;
-        for (int k = 0; k < (int)m.z && !redo; ++k) redo = s_chg[s_meta[yb + k].x] != 0;
-      } else {
-        const int32_t h = T.inc_hot[x];
-        for (int64_t y = T.hinc_ptr[h]; y < T.hinc_ptr[h + 1] && !redo; ++y) redo = s_chg[T.inc_cell[y] - oi0] != 0;
-      }
-      if (redo) greedy_ratio(T, K, x, oi0, [&](int b) { return s_w[b]; });
-    }
-    __syncthreads();  // (drains the stores: one workgroup, one L1 -- they are visible to the loads below)
-    if (t == 0) s_any = 0;
-    for (int b = t >> 6; b < nb; b += BT / 64) {  // a wave per cell, lane = cluster
-      const int c = t & 63;
-      const double sc = greedy_cell_score(T, K, c, b, oi0, hot_ptr, bm, bx);
-      if (c < K) s_sc[b * 64 + c] = sc;
-    }
-    __syncthreads();
-    if (t < nb) {
-      int best = 0;
-      double bs = s_sc[t * 64];
-      for (int c = 1; c < K; ++c)
-        if (s_sc[t * 64 + c] > bs) {
-          bs = s_sc[t * 64 + c];
-          best = c;
+  if (t < 64) {
+    bool ok = true;
+    if (t < n) {
+      unsigned long long v = 0;
+      for (unsigned spins = 0;; ++spins) {
+        v = __hip_atomic_load(words + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == tag) break;
+        if (spins > GREEDY_SPIN_LIMIT ||
+            ((spins & 255) == 255 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          ok = false;
+          break;
         }
-      s_chg[t] = best != s_w[t];
-      if (best != s_w[t]) {
-        s_w[t] = best;
-        s_any = 1;
+        __builtin_amdgcn_s_sleep(1);
       }
+      L.xv[t] = (unsigned)v;
     }
-    __syncthreads();
-    if (!s_any) {
-      if (pass_hist && t == 0) atomicAdd(pass_hist + pass + 1, 1);
-      break;
+    ok = __all(ok);
+    if (t == 0) {
+      if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.ok = ok;
     }
   }
-  if (t < nb) clust[hdr_cell[oi0 + t]] = s_w[t];
+  __syncthreads();
+  return L.ok != 0;
 }
 
-// the batch's merges: one thread per chain (the entries of the batch at one SNP), in cell order
-__global__ void __launch_bounds__(256)
-    greedy_apply_kernel(greedy_tabs T, int K, int64_t oi0, int nb, const int32_t* __restrict__ prev,
-                        const int32_t* __restrict__ next, const int32_t* __restrict__ hdr_cell,
-                        const int32_t* __restrict__ clust, double* __restrict__ diag, double* __restrict__ offd) {
-  const int64_t p0 = T.pos_ptr[oi0], p1 = T.pos_ptr[oi0 + nb];
-  for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x) {
-    if (prev[p] >= 0) continue;  // not the head of its chain
-    const int32_t i0 = T.pos_cell[p];
-    const int32_t snp = T.entry_snp[T.hdr_e0[i0] + (p - T.pos_ptr[i0])];
-    const double a = T.af[snp];
-    for (int32_t q = (int32_t)p; q >= 0; q = next[q]) {
-      const int32_t i = T.pos_cell[q];
-      const int w = clust[hdr_cell[i]];
-      double2* dg = reinterpret_cast<double2*>(diag + ((size_t)snp * K + w) * 4);
-      double2* od = reinterpret_cast<double2*>(offd + ((size_t)snp * K + w) * 6);
-      const double2 r0 = dg[0], r1 = dg[1];
-      const bool present = r1.y != 0.0;
-      double v[9];
-      if (present) {
-        const double2 r2 = od[0], r3 = od[1], r4 = od[2];
-        v[0] = r0.x, v[1] = r2.x, v[2] = r2.y, v[3] = r3.x, v[4] = r0.y, v[5] = r3.y, v[6] = r4.x, v[7] = r4.y, v[8] = r1.x;
+// every thread of the workgroup calls; wave 0 waits until flags[f0 .. f1) all carry `tag`
+__device__ __forceinline__ bool greedy_await(greedy_lds& L, const unsigned* flags, int f0, int f1, unsigned tag, unsigned* bar) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    bool ok = true;
+    for (int f = f0 + t; f < f1 && ok; f += 64)
+      for (unsigned spins = 0; __hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag; ++spins) {
+        if (spins > GREEDY_SPIN_LIMIT ||
+            ((spins & 255) == 255 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      greedy_merge9(v, present, T.egls + (size_t)(T.hdr_e0[i] + (q - T.pos_ptr[i])) * 9);
-      const double B = (v[0] * ((1.0 - a) * (1.0 - a)) + v[4] * (2.0 * a * (1.0 - a))) + v[8] * (a * a);
-      dg[0] = make_double2(v[0], v[4]);
-      dg[1] = make_double2(v[8], B);
-      od[0] = make_double2(v[1], v[2]);
-      od[1] = make_double2(v[3], v[5]);
-      od[2] = make_double2(v[6], v[7]);
+    ok = __all(ok);
+    if (t == 0) {
+      if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.ok = ok;
     }
   }
+  __syncthreads();
+  return L.ok != 0;
+}
+
+// ---- the grid barrier ------------------------------------------------------------------------------------------------------
+// every wave drains its stores, the workgroup meets, one lane releases at agent scope (write-back of the XCD's L2),
+// arrives on ONE monotonic counter (zeroed by the host before the launch), polls it relaxed, then acquires at agent scope.
+// The spins are bounded: a workgroup that gives up raises bar[1], everyone leaves, the host reports the failure.
+__device__ __forceinline__ bool greedy_grid_barrier(unsigned* bar, unsigned& epoch, int* s_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+#ifndef MUXGL_GREEDY_SC1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = epoch * gridDim.x;
+    bool ok = true;
+    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;) {
+      if (++spins > GREEDY_SPIN_LIMIT ||
+          ((spins & 255) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+#ifndef MUXGL_GREEDY_SC1
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// ---- the batches, in ONE launch --------------------------------------------------------------------------------------------
+// gridDim.x workgroups (at most one per compute unit, so all are resident; at least 2 GB) stay on the chip for the whole
+// cell list.  Workgroup b < GB DECIDES cell b of every batch; the others APPLY the batch's merges; all of them take the
+// chunks of the distance phase.  Per batch:
+//   (before the barrier that ends the previous batch: the chunk's SNPs and weights to LDS; deciders: the SNP, weights and
+//    predecessor likelihoods of their cell's incidences to registers, the chains' bytes to LDS)
+//   phase 1: the chunks' start products against the states -> pm / px                                               BARRIER
+//   phase 2: deciders: every cell's start scores and first guess, redundantly in each of them from the chunk partials (a
+//            barrier more would cost more than the 2 k products); then per PASS: the ratios of the own cell's incidences
+//            under the guesses, the own cell's score, its new guess -> wnew                                          BARRIER
+//            until no guess changed in a pass (chg[pass of the run], read by everyone after the barrier);
+//            appliers meanwhile fetch "their" position's chain head: links, SNP, weights, likelihoods;
+//   phase 3: appliers: the merges, with the decisions read from wnew                                                 BARRIER
+__global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* __restrict__ Tp) {
+  extern __shared__ __align__(16) unsigned char greedy_lds_raw[];
+  greedy_lds& L = *reinterpret_cast<greedy_lds*>(greedy_lds_raw);
+  const greedy_tabs& T = *Tp;  // (the table of pointers stays in memory: as an argument by value it spills)
+  const int t = threadIdx.x, sub = t / GA_T, ts = t % GA_T;
+  const int K = T.K, Kp = T.Kp;
+  const bool decider = blockIdx.x < GB;
+  const int napply = gridDim.x - GB;  // workgroups that apply
+  unsigned epoch = 0;
+  [[maybe_unused]] uint64_t tk = wall_clock64(), tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef MUXGL_GREEDY_TICKS  // (build knob: where a workgroup's time goes, printed under MUXGL_TIMING; the reads cost ~1 us each)
+#define GTICK(i) { const uint64_t now = wall_clock64(); tacc[i] += now - tk; tk = now; }
+#else
+#define GTICK(i)
+#endif
+
+  // what is fetched ahead for batch `oi0`
+  greedy_inc_regs IR;
+  int64_t X0 = 0, X1 = 0, cbase = 0, nch = 0;
+  auto meta_at = [&](int64_t x) { return x - X0 < ICAP ? L.meta[x - X0] : T.inc_meta[x]; };
+  auto fetch_inc_regs = [&](greedy_inc_regs& R, int64_t x) {
+    const int32_t hp = T.inc_hp[x];
+    R.snp = T.pos_snp[hp];
+    R.w = T.pos_w[hp];
+    greedy_load9(R.gl, T.egls + (size_t)T.inc_e[x] * 9);
+  };
+  auto fetch_pos_regs = [&](greedy_pos_regs& R, int64_t p) {
+    const uchar2 pl = T.pos_pl[p];
+    R.snp = T.pos_snp[p];
+    R.q = T.pos_q[p];
+    R.cell = T.pos_cell[p] % GB;
+    R.place = pl.x, R.len = pl.y;
+    R.af = T.pos_w[p].w;
+    greedy_load9(R.gl, T.egls + (size_t)T.pos_e[p] * 9);
+    R.before = 0, R.behind = 0;
+    if (R.len > 1) {
+      const int nbehind = (int)R.len - (int)R.place - 1;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < (int)R.place) R.before |= (uint64_t)T.srt_cell[R.q - 1 - k] << (8 * k);
+        if (k < nbehind) R.behind |= (uint64_t)T.srt_cell[R.q + 1 + k] << (8 * k);
+      }
+      if (nbehind > 0) greedy_load9(R.gl1, T.egls + (size_t)T.srt_e[R.q + 1] * 9);
+    }
+  };
+  auto fetch_ahead = [&](int64_t oi0) {
+    if (oi0 >= T.n) return;
+    const int nb = (int)(T.n - oi0 < GB ? T.n - oi0 : GB);
+    cbase = T.chunk_first[oi0], nch = T.chunk_first[oi0 + nb] - cbase;
+    const int64_t c = 2 * ((int64_t)blockIdx.x * GSUB + sub);
+    if (c < nch) greedy_dist_stage(L.dist[sub], ts, T, cbase + c, c + 1 < nch);
+    if (decider && (int)blockIdx.x < nb) {
+      if (t <= nb) L.cf[t] = (int32_t)(T.chunk_first[oi0 + t] - cbase);
+      X0 = T.cinc_ptr[oi0 + blockIdx.x], X1 = T.cinc_ptr[oi0 + blockIdx.x + 1];
+      for (int64_t x = X0 + t; x < X1 && x - X0 < ICAP; x += BT) L.meta[x - X0] = T.inc_meta[x];
+      if (X0 + t < X1) fetch_inc_regs(IR, X0 + t);
+    }
+  };
+  fetch_ahead(0);
+
+  for (int64_t oi0 = 0; oi0 < T.n; oi0 += GB) {
+    const int nb = (int)(T.n - oi0 < GB ? T.n - oi0 : GB);
+    const unsigned tag = (unsigned)(oi0 / GB + 1);  // of this batch's hand-overs
+    GTICK(6)
+    // ---- phase 1: chunk partials against the states at the start of the batch (first trip: staged before the barrier)
+    for (int64_t cb = 2 * (int64_t)blockIdx.x * GSUB; cb < nch; cb += 2 * (int64_t)gridDim.x * GSUB) {
+      const int64_t c = cb + 2 * sub;
+      const bool two = c + 1 < nch;
+      if (cb != 2 * (int64_t)blockIdx.x * GSUB) {
+        __syncthreads();  // the group's LDS is free for its next chunks
+        if (c < nch) greedy_dist_stage(L.dist[sub], ts, T, cbase + c, two);
+      }
+      __syncthreads();
+      if (c < nch) greedy_dist_terms(L.dist[sub], ts, K, Kp, T.diag);
+      __syncthreads();
+      if (c < nch) greedy_dist_fold(L.dist[sub], ts, Kp, two, T.pm + (size_t)c * Kp, T.px + (size_t)c * Kp);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows are written through: drained = in memory
+      __syncthreads();
+      if (c < nch && ts == 0) __hip_atomic_store(T.cflag + c / 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    GTICK(0)
+
+    // ---- phase 2
+    // appliers: what "their" position p_a brings -- SNP, weights, likelihoods, the cells of its chain's other members (and
+    // the likelihoods of the member behind it) -- fetched while the deciders work
+    const int64_t p0 = T.pos_ptr[oi0], p1 = T.pos_ptr[oi0 + nb];
+    const int64_t p_a = p0 + (int64_t)(blockIdx.x - GB) * BT + t;
+    greedy_pos_regs A;
+    if (!decider) {
+      if (p_a < p1) fetch_pos_regs(A, p_a);
+      fetch_ahead(oi0 + GB);  // (the chunk's LDS is free: only deciders use the union's other member)
+    }
+    const bool deciding = decider && (int)blockIdx.x < nb;
+    if (decider) {
+      // the own cell's start products (its chunks' partials: wait for their pairs' tags) and first guess (the one that
+      // ignores the batch's own merges); the deciders tell each other their guesses through one 8-byte word each,
+      // {tag, guess}: the data is the flag
+      const int b = blockIdx.x;
+      if (deciding && !greedy_await(L, T.cflag, L.cf[b] / 2, (L.cf[b + 1] + 1) / 2, tag, T.bar)) return;
+      GTICK(1)
+      if (deciding && t < 64) {
+        const double sc = t < Kp && t < K ? greedy_start_products(L, t, T, L.cf[b], L.cf[b + 1]) : 0.0;
+        const int best = greedy_wave_argmax(sc, t, K);
+        if (t == 0)
+          __hip_atomic_store(T.guess + b, ((unsigned long long)tag << 32) | (unsigned)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!greedy_collect(L, T.guess, nb, tag, T.bar)) return;
+      if (t < nb) L.g[t] = (int32_t)L.xv[t];
+      __syncthreads();
+    }
+    GTICK(8)
+    int passes = 0;
+    for (;;) {
+      if (deciding) {
+        for (int64_t x = X0 + t; x < X1; x += BT) {
+          if (x == X0 + t) {
+            greedy_ratio(L, T, x, X0, IR, meta_at);
+          } else {
+            greedy_inc_regs R2;
+            fetch_inc_regs(R2, x);
+            greedy_ratio(L, T, x, X0, R2, meta_at);
+          }
+        }
+        if (t < 4) {  // the scores read the clusters four at a time
+          const int64_t k = X1 - X0 + t;
+          if (k < ((X1 - X0 + 3) & ~(int64_t)3) && k < ICAP) L.ic[k] = -1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // (one workgroup, one L1: ratios beyond ICAP are visible to the loads below)
+        GTICK(9)
+        const int best = greedy_cell_decide(L, T, t, X0, X1);
+        if (t == 0)  // {tag, changed, guess} of this pass
+          __hip_atomic_store(T.passw + (size_t)passes * GB + blockIdx.x,
+                             ((unsigned long long)tag << 32) | (best != L.g[blockIdx.x] ? 0x100u : 0u) | (unsigned)best,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      GTICK(2)
+      // everyone reads the pass's guesses (appliers: the last pass's are the decisions)
+      if (!greedy_collect(L, T.passw + (size_t)passes * GB, nb, tag, T.bar)) return;
+      GTICK(3)
+      if (t < 64) {
+        const bool chg = t < nb && (L.xv[t] & 0x100u);
+        const bool any = __any(chg);
+        if (t == 0) L.any = any;
+      }
+      if (t < nb) L.g[t] = (int32_t)(L.xv[t] & 0xffu);
+      __syncthreads();
+      ++passes;
+      if (!L.any) break;  // (uniform over the grid)
+      if (passes > GB) {  // cell i is final after pass i + 1: cannot happen
+        if (t == 0) __hip_atomic_store(T.bar + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    if (T.pass_hist && blockIdx.x == 0 && t == 0) atomicAdd(T.pass_hist + (passes < GB + 1 ? passes : GB + 1), 1);
+    GTICK(7)
+
+    // ---- phase 3: the batch's merges.  The members of a chain (the batch's entries at one SNP) that join the same cluster
+    // are merged into its state in cell order (merge() clamps), by the thread of the first of them; members that join
+    // different clusters touch different states.
+    if (blockIdx.x == 0 && t < nb) T.clust[T.hdr_cell[oi0 + t]] = L.g[t];
+    if (!decider) {
+      for (int64_t p = p_a; p < p1; p += (int64_t)napply * BT) {
+        if (p != p_a) fetch_pos_regs(A, p);
+        const int w = L.g[A.cell];
+        bool first = true;
+        for (int k = 0; k < (int)A.place && first; ++k) {
+          const int c = k < 8 ? (int)((A.before >> (8 * k)) & 0xff) : (int)T.srt_cell[A.q - 1 - k];
+          first = L.g[c] != w;
+        }
+        if (!first) continue;
+        const double a = A.af;
+        const double h0 = (1.0 - a) * (1.0 - a), h1 = 2.0 * a * (1.0 - a), h2 = a * a;
+        const size_t row = (size_t)A.snp * K + w;
+        double v[9], B0;
+        bool present = greedy_state(T.diag, T.offd, row, v, B0);
+        greedy_merge9(v, present, A.gl);
+        const int nbehind = (int)A.len - (int)A.place - 1;
+        for (int k = 0; k < nbehind; ++k) {
+          const int c = k < 8 ? (int)((A.behind >> (8 * k)) & 0xff) : (int)T.srt_cell[A.q + 1 + k];
+          if (L.g[c] != w) continue;
+          if (k == 0) {
+            greedy_merge9(v, true, A.gl1);
+          } else {
+            double o[9];
+            greedy_load9(o, T.egls + (size_t)T.srt_e[A.q + 1 + k] * 9);
+            greedy_merge9(v, true, o);
+          }
+        }
+        const double B = (v[0] * h0 + v[4] * h1) + v[8] * h2;
+        greedy_state_store(T.diag, T.offd, row, v, B);
+      }
+    }
+    GTICK(4)
+    if (decider) fetch_ahead(oi0 + GB);
+    GTICK(5)
+    if (!greedy_grid_barrier(T.bar, epoch, &L.ok)) return;
+  }
+  if (T.pass_hist && t == 0 && (blockIdx.x == GB - 1 || blockIdx.x == GB))
+    for (int i = 0; i < 12; ++i) T.ticks[(blockIdx.x == GB ? 12 : 0) + i] = tacc[i];
 }
 
 }  // namespace
@@ -844,30 +1219,33 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   for (size_t i = 0; i < npad; ++i) pos_ptr[i + 1] = pos_ptr[i] + (i < n ? hlen[i] : 0);
   P = pos_ptr[n];
   const bool batched = K <= 64 && P > 0 && P < ((int64_t)1 << 31) && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP);
-  int32_t* d_chunk_cell = nullptr;
-  int64_t* d_chunk_first = nullptr;
+  int64_t *d_chunk_first = nullptr, *d_chunk_p0 = nullptr, *d_pos_e = nullptr, *d_cinc_ptr = nullptr, *d_inc_e = nullptr;
+  int32_t *d_chunk_n = nullptr, *d_pos_snp = nullptr, *d_inc_hp = nullptr;
+  unsigned long long* d_passw = nullptr;
+  unsigned* d_cflag = nullptr;
+  double4* d_pos_w = nullptr;
   double2* d_pm = nullptr;
   int2* d_px = nullptr;
   int64_t *d_pos_ptr = nullptr, *d_nhot = nullptr, *d_hot_ptr = nullptr, *d_hot_len = nullptr, *d_hinc_ptr = nullptr;
   uint64_t *d_key = nullptr, *d_key2 = nullptr;
   uint32_t *d_val = nullptr, *d_val2 = nullptr;
-  int32_t *d_pos_cell = nullptr, *d_prev = nullptr, *d_next = nullptr, *d_hot_pos = nullptr;
-  int32_t *d_inc_pos = nullptr, *d_inc_cell = nullptr, *d_inc_hot = nullptr, *d_ic = nullptr, *d_wguess = nullptr;
+  int32_t *d_pos_cell = nullptr, *d_prev = nullptr, *d_pos_q = nullptr, *d_hot_pos = nullptr, *d_ic = nullptr;
+  uchar2* d_pos_pl = nullptr;
+  uint8_t* d_srt_cell = nullptr;
+  int64_t* d_srt_e = nullptr;
+  unsigned* d_bar = nullptr;
+  unsigned long long* d_guess = nullptr;
+  greedy_tabs* d_tabs = nullptr;
+  uint64_t* d_ticks = nullptr;
   uchar4* d_inc_meta = nullptr;
   int32_t* d_hist = nullptr;
-  int32_t* d_wnew = nullptr;  // [GB] guesses after the first pass, [GB] changed flags, [1] any
-  double2 *d_rat = nullptr, *d_bm = nullptr;
-  int2* d_bx = nullptr;
+  double2* d_rat = nullptr;
   void* d_tmp = nullptr;
   std::vector<int64_t> chunk_first;
-  std::vector<int32_t> chunk_cell;
   int64_t max_batch_chunks = 0;
   if (batched) {
     chunk_first.assign(npad + 1, 0);
     for (size_t i = 0; i < npad; ++i) chunk_first[i + 1] = chunk_first[i] + (i < n ? (hlen[i] + GCH - 1) / GCH : 0);
-    chunk_cell.resize((size_t)chunk_first[n] + 1);
-    for (size_t i = 0; i < n; ++i)
-      for (int64_t c = chunk_first[i]; c < chunk_first[i + 1]; ++c) chunk_cell[(size_t)c] = (int32_t)i;
     for (size_t i = 0; i < n; i += GB) {
       const size_t e = std::min(n, i + GB);
       max_batch_chunks = std::max(max_batch_chunks, chunk_first[e] - chunk_first[i]);
@@ -891,21 +1269,26 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       e = hipGetLastError();
     }
     if (e == hipSuccess && batched) {
-      const size_t nP = (size_t)P;
-      if (dev_alloc(h, &d_chunk_cell, chunk_cell.size()) || dev_alloc(h, &d_chunk_first, chunk_first.size()) ||
-          dev_alloc(h, &d_pm, (size_t)max_batch_chunks * Kp) || dev_alloc(h, &d_px, (size_t)max_batch_chunks * Kp) ||
-          dev_alloc(h, &d_pos_ptr, npad + 1) || dev_alloc(h, &d_key, nP) || dev_alloc(h, &d_key2, nP) ||
-          dev_alloc(h, &d_val, nP) || dev_alloc(h, &d_val2, nP) || dev_alloc(h, &d_pos_cell, nP) ||
-          dev_alloc(h, &d_prev, nP) || dev_alloc(h, &d_next, nP) || dev_alloc(h, &d_nhot, npad + 1) ||
-          dev_alloc(h, &d_hot_ptr, npad + 1) || dev_alloc(h, &d_bm, (size_t)GB * 64) || dev_alloc(h, &d_bx, (size_t)GB * 64) ||
-          dev_alloc(h, &d_wguess, (size_t)GB) || dev_alloc(h, &d_wnew, (size_t)2 * GB + 1) || dev_alloc(h, &d_hist, (size_t)GB + 2))
+      const size_t nP = (size_t)P, nchunks = (size_t)chunk_first[n];
+      if (dev_alloc(h, &d_chunk_first, chunk_first.size()) || dev_alloc(h, &d_chunk_p0, nchunks + 1) ||
+          dev_alloc(h, &d_chunk_n, nchunks + 1) || dev_alloc(h, &d_pm, (size_t)max_batch_chunks * Kp) ||
+          dev_alloc(h, &d_px, (size_t)max_batch_chunks * Kp) || dev_alloc(h, &d_pos_ptr, npad + 1) || dev_alloc(h, &d_key, nP) ||
+          dev_alloc(h, &d_key2, nP) || dev_alloc(h, &d_val, nP) || dev_alloc(h, &d_val2, nP) || dev_alloc(h, &d_pos_cell, nP) ||
+          dev_alloc(h, &d_pos_snp, nP) || dev_alloc(h, &d_pos_w, nP) || dev_alloc(h, &d_pos_e, nP) ||
+          dev_alloc(h, &d_prev, nP) || dev_alloc(h, &d_pos_q, nP) || dev_alloc(h, &d_pos_pl, nP) ||
+          dev_alloc(h, &d_srt_cell, nP + 8) || dev_alloc(h, &d_srt_e, nP + 8) || dev_alloc(h, &d_nhot, npad + 1) ||
+          dev_alloc(h, &d_hot_ptr, npad + 1) || dev_alloc(h, &d_cinc_ptr, npad + 1) || dev_alloc(h, &d_passw, (size_t)(GB + 1) * GB) ||
+          dev_alloc(h, &d_cflag, (size_t)max_batch_chunks / 2 + 2) ||
+          dev_alloc(h, &d_hist, (size_t)GB + 2) || dev_alloc(h, &d_bar, (size_t)2) || dev_alloc(h, &d_guess, (size_t)GB) ||
+          dev_alloc(h, &d_ticks, (size_t)24) || dev_alloc(h, &d_tabs, (size_t)1))
         break;
       (void)hipMemsetAsync(d_hist, 0, sizeof(int32_t) * (GB + 2), h->stream);
-      (void)hipMemsetAsync(d_wnew, 0, sizeof(int32_t) * (2 * GB + 1), h->stream);
+      (void)hipMemsetAsync(d_passw, 0, sizeof(unsigned long long) * (GB + 1) * GB, h->stream);
+      (void)hipMemsetAsync(d_cflag, 0, sizeof(unsigned) * ((size_t)max_batch_chunks / 2 + 2), h->stream);
+      (void)hipMemsetAsync(d_bar, 0, sizeof(unsigned) * 2, h->stream);
+      (void)hipMemsetAsync(d_guess, 0, sizeof(unsigned long long) * GB, h->stream);
+      (void)hipMemsetAsync(d_ticks, 0, sizeof(uint64_t) * 24, h->stream);
       e = hipMemsetAsync(d_offd, 0, sizeof(double) * (size_t)S * K * 6, h->stream);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(d_chunk_cell, chunk_cell.data(), sizeof(int32_t) * chunk_cell.size(), hipMemcpyHostToDevice,
-                           h->stream);
       if (e == hipSuccess)
         e = hipMemcpyAsync(d_chunk_first, chunk_first.data(), sizeof(int64_t) * chunk_first.size(), hipMemcpyHostToDevice,
                            h->stream);
@@ -913,12 +1296,16 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
         e = hipMemcpyAsync(d_pos_ptr, pos_ptr.data(), sizeof(int64_t) * (npad + 1), hipMemcpyHostToDevice, h->stream);
       if (e == hipSuccess) e = hipMemsetAsync(d_nhot, 0, sizeof(int64_t) * (npad + 1), h->stream);
       if (e != hipSuccess) break;
-      // ---- chain tables: entries of a batch at the same SNP, linked in cell order (one stable sort of (batch, SNP))
+      if (tm.on) { (void)hipStreamSynchronize(h->stream); tm.lap("greedy_init:   allocations, copies"); }
+      // ---- tables in processing order; chains: entries of a batch at the same SNP, linked in cell order (one stable
+      //      sort of (batch, SNP))
       const unsigned cblocks = (unsigned)((n + 3) / 4);
-      hipLaunchKernelGGL(greedy_keys_kernel, dim3(cblocks), dim3(256), 0, h->stream, (int64_t)n, d_he0, d_pos_ptr,
-                         h->d_entry_snp, d_key, d_val, d_pos_cell);
-      unsigned sbits = 1, bbits = 1;
-      while (sbits < 31 && ((int64_t)1 << sbits) < S) ++sbits;
+      hipLaunchKernelGGL(greedy_pos_kernel, dim3(cblocks), dim3(256), 0, h->stream, (int64_t)n, d_he0, d_pos_ptr,
+                         h->d_entry_snp, h->d_egls, h->d_af, d_key, d_val, d_pos_cell, d_pos_snp, d_pos_w, d_pos_e);
+      hipLaunchKernelGGL(greedy_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (int64_t)n, d_pos_ptr,
+                         d_chunk_first, d_chunk_p0, d_chunk_n);
+      if (tm.on) { (void)hipStreamSynchronize(h->stream); tm.lap("greedy_init:   position tables"); }
+      unsigned bbits = 1;
       while (bbits < 31 && ((int64_t)1 << bbits) < (int64_t)(n / GB + 1)) ++bbits;
       size_t tmp_bytes = 0;
       e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key, d_key2, d_val, d_val2, nP, 0u, 32u + bbits, h->stream);
@@ -926,9 +1313,11 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_val, d_val2, nP, 0u, 32u + bbits, h->stream);
       if (e != hipSuccess) break;
-      (void)sbits;
+      if (tm.on) { (void)hipStreamSynchronize(h->stream); tm.lap("greedy_init:   sort"); }
       const unsigned pblocks = (unsigned)std::min<int64_t>((P + 255) / 256, 16384);
-      hipLaunchKernelGGL(greedy_links_kernel, dim3(pblocks), dim3(256), 0, h->stream, P, d_key2, d_val2, d_prev, d_next);
+      hipLaunchKernelGGL(greedy_links_kernel, dim3(pblocks), dim3(256), 0, h->stream, P, d_key2, d_val2, d_pos_cell, d_pos_e, d_prev,
+                         d_pos_q, d_pos_pl, d_srt_cell, d_srt_e);
+      if (tm.on) { (void)hipStreamSynchronize(h->stream); tm.lap("greedy_init:   links"); }
       hipLaunchKernelGGL(greedy_hot_count_kernel, dim3(cblocks), dim3(256), 0, h->stream, (int64_t)n, d_pos_ptr, d_prev,
                          d_nhot);
       auto scan = [&](int64_t* in, int64_t* out, size_t cnt) -> hipError_t {
@@ -946,9 +1335,11 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       int64_t H = 0;
       if (e == hipSuccess) e = hipMemcpy(&H, d_hot_ptr + n, sizeof(int64_t), hipMemcpyDeviceToHost);
       if (e != hipSuccess) break;
-      dev_free(&d_key);  // the unsorted keys and payloads are done with
+      dev_free(&d_key);  // the keys and payloads are done with
       dev_free(&d_val);
-      if (dev_alloc(h, &d_hot_pos, (size_t)H) || dev_alloc(h, &d_hot_len, (size_t)H + 1) ||
+      dev_free(&d_key2);
+      dev_free(&d_val2);
+      if (dev_alloc(h, &d_hot_pos, (size_t)H + 1) || dev_alloc(h, &d_hot_len, (size_t)H + 1) ||
           dev_alloc(h, &d_hinc_ptr, (size_t)H + 1))
         break;
       e = hipMemsetAsync(d_hot_len, 0, sizeof(int64_t) * ((size_t)H + 1), h->stream);
@@ -959,57 +1350,88 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       int64_t I = 0;
       if (e == hipSuccess) e = hipMemcpy(&I, d_hinc_ptr + H, sizeof(int64_t), hipMemcpyDeviceToHost);
       if (e != hipSuccess) break;
-      if (dev_alloc(h, &d_inc_pos, (size_t)I) || dev_alloc(h, &d_inc_cell, (size_t)I) || dev_alloc(h, &d_inc_hot, (size_t)I) ||
-          dev_alloc(h, &d_ic, (size_t)I) || dev_alloc(h, &d_rat, (size_t)I) || dev_alloc(h, &d_inc_meta, (size_t)I))
+      if (dev_alloc(h, &d_inc_hp, (size_t)I + 1) || dev_alloc(h, &d_inc_e, (size_t)I + 1) || dev_alloc(h, &d_ic, (size_t)I + 1) ||
+          dev_alloc(h, &d_rat, (size_t)I + 1) || dev_alloc(h, &d_inc_meta, (size_t)I + 1))
         break;
       if (H > 0)
         hipLaunchKernelGGL(greedy_inc_fill_kernel, dim3((unsigned)std::min<int64_t>((H + 255) / 256, 16384)), dim3(256), 0,
-                           h->stream, H, d_hot_pos, d_prev, d_hinc_ptr, d_pos_cell, d_inc_pos, d_inc_cell, d_inc_hot, d_inc_meta);
+                           h->stream, H, d_hot_pos, d_prev, d_hinc_ptr, d_pos_cell, d_pos_e, d_inc_meta, d_inc_hp, d_inc_e);
+      hipLaunchKernelGGL(greedy_cinc_kernel, dim3((unsigned)((npad + 1 + 255) / 256)), dim3(256), 0, h->stream,
+                         (int64_t)(npad + 1), d_hot_ptr, d_hinc_ptr, d_cinc_ptr);
       e = hipGetLastError();
       if (e != hipSuccess) break;
       if (tm.on) (void)hipStreamSynchronize(h->stream);
-      tm.lap("greedy_init: chain tables (sort, links, hot lists)");
+      tm.lap("greedy_init: tables in processing order (sort, links, hot lists)");
+      if (tm.on)
+        fprintf(stderr, "[muxgl] greedy_init: %lld positions, %lld hot entries, %lld incidences\n", (long long)P, (long long)H,
+                (long long)I);
       greedy_tabs T;
-      T.hdr_e0 = d_he0;
       T.pos_ptr = d_pos_ptr;
+      T.chunk_first = d_chunk_first;
+      T.chunk_p0 = d_chunk_p0;
+      T.chunk_n = d_chunk_n;
+      T.pos_snp = d_pos_snp;
+      T.pos_w = d_pos_w;
+      T.pos_e = d_pos_e;
       T.pos_cell = d_pos_cell;
-      T.hot_pos = d_hot_pos;
-      T.hinc_ptr = d_hinc_ptr;
-      T.inc_pos = d_inc_pos;
-      T.inc_cell = d_inc_cell;
-      T.inc_hot = d_inc_hot;
+      T.pos_q = d_pos_q;
+      T.pos_pl = d_pos_pl;
+      T.srt_cell = d_srt_cell;
+      T.srt_e = d_srt_e;
+      T.cinc_ptr = d_cinc_ptr;
       T.inc_meta = d_inc_meta;
-      T.entry_snp = h->d_entry_snp;
+      T.inc_hp = d_inc_hp;
+      T.inc_e = d_inc_e;
+      T.hdr_cell = d_hcell;
       T.egls = h->d_egls;
-      T.af = h->d_af;
       T.diag = d_diag;
       T.offd = d_offd;
       T.ic = d_ic;
       T.rat = d_rat;
-      for (size_t i = 0; i < n && e == hipSuccess; i += GB) {
-        const int nb = (int)std::min<size_t>(GB, n - i);
-        const int64_t nch = chunk_first[i + nb] - chunk_first[i];
-        if (nch > 0)
-          hipLaunchKernelGGL(greedy_dist_kernel, dim3((unsigned)nch), dim3(GA_T), 0, h->stream, chunk_first[i],
-                             d_chunk_cell, d_chunk_first, d_he0, d_hlen, h->d_entry_snp, h->d_egls, h->d_af, (int)K, Kp,
-                             d_diag, d_pm, d_px);
-        hipLaunchKernelGGL(greedy_argmax0_kernel, dim3(1), dim3(1024), 0, h->stream, (int64_t)i, nb, d_chunk_first, (int)K,
-                           Kp, d_pm, d_px, d_bm, d_bx, d_wguess);
-        hipLaunchKernelGGL(greedy_ratio_kernel, dim3(64), dim3(256), 0, h->stream, T, (int)K, (int64_t)i, nb, d_hot_ptr,
-                           d_wguess);
-        hipLaunchKernelGGL(greedy_score_kernel, dim3((unsigned)nb), dim3(64), 0, h->stream, T, (int)K, (int64_t)i, d_hot_ptr,
-                           d_bm, d_bx, d_wguess, d_wnew);
-        hipLaunchKernelGGL(greedy_decide_kernel, dim3(1), dim3(BT), 0, h->stream, T, (int)K, Kp, (int64_t)i, nb, d_hot_ptr,
-                           d_hcell, d_bm, d_bx, d_wnew, d_clust, tm.on ? d_hist : nullptr);
-        hipLaunchKernelGGL(greedy_apply_kernel, dim3(128), dim3(256), 0, h->stream, T, (int)K, (int64_t)i, nb, d_prev, d_next,
-                           d_hcell, d_clust, d_diag, d_offd);
-        e = hipGetLastError();
+      T.pm = d_pm;
+      T.px = d_px;
+      T.guess = d_guess;
+      T.passw = d_passw;
+      T.cflag = d_cflag;
+      T.clust = d_clust;
+      T.bar = d_bar;
+      T.pass_hist = tm.on ? d_hist : nullptr;
+      T.ticks = d_ticks;
+      T.n = (int64_t)n;
+      T.K = (int)K;
+      T.Kp = Kp;
+      // one workgroup per compute unit at most (all resident: the grid barrier needs that); GB of them decide a cell each
+      int cus = 0;
+      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+      if (e != hipSuccess) break;
+      int wgs = 128;
+      if (const char* s = getenv("MUXGL_GREEDY_WGS")) wgs = atoi(s);
+      wgs = std::max(2 * GB, std::min(wgs, cus));
+      if (cus < 2 * GB) {
+        h->err = "muxgl_fmx_greedy_init: the device has too few compute units for the batch size";
+        break;
       }
+      e = hipFuncSetAttribute((const void*)greedy_batches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(greedy_lds));
+      if (e == hipSuccess) e = hipMemcpy(d_tabs, &T, sizeof(T), hipMemcpyHostToDevice);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL(greedy_batches_kernel, dim3((unsigned)wgs), dim3(BT), sizeof(greedy_lds), h->stream,
+                         (const greedy_tabs*)d_tabs);
+      e = hipGetLastError();
     }
     tm.lap("greedy_init: batches enqueued");
     if (e == hipSuccess) e = hipMemcpyAsync(clust_out, d_clust, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     tm.lap("greedy_init: batches drained");
+    if (e == hipSuccess && d_bar) {
+      unsigned bar[2] = {0, 0};
+      e = hipMemcpy(bar, d_bar, sizeof(bar), hipMemcpyDeviceToHost);
+      if (e == hipSuccess && bar[1]) {
+        h->err = bar[1] == 2 ? "muxgl_fmx_greedy_init: a batch of greedy_batches_kernel did not reach its fixpoint"
+                             : "muxgl_fmx_greedy_init: a workgroup of greedy_batches_kernel gave up waiting at a grid barrier";
+        break;
+      }
+    }
     if (tm.on && d_hist) {
       int32_t hist[GB + 2];
       if (hipMemcpy(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1018,6 +1440,15 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
           if (hist[q]) fprintf(stderr, " %d:%d", q, hist[q]);
         fprintf(stderr, "\n");
       }
+      uint64_t tk[24];
+      if (d_ticks && hipMemcpy(tk, d_ticks, sizeof(tk), hipMemcpyDeviceToHost) == hipSuccess)
+        for (int w = 0; w < 2; ++w)
+          fprintf(stderr,
+                  "[muxgl] greedy_init: %s workgroup, ms: barrier %.1f | chunk products %.1f | barrier %.1f | start scores %.1f | "
+                  "passes: ratios %.1f scores %.1f barriers %.1f + %.1f | merges %.1f | fetch ahead %.1f\n",
+                  w ? "an applying" : "the last deciding", tk[w * 12 + 6] * 1e-5, tk[w * 12 + 0] * 1e-5, tk[w * 12 + 1] * 1e-5,
+                  tk[w * 12 + 8] * 1e-5, tk[w * 12 + 9] * 1e-5, tk[w * 12 + 2] * 1e-5, tk[w * 12 + 3] * 1e-5, tk[w * 12 + 7] * 1e-5,
+                  tk[w * 12 + 4] * 1e-5, tk[w * 12 + 5] * 1e-5);
     }
     if (e != hipSuccess) {
       h->err = std::string("muxgl_fmx_greedy_init: ") + hipGetErrorString(e);
@@ -1032,8 +1463,9 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_clust);
   dev_free(&d_diag);
   dev_free(&d_offd);
-  dev_free(&d_chunk_cell);
   dev_free(&d_chunk_first);
+  dev_free(&d_chunk_p0);
+  dev_free(&d_chunk_n);
   dev_free(&d_pm);
   dev_free(&d_px);
   dev_free(&d_pos_ptr);
@@ -1041,25 +1473,33 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_hot_ptr);
   dev_free(&d_hot_len);
   dev_free(&d_hinc_ptr);
+  dev_free(&d_cinc_ptr);
   dev_free(&d_key);
   dev_free(&d_key2);
   dev_free(&d_val);
   dev_free(&d_val2);
   dev_free(&d_pos_cell);
+  dev_free(&d_pos_snp);
+  dev_free(&d_pos_w);
+  dev_free(&d_pos_e);
   dev_free(&d_prev);
-  dev_free(&d_next);
+  dev_free(&d_pos_q);
+  dev_free(&d_pos_pl);
+  dev_free(&d_srt_cell);
+  dev_free(&d_srt_e);
   dev_free(&d_hot_pos);
-  dev_free(&d_inc_pos);
-  dev_free(&d_inc_cell);
-  dev_free(&d_inc_hot);
+  dev_free(&d_inc_hp);
+  dev_free(&d_inc_e);
   dev_free(&d_inc_meta);
   dev_free(&d_hist);
-  dev_free(&d_wnew);
+  dev_free(&d_passw);
+  dev_free(&d_cflag);
+  dev_free(&d_bar);
+  dev_free(&d_guess);
+  dev_free(&d_tabs);
+  dev_free(&d_ticks);
   dev_free(&d_ic);
-  dev_free(&d_wguess);
   dev_free(&d_rat);
-  dev_free(&d_bm);
-  dev_free(&d_bx);
   if (d_tmp) (void)hipFree(d_tmp);
   return rc;
 }
