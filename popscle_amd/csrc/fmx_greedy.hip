@@ -542,23 +542,13 @@ __device__ __forceinline__ bool greedy_state(const double* diag, const double* o
 __device__ __forceinline__ void greedy_state_store(double* diag, double* offd, size_t row, const double (&v)[9], double B) {
   double2* dg = reinterpret_cast<double2*>(diag + row * 4);
   double2* od = reinterpret_cast<double2*>(offd + row * 6);
-#ifdef MUXGL_GREEDY_WT_STATES  // (experiment: write-through stores of the states, so that the barrier's release has less to write back)
-  auto wt = [](double2* q, double2 x) {
-    __hip_atomic_store(&q->x, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&q->y, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  wt(dg, make_double2(v[0], v[4]));
-  wt(dg + 1, make_double2(v[8], B));
-  wt(od, make_double2(v[1], v[2]));
-  wt(od + 1, make_double2(v[3], v[5]));
-  wt(od + 2, make_double2(v[6], v[7]));
-#else
   xwg_st(dg, make_double2(v[0], v[4]));
   xwg_st(dg + 1, make_double2(v[8], B));
   xwg_st(od, make_double2(v[1], v[2]));
   xwg_st(od + 1, make_double2(v[3], v[5]));
   xwg_st(od + 2, make_double2(v[6], v[7]));
-#endif
+  // (write-through stores here -- 8-byte atomics or global_store_dwordx4 sc1 -- do not make the barrier's release cheaper:
+  //  measured 100 / 133 ms against 97 ms at configs[3])
 }
 
 // ---- LDS of a workgroup ------------------------------------------------------------------------------------------------
@@ -791,41 +781,34 @@ __device__ __forceinline__ void greedy_ratio(greedy_lds& L, const greedy_tabs& T
   }
 }
 
-// Scores of the workgroup's cell under the ratios: wave w takes a contiguous share of the cell's incidences, its lane c
-// holds cluster c and multiplies the ratios that belong to cluster c, in their order, into its partial product -- every
-// lane walks the share and reads (cluster, ratio) at a wave-uniform address (an LDS broadcast); the partials are folded in
-// wave order onto the start products.  Returns the first maximum.
+// Scores of the workgroup's cell under the ratios.  The cell's incidences are cut into GWAVES * (64 / Kp) contiguous
+// shares; lane (s, c) of wave w walks share w * (64 / Kp) + s and multiplies the ratios that belong to cluster c, in their
+// order, into its partial product (a ratio of another cluster counts as 1.0 -- exact -- so nothing diverges; the reads are
+// LDS broadcasts); the partials are folded in share order onto the start products.  Returns the first maximum.
 __device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_tabs& T, int t, int64_t X0, int64_t X1) {
-  const int K = T.K, lane = t & 63, wave = t >> 6;
+  const int K = T.K, Kp = T.Kp, lane = t & 63, wave = t >> 6;
+  const int ns = 64 / Kp, c = lane & (Kp - 1), sh = wave * ns + lane / Kp;
   double a2 = 1.0, a0 = 1.0;
   int32_t b2 = 0, b0 = 0;
-  int cnt = 0;
-  const int nx = (int)(X1 - X0), share = ((nx + GWAVES - 1) / GWAVES + 3) & ~3;  // (a multiple of 4: 16-byte reads of ic)
-  const int k0 = wave * share, k1 = k0 + share < nx ? k0 + share : nx;
-  auto mul = [&](int32_t ci, int k) {
-    if (ci != lane) return;
-    const double2 r = k < ICAP ? L.rat[k] : T.rat[X0 + k];
-    a2 *= r.x;
-    a0 *= r.y;
-    if (++cnt == 4) {  // a ratio lies within 1e-30 .. 1e30
-      cnt = 0;
-      prodacc_renorm(a2, b2);
-      prodacc_renorm(a0, b0);
-    }
-  };
+  const int nx = (int)(X1 - X0), nshares = GWAVES * ns;
+  const int share = ((nx + nshares - 1) / nshares + 3) & ~3;  // (a multiple of 4)
+  const int k0 = sh * share, k1 = k0 + share < nx ? k0 + share : nx;
   for (int k = k0; k < k1; k += 4) {
-    if (k + 4 <= ICAP) {
-      const int4 c4 = *reinterpret_cast<const int4*>(L.ic + k);  // (-1 beyond the cell's last incidence: see the ratios)
-      mul(c4.x, k);
-      mul(c4.y, k + 1);
-      mul(c4.z, k + 2);
-      mul(c4.w, k + 3);
-    } else {
-      for (int u = 0; u < 4 && k + u < k1; ++u) mul(T.ic[X0 + k + u], k + u);
+    int32_t ci[4];
+    double2 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // (-1 beyond the cell's last incidence: see the ratios)
+      ci[u] = k + u < ICAP ? L.ic[k + u] : (k + u < nx ? T.ic[X0 + k + u] : -1);
+      r[u] = k + u < ICAP ? L.rat[k + u] : (k + u < nx ? T.rat[X0 + k + u] : make_double2(1.0, 1.0));
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a2 *= ci[u] == c ? r[u].x : 1.0;
+      a0 *= ci[u] == c ? r[u].y : 1.0;
+    }
+    prodacc_renorm(a2, b2);  // (a ratio lies within 1e-30 .. 1e30)
+    prodacc_renorm(a0, b0);
   }
-  prodacc_renorm(a2, b2);
-  prodacc_renorm(a0, b0);
   L.s.part_m[wave][lane] = make_double2(a2, a0);
   L.s.part_x[wave][lane] = make_int2(b2, b0);
   __syncthreads();
@@ -835,10 +818,10 @@ __device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_ta
     if (lane < K) {
       double2 m = L.own_m[lane];
       int2 e = L.own_x[lane];
-      const int nw = share ? (nx + share - 1) / share : 0;
-      for (int w = 0; w < nw; ++w) {
-        const double2 pm = L.s.part_m[w][lane];
-        const int2 px = L.s.part_x[w][lane];
+      const int nsh = share ? (nx + share - 1) / share : 0;
+      for (int q = 0; q < nsh; ++q) {
+        const double2 pm = L.s.part_m[q / ns][(q % ns) * Kp + lane];
+        const int2 px = L.s.part_x[q / ns][(q % ns) * Kp + lane];
         m.x *= pm.x;
         m.y *= pm.y;
         e.x += px.x;
@@ -945,18 +928,23 @@ __device__ __forceinline__ bool greedy_grid_barrier(unsigned* bar, unsigned& epo
 }
 
 // ---- the batches, in ONE launch --------------------------------------------------------------------------------------------
-// gridDim.x workgroups (at most one per compute unit, so all are resident; at least 2 GB) stay on the chip for the whole
-// cell list.  Workgroup b < GB DECIDES cell b of every batch; the others APPLY the batch's merges; all of them take the
-// chunks of the distance phase.  Per batch:
-//   (before the barrier that ends the previous batch: the chunk's SNPs and weights to LDS; deciders: the SNP, weights and
-//    predecessor likelihoods of their cell's incidences to registers, the chains' bytes to LDS)
-//   phase 1: the chunks' start products against the states -> pm / px                                               BARRIER
-//   phase 2: deciders: every cell's start scores and first guess, redundantly in each of them from the chunk partials (a
-//            barrier more would cost more than the 2 k products); then per PASS: the ratios of the own cell's incidences
-//            under the guesses, the own cell's score, its new guess -> wnew                                          BARRIER
-//            until no guess changed in a pass (chg[pass of the run], read by everyone after the barrier);
-//            appliers meanwhile fetch "their" position's chain head: links, SNP, weights, likelihoods;
-//   phase 3: appliers: the merges, with the decisions read from wnew                                                 BARRIER
+// gridDim.x workgroups (at most one per compute unit, so all are resident; at least 2 GB; 128 by default -- measured best
+// at configs[3] and configs[4]: more only make the grid barrier dearer) stay on the chip for the whole cell list.
+// Workgroup b < GB DECIDES cell b of every batch; the others APPLY the batch's merges; all of them take the chunks of the
+// distance phase.  Per batch:
+//   (fetched before the grid barrier that ends the previous batch: the chunk pair's SNPs and weights to LDS; deciders:
+//    the SNP, weights and predecessor likelihoods of their cell's incidences to registers, the chains' bytes to LDS)
+//   phase 1: the chunks' start products against the states -> pm / px (written through), a tag word per chunk pair once
+//            they are in memory;
+//   phase 2: decider b waits for the tags of ITS cell's chunks, folds them into its cell's start products, publishes its
+//            first guess {tag, guess} and collects the other deciders'; then per PASS: the ratios of its cell's incidences
+//            under the guesses, its cell's score, its new guess -> {tag, changed, guess}, collected by everyone, until a
+//            pass changed no guess; appliers meanwhile fetch what "their" position brings (SNP, weights, likelihoods, the
+//            cells of the other members of its chain) and stage the next batch's chunks;
+//   phase 3: appliers: the merges under the last pass's guesses;                                                GRID BARRIER
+// -- the only all-to-all dependency of a batch is states -> next batch's products, so that is the one grid barrier; the
+// other hand-overs are point to point (tags: batch + 1, so a word of an earlier batch never matches).  A decider's state
+// reads are complete before it publishes (its guess depends on them), so no merge starts before every decider has read.
 __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* __restrict__ Tp) {
   extern __shared__ __align__(16) unsigned char greedy_lds_raw[];
   greedy_lds& L = *reinterpret_cast<greedy_lds*>(greedy_lds_raw);
@@ -1444,8 +1432,9 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       if (d_ticks && hipMemcpy(tk, d_ticks, sizeof(tk), hipMemcpyDeviceToHost) == hipSuccess)
         for (int w = 0; w < 2; ++w)
           fprintf(stderr,
-                  "[muxgl] greedy_init: %s workgroup, ms: barrier %.1f | chunk products %.1f | barrier %.1f | start scores %.1f | "
-                  "passes: ratios %.1f scores %.1f barriers %.1f + %.1f | merges %.1f | fetch ahead %.1f\n",
+                  "[muxgl] greedy_init: %s workgroup, ms: grid barrier %.1f | chunk products %.1f | wait for the cell's chunks %.1f | "
+                  "start scores, first guesses %.1f | passes: ratios %.1f scores %.1f wait for the guesses %.1f + %.1f | merges %.1f | "
+                  "fetch ahead %.1f\n",
                   w ? "an applying" : "the last deciding", tk[w * 12 + 6] * 1e-5, tk[w * 12 + 0] * 1e-5, tk[w * 12 + 1] * 1e-5,
                   tk[w * 12 + 8] * 1e-5, tk[w * 12 + 9] * 1e-5, tk[w * 12 + 2] * 1e-5, tk[w * 12 + 3] * 1e-5, tk[w * 12 + 7] * 1e-5,
                   tk[w * 12 + 4] * 1e-5, tk[w * 12 + 5] * 1e-5);
