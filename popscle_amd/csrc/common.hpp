@@ -185,7 +185,7 @@ struct muxgl_handle {
   int32_t* d_snp_cell = nullptr;  // [nnz] cell id of the same SNP-major element
   double* d_segls = nullptr;      // [nnz][9] entry likelihoods in SNP-major order (freemuxlet-old's kernels)
   double* d_segls6 = nullptr;     // [nnz][6] their six distinct values {00,11,22,01,02,12}: the ordered M-step streams them
-  double* d_egls6 = nullptr;      // [nnz][6] the six distinct likelihoods {00,11,22,01,02,12} (quad E-step)
+  double* d_egls6 = nullptr;      // (unused since round 4: the oct E-step's streams are repacked from d_egls)
   int32_t* d_secnt = nullptr;     // [nnz][3] entry counts in SNP-major order
   bool fmx_prepared = false;
   int64_t fc0 = 0, fc1 = 0, fs0 = 0, fs1 = 0;  // active cell / SNP shard of the EM phases (default: everything)
@@ -466,6 +466,7 @@ int fmx_attach_column_slab(muxgl_handle* h, int64_t C_total, int64_t c0, int64_t
                            const int64_t* cell_ptr_s, const int32_t* entry_snp_s, const int64_t* entry_rptr_s,
                            const uint8_t* reads_s, bool trusted);
 int fmx_cluster_counts_device(muxgl_handle* m);  // m->d_ccnt := read counts of the cluster pileups (stream-ordered)
+int fmx_snp_major_full(muxgl_handle* h);  // d_segls / d_secnt on first use (freemuxlet-old)
 int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_mstep(muxgl_handle* h);

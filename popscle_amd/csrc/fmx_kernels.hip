@@ -676,13 +676,19 @@ __global__ void __launch_bounds__(256)
     double g[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) g[i] = egls[(size_t)e * 9 + i];
+    if (segls) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) segls[(size_t)p * 9 + i] = g[i];
+      for (int i = 0; i < 9; ++i) segls[(size_t)p * 9 + i] = g[i];
+    }
     // the six distinct values {00, 11, 22, 01, 02, 12} of the symmetric matrix: what the ordered M-step streams
-    double* o6 = segls6 + (size_t)p * 6;
-    o6[0] = g[0], o6[1] = g[4], o6[2] = g[8], o6[3] = g[1], o6[4] = g[2], o6[5] = g[5];
+    if (segls6) {
+      double* o6 = segls6 + (size_t)p * 6;
+      o6[0] = g[0], o6[1] = g[4], o6[2] = g[8], o6[3] = g[1], o6[4] = g[2], o6[5] = g[5];
+    }
+    if (secnt) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) secnt[(size_t)p * 3 + i] = ecnt[(size_t)e * 3 + i];
+      for (int i = 0; i < 3; ++i) secnt[(size_t)p * 3 + i] = ecnt[(size_t)e * 3 + i];
+    }
   }
 }
 
@@ -829,18 +835,37 @@ static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm) {
   const int64_t nnz = h->nnz;
   if (plan_build_snp_major(h)) return 1;
   tm.lap("fmx_prepare: SNP-major view (device sort)");
-  if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
+  // (the nine-value copy and the counts are read by freemuxlet-old's pair kernel only: fmx_snp_major_full builds them on
+  //  its first call -- 84 B per entry that a freemux2 run neither allocates nor writes: 40 GB at configs[4])
+  dev_free(&h->d_segls);
+  dev_free(&h->d_secnt);
   if (dev_alloc(h, &h->d_segls6, (size_t)nnz * 6)) return 1;
+  if (nnz) {
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
+                       h->d_egls, h->d_ecnt, (double*)nullptr, h->d_segls6, (int32_t*)nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  tm.lap("fmx_prepare: SNP-major gather of likelihoods");
+  return 0;
+}
+
+// SNP-major copies of the nine-value likelihoods and of the read counts (freemuxlet-old's pair kernel), on first use
+int fmx_snp_major_full(muxgl_handle* h) {
+  if (h->d_segls && h->d_secnt) return 0;
+  const int64_t nnz = h->nnz;
+  if (!h->d_egls || !h->d_snp_entry) MUXGL_FAIL(h, "the cell-major likelihoods or the SNP-major view are gone");
+  if (dev_alloc(h, &h->d_segls, (size_t)nnz * 9)) return 1;
   if (dev_alloc(h, &h->d_secnt, (size_t)nnz * 3)) return 1;
   if (nnz) {
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
-                       h->d_egls, h->d_ecnt, h->d_segls, h->d_segls6, h->d_secnt);
+                       h->d_egls, h->d_ecnt, h->d_segls, (double*)nullptr, h->d_secnt);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  tm.lap("fmx_prepare: SNP-major gather of likelihoods");
   return 0;
 }
 
@@ -889,7 +914,6 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   if (S) HIPCHK(h, hipMemcpyAsync(h->d_af, af, sizeof(double) * S, hipMemcpyHostToDevice, h->stream));
   if (dev_alloc(h, &h->d_egls, (size_t)nnz * 9)) return 1;
   if (dev_alloc(h, &h->d_ecnt, (size_t)nnz * 3)) return 1;
-  if (dev_alloc(h, &h->d_egls6, (size_t)nnz * 6)) return 1;
   if (dev_alloc(h, &h->d_flin, (size_t)((nnz + 31) / 32))) return 1;
   fmx_wave_streams_release(h);  // they are made of the likelihoods computed below
   double *d_l0 = nullptr, *d_l2 = nullptr, *d_c0 = nullptr, *d_c2 = nullptr;
@@ -912,7 +936,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(fmx_entry_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_entry_rptr,
-                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, h->d_egls6, h->d_ecnt, d_l0, d_l2, h->d_flin);
+                       h->d_reads, h->d_entry_snp, h->d_af, h->d_lut, h->d_egls, (double*)nullptr, h->d_ecnt, d_l0, d_l2, h->d_flin);
   }
   if (C)
     hipLaunchKernelGGL(fmx_cell_score_kernel, dim3((unsigned)C), dim3(64), 0, h->stream, h->d_cell_ptr, d_l0, d_l2,

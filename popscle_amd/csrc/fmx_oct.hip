@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64)
 // behind the end of a list.
 __global__ void __launch_bounds__(256)
     fo_repack_kernel(int n_units, int n_chunks, const row_chunk* __restrict__ chunks, const int32_t* __restrict__ order,
-                     const uint32_t* __restrict__ flin, const int32_t* __restrict__ entry_snp, const double* __restrict__ egls6,
+                     const uint32_t* __restrict__ flin, const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
                      const int32_t* __restrict__ lsteps, const int64_t* __restrict__ lptr, const int32_t* __restrict__ gsteps,
                      const int64_t* __restrict__ gptr, uint32_t S, uint32_t* __restrict__ loff, double2* __restrict__ lc,
                      uint32_t* __restrict__ goff, double* __restrict__ ggl) {
@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(256)
   int il = 0, ig = 0;
   for (int i = 0; i < len; ++i) {
     const int64_t e = e0 + i;
-    const double* g = egls6 + (size_t)e * 6;
+    const double* g9 = egls + (size_t)e * 9;  // the six distinct values {00,11,22,01,02,12} of the symmetric matrix
+    const double g[6] = {g9[0], g9[4], g9[8], g9[1], g9[2], g9[5]};
     if (flin && ((flin[e >> 5] >> (e & 31)) & 1u)) {
       lo[(size_t)il * SLOTS] = (uint32_t)entry_snp[e] * 128u;
       ld[(size_t)il * SLOTS] = double2{g[0], g[3] - g[0]};
@@ -416,7 +417,7 @@ int fmx_oct_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64
         dev_alloc(h, &st->d_fo_goff, (size_t)ng_total + 1) || dev_alloc(h, &st->d_fo_ggl, ((size_t)ng_total + 1) * 6))
       return 1;
     hipLaunchKernelGGL(fo_repack_kernel, dim3((unsigned)(((size_t)blocks * SLOTS + 255) / 256)), dim3(256), 0, h->stream,
-                       (int)blocks, (int)st->n_chunks, st->d_chunks, st->d_fq_order, flin, h->d_entry_snp, h->d_egls6,
+                       (int)blocks, (int)st->n_chunks, st->d_chunks, st->d_fq_order, flin, h->d_entry_snp, h->d_egls,
                        st->d_fo_lsteps, st->d_fo_lptr, st->d_fo_gsteps, st->d_fo_gptr, (uint32_t)h->S,
                        st->d_fo_loff, st->d_fo_lc, st->d_fo_goff, st->d_fo_ggl);
     HIPCHK(h, hipGetLastError());

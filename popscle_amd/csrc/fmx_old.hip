@@ -431,6 +431,7 @@ int muxgl_fmxold_pair_dist(muxgl_handle* h, double bf_thres, muxgl_dropd* full) 
   if (h->col) MUXGL_FAIL(h, "muxgl_fmxold_pair_dist: needs the whole pileup on one handle (this one holds slabs)");
   HIPCHK(h, hipSetDevice(h->device));
   if (fmxold_check(h, "muxgl_fmxold_pair_dist", 0)) return 1;
+  if (fmx_snp_major_full(h)) return 1;
   const int64_t C = h->C;
   if (C > INT32_MAX / 2) MUXGL_FAIL(h, "muxgl_fmxold_pair_dist: too many cells");
   const int64_t ld = (C + 15) / 16 * 16 + 16;
