@@ -831,7 +831,7 @@ static int fmx_mstep_launch(muxgl_handle* h) {
 
 // SNP-major view of the entries (cells ascending inside each SNP) and SNP-major copies of the entry likelihoods for the
 // ordered M-step, built on the device
-static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm) {
+static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm, bool keep_segls6 = false /* allocated by the caller */) {
   const int64_t nnz = h->nnz;
   if (plan_build_snp_major(h)) return 1;
   tm.lap("fmx_prepare: SNP-major view (device sort)");
@@ -839,7 +839,7 @@ static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm) {
   //  its first call -- 84 B per entry that a freemux2 run neither allocates nor writes: 40 GB at configs[4])
   dev_free(&h->d_segls);
   dev_free(&h->d_secnt);
-  if (dev_alloc(h, &h->d_segls6, (size_t)nnz * 6)) return 1;
+  if (!keep_segls6 && dev_alloc(h, &h->d_segls6, (size_t)nnz * 6)) return 1;
   if (nnz) {
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -919,14 +919,17 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   double *d_l0 = nullptr, *d_l2 = nullptr, *d_c0 = nullptr, *d_c2 = nullptr;
   int32_t *d_ns = nullptr, *d_nr = nullptr;
   auto cleanup = [&]() {
-    dev_free(&d_l0);
-    dev_free(&d_l2);
     dev_free(&d_c0);
     dev_free(&d_c2);
     dev_free(&d_ns);
     dev_free(&d_nr);
   };
-  if (dev_alloc(h, &d_l0, (size_t)nnz) || dev_alloc(h, &d_l2, (size_t)nnz) || dev_alloc(h, &d_c0, (size_t)C) ||
+  // the two per-entry log-likelihoods live until the cells' scores are summed: in the buffer of the SNP-major six-value
+  // copy, which is filled after that (16 B per entry less to allocate)
+  if (dev_alloc(h, &h->d_segls6, (size_t)nnz * 6)) return 1;
+  d_l0 = h->d_segls6;
+  d_l2 = h->d_segls6 + nnz;
+  if (dev_alloc(h, &d_c0, (size_t)C) ||
       dev_alloc(h, &d_c2, (size_t)C) || dev_alloc(h, &d_ns, (size_t)C) || dev_alloc(h, &d_nr, (size_t)C)) {
     cleanup();
     return 1;
@@ -961,7 +964,7 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
     dev_free(&h->d_segls);
     dev_free(&h->d_segls6);
     dev_free(&h->d_secnt);
-  } else if (fmx_build_snp_major(h, tm)) {
+  } else if (fmx_build_snp_major(h, tm, true)) {
     return 1;
   }
   h->fmx_prepared = true;

@@ -193,8 +193,8 @@ int cmd_demuxlet(int argc, char** argv) {
 // ------------------------------------------------------------------------------------------------ freemuxlet
 // old_clust0: the .clust0.vcf.gz of freemuxlet-old (cmd_cram_freemuxlet.cpp:377-431) differs from every other cluster
 // VCF in two expressions: pps = gps * gls / maxGL (:409-411) and gq = (int)(-0.1*log10(..)) (:421)
-void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const std::vector<double>& gls,
-                       const std::vector<int32_t>& cnt, const std::vector<uint8_t>& snps_observed, const tm* ltm,
+void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const double* gls /* [K][S][9] */,
+                       const int32_t* cnt /* [K][S][3] */, const std::vector<uint8_t>& snps_observed, const tm* ltm,
                        bool old_clust0 = false) {
   // cmd_cram_freemux2.cpp:608-658 == cmd_cram_freemuxlet.cpp:655-707
   OutFile vc(path, true);
@@ -396,15 +396,23 @@ int cmd_freemuxlet(int argc, char** argv) {
     for (int64_t i = 0; i < C; ++i) wc0.printf("%d\t%s\t%d\n", (int)i, p.bcs[(size_t)i].c_str(), clusts[(size_t)i]);
   }
   std::vector<uint8_t> snps_observed((size_t)S, 0);  // :279-288
-  for (int64_t e = 0; e < p.nnz(); ++e) snps_observed[(size_t)p.entry_snp[(size_t)e]] = 1;
+  {  // (every writer stores 1; a set flag is only read, so that its cache line stays shared between the threads)
+    const int64_t nnz = p.nnz(), grain = 1 << 20;
+    const int32_t* es = p.entry_snp.data();
+    uint8_t* so = snps_observed.data();
+    parallel_for((nnz + grain - 1) / grain, plp_threads(), [&](int64_t b) {
+      for (int64_t e = b * grain, e1 = std::min(nnz, (b + 1) * grain); e < e1; ++e)
+        if (!so[es[e]]) so[es[e]] = 1;
+    });
+  }
   check(h, muxgl_fmx_set_clusters(h, K, clusts.data()), "muxgl_fmx_set_clusters");
   time_t now = std::time(nullptr);
   tm* ltm = localtime(&now);
-  std::vector<double> cgls((size_t)K * S * 9);
-  std::vector<int32_t> ccnt((size_t)K * S * 3);
+  BigVec<double> cgls((size_t)K * S * 9);  // (not zero-filled: 2.3 GB at configs[4]; muxgl_fmx_get_cluster_pileup writes all of it)
+  BigVec<int32_t> ccnt((size_t)K * S * 3);
   if (auxFiles) {
     check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
-    write_cluster_vcf(cf.outPrefix + ".clust0.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+    write_cluster_vcf(cf.outPrefix + ".clust0.vcf.gz", p, K, cgls.data(), ccnt.data(), snps_observed, ltm);
   }
 
   std::vector<muxgl_fmx_cell> cells((size_t)C);
@@ -423,7 +431,7 @@ int cmd_freemuxlet(int argc, char** argv) {
   }
   tmr.lap("freemuxlet: EM iterations");
   check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
-  write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+  write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls.data(), ccnt.data(), snps_observed, ltm);
   tmr.lap("freemuxlet: write .clust1.vcf.gz");
 
   OutFile wc1(cf.outPrefix + ".clust1.samples.gz", true);  // :660-665
@@ -622,15 +630,23 @@ int cmd_freemuxlet_old(int argc, char** argv) {
     for (int64_t i = 0; i < C; ++i) wc0.printf("%d\t%s\t%d\n", (int)i, p.bcs[(size_t)i].c_str(), clusts[(size_t)i]);
   }
   std::vector<uint8_t> snps_observed((size_t)S, 0);  // :367-376
-  for (int64_t e = 0; e < p.nnz(); ++e) snps_observed[(size_t)p.entry_snp[(size_t)e]] = 1;
+  {  // (every writer stores 1; a set flag is only read, so that its cache line stays shared between the threads)
+    const int64_t nnz = p.nnz(), grain = 1 << 20;
+    const int32_t* es = p.entry_snp.data();
+    uint8_t* so = snps_observed.data();
+    parallel_for((nnz + grain - 1) / grain, plp_threads(), [&](int64_t b) {
+      for (int64_t e = b * grain, e1 = std::min(nnz, (b + 1) * grain); e < e1; ++e)
+        if (!so[es[e]]) so[es[e]] = 1;
+    });
+  }
   check(h, muxgl_fmx_set_clusters(h, K, clusts.data()), "muxgl_fmx_set_clusters");
   time_t now = std::time(nullptr);
   tm* ltm = localtime(&now);
-  std::vector<double> cgls((size_t)K * S * 9);
-  std::vector<int32_t> ccnt((size_t)K * S * 3);
+  BigVec<double> cgls((size_t)K * S * 9);  // (not zero-filled: 2.3 GB at configs[4]; muxgl_fmx_get_cluster_pileup writes all of it)
+  BigVec<int32_t> ccnt((size_t)K * S * 3);
   if (auxFiles) {
     check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
-    write_cluster_vcf(cf.outPrefix + ".clust0.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm, true);
+    write_cluster_vcf(cf.outPrefix + ".clust0.vcf.gz", p, K, cgls.data(), ccnt.data(), snps_observed, ltm, true);
   }
 
   std::vector<muxgl_fmx_cell> cells((size_t)C);
@@ -645,7 +661,7 @@ int cmd_freemuxlet_old(int argc, char** argv) {
   }
   tmr.lap("freemuxlet-old: EM iterations");
   check(h, muxgl_fmx_get_cluster_pileup(h, cgls.data(), ccnt.data()), "muxgl_fmx_get_cluster_pileup");
-  write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls, ccnt, snps_observed, ltm);
+  write_cluster_vcf(cf.outPrefix + ".clust1.vcf.gz", p, K, cgls.data(), ccnt.data(), snps_observed, ltm);
 
   OutFile wc1(cf.outPrefix + ".clust1.samples.gz", true);  // :709-714
   wc1.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"

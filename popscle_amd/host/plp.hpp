@@ -37,9 +37,10 @@ struct Pileup {
   std::vector<SnpInfo> snps;
   std::vector<std::string> rid2chr;
   // packed pileup
-  std::vector<int64_t> cell_ptr, entry_rptr;
-  std::vector<int32_t> entry_snp;
-  std::vector<uint8_t> reads;
+  std::vector<int64_t> cell_ptr;
+  BigVec<int64_t> entry_rptr;
+  BigVec<int32_t> entry_snp;
+  BigVec<uint8_t> reads;
   // demuxlet only
   int32_t nv = 0;
   std::vector<std::string> sample_ids;
@@ -51,9 +52,10 @@ struct Pileup {
   // slab_s0 <= marker < slab_s1, marker ids unchanged (the arguments of muxgl_fmx_set_column_slab).
   bool slabbed = false;
   int64_t slab_c0 = 0, slab_c1 = 0, slab_s0 = 0, slab_s1 = 0;
-  std::vector<int64_t> col_cell_ptr, col_entry_rptr;
-  std::vector<int32_t> col_entry_snp;
-  std::vector<uint8_t> col_reads;
+  std::vector<int64_t> col_cell_ptr;
+  BigVec<int64_t> col_entry_rptr;
+  BigVec<int32_t> col_entry_snp;
+  BigVec<uint8_t> col_reads;
   int64_t C() const { return (int64_t)bcs.size(); }
   int64_t S() const { return (int64_t)snps.size(); }
   int64_t nnz() const { return (int64_t)entry_snp.size(); }

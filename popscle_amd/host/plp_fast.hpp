@@ -12,6 +12,7 @@
 #pragma once
 
 
+#include <sys/mman.h>
 #include <memory>
 
 #include "util.hpp"
@@ -48,6 +49,10 @@ class PlpReadVec {
     if (c <= cap_) return;
     PlpRead* q = (PlpRead*)malloc(c * sizeof(PlpRead));
     if (!q) fatal("out of memory (%zu reads)", c);
+    if (c * sizeof(PlpRead) >= (64u << 20)) {  // fewer page faults where transparent huge pages are on request
+      const uintptr_t a = ((uintptr_t)q + 4095) & ~(uintptr_t)4095, z = ((uintptr_t)q + c * sizeof(PlpRead)) & ~(uintptr_t)4095;
+      if (z > a) (void)madvise((void*)a, z - a, MADV_HUGEPAGE);
+    }
     if (n_) {  // rare (the size hint normally covers the file): copy with all threads
       const size_t nb = (n_ + (1u << 16) - 1) >> 16;
       PlpRead* src = p_;
@@ -297,7 +302,7 @@ class GzBlockReader : public BlockSource {
 // trailer -- so a batch of members is inflated by the whole worker pool straight to its place in the text block.
 class BgzfBlockReader : public BlockSource {
  public:
-  static constexpr size_t TEXT = 16u << 20;  // inflated bytes per block (about)
+  static constexpr size_t TEXT = 64u << 20;  // inflated bytes per block (about): 1024 members, so that the pool's hand-overs are rare
   static bool is_bgzf(const std::string& path) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -420,12 +425,16 @@ class BgzfBlockReader : public BlockSource {
 inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& po, PlpReadVec& rds,
                              bool* sorted) {
   using namespace detail;
-  {  // size hint: the gzip trailer holds the uncompressed length (mod 2^32); a kept base costs >= ~9 bytes of text
+  {  // size hint: the gzip trailer holds the uncompressed length (mod 2^32; of the LAST member: nothing for a BGZF file,
+     // which ends in an empty one), a kept base costs >= ~9 bytes of text and -- measured on dsc-pileup-like tables --
+     // 4 to 6 compressed bytes: reserve for the larger guess (address space only: untouched pages cost nothing)
     FILE* f = fopen((prefix + ".plp.gz").c_str(), "rb");
     unsigned char t[4];
-    if (f && fseek(f, -4, SEEK_END) == 0 && fread(t, 1, 4, f) == 4) {
-      const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
-      rds.reserve(rds.size() + (size_t)(isize / 9));
+    if (f && fseek(f, -4, SEEK_END) == 0) {
+      const uint64_t fsize = (uint64_t)ftell(f) + 4;
+      uint64_t isize = 0;
+      if (fread(t, 1, 4, f) == 4) isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+      rds.reserve(rds.size() + (size_t)std::max<uint64_t>(isize / 9, fsize / 4 + (fsize >> 5)));
     }
     if (f) fclose(f);
   }
@@ -594,8 +603,8 @@ inline void plp_order_by_cell(PlpReadVec& rds, int64_t C, bool already_sorted, s
 
 // ordered reads -> CSR (cell_ptr, entry_snp, entry_rptr, reads)
 inline void plp_pack(const PlpReadVec& rds, int64_t C, const std::vector<int64_t>& cell_rd0,
-                     std::vector<int64_t>& cell_ptr, std::vector<int32_t>& entry_snp, std::vector<int64_t>& entry_rptr,
-                     std::vector<uint8_t>& reads) {
+                     std::vector<int64_t>& cell_ptr, BigVec<int32_t>& entry_snp, BigVec<int64_t>& entry_rptr,
+                     BigVec<uint8_t>& reads) {
   const int nth = plp_threads();
   const int64_t n = (int64_t)rds.size();
   cell_ptr.assign((size_t)C + 1, 0);

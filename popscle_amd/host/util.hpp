@@ -8,6 +8,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <cstdarg>
@@ -195,6 +196,29 @@ class WorkerPool {
   uint64_t gen_ = 0;
   bool quit_ = false;
 };
+
+// std::vector whose resize() leaves new elements of a trivial type uninitialised: a plain vector zero-fills them on one
+// thread -- seconds of page faults for the multi-GB arrays of a packed pileup; here the parallel fill touches the pages
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U>
+  void construct(U* q) noexcept(std::is_nothrow_default_constructible<U>::value) {
+    ::new (static_cast<void*>(q)) U;
+  }
+  template <class U, class... A>
+  void construct(U* q, A&&... a) {
+    ::new (static_cast<void*>(q)) U(std::forward<A>(a)...);
+  }
+};
+template <class T>
+using BigVec = std::vector<T, NoInitAlloc<T>>;
 
 inline void parallel_for(int64_t n, int nth, const std::function<void(int64_t)>& fn) { WorkerPool::get().run(n, nth, fn); }
 

@@ -87,7 +87,7 @@ class VcfReader {
     std::string line;
     while (rd_->getline(line)) {
       if (line.empty() || line[0] == '#') continue;
-      fields_ = split_tab(line);
+      split_reuse(line, '\t', fields_);  // (the strings of the previous record are overwritten in place: no allocation)
       if (fields_.size() < 8) fatal("%s: VCF record with %zu columns", path.c_str(), fields_.size());
       alleles.clear();
       alleles.push_back(fields_[3]);
@@ -103,7 +103,15 @@ class VcfReader {
       }
       rid = contig_id(fields_[0]);
       pos = atoi(fields_[1].c_str());
-      fmt_keys_ = fields_.size() > 8 ? split_char(fields_[8], ':') : std::vector<std::string>();
+      if (fields_.size() > 8) {
+        if (fields_[8] != fmt_str_) {  // (nearly every record repeats the previous FORMAT string)
+          fmt_str_ = fields_[8];
+          fmt_keys_ = split_char(fmt_str_, ':');
+        }
+      } else {
+        fmt_str_.clear();
+        fmt_keys_.clear();
+      }
       if (!passed_vfilter()) continue;
       return true;
     }
@@ -205,6 +213,17 @@ class VcfReader {
     return out;
   }
   static std::vector<std::string> split_tab(const std::string& s) { return split_char(s, '\t'); }
+  static void split_reuse(const std::string& s, char c, std::vector<std::string>& out) {
+    size_t n = 0, b = 0;
+    while (true) {
+      const size_t e = s.find(c, b);
+      if (n == out.size()) out.emplace_back();
+      out[n++].assign(s, b, e == std::string::npos ? std::string::npos : e - b);
+      if (e == std::string::npos) break;
+      b = e + 1;
+    }
+    out.resize(n);
+  }
   bool want_all() const { return wanted.empty(); }
   int contig_id(const std::string& name) {
     auto it = contig_ids_.find(name);
@@ -222,8 +241,15 @@ class VcfReader {
   std::string sample_field(int isel, int fi) const {
     const size_t col = 9 + (size_t)sm_cols_[(size_t)isel];
     if (col >= fields_.size()) return ".";
-    std::vector<std::string> v = split_char(fields_[col], ':');
-    return fi < (int)v.size() ? v[(size_t)fi] : ".";
+    const std::string& f = fields_[col];  // the fi-th of its ':'-separated values, without splitting all of them
+    size_t b = 0;
+    for (int k = 0; k < fi; ++k) {
+      b = f.find(':', b);
+      if (b == std::string::npos) return ".";
+      ++b;
+    }
+    const size_t e = f.find(':', b);
+    return f.substr(b, e == std::string::npos ? std::string::npos : e - b);
   }
   // bcf_filtered_reader.cpp:192-248: allele counts over the selected samples; gts_[2i], gts_[2i+1] = allele or -1
   bool parse_genotypes() {
@@ -313,6 +339,7 @@ class VcfReader {
   std::vector<int> sm_cols_;
   int n_vcf_samples_ = 0;
   std::vector<std::string> fields_, fmt_keys_;
+  std::string fmt_str_;  // the FORMAT string fmt_keys_ was split from
   std::vector<int> gts_;
   std::vector<double> acs_;
   int an_ = 0;
