@@ -13,6 +13,7 @@
 
 
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <memory>
 
 #include "util.hpp"
@@ -314,8 +315,20 @@ class BgzfBlockReader : public BlockSource {
   explicit BgzfBlockReader(const std::string& path) : path_(path) {
     f_ = fopen(path.c_str(), "rb");
     if (!f_) fatal("Cannot open %s for reading", path.c_str());
+    // the members are inflated straight from a read-only mapping of the file (no copy of the compressed bytes through a
+    // buffer on the one thread that walks the member headers); a file that cannot be mapped is read in 8 MB pieces
+    struct stat st;
+    if (fstat(fileno(f_), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+      void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
+      if (m != MAP_FAILED) {
+        map_ = (const unsigned char*)m;
+        map_n_ = (size_t)st.st_size;
+        (void)madvise(m, map_n_, MADV_SEQUENTIAL);
+      }
+    }
   }
   ~BgzfBlockReader() override {
+    if (map_) munmap((void*)map_, map_n_);
     if (f_) fclose(f_);
   }
   bool next(std::vector<char>& blk) override {
@@ -326,15 +339,19 @@ class BgzfBlockReader : public BlockSource {
     };
     std::vector<Member> mem;
     size_t text = carry_.size();
-    fpos_ += cpos_;  // drop what the previous call consumed; from here on the buffer only grows (members keep offsets)
-    cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (long)cpos_);
-    cpos_ = 0;
+    if (!map_) {
+      fpos_ += cpos_;  // drop what the previous call consumed; from here on the buffer only grows (members keep offsets)
+      cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (long)cpos_);
+      cpos_ = 0;
+    }
+    auto have = [&]() { return (map_ ? map_n_ : cbuf_.size()) - cpos_; };
+    auto refill = [&]() { return map_ ? false : this->refill(); };
     // gather whole members until the block is large enough
     for (;;) {
-      if (cbuf_.size() - cpos_ < 18 && !refill()) break;
-      if (cbuf_.size() - cpos_ == 0) break;
-      const unsigned char* p = (const unsigned char*)cbuf_.data() + cpos_;
-      const size_t avail = cbuf_.size() - cpos_;
+      if (have() < 18 && !refill()) break;
+      if (have() == 0) break;
+      const unsigned char* p = (map_ ? map_ : (const unsigned char*)cbuf_.data()) + cpos_;
+      const size_t avail = have();
       const long ms = avail >= 18 ? member_size(p, avail) : -1;
       if (ms <= 0) fatal("%s: not a BGZF member at compressed offset %zu", path_.c_str(), fpos_ + cpos_);
       if ((size_t)ms > avail) {
@@ -352,7 +369,7 @@ class BgzfBlockReader : public BlockSource {
     blk.resize(text);
     if (!carry_.empty()) memcpy(blk.data(), carry_.data(), carry_.size());
     std::atomic<bool> bad(false);
-    const unsigned char* base = (const unsigned char*)cbuf_.data();
+    const unsigned char* base = map_ ? map_ : (const unsigned char*)cbuf_.data();
     parallel_for_blocked((int64_t)mem.size(), 8, plp_threads(), [&](int64_t i) {
       const Member& m = mem[(size_t)i];
       if (m.isize == 0) return;  // e.g. the end-of-file marker
@@ -376,7 +393,7 @@ class BgzfBlockReader : public BlockSource {
       if (!ok || (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(blk.data() + m.out), m.isize) != want) bad = true;
     });
     if (bad) fatal("%s: corrupt BGZF member", path_.c_str());
-    const bool eof = cbuf_.size() == cpos_ && feof_;
+    const bool eof = map_ ? cpos_ == map_n_ : (cbuf_.size() == cpos_ && feof_);
     size_t cut = blk.size();
     if (!eof) {
       while (cut > 0 && blk[cut - 1] != '\n') --cut;
@@ -414,6 +431,8 @@ class BgzfBlockReader : public BlockSource {
   std::string path_;
   FILE* f_ = nullptr;
   std::vector<char> cbuf_, carry_;
+  const unsigned char* map_ = nullptr;  // the whole file, when it could be mapped (cpos_ then counts from its start)
+  size_t map_n_ = 0;
   size_t cpos_ = 0, fpos_ = 0;
   bool feof_ = false, finished_ = false;
 };
