@@ -70,15 +70,17 @@ def demux_flops_per_entry(V, A, rpe):
     return A * (18.0 * V + 7.0 * V * V) + rpe * A * 27.0  # the reference's own operation count
 
 
-def demux_issued_flops_model(V, alphas, rpe):
-    """FP64 operations the kernels issue per entry (model, used when no fresh PMC pass exists): a hypothesis costs a
-    3-term dot product (MUL + 2 FMA = 5) and one multiply into its product accumulator; the u-factors 3 dots per sample
-    and alpha; singlets a dot, the sample-0 factor and the accumulate; alpha = 0.5 pairs are evaluated once (k < j)."""
+def demux_issued_flops_model(V, alphas, rpe, f_lin=0.0):
+    """FP64 operations the kernels issue per entry (model, used when no fresh PMC pass exists; counted like the counters
+    do: FMA = 2, MUL = ADD = 1): a hypothesis of a general entry costs a 3-term dot product (MUL + 2 FMA = 5) and one
+    multiply into its product accumulator, a hypothesis of a linear entry (share f_lin: at most one usable read) one FMA
+    and that multiply (3); the u-factors 3 dots per sample and alpha; singlets a dot, the sample-0 factor and the
+    accumulate; alpha = 0.5 pairs are evaluated once (k < j)."""
     nsym = sum(1 for a in alphas[1:] if a == 0.5)
     nns = len(alphas) - 1 - nsym
     pairs = V * (V - 1)
     hyp = nsym * pairs / 2 + nns * pairs
-    return hyp * 6.0 + (nsym + nns) * V * 15.0 + V * 7.0 + rpe * len(alphas) * 27.0
+    return hyp * (3.0 * f_lin + 6.0 * (1.0 - f_lin)) + (nsym + nns) * V * 15.0 + V * 7.0 + rpe * len(alphas) * 27.0
 
 
 def fmx_bytes_per_entry(K):
@@ -89,8 +91,8 @@ def fmx_flops_per_entry(K):
     return 33.0 * K + 3.5 * K * (K + 1)
 
 
-def fmx_issued_flops_model(K):
-    return K * (K + 1) / 2 * 6.0 + K * 15.0
+def fmx_issued_flops_model(K, f_lin=0.0):
+    return K * (K + 1) / 2 * (3.0 * f_lin + 6.0 * (1.0 - f_lin)) + K * 15.0
 
 
 # ---- the floor: the least work the algorithm AS BUILT must do (DESIGN.md section 6.1 states the same table) -----------
@@ -514,6 +516,7 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
         kern_ms /= steps
         rpe = p.R / max(p.nnz, 1)
         sweep_s = kern_ms[muxgl.T_DEMUX_SWEEP] * 1e-3
+        frac_lin = linear_fraction(p.entry_rptr, p.reads)
         out = {
             "metric": METRIC if config == 1 else f"cell-sample-pair LLs/sec (singlet+doublet), demuxlet BASELINE.json configs[{config}]",
             "value": total_cells * lls_per_cell / step_s, "unit": "LLs/s", "n_gpus": ctx.world, "steps": steps,
@@ -536,9 +539,9 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
                           "call": float(kern_ms[muxgl.T_DEMUX_CALL]), "d2h": float(kern_ms[muxgl.T_DEMUX_D2H])},
             "roofline": roofline(demux_sweep_kernel(V, alphas), sweep_s, demux_bytes_per_entry(V, rpe) * p.nnz,
                                  demux_flops_per_entry(V, A, rpe) * p.nnz,
-                                 demux_issued_flops_model(V, alphas, rpe) * p.nnz, config, scale=float(p.nnz)),
+                                 demux_issued_flops_model(V, alphas, rpe, 0.0 if args.no_linear else frac_lin) * p.nnz, config,
+                                 scale=float(p.nnz)),
         }
-        frac_lin = linear_fraction(p.entry_rptr, p.reads)
         out["roofline"]["floor"] = demux_floor(V, alphas, float(p.nnz), 0.0 if args.no_linear else frac_lin, rpe, cfg["S"],
                                                C, sweep_s * 1e3)
         if reads_lambda is not None or args.no_linear:
@@ -663,7 +666,7 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
             # device-event times of the two exchanges per iteration on rank 0 (RCCL only): DESIGN.md 4.3's scaling model
             "exchange_ms_rank0": tm.get("exchange_ms"),
             "roofline": roofline(fmx_estep_kernel(K), est_s, fmx_bytes_per_entry(K) * my_entries,
-                                 fmx_flops_per_entry(K) * my_entries, fmx_issued_flops_model(K) * my_entries, config,
+                                 fmx_flops_per_entry(K) * my_entries, fmx_issued_flops_model(K, frac_lin) * my_entries, config,
                                  scale=my_entries),
         }
         out["roofline"]["floor"] = fmx_floor(K, my_entries, frac_lin, S, est_s * 1e3)
