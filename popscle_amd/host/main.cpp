@@ -191,6 +191,22 @@ int cmd_demuxlet(int argc, char** argv) {
 }
 
 // ------------------------------------------------------------------------------------------------ freemuxlet
+// rows [0, n) of a table, formatted by the worker pool in batches and written in order
+template <class F>
+void write_rows_parallel(OutFile& w, int64_t n, F format_row) {
+  constexpr int64_t GRAIN = 1024, BATCH = 64;  // rows per work item, work items per batch
+  std::vector<std::string> parts((size_t)BATCH);
+  for (int64_t r0 = 0; r0 < n; r0 += GRAIN * BATCH) {
+    const int64_t nparts = std::min<int64_t>(BATCH, (n - r0 + GRAIN - 1) / GRAIN);
+    parallel_for(nparts, plp_threads(), [&](int64_t i) {
+      std::string& o = parts[(size_t)i];
+      o.clear();
+      for (int64_t r = r0 + i * GRAIN, re = std::min(n, r + GRAIN); r < re; ++r) format_row(r, o);
+    });
+    for (int64_t i = 0; i < nparts; ++i) w.write(parts[(size_t)i].data(), parts[(size_t)i].size());
+  }
+}
+
 // old_clust0: the .clust0.vcf.gz of freemuxlet-old (cmd_cram_freemuxlet.cpp:377-431) differs from every other cluster
 // VCF in two expressions: pps = gps * gls / maxGL (:409-411) and gq = (int)(-0.1*log10(..)) (:421)
 void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const double* gls /* [K][S][9] */,
@@ -438,15 +454,30 @@ int cmd_freemuxlet(int argc, char** argv) {
   wc1.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"
              "DIFF.LLK.BEST.NEXT\tBEST.POSTERIOR\tSNG.POSTERIOR\tSNG.BEST.GUESS\tSNG.BEST.LLK\tSNG.NEXT.GUESS\t"
              "SNG.NEXT.LLK\tSNG.ONLY.POSTERIOR\tDBL.BEST.GUESS\tDBL.BEST.LLK\tDIFF.LLK.SNG.DBL\n");
-  for (int64_t i = 0; i < C; ++i) {
+  write_rows_parallel(wc1, C, [&](int64_t i, std::string& o) {  // rows formatted by the worker pool, written in order
     const muxgl_fmx_cell& c = cells[(size_t)i];
-    wc1.printf("%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
+    char buf[1024];
+    const int n = snprintf(buf, sizeof(buf),
+               "%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
                "%.2lf\t%.2lf\n",
                (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i], nReads[(size_t)i],
                (c.type == 2) ? "AMB" : ((c.type == 0) ? "SNG" : "DBL"), c.jBest, c.kBest, c.bestLLK, c.jNext, c.kNext,
                c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, c.sBest, c.sngBestLLK, c.sNext, c.sngNextLLK,
                c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
-  }
+    if (n < (int)sizeof(buf)) {
+      o.append(buf, (size_t)n);
+    } else {  // (a barcode of a kilobyte)
+      std::vector<char> big((size_t)n + 1);
+      snprintf(big.data(), big.size(),
+               "%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
+               "%.2lf\t%.2lf\n",
+               (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i], nReads[(size_t)i],
+               (c.type == 2) ? "AMB" : ((c.type == 0) ? "SNG" : "DBL"), c.jBest, c.kBest, c.bestLLK, c.jNext, c.kNext,
+               c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, c.sBest, c.sngBestLLK, c.sNext, c.sngNextLLK,
+               c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
+      o.append(big.data(), (size_t)n);
+    }
+  });
   wc1.close();
   tmr.lap("freemuxlet: write .clust1.samples.gz");
   muxgl_destroy(h);
@@ -667,15 +698,30 @@ int cmd_freemuxlet_old(int argc, char** argv) {
   wc1.printf("INT_ID\tBARCODE\tNUM.SNPS\tNUM.READS\tDROPLET.TYPE\tBEST.GUESS\tBEST.LLK\tNEXT.GUESS\tNEXT.LLK\t"
              "DIFF.LLK.BEST.NEXT\tBEST.POSTERIOR\tSNG.POSTERIOR\tSNG.BEST.GUESS\tSNG.BEST.LLK\tSNG.NEXT.GUESS\t"
              "SNG.NEXT.LLK\tSNG.ONLY.POSTERIOR\tDBL.BEST.GUESS\tDBL.BEST.LLK\tDIFF.LLK.SNG.DBL\n");
-  for (int64_t i = 0; i < C; ++i) {
+  write_rows_parallel(wc1, C, [&](int64_t i, std::string& o) {  // rows formatted by the worker pool, written in order
     const muxgl_fmx_cell& c = cells[(size_t)i];
-    wc1.printf("%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
+    char buf[1024];
+    const int n = snprintf(buf, sizeof(buf),
+               "%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
                "%.2lf\t%.2lf\n",
                (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i], nReads[(size_t)i],
                (c.type == 2) ? "AMB" : ((c.type == 0) ? "SNG" : "DBL"), c.jBest, c.kBest, c.bestLLK, c.jNext, c.kNext,
                c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, c.sBest, c.sngBestLLK, c.sNext, c.sngNextLLK,
                c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
-  }
+    if (n < (int)sizeof(buf)) {
+      o.append(buf, (size_t)n);
+    } else {  // (a barcode of a kilobyte)
+      std::vector<char> big((size_t)n + 1);
+      snprintf(big.data(), big.size(),
+               "%d\t%s\t%d\t%d\t%s\t%d,%d\t%.2lf\t%d,%d\t%.2lf\t%.2lf\t%.5lf\t%.2lg\t%d\t%.2lf\t%d\t%.2lf\t%.5lf\t%d,%d\t"
+               "%.2lf\t%.2lf\n",
+               (int)i, p.bcs[(size_t)i].c_str(), nSNPs[(size_t)i], nReads[(size_t)i],
+               (c.type == 2) ? "AMB" : ((c.type == 0) ? "SNG" : "DBL"), c.jBest, c.kBest, c.bestLLK, c.jNext, c.kNext,
+               c.nextLLK, c.bestLLK - c.nextLLK, c.bestPP, c.sngPP, c.sBest, c.sngBestLLK, c.sNext, c.sngNextLLK,
+               c.sngOnlyPP, c.dBest1, c.dBest2, c.dblBestLLK, c.sngBestLLK - c.dblBestLLK);
+      o.append(big.data(), (size_t)n);
+    }
+  });
   wc1.close();
   tmr.lap("freemuxlet-old: writers");
   muxgl_destroy(h);
