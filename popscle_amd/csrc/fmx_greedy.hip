@@ -1206,7 +1206,12 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   std::vector<int64_t> pos_ptr(npad + 1, 0);
   for (size_t i = 0; i < npad; ++i) pos_ptr[i + 1] = pos_ptr[i] + (i < n ? hlen[i] : 0);
   P = pos_ptr[n];
-  const bool batched = K <= 64 && P > 0 && P < ((int64_t)1 << 31) && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP);
+  // (the batched kernel keeps 2 GB or more workgroups resident, one per compute unit: a device -- or partition -- with fewer
+  //  takes the serial kernel)
+  int cus = 0;
+  HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+  const bool batched =
+      K <= 64 && P > 0 && P < ((int64_t)1 << 31) && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP) && cus >= 2 * GB;
   int64_t *d_chunk_first = nullptr, *d_chunk_p0 = nullptr, *d_pos_e = nullptr, *d_cinc_ptr = nullptr, *d_inc_e = nullptr;
   int32_t *d_chunk_n = nullptr, *d_pos_snp = nullptr, *d_inc_hp = nullptr;
   unsigned long long* d_passw = nullptr;
@@ -1389,16 +1394,9 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       T.K = (int)K;
       T.Kp = Kp;
       // one workgroup per compute unit at most (all resident: the grid barrier needs that); GB of them decide a cell each
-      int cus = 0;
-      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-      if (e != hipSuccess) break;
       int wgs = 128;
       if (const char* s = getenv("MUXGL_GREEDY_WGS")) wgs = atoi(s);
       wgs = std::max(2 * GB, std::min(wgs, cus));
-      if (cus < 2 * GB) {
-        h->err = "muxgl_fmx_greedy_init: the device has too few compute units for the batch size";
-        break;
-      }
       e = hipFuncSetAttribute((const void*)greedy_batches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sizeof(greedy_lds));
       if (e == hipSuccess) e = hipMemcpy(d_tabs, &T, sizeof(T), hipMemcpyHostToDevice);

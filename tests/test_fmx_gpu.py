@@ -144,6 +144,7 @@ def test_em_trajectory_deep(eng, K, C, S, ment, lam):
     (20, 160, 1.0, -1e300),    # 32 lanes per entry stripe
     (64, 200, 1.0, -1e300),    # one stripe per wave
     (100, 260, 1.0, -1e300),   # clusters spread over two waves
+    (4, 20, 1.0, -1e300),      # fewer cells than one batch
 ])
 def test_greedy_init_vs_oracle(geng, K, C, frac, thres):
     eng = geng
@@ -161,11 +162,12 @@ def test_greedy_init_vs_oracle(geng, K, C, frac, thres):
     assert np.max(np.abs((llk2 - llk0) - scores)) < 1e-8
 
 
-@pytest.mark.parametrize("K,C,S,me", [(8, 1500, 3000, 300), (48, 700, 1200, 200), (3, 400, 150, 100)])
+@pytest.mark.parametrize("K,C,S,me", [(8, 1500, 3000, 300), (48, 700, 1200, 200), (3, 400, 150, 100), (64, 96, 300, 250)])
 def test_greedy_init_many_batches(geng, K, C, S, me):
     eng = geng
     """many batches of the batched kernel (32 cells each), dense SNP sharing between the cells of a batch (every cell
-    of the third case covers two thirds of the markers, so most of its terms are corrected)"""
+    of the third case covers two thirds of the markers, so most of its terms are corrected; in the fourth a cell has
+    several thousand predecessors in its batch -- more than the kernel keeps in LDS -- and chains of more than eight)"""
     p = synth.make_pileup(C, S, min(K, 12), seed=31 + K, mean_entries=me, min_entries=20, with_gp=False)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.fmx_prepare(p.af)
