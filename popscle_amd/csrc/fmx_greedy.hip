@@ -22,6 +22,8 @@
 // The per-(cluster, SNP) states built here are discarded afterwards, exactly as in the reference, which rebuilds the
 // cluster pileups from the assignment in ascending cell order (:277-288 -> muxgl_fmx_set_clusters).
 #include <algorithm>
+#include <cmath>
+#include <thread>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -927,9 +929,56 @@ __device__ __forceinline__ bool greedy_grid_barrier(unsigned* bar, unsigned& epo
   return *s_ok != 0;
 }
 
+// The same barrier by XCD (MI355X: eight XCDs, a private L2 each): a workgroup arrives on its XCD's counter; the XCD's
+// last arriver -- every other workgroup of the XCD has drained its stores into the shared L2 by then -- writes that L2
+// back ONCE, arrives on the top counter, waits for the other XCDs, acquires and releases its XCD's generation word, on
+// which the others wait (and acquire: their L1s).  Eight write-backs instead of one per workgroup.  Which XCD a workgroup
+// runs on is read from the hardware (HW_REG_XCC_ID) and the workgroups per XCD are counted at the start of the launch, so
+// nothing is assumed about the placement.  bar[]: [0] flat counter (the census), [1] gave up, [16] top, then 16 words
+// apart per XCD: [32 + 16 x] workgroups, [160 + 16 x] arrivals, [288 + 16 x] generation.
+constexpr int GBAR_WORDS = 416, GBAR_TOP = 16, GBAR_CNT = 32, GBAR_ARR = 160, GBAR_GEN = 288;
+struct greedy_xbar {
+  unsigned x = 0, mine = 0, nx = 0, epoch = 0;  // this workgroup's XCD, its workgroups, XCDs in use, barriers passed
+};
+
+__device__ __forceinline__ bool greedy_xcd_barrier(unsigned* bar, greedy_xbar& X, int* s_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ++X.epoch;
+  if (threadIdx.x == 0) {
+    bool ok = true;
+    auto wait_for = [&](unsigned* word, unsigned target) {
+      for (unsigned spins = 0; __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;) {
+        if (++spins > GREEDY_SPIN_LIMIT ||
+            ((spins & 255) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    };
+    const unsigned old = __hip_atomic_fetch_add(bar + GBAR_ARR + 16 * X.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == X.epoch * X.mine) {  // the XCD's last arriver
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(bar + GBAR_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_for(bar + GBAR_TOP, X.epoch * X.nx);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(bar + GBAR_GEN + 16 * X.x, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      wait_for(bar + GBAR_GEN + 16 * X.x, X.epoch);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
 // ---- the batches, in ONE launch --------------------------------------------------------------------------------------------
-// gridDim.x workgroups (at most one per compute unit, so all are resident; at least 2 GB; 128 by default -- measured best
-// at configs[3] and configs[4]: more only make the grid barrier dearer) stay on the chip for the whole cell list.
+// gridDim.x workgroups (at most one per compute unit, so all are resident; at least 2 GB; 192 by default -- measured best
+// at configs[3] and configs[4] with the barrier by XCD) stay on the chip for the whole cell list.
 // Workgroup b < GB DECIDES cell b of every batch; the others APPLY the batch's merges; all of them take the chunks of the
 // distance phase.  Per batch:
 //   (fetched before the grid barrier that ends the previous batch: the chunk pair's SNPs and weights to LDS; deciders:
@@ -942,7 +991,7 @@ __device__ __forceinline__ bool greedy_grid_barrier(unsigned* bar, unsigned& epo
 //            pass changed no guess; appliers meanwhile fetch what "their" position brings (SNP, weights, likelihoods, the
 //            cells of the other members of its chain) and stage the next batch's chunks;
 //   phase 3: appliers: the merges under the last pass's guesses;                                                GRID BARRIER
-// -- the only all-to-all dependency of a batch is states -> next batch's products, so that is the one grid barrier; the
+// -- the only all-to-all dependency of a batch is states -> next batch's products, so that is the one grid barrier (greedy_xcd_barrier); the
 // other hand-overs are point to point (tags: batch + 1, so a word of an earlier batch never matches).  A decider's state
 // reads are complete before it publishes (its guess depends on them), so no merge starts before every decider has read.
 __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* __restrict__ Tp) {
@@ -1003,6 +1052,14 @@ __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* _
       if (X0 + t < X1) fetch_inc_regs(IR, X0 + t);
     }
   };
+  // census: which XCD this workgroup runs on, how many workgroups each XCD got
+  greedy_xbar XB;
+  XB.x = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID, bits 3:0
+  if (t == 0) __hip_atomic_fetch_add(T.bar + GBAR_CNT + 16 * XB.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!greedy_grid_barrier(T.bar, epoch, &L.ok)) return;
+  XB.mine = __hip_atomic_load(T.bar + GBAR_CNT + 16 * XB.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int x = 0; x < 8; ++x)
+    XB.nx += __hip_atomic_load(T.bar + GBAR_CNT + 16 * x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   fetch_ahead(0);
 
   for (int64_t oi0 = 0; oi0 < T.n; oi0 += GB) {
@@ -1141,7 +1198,7 @@ __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* _
     GTICK(4)
     if (decider) fetch_ahead(oi0 + GB);
     GTICK(5)
-    if (!greedy_grid_barrier(T.bar, epoch, &L.ok)) return;
+    if (!greedy_xcd_barrier(T.bar, XB, &L.ok)) return;
   }
   if (T.pass_hist && t == 0 && (blockIdx.x == GB - 1 || blockIdx.x == GB))
     for (int i = 0; i < 12; ++i) T.ticks[(blockIdx.x == GB ? 12 : 0) + i] = tacc[i];
@@ -1163,13 +1220,45 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   const int64_t C = h->C, S = h->S;
   host_timer tm;
   // sort: score descending, ties by id descending (sc_drop_seq.h:187-198); then the eligibility rules of :222-223
-  std::vector<int32_t> order((size_t)C);
-  for (int64_t i = 0; i < C; ++i) order[(size_t)i] = (int32_t)i;
-  std::sort(order.begin(), order.end(), [&](int32_t lhs, int32_t rhs) {
-    const double cmp = scores[lhs] - scores[rhs];
+  struct scored {  // (score, id) side by side: the comparisons do not chase the ids into the score array
+    double s;
+    int32_t id;
+  };
+  std::vector<scored> keyed((size_t)C);
+  for (int64_t i = 0; i < C; ++i) keyed[(size_t)i] = scored{scores[i], (int32_t)i};
+  auto before = [](const scored& lhs, const scored& rhs) {
+    const double cmp = lhs.s - rhs.s;
     if (cmp != 0) return cmp > 0;
-    return lhs > rhs;
-  });
+    return lhs.id > rhs.id;
+  };
+  bool finite = true;
+  for (int64_t i = 0; i < C && finite; ++i) finite = std::isfinite(scores[i]);
+  if (finite && C >= (1 << 14)) {
+    // a total order (the ids break every tie): any correct sort gives the one permutation, so eight threads sort an eighth
+    // each and merge pairwise.  (With a NaN or an infinity among the scores the comparator is not a strict weak order and
+    // the result is whatever ONE std::sort makes of it -- that case keeps the single call.)
+    constexpr int NT = 8;
+    size_t cut[NT + 1];
+    for (int k = 0; k <= NT; ++k) cut[k] = (size_t)C * (size_t)k / NT;
+    {
+      std::vector<std::thread> th;
+      for (int k = 0; k < NT; ++k) th.emplace_back([&, k] { std::sort(keyed.begin() + (long)cut[k], keyed.begin() + (long)cut[k + 1], before); });
+      for (auto& t : th) t.join();
+    }
+    for (int w = 1; w < NT; w *= 2) {
+      std::vector<std::thread> th;
+      for (int k = 0; k + w < NT; k += 2 * w)
+        th.emplace_back([&, k, w] {
+          std::inplace_merge(keyed.begin() + (long)cut[k], keyed.begin() + (long)cut[k + w],
+                             keyed.begin() + (long)cut[std::min(k + 2 * w, NT)], before);
+        });
+      for (auto& t : th) t.join();
+    }
+  } else {
+    std::sort(keyed.begin(), keyed.end(), before);
+  }
+  std::vector<int32_t> order((size_t)C);
+  for (int64_t i = 0; i < C; ++i) order[(size_t)i] = keyed[(size_t)i].id;
   std::vector<int32_t> todo;
   todo.reserve((size_t)C);
   for (int64_t i = 0; i < C; ++i) {
@@ -1265,20 +1354,19 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       const size_t nP = (size_t)P, nchunks = (size_t)chunk_first[n];
       if (dev_alloc(h, &d_chunk_first, chunk_first.size()) || dev_alloc(h, &d_chunk_p0, nchunks + 1) ||
           dev_alloc(h, &d_chunk_n, nchunks + 1) || dev_alloc(h, &d_pm, (size_t)max_batch_chunks * Kp) ||
-          dev_alloc(h, &d_px, (size_t)max_batch_chunks * Kp) || dev_alloc(h, &d_pos_ptr, npad + 1) || dev_alloc(h, &d_key, nP) ||
+          dev_alloc(h, &d_px, (size_t)max_batch_chunks * Kp) || dev_alloc(h, &d_pos_ptr, npad + 1) || dev_alloc(h, &d_key, nP + 8) ||
           dev_alloc(h, &d_key2, nP) || dev_alloc(h, &d_val, nP) || dev_alloc(h, &d_val2, nP) || dev_alloc(h, &d_pos_cell, nP) ||
           dev_alloc(h, &d_pos_snp, nP) || dev_alloc(h, &d_pos_w, nP) || dev_alloc(h, &d_pos_e, nP) ||
-          dev_alloc(h, &d_prev, nP) || dev_alloc(h, &d_pos_q, nP) || dev_alloc(h, &d_pos_pl, nP) ||
-          dev_alloc(h, &d_srt_cell, nP + 8) || dev_alloc(h, &d_srt_e, nP + 8) || dev_alloc(h, &d_nhot, npad + 1) ||
+          dev_alloc(h, &d_prev, nP) || dev_alloc(h, &d_pos_pl, nP) || dev_alloc(h, &d_srt_cell, nP + 8) || dev_alloc(h, &d_nhot, npad + 1) ||
           dev_alloc(h, &d_hot_ptr, npad + 1) || dev_alloc(h, &d_cinc_ptr, npad + 1) || dev_alloc(h, &d_passw, (size_t)(GB + 1) * GB) ||
           dev_alloc(h, &d_cflag, (size_t)max_batch_chunks / 2 + 2) ||
-          dev_alloc(h, &d_hist, (size_t)GB + 2) || dev_alloc(h, &d_bar, (size_t)2) || dev_alloc(h, &d_guess, (size_t)GB) ||
+          dev_alloc(h, &d_hist, (size_t)GB + 2) || dev_alloc(h, &d_bar, (size_t)GBAR_WORDS) || dev_alloc(h, &d_guess, (size_t)GB) ||
           dev_alloc(h, &d_ticks, (size_t)24) || dev_alloc(h, &d_tabs, (size_t)1))
         break;
       (void)hipMemsetAsync(d_hist, 0, sizeof(int32_t) * (GB + 2), h->stream);
       (void)hipMemsetAsync(d_passw, 0, sizeof(unsigned long long) * (GB + 1) * GB, h->stream);
       (void)hipMemsetAsync(d_cflag, 0, sizeof(unsigned) * ((size_t)max_batch_chunks / 2 + 2), h->stream);
-      (void)hipMemsetAsync(d_bar, 0, sizeof(unsigned) * 2, h->stream);
+      (void)hipMemsetAsync(d_bar, 0, sizeof(unsigned) * GBAR_WORDS, h->stream);
       (void)hipMemsetAsync(d_guess, 0, sizeof(unsigned long long) * GB, h->stream);
       (void)hipMemsetAsync(d_ticks, 0, sizeof(uint64_t) * 24, h->stream);
       e = hipMemsetAsync(d_offd, 0, sizeof(double) * (size_t)S * K * 6, h->stream);
@@ -1307,6 +1395,9 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
         e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_val, d_val2, nP, 0u, 32u + bbits, h->stream);
       if (e != hipSuccess) break;
       if (tm.on) { (void)hipStreamSynchronize(h->stream); tm.lap("greedy_init:   sort"); }
+      // (the unsorted keys and payloads are done with: their buffers take the entries and indices in sorted order)
+      d_srt_e = reinterpret_cast<int64_t*>(d_key);
+      d_pos_q = reinterpret_cast<int32_t*>(d_val);
       const unsigned pblocks = (unsigned)std::min<int64_t>((P + 255) / 256, 16384);
       hipLaunchKernelGGL(greedy_links_kernel, dim3(pblocks), dim3(256), 0, h->stream, P, d_key2, d_val2, d_pos_cell, d_pos_e, d_prev,
                          d_pos_q, d_pos_pl, d_srt_cell, d_srt_e);
@@ -1328,8 +1419,6 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       int64_t H = 0;
       if (e == hipSuccess) e = hipMemcpy(&H, d_hot_ptr + n, sizeof(int64_t), hipMemcpyDeviceToHost);
       if (e != hipSuccess) break;
-      dev_free(&d_key);  // the keys and payloads are done with
-      dev_free(&d_val);
       dev_free(&d_key2);
       dev_free(&d_val2);
       if (dev_alloc(h, &d_hot_pos, (size_t)H + 1) || dev_alloc(h, &d_hot_len, (size_t)H + 1) ||
@@ -1394,7 +1483,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       T.K = (int)K;
       T.Kp = Kp;
       // one workgroup per compute unit at most (all resident: the grid barrier needs that); GB of them decide a cell each
-      int wgs = 128;
+      int wgs = 192;
       if (const char* s = getenv("MUXGL_GREEDY_WGS")) wgs = atoi(s);
       wgs = std::max(2 * GB, std::min(wgs, cus));
       e = hipFuncSetAttribute((const void*)greedy_batches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1470,10 +1559,8 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_pos_w);
   dev_free(&d_pos_e);
   dev_free(&d_prev);
-  dev_free(&d_pos_q);
   dev_free(&d_pos_pl);
   dev_free(&d_srt_cell);
-  dev_free(&d_srt_e);
   dev_free(&d_hot_pos);
   dev_free(&d_inc_hp);
   dev_free(&d_inc_e);
