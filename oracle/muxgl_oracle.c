@@ -1,8 +1,10 @@
 /*
  * muxgl_oracle.c -- CPU restatement of popscle's demuxlet / freemuxlet genotype-likelihood path.
  *
- * TEST INFRASTRUCTURE ONLY (see muxgl_oracle.h).  PARITY STATUS: parity unpinned, except
- * oracle_phred_tables() which is pinned bit-for-bit to the reference's own PhredHelper.cpp (oracle/_ref).
+ * TEST INFRASTRUCTURE ONLY (see muxgl_oracle.h).  PARITY STATUS: pinned bit for bit to the reference's own code
+ * compiled from /root/reference (oracle/_ref/libphred_ref.so, libmerge_ref.so, libscdrop_ref.so;
+ * tests/test_oracle.py, tests/test_oracle_ref.py) for every function except the freemuxlet-old block; the file
+ * parsers and text writers of the reference (htslib) stay "parity unpinned" -- see muxgl_oracle.h.
  *
  * Rules followed here: IEEE doubles, the reference's operation order and association, glibc log/exp/pow,
  * no FMA contraction (-ffp-contract=off), no reassociation.  Every function cites the reference lines it restates.
@@ -414,6 +416,44 @@ void oracle_fmx_sort(int64_t C, const double* scores, int32_t* order) {
   qsort(order, (size_t)C, sizeof(int32_t), fmx_cmp); /* total order => same permutation as std::sort */
 }
 
+/* one marker of calculate_droplet_clust_distance, sc_drop_seq.cpp:552-568 */
+static void clust_dist_term(const double* glis, const double* gljs, double af, double* plk0, double* plk2) {
+  double lk0 = 0, lk2 = 0;
+  double gps[3];
+  gps[0] = (1.0 - af) * (1.0 - af);
+  gps[1] = 2.0 * af * (1.0 - af);
+  gps[2] = af * af;
+  for (int32_t gi = 0; gi < 3; ++gi) {
+    lk2 += (glis[gi * 3 + gi] * gljs[gi * 3 + gi] * gps[gi]);
+    for (int32_t gj = 0; gj < 3; ++gj) {
+      lk0 += (glis[gi * 3 + gi] * gljs[gj * 3 + gj] * gps[gi] * gps[gj]);
+    }
+  }
+  *plk0 = lk0;
+  *plk2 = lk2;
+}
+
+/* sc_dropseq_lib_t::calculate_droplet_clust_distance, sc_drop_seq.cpp:544-578, on a droplet of n entries in ascending
+ * marker order: d[i] its pileup at marker i, c[i] the cluster's state there and present[i] != 0 iff the cluster's
+ * std::map holds that marker (jt != end, :550).  out = {llk0, llk2}; counts = {nsnps, nread1, nread2}. */
+void oracle_fmx_clust_distance(int64_t n, const oracle_plp* d, const oracle_plp* c, const uint8_t* present,
+                               const double* af, double* out, int32_t* counts) {
+  double llk0 = 0, llk2 = 0;
+  counts[0] = counts[1] = counts[2] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!present[i]) continue;
+    double lk0, lk2;
+    clust_dist_term(d[i].gls, c[i].gls, af[i], &lk0, &lk2);
+    ++counts[0];
+    counts[1] += d[i].nreads;
+    counts[2] += c[i].nreads;
+    llk2 += log(lk2);
+    llk0 += log(lk0);
+  }
+  out[0] = llk0;
+  out[1] = llk2;
+}
+
 /* cmd_cram_freemux2.cpp:217-261; distance = sc_drop_seq.cpp:544-578 */
 void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
                             const oracle_plp* eplp, const double* afs, const double* scores, const int32_t* order,
@@ -434,20 +474,8 @@ void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell
         int32_t snp = entry_snp[e];
         size_t ci = (size_t)j * S + snp;
         if (!present[ci]) continue;
-        double af = afs[snp];
-        double lk0 = 0, lk2 = 0;
-        double gps[3];
-        gps[0] = (1.0 - af) * (1.0 - af);
-        gps[1] = 2.0 * af * (1.0 - af);
-        gps[2] = af * af;
-        const double* glis = eplp[e].gls;
-        const double* gljs = cp[ci].gls;
-        for (int32_t gi = 0; gi < 3; ++gi) {
-          lk2 += (glis[gi * 3 + gi] * gljs[gi * 3 + gi] * gps[gi]);
-          for (int32_t gj = 0; gj < 3; ++gj) {
-            lk0 += (glis[gi * 3 + gi] * gljs[gj * 3 + gj] * gps[gi] * gps[gj]);
-          }
-        }
+        double lk0, lk2;
+        clust_dist_term(eplp[e].gls, cp[ci].gls, afs[snp], &lk0, &lk2);
         llk2 += log(lk2);
         llk0 += log(lk0);
       }

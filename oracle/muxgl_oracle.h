@@ -4,14 +4,30 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under popscle_amd/ may include, link or call this.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
  *
- * PARITY STATUS: "parity unpinned" for everything except the Phred tables.
- *   - The reference (statgen/popscle) ships no tests, fixtures or golden vectors for this path.
- *   - Its hot loops live inline in cmdCramDemuxlet / cmdCramFreemux2, whose translation units include
- *     htslib headers (via cramore.h -> hts_utils.h and sc_drop_seq.h -> bcf_filtered_reader.h).  htslib is
- *     absent from this image, so those TUs are unbuildable here without stand-in headers, which we do not write.
- *   - The only on-path TU that compiles from its own source is PhredHelper.cpp; oracle/Makefile builds it into
- *     oracle/_ref/libphred_ref.so and tests/test_oracle.py pins oracle_phred_tables() to it bit-for-bit.
- *   - Everything else below is a literal, operation-order-preserving restatement, each function citing the
+ * PARITY STATUS (round 5): PINNED to the reference's own code for every arithmetic row of the path; "parity unpinned"
+ * remains for the file parsers and text writers only.
+ *   - The reference (statgen/popscle) ships no tests, fixtures or golden vectors, and its command translation units
+ *     include htslib headers (absent from this image), so the binaries cannot be built here and no stand-in header,
+ *     type or function body is written for them.
+ *   - What does compile from the reference's own text, unmodified, where it lies under /root/reference
+ *     (oracle/Makefile; nothing is copied into the repository):
+ *       _ref/libphred_ref.so   PhredHelper.cpp                                   -> oracle_phred_tables
+ *       _ref/libmerge_ref.so   sc_drop_seq.h (merge(), sc_drop_comp_t)           -> oracle_plp_merge*, oracle_fmx_sort
+ *       _ref/libscdrop_ref.so  sc_drop_seq.cpp:1-92,386-578 (logAdd, add_snp/add_cell/add_read with the real
+ *                              std::map<std::string> containers, calculate_snp_droplet_pileup,
+ *                              calculate_droplet_clust_distance) and, as VERBATIM LINE RANGES inside wrapper functions
+ *                              that only declare the locals those lines name (oracle/ref_hot.cpp.in),
+ *                              cmd_cram_demuxlet.cpp:428-440,590-622,634-991 (the whole droplet loop up to the hprintf)
+ *                              and cmd_cram_freemux2.cpp:108-109,114-159,184-189,192-262,277-288,350-370,373-605
+ *                              (entry pileups + singlet scores, sort, given / greedy initial clusters, cluster
+ *                              pileups, the EM loop with its early stop).
+ *     tests/test_oracle_ref.py holds every function below (except the freemuxlet-old block) to those libraries BIT FOR
+ *     BIT -- all record fields, the full LL tensors, cluster pileups after every M-step, on shallow and deep entries,
+ *     allele "2", Q < 2, missing genotypes, empty cells, the nAlpha == 1 and nv == 1 quirks, --init-cluster starts,
+ *     frac-init / score-threshold skips -- and tests/golden/*.npz (demux_*, fmx_k4*) are outputs of those libraries.
+ *   - Still unpinned (need htslib / tsv_reader): load_from_plp's file parsing, parse_posteriors (VCF -> GP), the
+ *     hprintf row formats; freemuxlet-old's pairwise init (out of scope).
+ *   - Everything below is a literal, operation-order-preserving restatement, each function citing the
  *     reference file:line it follows (paths relative to the reference root).
  *
  * Packed pileup (same layout the C-ABI in include/muxgl.h takes):
@@ -102,6 +118,11 @@ void oracle_fmx_cell_scores(int64_t C, const int64_t* cell_ptr, const int32_t* e
 /* freemuxlet b3: order = cells sorted by score descending, ties by id descending
  * (cmd_cram_freemux2.cpp:184-189, comparator sc_drop_seq.h:187-198) */
 void oracle_fmx_sort(int64_t C, const double* scores, int32_t* order);
+
+/* freemuxlet b4: the droplet-to-cluster distance of the greedy loop, sc_drop_seq.cpp:544-578.  d[n], c[n], present[n],
+ * af[n] aligned to the droplet's entries (ascending marker id); out = {llk0, llk2}, counts = {nsnps, nread1, nread2} */
+void oracle_fmx_clust_distance(int64_t n, const oracle_plp* d, const oracle_plp* c, const uint8_t* present,
+                               const double* af, double* out, int32_t* counts);
 
 /* freemuxlet b4: greedy initial clustering, cmd_cram_freemux2.cpp:217-261 + sc_drop_seq.cpp:544-578.
  * clust[C] receives the cluster id (or -1 if skipped by frac_init / score threshold). */

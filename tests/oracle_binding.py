@@ -177,6 +177,18 @@ def fmx_sort(scores):
     return order
 
 
+def fmx_clust_distance(d, c, present, af):
+    """oracle_fmx_clust_distance: (llk0, llk2, counts[3]) of a droplet's entries d against the aligned states c"""
+    d = np.ascontiguousarray(d, dtype=PLP)
+    c = np.ascontiguousarray(c, dtype=PLP)
+    present = np.ascontiguousarray(present, dtype=np.uint8)
+    af = np.ascontiguousarray(af, dtype=np.float64)
+    out = np.zeros(2)
+    cnt = np.zeros(3, dtype=np.int32)
+    lib().oracle_fmx_clust_distance(C.c_int64(d.size), _p(d), _p(c), _p(present), _p(af), _p(out), _p(cnt))
+    return out[0], out[1], cnt
+
+
 def fmx_greedy_init(plp, eplp, K, scores, order, frac_init_clust=1.0, singlet_score_thres=-1e300):
     clust = np.zeros(plp.C, dtype=np.int32)
     af = np.ascontiguousarray(plp.af, dtype=np.float64)

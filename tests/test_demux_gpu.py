@@ -36,7 +36,7 @@ def run_gpu(eng, p, alphas, doublet_prior=0.5, full=False):
     return eng.demux_run(alphas, doublet_prior, want_full_ll=full)
 
 
-@pytest.mark.parametrize("name", ["demux_v4_a2", "demux_v4_a6", "demux_v16_a2"])
+@pytest.mark.parametrize("name", ["demux_v4_a2", "demux_v4_a6", "demux_v16_a2", "demux_v8_a3_deep", "demux_v64_a6"])
 def test_golden(eng, name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = synth.Pileup(int(z["C"]), int(z["S"]), z["cell_ptr"], z["entry_snp"], z["entry_rptr"], z["reads"], z["af"],

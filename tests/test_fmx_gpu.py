@@ -82,8 +82,9 @@ def run_em(eng, p, K, n_iter, clust=None, doublet_prior=0.5, geno_error=0.1):
     return worst
 
 
-def test_golden(eng):
-    z = np.load(os.path.join(GOLDEN, "fmx_k4.npz"))
+@pytest.mark.parametrize("name", ["fmx_k4", "fmx_k4_mixed"])
+def test_golden(eng, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = synth.Pileup(int(z["C"]), int(z["S"]), z["cell_ptr"], z["entry_snp"], z["entry_rptr"], z["reads"], z["af"])
     K = int(z["K"])
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)

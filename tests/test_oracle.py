@@ -1,10 +1,12 @@
-"""CPU tests of the oracle (oracle/muxgl_oracle.c): pinned where the reference allows it, cross-checked elsewhere.
+"""CPU tests of the oracle (oracle/muxgl_oracle.c) against an independent pure-Python restatement (tests/pyref.py),
+hand-derivable cases and the committed golden vectors.
 
-What is pinned to the reference itself: the Phred tables, against the reference's own PhredHelper.cpp compiled from
-/root/reference into oracle/_ref/libphred_ref.so.  Everything else on this path is "parity unpinned" (the reference has
-no tests/fixtures and its hot-path TUs need htslib, absent here); for those the C oracle is cross-checked against an
-independent pure-Python restatement (tests/pyref.py), against hand-derivable cases, and against the committed golden
-vectors (tests/golden, produced by tests/golden/make_golden.py from the oracle = regression vectors).
+Where the oracle is pinned to the REFERENCE ITSELF: the Phred tables, merge() and the sort comparator below
+(oracle/_ref/libphred_ref.so, libmerge_ref.so), and -- round 5 -- everything else on the arithmetic path in
+tests/test_oracle_ref.py (oracle/_ref/libscdrop_ref.so: the reference's sc_drop_seq.cpp and the hot loops of
+cmd_cram_demuxlet.cpp / cmd_cram_freemux2.cpp compiled from /root/reference).  The golden vectors demux_*.npz and
+fmx_k4*.npz under tests/golden are outputs of that library (tests/golden/make_golden.py), so
+test_oracle_reproduces_golden_* holds the oracle to the reference's numbers on machines without /root/reference too.
 """
 import math
 import os
@@ -287,7 +289,7 @@ def test_fmx_estep_vs_pyref_and_em_runs():
 
 # ---------------------------------------------------------------------------------------------- golden vectors
 
-@pytest.mark.parametrize("name", ["demux_v4_a2", "demux_v4_a6", "demux_v16_a2"])
+@pytest.mark.parametrize("name", ["demux_v4_a2", "demux_v4_a6", "demux_v16_a2", "demux_v8_a3_deep", "demux_v64_a6"])
 def test_oracle_reproduces_golden_demux(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = synth.Pileup(int(z["C"]), int(z["S"]), z["cell_ptr"], z["entry_snp"], z["entry_rptr"], z["reads"], z["af"],
@@ -296,8 +298,9 @@ def test_oracle_reproduces_golden_demux(name):
     assert out.tobytes() == z["cells"].tobytes()
 
 
-def test_oracle_reproduces_golden_fmx():
-    z = np.load(os.path.join(GOLDEN, "fmx_k4.npz"))
+@pytest.mark.parametrize("name", ["fmx_k4", "fmx_k4_mixed"])
+def test_oracle_reproduces_golden_fmx(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
     p = synth.Pileup(int(z["C"]), int(z["S"]), z["cell_ptr"], z["entry_snp"], z["entry_rptr"], z["reads"], z["af"])
     K = int(z["K"])
     e = ob.fmx_entry_pileup(p)
