@@ -171,6 +171,21 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
  * receiving llksAB for the entries the reference ever reads: (j,0,0) and (j,k!=j,n>=1); other slots are 0. */
 int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_cell* out, double* full_ll);
 
+/* The reference's order of a mirrored alpha = 0.5 pair -- HOST pass, no device work, no handle.  The likelihood of a
+ * doublet at alpha 0.5 is symmetric in its two samples; the reference nevertheless evaluates llksAB[j][k][n] and
+ * llksAB[k][j][n] with transposed summation orders (cmd_cram_demuxlet.cpp:738-746), so they differ by rounding noise, and
+ * its strict-'<' scan (:883-906) prints whichever order came out larger as DBL.BEST.GUESS (the other one becomes the
+ * runner-up).  muxgl_demux_run computes such a pair once and names it (lo, hi).  This call recomputes, for the best and
+ * next doublet of every cell whose alpha is 0.5, the two log-likelihoods in the reference's own association on the host
+ * (IEEE doubles, glibc log) and rewrites dBest1/2, dNext1/2 and the derived jBest/kBest/jNext/kNext of cells[C] in the
+ * order the reference reports; log-likelihood fields are left as the device computed them.  The pileup and gp / has_gp
+ * are the arrays handed to muxgl_set_pileup / muxgl_demux_set_gp.  nthreads host threads (cells are independent).
+ * stats: NULL or int64[3] = cells looked at, pairs put into (hi, lo) order, pairs whose two orders tied exactly. */
+int muxgl_demux_reference_pair_order(int64_t C, int32_t V, const int64_t* cell_ptr, const int32_t* entry_snp,
+                                     const int64_t* entry_rptr, const uint8_t* reads, const double* gp,
+                                     const uint8_t* has_gp, const muxgl_demux_params* p, muxgl_demux_cell* cells,
+                                     int32_t nthreads, int64_t* stats);
+
 /* pinned host view of the last run's [C] records (valid until the next run or destroy) */
 const muxgl_demux_cell* muxgl_demux_results(const muxgl_handle* h);
 

@@ -12,6 +12,7 @@
 // behind muxgl_* calls; there is no CPU implementation of it in this program.
 #include <cmath>
 
+#include "pair_order.hpp"
 #include "plp.hpp"
 #include "synthplp.hpp"
 
@@ -101,8 +102,10 @@ int cmd_demuxlet(int argc, char** argv) {
   double doublet_prior = 0.5;  // cmd_cram_demuxlet.cpp:32
   std::string sam, tagGroup, tagUMI;
   int32_t dummy_i = 0;
+  bool devicePairOrder = false;  // (ours) skip the host pass that orders mirrored alpha = 0.5 pairs as the reference does
   Args a;
   cf.add(a);
+  a.add_bool("device-pair-order", &devicePairOrder);
   a.add_string("vcf", &vr.path);
   a.add_string("field", &cf.lo.field);
   a.add_double("geno-error-offset", &cf.lo.genoErrorOffset);
@@ -157,6 +160,15 @@ int cmd_demuxlet(int argc, char** argv) {
   std::vector<muxgl_demux_cell> cells((size_t)p.C());
   check(h, muxgl_demux_run(h, &dp, cells.data(), nullptr), "muxgl_demux_run");
   tm.lap("demuxlet: muxgl_demux_run");
+  if (!devicePairOrder) {
+    // DBL.BEST.GUESS / NEXT.GUESS of a mirrored alpha = 0.5 pair in the order the reference's scan reports
+    // (cmd_cram_demuxlet.cpp:738-746,883-906; pair_order.hpp)
+    int64_t st[3];
+    pair_order::reference_pair_order(p.C(), p.nv, p.cell_ptr.data(), p.entry_snp.data(), p.entry_rptr.data(),
+                                     p.reads.data(), p.gp.data(), p.has_gp.data(), dp.n_alpha, dp.alpha, cells.data(),
+                                     plp_threads(), st);
+    tm.lap("demuxlet: reference pair order (host)");
+  }
 
   // .best, cmd_cram_demuxlet.cpp:629,636-641,993-1013: rows in barcode-sorted order, INT_ID counts skipped cells too
   OutFile w(cf.outPrefix + ".best", false);

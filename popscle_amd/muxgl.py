@@ -85,6 +85,8 @@ SYMBOLS = {
     "muxgl_demux_set_gp": (C.c_int, [_VP, C.c_int32, _VP, _VP]),
     "muxgl_demux_run": (C.c_int, [_VP, C.POINTER(_DemuxParams), _VP, _VP]),
     "muxgl_demux_results": (_VP, [_VP]),
+    "muxgl_demux_reference_pair_order": (C.c_int, [C.c_int64, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP,
+                                                   C.POINTER(_DemuxParams), _VP, C.c_int32, _VP]),
     "muxgl_demux_get_entry_pg": (C.c_int, [_VP, _VP]),
     "muxgl_fmx_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_entry_gls": (C.c_int, [_VP, _VP, _VP]),
@@ -134,6 +136,33 @@ def load_library(path: str | None = None) -> C.CDLL:
 
 class MuxglError(RuntimeError):
     pass
+
+
+def demux_reference_pair_order(p, alphas, cells, nthreads=0):
+    """muxgl_demux_reference_pair_order: the host pass (no device) that puts the alpha = 0.5 pairs of `cells` (records of
+    demux_run over pileup p, modified in place) into the order the reference's scan reports
+    (cmd_cram_demuxlet.cpp:738-746,883-906).  Returns (cells looked at, pairs turned to (hi, lo), exact ties)."""
+    lib = load_library()
+    dp = _DemuxParams()
+    dp.n_alpha = len(alphas)
+    for i, a in enumerate(alphas):
+        dp.alpha[i] = float(a)
+    cell_ptr = _arr(p.cell_ptr, np.int64, "cell_ptr")
+    entry_snp = _arr(p.entry_snp, np.int32, "entry_snp")
+    entry_rptr = _arr(p.entry_rptr, np.int64, "entry_rptr")
+    reads = _arr(p.reads, np.uint8, "reads")
+    gp = _arr(p.gp, np.float64, "gp")
+    has_gp = _arr(p.has_gp, np.uint8, "has_gp")
+    if cells.dtype != DEMUX_CELL or not cells.flags.c_contiguous or cells.shape != (cell_ptr.size - 1,):
+        raise ValueError("cells must be the contiguous [C] record array demux_run returned")
+    stats = np.zeros(3, dtype=np.int64)
+    rc = lib.muxgl_demux_reference_pair_order(cell_ptr.size - 1, gp.shape[1], _ptr(cell_ptr), _ptr(entry_snp),
+                                              _ptr(entry_rptr), _ptr(reads), _ptr(gp), _ptr(has_gp), C.byref(dp),
+                                              _ptr(cells), int(nthreads) if nthreads else (os.cpu_count() or 1),
+                                              _ptr(stats))
+    if rc != 0:
+        raise MuxglError(f"muxgl_demux_reference_pair_order failed ({rc})")
+    return tuple(int(x) for x in stats)
 
 
 def _ptr(a):
