@@ -421,6 +421,34 @@ class Ctx:
             else:
                 dist.init_process_group(self.backend, timeout=to)
         self.tdev = "cuda" if self.backend == "nccl" else "cpu"
+        # every rank of the job must be IN the collective world: an all-reduce of 1 over the backend that carries the
+        # exchanges (RCCL under the driver's launch).  A launcher that started fewer processes than --gpus, or ranks that
+        # ended up in different worlds, fail here, loudly, instead of producing a plausible line.
+        self.ranks_seen = 1
+        if self.dist_on:
+            t = torch.ones(1, dtype=torch.int64, device=self.tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self.ranks_seen = int(t.item())
+            if self.ranks_seen != max(1, args.gpus):
+                raise SystemExit(f"[bench rank {self.rank}] {self.ranks_seen} ranks answered the all-reduce over "
+                                 f"{self.backend}, --gpus says {args.gpus}")
+
+    def stamp(self, out):
+        """what an N > 1 line says about the world it ran in"""
+        if out is not None and self.dist_on:
+            out["dist"] = {"backend": "rccl (torch nccl)" if self.backend == "nccl" else self.backend,
+                           "ranks_seen": self.ranks_seen, "world_size": self.world}
+            out["rccl_ranks_seen" if self.backend == "nccl" else "ranks_seen"] = self.ranks_seen
+        return out
+
+    def gather_floats(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank"""
+        if self.world == 1:
+            return [float(x)]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.tdev)
+        t[self.rank] = float(x)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
 
     def barrier(self):
         if self.dist_on:
@@ -474,7 +502,11 @@ def free_torch_cache(ctx):
 
 
 # ---- demuxlet leg (configs 1, 2): weak scaling -----------------------------------------------------------------------
-def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu_budget_s=9.0):
+def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu_budget_s=9.0, strong=False):
+    """strong = False: weak scaling, every rank sweeps a config-sized shard of its own (the driver's contract for the
+    headline).  strong = True: ONE config-sized job, the same on every rank count, its cells cut into contiguous ranges
+    balanced by entries (shard.cell_shards, what popscle_amd/demuxlet.py does): the N-GPU number then says how much
+    faster the same job got."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     ramp_seconds = args.ramp_seconds if ramp_seconds is None else ramp_seconds
@@ -483,17 +515,27 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
     V, A = cfg["V"], len(alphas)
     # weak scaling: every rank owns a full config-sized shard of cells (its own seed), GP tensor replicated
     C = max(1, int(round(cfg["C"] * args.scale)))
-    seeds = dict(seed=synth.BASE_SEED + config + 1000 * ctx.rank, donor_seed=synth.BASE_SEED + config)
+    seeds = dict(seed=synth.BASE_SEED + config + (0 if strong else 1000 * ctx.rank), donor_seed=synth.BASE_SEED + config)
     reads_lambda = args.reads_lambda if args.reads_lambda is not None else (2.0 if args.dense else None)
     if reads_lambda is not None:
         seeds["reads_lambda"] = reads_lambda
     t_gen = time.perf_counter()
     on_device = use_device_synth(args, C * 950.0)
+    job_cells = C
     if on_device:
-        p = synth.make_pileup_device(C, cfg["S"], V, device=f"cuda:{ctx.dev}", **seeds).host()
+        d = synth.make_pileup_device(C, cfg["S"], V, device=f"cuda:{ctx.dev}", **seeds)
+        if strong and ctx.world > 1:
+            c0, c1 = shard.cell_shards(d.cell_ptr.cpu().numpy(), ctx.world)[ctx.rank]
+            p = d.take_cells(c0, c1)
+        else:
+            p = d.host()
+        del d
         free_torch_cache(ctx)
     else:
         p = synth.make_pileup(C, cfg["S"], V, **seeds)
+        if strong and ctx.world > 1:
+            p = shard.take_cells(p, *shard.cell_shards(p.cell_ptr, ctx.world)[ctx.rank])
+    C = p.C
     gen_s = time.perf_counter() - t_gen
     eng = muxgl.Engine(ctx.dev, muxgl.FLAG_NO_LINEAR_ENTRIES if args.no_linear else 0)
     t_h = time.perf_counter()
@@ -514,12 +556,15 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
     for _ in range(steps):
         eng.demux_run(alphas, 0.5, want_cells=False)  # returns with the stream drained and the records on the host
     ctx.barrier()
-    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    own_s = time.perf_counter() - t0
+    elapsed = ctx.max_over_ranks(own_s)
     # hipEvent times of the timed passes (the live kernel durations of the roofline), summed inside the library: a fetch
     # per pass cost 7.6 us of the 350 us step
     kern_ms, n_timed = eng.timing_sum()
     assert n_timed == steps
     total_cells, total_entries = ctx.sum_over_ranks([p.C, p.nnz])
+    rank_sweep_ms = ctx.gather_floats(kern_ms[muxgl.T_DEMUX_SWEEP] / steps)
+    rank_entries = ctx.gather_floats(p.nnz)
     out = None
     if ctx.rank == 0:
         lls_per_cell = V + V * (V - 1) * (A - 1)
@@ -531,7 +576,7 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
         out = {
             "metric": METRIC if config == 1 else f"cell-sample-pair LLs/sec (singlet+doublet), demuxlet BASELINE.json configs[{config}]",
             "value": total_cells * lls_per_cell / step_s, "unit": "LLs/s", "n_gpus": ctx.world, "steps": steps,
-            "warmup": warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             # untimed passes before the W warmup steps (the engine clock ramps up over a few hundred launches)
             "ramp": {"seconds": ramp_seconds, "untimed_passes": ramp_passes},
@@ -560,11 +605,17 @@ def demux_leg(args, ctx, config, steps=None, warmup=None, ramp_seconds=None, cpu
                                   "linear_entry_share": frac_lin, "linear_entry_form": not args.no_linear,
                                   "note": "not the BASELINE workload: the default line's entries carry 1 + Poisson(0.3) reads "
                                           "(three quarters linear: two FP64 instructions per hypothesis instead of four)"}
-        if ctx.world > 1:  # every rank swept a full config-sized shard of its own: N x the one-GPU value by construction
+        if ctx.world > 1 and strong:
+            out["scaling_note"] = ("strong scaling: ONE job of %d cells, cut into %d contiguous cell ranges balanced by entries "
+                                   "(no data-path collective; cells are independent, cmd_cram_demuxlet.cpp:636-1013); "
+                                   "value = the job's LLs / max-rank time" % (job_cells, ctx.world))
+            out["per_rank"] = {"sweep_kernel_ms": rank_sweep_ms, "entries": rank_entries}
+        elif ctx.world > 1:  # every rank swept a full config-sized shard of its own: N x the one-GPU value by construction
             out["scaling_note"] = ("weak scaling: each of the %d ranks owns %d cells (no data-path collective; cells are "
                                    "independent, cmd_cram_demuxlet.cpp:636-1013); value = sum over ranks / max-rank time"
                                    % (ctx.world, C))
             out["per_rank_value"] = out["value"] / ctx.world
+            out["per_rank"] = {"sweep_kernel_ms": rank_sweep_ms, "entries": rank_entries}
         out["roofline"]["note_8d"] = ("SURVEY 8d's per-entry bytes / flops (reference_equiv_*) exceed the roofs for V <= 16: they count "
                                       "cache-resident GP-row gathers as HBM bytes and all V*V*A slots of the reference's loop "
                                       "nest as work; `floor` is the recomputable bound of the algorithm as built")
@@ -648,6 +699,8 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
     cells, hist = run(steps, tm)  # exactly `steps` EM iterations, bracketed by barrier + device synchronize on both sides
     kern = eng.timing()           # kernels of the last iteration on this rank
     elapsed = ctx.max_over_ranks(tm["loop_s"])
+    rank_loop_ms = ctx.gather_floats(tm["loop_s"] / steps * 1e3)
+    rank_estep_ms = ctx.gather_floats(float(kern[muxgl.T_FMX_ESTEP]))
     out = None
     if ctx.rank == 0:
         npairs = K * (K + 1) // 2
@@ -682,6 +735,7 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
         }
         out["roofline"]["floor"] = fmx_floor(K, my_entries, frac_lin, S, est_s * 1e3)
         if ctx.world > 1:
+            out["per_rank"] = {"ms_per_iteration": rank_loop_ms, "estep_kernel_ms_last_iteration": rank_estep_ms}
             # DESIGN.md 4.3's model next to the measurement: this rank's kernels + the two exchanges (xGMI: point to
             # point, ~70 GB/s usable per link and direction; a small collective ~25 us end to end) + the host's wait
             N = ctx.world
@@ -713,6 +767,7 @@ LEGS = {  # secondary legs of the default run: JSON key, config, (steps, warmup)
     3: ("freemuxlet_em", "fmx"),
     2: ("demuxlet_config2", "demux"),
     4: ("freemuxlet_config4", "fmx"),
+    "2s": ("demuxlet_config2_strong", "demux_strong"),  # N > 1 only: the configs[2] job cut over the ranks
 }
 
 
@@ -735,6 +790,8 @@ def guarded_leg(args, ctx, headline, config):
         if kind == "fmx":
             st, wu = (args.fmx_leg_steps, 2) if config == 3 else (2, 1)
             leg = fmx_leg(args, ctx, config, st, wu, cpu_baseline=True, cpu_budget_s=5.0)
+        elif kind == "demux_strong":
+            leg = demux_leg(args, ctx, 2, steps=3, warmup=1, ramp_seconds=0.0, cpu_budget_s=5.0, strong=True)
         else:
             leg = demux_leg(args, ctx, config, steps=3, warmup=1, ramp_seconds=0.0, cpu_budget_s=5.0)
         signal.alarm(0)
@@ -771,7 +828,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", "--no-fmx-leg", dest="no_legs", action="store_true",
                     help="default run: only the headline (configs[1]), none of the secondary legs")
-    ap.add_argument("--legs", default="3,2,4", help="default run: secondary legs (BASELINE.json config indices), in order")
+    ap.add_argument("--legs", default=None,
+                    help="default run: secondary legs, in order: BASELINE.json config indices 3, 2, 4 and, with N > 1 ranks, "
+                         "2s = configs[2] as ONE job cut over the ranks (strong scaling).  Default 3,2,4 (N = 1) / "
+                         "3,2,2s,4 (N > 1); given explicitly, the legs also run at --scale != 1 (tests)")
     ap.add_argument("--fmx-leg-steps", type=int, default=20, help="EM iterations of the configs[3] leg")
     ap.add_argument("--leg-timeout", "--fmx-leg-timeout", dest="leg_timeout", type=float, default=300.0,
                     help="watchdog per secondary leg, seconds")
@@ -807,11 +867,15 @@ def main():
     ctx = Ctx(args)
     if args.config in (1, 2):
         out = demux_leg(args, ctx, args.config)
-        if args.config == 1 and not args.no_legs and args.scale == 1.0:
-            for cfg in [int(x) for x in args.legs.split(",") if x.strip()]:
+        legs = args.legs if args.legs is not None else ("3,2,2s,4" if ctx.world > 1 else "3,2,4")
+        if args.config == 1 and not args.no_legs and (args.scale == 1.0 or args.legs is not None):
+            for cfg in [x.strip() for x in legs.split(",") if x.strip()]:
+                cfg = int(cfg) if cfg.isdigit() else cfg
                 if cfg not in LEGS:
-                    raise SystemExit("--legs: a comma-separated subset of 3,2,4")
-                leg = guarded_leg(args, ctx, out, cfg)
+                    raise SystemExit("--legs: a comma-separated subset of 3,2,2s,4")
+                if cfg == "2s" and ctx.world == 1:
+                    continue
+                leg = ctx.stamp(guarded_leg(args, ctx, out, cfg))
                 if ctx.rank == 0:
                     out[LEGS[cfg][0]] = leg
     else:
@@ -820,7 +884,7 @@ def main():
         ctx.barrier()
         flush_c_stdio()
     if ctx.rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(ctx.stamp(out)), flush=True)
     if ctx.dist_on:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()

@@ -208,14 +208,22 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
  * possibly shuffled by --randomize-singlet-score on the caller side).  The procedure is sequential over cells by
  * construction (each assignment changes the cluster pileups the next cell is scored against): the cells are sorted on
  * the host; the device then decides them in batches of 32, each batch as a fixpoint of the sequential rule (guess from
- * the state at the start of the batch, replay of the predecessors' merges at shared SNPs, iterate until no guess changes:
- * the fixpoint is the sequential result in exact arithmetic; in floating point the scores are start product x
- * term(replayed)/term(start) rather than the product over the replayed state, so a near tie within a few ulp could
- * resolve differently from the reference's loop -- not seen on any test, including 12 000 near-tie cells), or, beyond 64 clusters, with one persistent workgroup walking the cells in
- * order (fmx_greedy.hip).  One device, whole pileup: not available on a device group or a slabbed handle.
+ * the state at the start of the batch, replay of the predecessors' merges at shared SNPs, iterate until no guess
+ * changes), or, beyond 64 clusters or where the batched kernel cannot be resident, with one persistent workgroup walking
+ * the cells in order (fmx_greedy.hip).  The kernels form their scores in another association than the reference's
+ * (products instead of sums of logs), equal to ~1e-13 relative: a decision whose margin over the runner-up is within
+ * 1e-9 x max(1, |score|) is therefore not taken by them but by greedy_exact.hpp, which recomputes that step's K distances
+ * in the reference's own arithmetic (IEEE operations in the reference's order on the device, glibc log on the host) given
+ * the earlier decisions; if it overrules the kernel the run is repeated with that decision forced.  The result is the
+ * reference's clustering, not an approximation of it (muxgl_fmx_greedy_stats reports how often the exact path was taken).
+ * One device, whole pileup: not available on a device group or a slabbed handle.
  * clust_out[C] receives the cluster id, or -1 for cells skipped by frac_init_clust / singlet_score_thres. */
 int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* scores, double frac_init_clust,
                           double singlet_score_thres, int32_t* clust_out);
+
+/* of the last muxgl_fmx_greedy_init: steps whose margin was a near tie and went through the exact path, and how many of
+ * those it decided differently from the kernel (each such step repeats the run once).  Either pointer may be NULL. */
+int muxgl_fmx_greedy_stats(const muxgl_handle* h, int64_t* near_ties, int64_t* overruled);
 
 /* initial clusters (after --init-cluster or greedy init): builds the cluster pileups in ascending cell id
  * (cmd_cram_freemux2.cpp:277-288) and resets types/jBest/kBest (:263-265,349-350).  clust[C], -1 = unassigned. */

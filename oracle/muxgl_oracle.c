@@ -455,9 +455,10 @@ void oracle_fmx_clust_distance(int64_t n, const oracle_plp* d, const oracle_plp*
 }
 
 /* cmd_cram_freemux2.cpp:217-261; distance = sc_drop_seq.cpp:544-578 */
-void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
-                            const oracle_plp* eplp, const double* afs, const double* scores, const int32_t* order,
-                            double frac_init_clust, double singlet_score_thres, int32_t* clust) {
+static void greedy_init_impl(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                             const oracle_plp* eplp, const double* afs, const double* scores, const int32_t* order,
+                             double frac_init_clust, double singlet_score_thres, int32_t* clust, double* step_scores) {
+  int64_t step = 0; /* visited cells so far */
   oracle_plp* cp = (oracle_plp*)malloc(sizeof(oracle_plp) * (size_t)K * S);
   uint8_t* present = (uint8_t*)calloc((size_t)K * S, 1); /* key exists in the std::map (jt != end, :550) */
   for (size_t i = 0; i < (size_t)K * S; ++i) plp_default(&cp[i]);
@@ -482,6 +483,9 @@ void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell
       d2[j] = llk2;
       d0[j] = llk0;
     }
+    if (step_scores)
+      for (int32_t j = 0; j < K; ++j) step_scores[step * K + j] = d2[j] - d0[j];
+    ++step;
     int32_t maxClust = 0; /* :233-242 */
     double maxScore = d2[0] - d0[0];
     for (int32_t j = 1; j < K; ++j) {
@@ -501,6 +505,21 @@ void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell
   free(present);
   free(d2);
   free(d0);
+}
+
+void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                            const oracle_plp* eplp, const double* afs, const double* scores, const int32_t* order,
+                            double frac_init_clust, double singlet_score_thres, int32_t* clust) {
+  greedy_init_impl(C, S, K, cell_ptr, entry_snp, eplp, afs, scores, order, frac_init_clust, singlet_score_thres, clust, NULL);
+}
+
+/* the same, also returning dropDs[j].llk2 - dropDs[j].llk0 (:235-240) of every visited cell: step_scores[visit][K] */
+void oracle_fmx_greedy_init_scores(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                                   const oracle_plp* eplp, const double* afs, const double* scores, const int32_t* order,
+                                   double frac_init_clust, double singlet_score_thres, int32_t* clust,
+                                   double* step_scores) {
+  greedy_init_impl(C, S, K, cell_ptr, entry_snp, eplp, afs, scores, order, frac_init_clust, singlet_score_thres, clust,
+                   step_scores);
 }
 
 /* cmd_cram_freemux2.cpp:277-288 */

@@ -130,6 +130,13 @@ void oracle_fmx_greedy_init(int64_t C, int64_t S, int32_t K, const int64_t* cell
                             const oracle_plp* eplp, const double* af, const double* scores, const int32_t* order,
                             double frac_init_clust, double singlet_score_thres, int32_t* clust);
 
+/* the same, also returning the K distances llk2 - llk0 (:235-240) of every visited cell in visiting order:
+ * step_scores[visit][K] */
+void oracle_fmx_greedy_init_scores(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,
+                                   const oracle_plp* eplp, const double* af, const double* scores, const int32_t* order,
+                                   double frac_init_clust, double singlet_score_thres, int32_t* clust,
+                                   double* step_scores);
+
 /* cluster pileup from assignments, ascending cell id, cmd_cram_freemux2.cpp:277-288.
  * cplp = [K][S], default-constructed (gls all 1, counts 0) where nothing merged. */
 void oracle_fmx_build_cluster_pileup(int64_t C, int64_t S, int32_t K, const int64_t* cell_ptr, const int32_t* entry_snp,

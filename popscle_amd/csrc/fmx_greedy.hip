@@ -30,11 +30,25 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.hpp"
+#include "greedy_exact.hpp"
 
 namespace {
 
 // workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// A decision is a NEAR TIE when the runner-up's score is within eps x max(1, |scores|) of the winner's.  The scores here
+// are formed in another association than the reference's (products instead of sums of logs, lk0 as A x B, ratios of
+// replayed states): they agree with it to ~1e-13 relative, so a margin beyond eps (default 1e-9) cannot come out the
+// other way there; a margin within eps is not decided here but by greedy_exact.hpp in the reference's own arithmetic
+// (muxgl_fmx_greedy_init).  Two scores of exactly 0 are the structural tie of clusters that share no SNP with the cell
+// (sums over nothing on both sides, also in the reference): the first of them wins there as here, no flag.
+__device__ __forceinline__ bool greedy_near_tie(double bs, double ss, double eps) {
+  if (!(ss > -HUGE_VAL)) return false;  // a single cluster
+  if (bs == 0.0 && ss == 0.0) return false;
+  const double scale = fmax(1.0, fmax(fabs(bs), fabs(ss)));
+  return !(bs - ss > eps * scale);  // (also true for NaN scores: let the exact path look at them)
+}
 
 constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
 constexpr int GT = 1024;             // threads of the persistent workgroup
@@ -45,7 +59,8 @@ __global__ void __launch_bounds__(GT)
     fmx_greedy_kernel(const int64_t* __restrict__ hdr_e0, const int32_t* __restrict__ hdr_len,
                       const int32_t* __restrict__ hdr_cell, int64_t n_order, const int32_t* __restrict__ entry_snp, const double* __restrict__ egls,
                       const double* __restrict__ af, int K, int Kp /* K rounded up to a power of two */,
-                      double* diag, double* offd, int32_t* __restrict__ clust) {
+                      double* diag, double* offd, int32_t* __restrict__ clust, uint8_t* __restrict__ near_flag,
+                      const int32_t* __restrict__ forced, double tie_eps, int64_t misdecide) {
   __shared__ int32_t s_snp[ST];
   __shared__ __align__(16) double s_w[ST][4];  // w0, w1, w2, allele frequency
   __shared__ double p_m2[GT], p_m0[GT];
@@ -182,7 +197,7 @@ __global__ void __launch_bounds__(GT)
     }
     lds_barrier();
     if (t < 64) {  // wave 0: scores of clusters t, t+64, ...; running argmax with strict `>` in cluster order (:233-242)
-      double bs = 0.0;
+      double bs = -HUGE_VAL, ss = -HUGE_VAL;  // the lane's best and second-best score
       int best = -1;
       for (int c = t; c < K; c += 64) {
         double a2 = 1.0, a0 = 1.0;
@@ -195,21 +210,37 @@ __global__ void __launch_bounds__(GT)
         }
         const double sc = prodacc_log(a2, b2) - prodacc_log(a0, b0);
         if (best < 0 || sc > bs) {
+          ss = bs;
           bs = sc;
           best = c;
+        } else {
+          ss = fmax(ss, sc);
         }
       }
-      // the first maximum in cluster order == largest value, smallest index among equals
+      // the first maximum in cluster order == largest value, smallest index among equals; the runner-up's score with it
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        const double os = __shfl_xor(bs, off, 64);
+        const double os = __shfl_xor(bs, off, 64), o2 = __shfl_xor(ss, off, 64);
         const int ob = __shfl_xor(best, off, 64);
         if (ob >= 0 && (best < 0 || os > bs || (os == bs && ob < best))) {
+          ss = best >= 0 ? fmax(bs, o2) : o2;
           bs = os;
           best = ob;
+        } else if (ob >= 0) {
+          ss = fmax(ss, os);
         }
       }
       if (t == 0) {
+        const int32_t fc = forced[oi];
+        bool near = greedy_near_tie(bs, ss, tie_eps);
+        if (fc >= 0) {
+          best = fc;
+          near = false;
+        } else if (oi == misdecide) {
+          best = (best + 1) % K;
+          near = true;
+        }
+        near_flag[oi] = near ? 1 : 0;
         winner = best;
         clust[cell] = best;
       }
@@ -332,6 +363,10 @@ struct greedy_tabs {
   unsigned long long* passw;   // [GB + 1][GB] {batch + 1, changed << 8 | guess} after each pass of the batch
   unsigned* cflag;             // per pair of chunks of the batch: batch + 1 once its partials are in memory
   int32_t* clust;
+  uint8_t* near;               // [n] by step: the decision was a near tie (greedy_near_tie)
+  const int32_t* forced;       // [n] by step: >= 0: the cluster this cell joins whatever its scores say (decided by the exact path)
+  double tie_eps;
+  int64_t misdecide;           // -1, or (tests) the step at which the kernel takes the NEXT cluster and raises the flag
   unsigned* bar;               // [0] arrivals, [1] a workgroup gave up
   int32_t* pass_hist;          // NULL or [GB + 2] (MUXGL_TIMING)
   uint64_t* ticks;
@@ -722,6 +757,26 @@ __device__ __forceinline__ int greedy_wave_argmax(double sc, int c, int K) {
   return best;
 }
 
+// the same with the runner-up's score: near = the decision is a near tie (every lane of the wave returns the same)
+__device__ __forceinline__ int greedy_wave_argmax2(double sc, int c, int K, double eps, bool& near) {
+  double bs = c < K ? sc : -HUGE_VAL, ss = -HUGE_VAL;
+  int best = c < K ? c : -1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double os = __shfl_xor(bs, off, 64), o2 = __shfl_xor(ss, off, 64);
+    const int ob = __shfl_xor(best, off, 64);
+    if (ob >= 0 && (best < 0 || os > bs || (os == bs && ob < best))) {
+      ss = best >= 0 ? fmax(bs, o2) : o2;  // the loser's best and the other side's runner-up
+      bs = os;
+      best = ob;
+    } else if (ob >= 0) {
+      ss = fmax(ss, os);
+    }
+  }
+  near = greedy_near_tie(bs, ss, eps);
+  return best;
+}
+
 // what an applying thread keeps of "its" position, fetched before the decisions are known
 struct greedy_pos_regs {
   int32_t snp, q;       // SNP; index in (batch, SNP) order
@@ -787,7 +842,7 @@ __device__ __forceinline__ void greedy_ratio(greedy_lds& L, const greedy_tabs& T
 // shares; lane (s, c) of wave w walks share w * (64 / Kp) + s and multiplies the ratios that belong to cluster c, in their
 // order, into its partial product (a ratio of another cluster counts as 1.0 -- exact -- so nothing diverges; the reads are
 // LDS broadcasts); the partials are folded in share order onto the start products.  Returns the first maximum.
-__device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_tabs& T, int t, int64_t X0, int64_t X1) {
+__device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_tabs& T, int t, int64_t X0, int64_t X1, bool& near) {
   const int K = T.K, Kp = T.Kp, lane = t & 63, wave = t >> 6;
   const int ns = 64 / Kp, c = lane & (Kp - 1), sh = wave * ns + lane / Kp;
   double a2 = 1.0, a0 = 1.0;
@@ -833,7 +888,7 @@ __device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_ta
       }
       sc = prodacc_log(m.x, e.x) - prodacc_log(m.y, e.y);
     }
-    best = greedy_wave_argmax(sc, lane, K);
+    best = greedy_wave_argmax2(sc, lane, K, T.tie_eps, near);
   }
   return best;  // (wave 0)
 }
@@ -1095,6 +1150,7 @@ __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* _
       fetch_ahead(oi0 + GB);  // (the chunk's LDS is free: only deciders use the union's other member)
     }
     const bool deciding = decider && (int)blockIdx.x < nb;
+    const int32_t fc = deciding ? T.forced[oi0 + blockIdx.x] : -1;  // (requested here, used behind the waits below)
     if (decider) {
       // the own cell's start products (its chunks' partials: wait for their pairs' tags) and first guess (the one that
       // ignores the batch's own merges); the deciders tell each other their guesses through one 8-byte word each,
@@ -1104,7 +1160,8 @@ __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* _
       GTICK(1)
       if (deciding && t < 64) {
         const double sc = t < Kp && t < K ? greedy_start_products(L, t, T, L.cf[b], L.cf[b + 1]) : 0.0;
-        const int best = greedy_wave_argmax(sc, t, K);
+        int best = greedy_wave_argmax(sc, t, K);
+        if (fc >= 0) best = fc;
         if (t == 0)
           __hip_atomic_store(T.guess + b, ((unsigned long long)tag << 32) | (unsigned)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1132,7 +1189,18 @@ __global__ void __launch_bounds__(BT) greedy_batches_kernel(const greedy_tabs* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // (one workgroup, one L1: ratios beyond ICAP are visible to the loads below)
         GTICK(9)
-        const int best = greedy_cell_decide(L, T, t, X0, X1);
+        bool near = false;
+        int best = greedy_cell_decide(L, T, t, X0, X1, near);
+        if (t < 64) {
+          if (fc >= 0) {
+            best = fc;
+            near = false;
+          } else if (oi0 + blockIdx.x == T.misdecide) {
+            best = (best + 1) % K;
+            near = true;
+          }
+          if (t == 0) T.near[oi0 + blockIdx.x] = near ? 1 : 0;  // (the last pass's flag stands)
+        }
         if (t == 0)  // {tag, changed, guess} of this pass
           __hip_atomic_store(T.passw + (size_t)passes * GB + blockIdx.x,
                              ((unsigned long long)tag << 32) | (best != L.g[blockIdx.x] ? 0x100u : 0u) | (unsigned)best,
@@ -1336,8 +1404,22 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   int rc = 1;
   h->err.clear();
   tm.lap("greedy_init: host sort + step headers");
+  uint8_t* d_near = nullptr;    // [npad] by step: near tie (greedy_near_tie)
+  int32_t* d_forced = nullptr;  // [npad] by step: cluster decided by the exact path, or -1
+  int32_t* d_step = nullptr;    // [C] step index of a cell (exact path, on first use)
+  bool use_batched = batched;
+  int wgs = 0;
+  double tie_eps = 1e-9;
+  if (const char* ev = getenv("MUXGL_GREEDY_TIE_EPS")) tie_eps = atof(ev);  // (tests: 1e300 sends every step through the exact path)
+  int64_t misdecide = -1;  // (tests of the rerun path: the kernel decides this step wrongly and flags it)
+  if (const char* ev = getenv("MUXGL_GREEDY_TEST_MISDECIDE")) misdecide = atoll(ev);
+  FILE* dump = nullptr;    // (tests: the exact path's scores of every step it decides, as {int64 step, double[K]} records)
+  if (const char* ev = getenv("MUXGL_GREEDY_DUMP_SCORES")) dump = fopen(ev, "wb");
+  std::vector<double> exact_scores((size_t)K);
+  h->greedy_near_ties = h->greedy_overruled = 0;
   do {
     if (dev_alloc(h, &d_he0, npad) || dev_alloc(h, &d_hlen, npad) || dev_alloc(h, &d_hcell, npad)) break;
+    if (dev_alloc(h, &d_near, npad) || dev_alloc(h, &d_forced, npad)) break;
     if (dev_alloc(h, &d_clust, (size_t)C)) break;
     if (dev_alloc(h, &d_diag, (size_t)S * K * 4) || dev_alloc(h, &d_offd, (size_t)S * K * 6)) break;
     hipError_t e = hipMemcpyAsync(d_he0, he0.data(), sizeof(int64_t) * npad, hipMemcpyHostToDevice, h->stream);
@@ -1345,11 +1427,6 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
     if (e == hipSuccess) e = hipMemcpyAsync(d_hcell, hcell.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_clust, 0xFF, sizeof(int32_t) * (size_t)C, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_diag, 0, sizeof(double) * (size_t)S * K * 4, h->stream);
-    if (e == hipSuccess && !batched) {
-      hipLaunchKernelGGL(fmx_greedy_kernel, dim3(1), dim3(GT), 0, h->stream, d_he0, d_hlen, d_hcell, (int64_t)n,
-                         h->d_entry_snp, h->d_egls, h->d_af, (int)K, Kp, d_diag, d_offd, d_clust);
-      e = hipGetLastError();
-    }
     if (e == hipSuccess && batched) {
       const size_t nP = (size_t)P, nchunks = (size_t)chunk_first[n];
       if (dev_alloc(h, &d_chunk_first, chunk_first.size()) || dev_alloc(h, &d_chunk_p0, nchunks + 1) ||
@@ -1482,30 +1559,122 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       T.n = (int64_t)n;
       T.K = (int)K;
       T.Kp = Kp;
-      // one workgroup per compute unit at most (all resident: the grid barrier needs that); GB of them decide a cell each
-      int wgs = 192;
+      T.near = d_near;
+      T.forced = d_forced;
+      T.tie_eps = tie_eps;
+      T.misdecide = misdecide;
+      // one workgroup per compute unit at most, and no more than the device can keep resident at once (the grid barrier
+      // spins until every workgroup has arrived): GB of them decide a cell each, the others apply the merges
+      wgs = 192;
       if (const char* s = getenv("MUXGL_GREEDY_WGS")) wgs = atoi(s);
       wgs = std::max(2 * GB, std::min(wgs, cus));
       e = hipFuncSetAttribute((const void*)greedy_batches_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sizeof(greedy_lds));
+      int per_cu = 0;
+      if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)greedy_batches_kernel, BT, sizeof(greedy_lds));
       if (e == hipSuccess) e = hipMemcpy(d_tabs, &T, sizeof(T), hipMemcpyHostToDevice);
-      if (e != hipSuccess) break;
-      hipLaunchKernelGGL(greedy_batches_kernel, dim3((unsigned)wgs), dim3(BT), sizeof(greedy_lds), h->stream,
-                         (const greedy_tabs*)d_tabs);
-      e = hipGetLastError();
+      if (e != hipSuccess || (int64_t)per_cu * cus < wgs) {
+        // (an LDS limit below sizeof(greedy_lds), a partition that cannot hold the workgroups: the serial kernel does it)
+        (void)hipGetLastError();
+        e = hipSuccess;
+        use_batched = false;
+        if (tm.on) fprintf(stderr, "[muxgl] greedy_init: the batched kernel cannot be resident here, taking the serial one\n");
+      }
     }
-    tm.lap("greedy_init: batches enqueued");
-    if (e == hipSuccess) e = hipMemcpyAsync(clust_out, d_clust, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    tm.lap("greedy_init: batches drained");
-    if (e == hipSuccess && d_bar) {
-      unsigned bar[2] = {0, 0};
-      e = hipMemcpy(bar, d_bar, sizeof(bar), hipMemcpyDeviceToHost);
-      if (e == hipSuccess && bar[1]) {
-        h->err = bar[1] == 2 ? "muxgl_fmx_greedy_init: a batch of greedy_batches_kernel did not reach its fixpoint"
-                             : "muxgl_fmx_greedy_init: a workgroup of greedy_batches_kernel gave up waiting at a grid barrier";
+    tm.lap("greedy_init: tables ready");
+    // ---- run, and let the exact path (greedy_exact.hpp) decide what the kernels flag as near ties.  The kernels'
+    //      decisions before the first flagged step are the reference's (their margins exceed what the arithmetic can
+    //      differ by); the flagged step is decided in the reference's own arithmetic given those.  If that confirms the
+    //      kernel's choice, everything behind it stands as well and the next flagged step is looked at; if not, the
+    //      choice is forced and the run repeated (the steps behind it saw another state).
+    std::vector<int32_t> forced(npad, -1);
+    std::vector<uint8_t> near(npad, 0);
+    int reruns = 0;
+    int64_t n_near = 0, n_overruled = 0;
+    for (;;) {
+      if (e == hipSuccess) e = hipMemcpyAsync(d_forced, forced.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(d_near, 0, npad, h->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(d_clust, 0xFF, sizeof(int32_t) * (size_t)C, h->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(d_diag, 0, sizeof(double) * (size_t)S * K * 4, h->stream);
+      if (e != hipSuccess) break;
+      if (use_batched) {
+        (void)hipMemsetAsync(d_hist, 0, sizeof(int32_t) * (GB + 2), h->stream);
+        (void)hipMemsetAsync(d_passw, 0, sizeof(unsigned long long) * (GB + 1) * GB, h->stream);
+        (void)hipMemsetAsync(d_cflag, 0, sizeof(unsigned) * ((size_t)max_batch_chunks / 2 + 2), h->stream);
+        (void)hipMemsetAsync(d_bar, 0, sizeof(unsigned) * GBAR_WORDS, h->stream);
+        (void)hipMemsetAsync(d_guess, 0, sizeof(unsigned long long) * GB, h->stream);
+        (void)hipMemsetAsync(d_ticks, 0, sizeof(uint64_t) * 24, h->stream);
+        e = hipMemsetAsync(d_offd, 0, sizeof(double) * (size_t)S * K * 6, h->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(greedy_batches_kernel, dim3((unsigned)wgs), dim3(BT), sizeof(greedy_lds), h->stream,
+                           (const greedy_tabs*)d_tabs);
+      } else {
+        hipLaunchKernelGGL(fmx_greedy_kernel, dim3(1), dim3(GT), 0, h->stream, d_he0, d_hlen, d_hcell, (int64_t)n,
+                           h->d_entry_snp, h->d_egls, h->d_af, (int)K, Kp, d_diag, d_offd, d_clust, d_near, d_forced, tie_eps, misdecide);
+      }
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(clust_out, d_clust, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(near.data(), d_near, npad, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (use_batched) {
+        unsigned bar[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(bar, d_bar, sizeof(bar), hipMemcpyDeviceToHost);
+        if (e != hipSuccess || bar[1]) {
+          // a launch failure, or a workgroup that gave up at a barrier (workgroups that are not co-resident after all: a CU
+          // mask, another process on the device) or a batch without fixpoint: the serial kernel repeats the run
+          if (tm.on)
+            fprintf(stderr, "[muxgl] greedy_init: the batched kernel failed (%s), repeating with the serial one\n",
+                    e != hipSuccess ? hipGetErrorString(e) : bar[1] == 2 ? "a batch did not reach its fixpoint" : "gave up at a grid barrier");
+          (void)hipGetLastError();
+          e = hipDeviceSynchronize();
+          use_batched = false;
+          if (e != hipSuccess) break;
+          continue;
+        }
+      }
+      if (e != hipSuccess) break;
+      tm.lap(use_batched ? "greedy_init: batches drained" : "greedy_init: serial kernel drained");
+      bool overruled = false;
+      for (size_t i = 0; i < n && !overruled; ++i) {
+        if (!near[i] || forced[i] >= 0) continue;
+        ++n_near;
+        if (!d_step) {  // step index of every cell, once
+          if (!h->d_snp_ptr && plan_build_snp_major(h)) { e = hipErrorUnknown; break; }
+          std::vector<int32_t> step((size_t)C, 0x7fffffff);
+          for (size_t k = 0; k < n; ++k) step[(size_t)todo[k]] = (int32_t)k;
+          if (dev_alloc(h, &d_step, (size_t)C)) { e = hipErrorOutOfMemory; break; }
+          e = hipMemcpy(d_step, step.data(), sizeof(int32_t) * (size_t)C, hipMemcpyHostToDevice);
+          if (e != hipSuccess) break;
+        }
+        const int w = greedy_exact::decide(h, he0[i], hlen[i], (int)K, (int32_t)i, d_step, d_clust, exact_scores.data());
+        if (w < 0) { e = hipErrorUnknown; break; }
+        if (dump) {
+          const int64_t st = (int64_t)i;
+          fwrite(&st, sizeof(st), 1, dump);
+          fwrite(exact_scores.data(), sizeof(double), (size_t)K, dump);
+        }
+        forced[i] = w;
+        if (w != clust_out[hcell[i]]) {
+          overruled = true;
+          ++n_overruled;
+        }
+      }
+      if (e != hipSuccess || !overruled) break;
+      if (++reruns > 64) {
+        h->err = "muxgl_fmx_greedy_init: more than 64 near-tie decisions overruled by the exact path";
+        e = hipErrorUnknown;
         break;
       }
+    }
+    h->greedy_near_ties = n_near;
+    h->greedy_overruled = n_overruled;
+    if (tm.on)
+      fprintf(stderr, "[muxgl] greedy_init: %lld near ties decided by the exact path, %lld of them against the kernel's choice (%d reruns)\n",
+              (long long)n_near, (long long)n_overruled, reruns);
+    if (e != hipSuccess) {
+      if (h->err.empty()) h->err = std::string("muxgl_fmx_greedy_init: ") + hipGetErrorString(e);
+      break;
     }
     if (tm.on && d_hist) {
       int32_t hist[GB + 2];
@@ -1536,6 +1705,10 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_he0);
   dev_free(&d_hlen);
   dev_free(&d_hcell);
+  if (dump) fclose(dump);
+  dev_free(&d_near);
+  dev_free(&d_forced);
+  dev_free(&d_step);
   dev_free(&d_clust);
   dev_free(&d_diag);
   dev_free(&d_offd);
@@ -1576,4 +1749,11 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_rat);
   if (d_tmp) (void)hipFree(d_tmp);
   return rc;
+}
+
+extern "C" int muxgl_fmx_greedy_stats(const muxgl_handle* h, int64_t* near_ties, int64_t* overruled) {
+  if (!h) return 1;
+  if (near_ties) *near_ties = h->greedy_near_ties;
+  if (overruled) *overruled = h->greedy_overruled;
+  return 0;
 }

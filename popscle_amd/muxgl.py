@@ -91,6 +91,7 @@ SYMBOLS = {
     "muxgl_fmx_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_entry_gls": (C.c_int, [_VP, _VP, _VP]),
     "muxgl_fmx_greedy_init": (C.c_int, [_VP, C.c_int32, _VP, C.c_double, C.c_double, _VP]),
+    "muxgl_fmx_greedy_stats": (C.c_int, [_VP, _VP, _VP]),
     "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
@@ -324,6 +325,12 @@ class Engine:
         self._check(self.lib.muxgl_fmx_greedy_init(self.h, int(K), _ptr(scores), float(frac_init_clust),
                                                     float(singlet_score_thres), _ptr(clust)))
         return clust
+
+    def fmx_greedy_stats(self):
+        """(near ties decided by the exact path, of those against the kernel's choice) of the last fmx_greedy_init"""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.muxgl_fmx_greedy_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def fmx_set_clusters(self, K, clust):
         clust = _arr(clust, np.int32, "clust")

@@ -199,6 +199,19 @@ def fmx_greedy_init(plp, eplp, K, scores, order, frac_init_clust=1.0, singlet_sc
     return clust
 
 
+def fmx_greedy_init_scores(plp, eplp, K, scores, order, frac_init_clust=1.0, singlet_score_thres=-1e300):
+    """(clust, step_scores[C][K]): the greedy loop and the K distances of every visited cell in visiting order (rows
+    beyond the number of visited cells stay 0)"""
+    clust = np.zeros(plp.C, dtype=np.int32)
+    ss = np.zeros((plp.C, K))
+    af = np.ascontiguousarray(plp.af, dtype=np.float64)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    lib().oracle_fmx_greedy_init_scores(C.c_int64(plp.C), C.c_int64(plp.S), C.c_int32(K), _p(plp.cell_ptr),
+                                        _p(plp.entry_snp), _p(eplp), _p(af), _p(scores), _p(order),
+                                        C.c_double(frac_init_clust), C.c_double(singlet_score_thres), _p(clust), _p(ss))
+    return clust, ss
+
+
 def fmx_build_cluster_pileup(plp, eplp, K, clust):
     cplp = np.zeros((K, plp.S), dtype=PLP)
     clust = np.ascontiguousarray(clust, dtype=np.int32)

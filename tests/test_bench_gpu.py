@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def run(cmd):
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+def run(cmd, timeout=900):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
@@ -52,6 +52,8 @@ def test_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["parity_max_abs_ll_diff"] < 1e-5
+    # with the product's host pass for mirrored alpha = 0.5 pairs the checked records need no pair-order excuse
+    assert cb["parity_excuses_used"]["mirrored_pair_order"] == 0 and cb["pair_order_pass"]["cells"] == cb["parity_checked_cells"]
     # value = LLs of the job / step time
     assert abs(d["value"] - 10000 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
     assert d["value"] > 50 * cb["value"]
@@ -113,6 +115,36 @@ def test_two_rank_launch_line():
     assert sm["kernels_ms_rank0_last_iteration"] > 0 and sm["measured_ms_per_iteration"] == fx["ms_per_step"]
     assert sm["predicted_ms_per_iteration"]["direct"] <= sm["predicted_ms_per_iteration"]["ring"]
     assert "exchange_ms_rank0" in fx
+
+
+def test_eight_ranks_line_explains_itself():
+    """what the driver's first 8-GPU run will print, as far as a 1-GPU box can show it: eight real processes (gloo staging,
+    every rank on device 0), a hundredth of the cells, the legs that have an exchange step (configs[3], [4]) and the
+    strong-scaling demuxlet leg.  Every N > 1 line names the ranks that answered an all-reduce, the per-rank rates, the
+    exchange times and the scaling model next to the measurement."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+             "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "8", "--steps", "5", "--warmup", "1",
+             "--ramp-seconds", "0", "--dist-backend", "gloo", "--single-device", "--scale", "0.01", "--fmx-leg-steps", "2",
+             "--legs", "3,2s,4", "--no-cpu-baseline"], timeout=900)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["dist"]["world_size"] == 8
+    assert len(d["per_rank"]["sweep_kernel_ms"]) == 8 and min(d["per_rank"]["sweep_kernel_ms"]) > 0
+    for key in ("freemuxlet_em", "freemuxlet_config4"):
+        fx = d[key]
+        assert "error" not in fx, fx
+        assert fx["n_gpus"] == 8 and fx["scaling"] == "strong" and fx["ranks_seen"] == 8
+        assert "exchange_ms_rank0" in fx and "scaling_model" in fx
+        assert len(fx["per_rank"]["ms_per_iteration"]) == 8 and min(fx["per_rank"]["ms_per_iteration"]) > 0
+        assert fx["scaling_model"]["measured_ms_per_iteration"] == fx["ms_per_step"]
+    st = d["demuxlet_config2_strong"]
+    assert "error" not in st, st
+    assert st["scaling"] == "strong" and st["n_gpus"] == 8 and "ONE job" in st["scaling_note"]
+    ents = st["per_rank"]["entries"]
+    assert len(ents) == 8 and max(ents) < 1.2 * min(ents)       # ranges balanced by entries
+    # the job's LLs, not N x a shard's: 1000 cells x (64 + 64 x 63 x 5) hypotheses per pass
+    assert abs(st["value"] - 1000 * 20224 / (st["ms_per_step"] * 1e-3)) / st["value"] < 1e-9
 
 
 def test_dense_pileup_sensitivity_line():

@@ -292,6 +292,74 @@ def test_greedy_init_near_ties(geng, C, S, K, me):
     assert flips.size == 0, f"{flips.size} of {C} assignments differ from the oracle, first at cells {flips[:5]}"
 
 
+def _read_score_dump(path, K):
+    rec = np.dtype([("step", np.int64), ("sc", np.float64, (K,))])
+    return np.fromfile(path, dtype=rec)
+
+
+@pytest.mark.parametrize("flags", [0, muxgl.FLAG_FORCE_TILE_SWEEP])
+@pytest.mark.parametrize("K,C,S,me", [(4, 150, 800, 150), (16, 120, 1500, 250), (7, 100, 300, 60)])
+def test_greedy_exact_path_is_the_references_arithmetic(tmp_path, monkeypatch, flags, K, C, S, me):
+    """Every step through the exact path (greedy_exact.hpp; MUXGL_GREEDY_TIE_EPS = 1e300 makes every margin a "near
+    tie"): its K distances must be the oracle's -- i.e. the reference's, tests/test_oracle_ref.py -- BIT FOR BIT, since
+    it claims to redo the reference's arithmetic (IEEE operations in the reference's order on the device, glibc log on the
+    host), and the clustering must be the oracle's.  Both kernels (batched and serial) deliver the flags."""
+    p = synth.make_pileup(C, S, min(K, 8), seed=300 + K, mean_entries=me, min_entries=3, with_gp=False, reads_lambda=1.0,
+                          other=0.03)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want, want_sc = ob.fmx_greedy_init_scores(p, e, K, scores, ob.fmx_sort(scores))
+    dump = str(tmp_path / "scores.bin")
+    monkeypatch.setenv("MUXGL_GREEDY_TIE_EPS", "1e300")
+    monkeypatch.setenv("MUXGL_GREEDY_DUMP_SCORES", dump)
+    with muxgl.Engine(0, flags) as en:
+        en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        en.fmx_prepare(p.af)
+        got = en.fmx_greedy_init(K, scores)
+        near, over = en.fmx_greedy_stats()
+    assert np.array_equal(got, want)
+    d = _read_score_dump(dump, K)
+    assert over == 0 and near == d.size and near > 0.8 * C   # (steps whose scores are all exactly 0 are not flagged)
+    assert np.array_equal(d["sc"], want_sc[d["step"]]), "the exact path's distances are not the reference's bits"
+
+
+@pytest.mark.parametrize("flags", [0, muxgl.FLAG_FORCE_TILE_SWEEP])
+def test_greedy_exact_path_overrules_a_wrong_decision(monkeypatch, flags):
+    """MUXGL_GREEDY_TEST_MISDECIDE makes the kernel take the wrong cluster at one step and flag it: the exact path must
+    overrule it, force the reference's choice and repeat the run -- the clustering is the oracle's again"""
+    K = 6
+    p = synth.make_pileup(400, 1200, K, seed=333, mean_entries=150, min_entries=10, with_gp=False)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    monkeypatch.setenv("MUXGL_GREEDY_TEST_MISDECIDE", "137")
+    with muxgl.Engine(0, flags) as en:
+        en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        en.fmx_prepare(p.af)
+        got = en.fmx_greedy_init(K, scores)
+        near, over = en.fmx_greedy_stats()
+    assert np.array_equal(got, want)
+    assert near >= 1 and over == 1
+
+
+def test_greedy_default_run_reports_its_near_ties(geng):
+    """an ordinary run: few or no near ties, none overruled, and the getter says so"""
+    K = 8
+    p = synth.make_pileup(1200, 2000, K, seed=444, mean_entries=200, min_entries=10, with_gp=False)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    geng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    geng.fmx_prepare(p.af)
+    got = geng.fmx_greedy_init(K, scores)
+    near, over = geng.fmx_greedy_stats()
+    assert np.array_equal(got, want)
+    assert near <= 3 and over == 0
+
+
 @pytest.mark.parametrize("K,C,S,me", [(3, 2500, 60, 30), (16, 3000, 50, 25), (20, 2500, 40, 20), (32, 4000, 64, 30),
                                       (40, 3000, 48, 24), (64, 6000, 70, 40), (16, 64, 40, 30)])
 def test_mstep_stream_vs_lds_states_and_oracle(K, C, S, me):

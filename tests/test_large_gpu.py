@@ -199,6 +199,47 @@ def _masked(p, keep):
     return cp, np.ascontiguousarray(p.entry_snp[eidx]), er, np.ascontiguousarray(p.reads[_ranges(p.entry_rptr[eidx], rl)])
 
 
+def test_config3_full_size_greedy_init_vs_oracle():
+    """BASELINE configs[3] at FULL size (50 k cells x 100 k SNPs, K = 16): the greedy initial clustering of the device
+    (one launch of the batched kernel, near ties through the exact path) must be the oracle's sequential loop
+    (cmd_cram_freemux2.cpp:217-261; ~40 s on one core) cell for cell -- about 3 000 cells per cluster, clamps saturated,
+    which is where start product x ratio-of-replayed-terms has the most to get wrong."""
+    cfg = synth.CONFIGS[3]
+    K, S, C = cfg["V"], cfg["S"], cfg["C"]
+    p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + 3, with_gp=False)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    with muxgl.Engine(0) as en:
+        en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        en.fmx_prepare(p.af)
+        got = en.fmx_greedy_init(K, scores)
+        near, over = en.fmx_greedy_stats()
+    diff = np.flatnonzero(got != want)
+    assert diff.size == 0, f"{diff.size} of {C} cells differ, first {diff[:5]}"
+    print(f"configs[3] greedy init: {near} near ties through the exact path, {over} overruled")
+    assert np.bincount(want, minlength=K).min() > 1000
+
+
+def test_greedy_init_k64_20k_cells_vs_oracle():
+    """K = 64 at 20 000 cells x 100 k SNPs (configs[4]'s cluster count; the oracle's loop takes about a minute)"""
+    K, S, C = 64, 100_000, 20_000
+    p = synth.make_pileup(C, S, K, seed=synth.BASE_SEED + 44, with_gp=False)
+    e = ob.fmx_entry_pileup(p)
+    o0, o2, _, _ = ob.fmx_cell_scores(p, e)
+    scores = o2 - o0
+    want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    with muxgl.Engine(0) as en:
+        en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        en.fmx_prepare(p.af)
+        got = en.fmx_greedy_init(K, scores)
+        near, over = en.fmx_greedy_stats()
+    diff = np.flatnonzero(got != want)
+    assert diff.size == 0, f"{diff.size} of {C} cells differ, first {diff[:5]}"
+    print(f"K = 64 greedy init: {near} near ties through the exact path, {over} overruled")
+
+
 def test_config3_shape_freemuxlet():
     cfg = synth.CONFIGS[3]
     K = cfg["V"]
