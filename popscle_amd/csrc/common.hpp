@@ -52,7 +52,6 @@ struct muxgl_row_state {
   int32_t* d_kmap = nullptr;            // [16][16]: sample held by lane j after t DPP row rotations
   int32_t* d_tmap = nullptr;            // [P/2][P]: position seen by a lane of the oct tiling after each rotation (P = tmap_p)
   int tmap_p = 0;
-  int oct_G = 0, demux_oct_G = 0;       // unit_of_block's interleave factor the unit tables were built for
   double* d_part = nullptr;             // per-chunk partial log-likelihoods (row kernels) / mantissas (quad kernel)
   quad_entry* d_qent_lin = nullptr;     // quad kernel: the entry records with every chunk's linear entries first ...
   int32_t* d_chunk_nlin = nullptr;      // ... and how many they are, per chunk (demux_oct.hip, built on first use)
@@ -140,6 +139,7 @@ struct muxgl_handle {
   double* d_gp = nullptr;
   uint8_t* d_has_gp = nullptr;
   double* d_gpq = nullptr;   // V <= 16: GP tensor re-laid for the quad kernel, [S][6][4][2] (demux_oct.hip)
+  double gp_min_sum = 1.0;    // V > 32: smallest sum of a genotype triple (muxgl_demux_set_gp): below 0.35 the split sweep
   bool gp_unit_sums = false;  // V <= 16: every triple sums to 1 within 4 ulp; d_gpq / d_gmq then carry no sums (demux_oct.hip)
   double* d_gp0s = nullptr;  // V <= 16: per-SNP sum of sample 0's triple (the factor every singlet carries, :806)
   double* d_gmq = nullptr;   // V <= 16: moments (s, rho) of every triple in the quad layout, [S + 1][4][4][2] (demux_oct.hip)
@@ -382,36 +382,6 @@ __device__ __forceinline__ void wave_stream_range(const uint32_t* __restrict__ b
 // the GP tensor, which then fit that XCD's 4 MiB L2.  n8 = ceil(n/8); the result may be >= n (caller checks).
 __device__ __forceinline__ int xcd_swizzle(int b, int n8) { return (b & 7) * n8 + (b >> 3); }
 
-// Workgroup -> work unit of the oct kernels, whose units are sorted by the first SNP of their chunks and walk a span of
-// SNPs each (a chunk of <= 192 entries spans a fifth of the SNP axis of a typical cell).  What the L2 of an XCD must hold
-// is the SNP range between the slowest and the fastest of its resident waves.  With a contiguous eighth of the unit
-// list per XCD (xcd_swizzle) consecutive units start at almost the same SNP, so waves launched one after the other sit
-// a whole chunk span apart once the first is done: the window is the span (10 MB of posterior rows at configs[3]).
-// Interleaved instead -- XCD x walks the units g, g + G, g + 2G ... for g = x, x + 8, ... < G, one such sub-list after the
-// other, each a full sweep of the SNP axis -- the start SNP of successive units on an XCD advances by G / n of the axis,
-// and with G = span x n / (resident waves per XCD x time share of a phase) a wave that starts later starts as far ahead
-// as its predecessors have walked meanwhile: the resident waves move along the axis together.  n (the grid) is a
-// multiple of G, G a multiple of 8; G = 0 selects xcd_swizzle.
-__device__ __forceinline__ int unit_of_block(int b, int n, int G) {
-  if (G <= 0) return xcd_swizzle(b, n >> 3);
-  const int per = n / G, x = b & 7, i = b >> 3;
-  const int s = i / per, pos = i - s * per;
-  return pos * G + x + 8 * s;
-}
-// staggered chunk boundaries for the oct kernels' plans (plan_kernels.hip: chunk_geom): MUXGL_OCT_STAGGER (tuning)
-inline int oct_stagger(int dflt) {
-  if (const char* ev = getenv("MUXGL_OCT_STAGGER")) return atoi(ev) != 0;
-  return dflt;
-}
-// the interleave factor: MUXGL_OCT_G (tuning), else dflt; a multiple of 8 or 0
-inline int oct_interleave(int dflt) {
-  if (const char* ev = getenv("MUXGL_OCT_G")) {
-    const int g = atoi(ev);
-    return g <= 0 ? 0 : (g + 7) / 8 * 8;
-  }
-  return dflt;
-}
-
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -460,7 +430,7 @@ void demux_ring_release(muxgl_handle* h);
 int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 void demux_row_free(muxgl_handle* h);
-int demux_row_build(muxgl_handle* h, muxgl_row_state** st, int64_t c0, int64_t c1, int ch, int stagger = 0);
+int demux_row_build(muxgl_handle* h, muxgl_row_state** st, int64_t c0, int64_t c1, int ch);
 int demux_oct_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable
 int demux_row2_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable (demux_row2.hip)
 int demux_call16_launch(muxgl_handle* h, const muxgl_demux_params* p);
@@ -479,7 +449,7 @@ int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p);
 void demux_wave_free(muxgl_handle* h);
 int demux_gp_neutral_rows(muxgl_handle* h, int V);  // d_gp rows of markers without genotypes := (1,0,0) (demux_wave.hip)
 void demux_row_release(muxgl_row_state** st);
-int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch, int stagger);  // chunk tables (plan_kernels.hip)
+int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch);  // chunk tables (plan_kernels.hip)
 int plan_build_qent(muxgl_handle* h);       // packed entry records of the quad kernel, on the device (plan_kernels.hip)
 int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t* d_nlin, int64_t n, int32_t** order);
 int plan_build_lin(muxgl_handle* h);        // d_lin (plan_kernels.hip)

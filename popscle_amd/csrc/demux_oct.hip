@@ -45,9 +45,6 @@ namespace {
 #ifndef OCT_EXP
 #define OCT_EXP 0  // timing experiments (tools/gpu_quadx.sh): 1 no nine-term loop, 2 no linear loop
 #endif
-#ifndef DO_INTERLEAVE
-#define DO_INTERLEAVE 0  // unit_of_block's G (common.hpp); MUXGL_OCT_G overrides
-#endif
 constexpr int O_NLUT = 129;        // {A, B, 2B} by (allele << 6 | base quality <= 63), and one neutral entry
 constexpr int O_LPAD = 3;          // steps of neutral records behind a unit's longest linear list (the loop reads ahead)
 
@@ -208,8 +205,7 @@ __global__ void __launch_bounds__(64, P == 8 ? 3 : 2)
                      const int32_t* __restrict__ order, const uint8_t* __restrict__ reads,
                      const double* __restrict__ gpo, const double* __restrict__ gmo,
                      const double* __restrict__ gp0s, int32_t S_dummy, const double* __restrict__ lut_g,
-                     const int32_t* __restrict__ chunk_pos, double* __restrict__ part_m, int32_t* __restrict__ part_e,
-                     int interleave) {
+                     const int32_t* __restrict__ chunk_pos, double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   __shared__ double lut[384];
   __shared__ __align__(16) double ablut[O_NLUT * 4];
   using G = og<P>;
@@ -245,7 +241,7 @@ __global__ void __launch_bounds__(64, P == 8 ? 3 : 2)
   }
   __syncthreads();  // the tables are complete
 
-  const int unit = unit_of_block(blockIdx.x, gridDim.x, interleave);  // eight chunks that are neighbours in the launch order
+  const int unit = xcd_swizzle(blockIdx.x, gridDim.x >> 3);  // eight chunks that are neighbours in the launch order
   const int wq = unit * O_SLOTS + slot;
   const uint32_t p16 = (uint32_t)p * 16u;
   const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
@@ -975,9 +971,7 @@ int oct_launch_t(muxgl_handle* h, const muxgl_demux_params* p) {
     HIPCHK(h, hipGetLastError());
   }
   const bool use_lin = h->d_lin && h->d_gmq && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
-  if (!st->d_unit_ptr) st->demux_oct_G = oct_interleave(DO_INTERLEAVE);  // fixed with the unit tables below
-  const unsigned gq = (unsigned)(st->demux_oct_G > 0 ? st->demux_oct_G : 8);
-  const unsigned blocks = (unsigned)((((st->n_chunks + O_SLOTS - 1) / O_SLOTS) + gq - 1) / gq * gq);  // a multiple of G for unit_of_block
+  const unsigned blocks = (unsigned)((((st->n_chunks + O_SLOTS - 1) / O_SLOTS) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
   if (use_lin && !st->d_chunk_nlin && st->n_chunks) {  // once per pileup and GP tensor: every chunk's linear entries first
     quad_lrec* d_lrec = nullptr;  // chunk-major records, repacked below
     int32_t* d_steps = nullptr;
@@ -1031,8 +1025,7 @@ int oct_launch_t(muxgl_handle* h, const muxgl_demux_params* p) {
                        use_lin ? st->d_qent_lin : h->d_qent, st->d_orec, st->d_unit_ptr,
                        use_lin ? st->d_chunk_nlin : (const int32_t*)nullptr,
                        use_lin ? st->d_quad_order : (const int32_t*)nullptr, h->d_reads,
-                       h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_chunk_pos, st->d_part, st->d_part_e,
-                       st->demux_oct_G);
+                       h->d_gpq, h->d_gmq, h->d_gp0s, (int32_t)h->S, h->d_lut, st->d_chunk_pos, st->d_part, st->d_part_e);
     HIPCHK(h, hipGetLastError());
   }
   toc_tic(h, MUXGL_T_DEMUX_SWEEP, MUXGL_T_DEMUX_REDUCE);

@@ -322,15 +322,15 @@ int demux_row_plan(muxgl_handle* h) {
   if (demux_row_build(h, &h->row, 0, h->C, MUXGL_ROW_CH)) return 1;
   int qch = MUXGL_OCT_CH;
   if (const char* ev = getenv("MUXGL_OCT_CH")) qch = atoi(ev) >= 16 ? atoi(ev) / 4 * 4 : qch;  // (tuning)
-  return demux_row_build(h, &h->qrow, 0, h->C, qch, oct_stagger(0));
+  return demux_row_build(h, &h->qrow, 0, h->C, qch);
 }
 
 // chunk tables of the cells [cb, ce): built on the device (plan_kernels.hip) from the device copy of the CSR arrays
-int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, int64_t cb, int64_t ce, int ch, int stagger) {
+int demux_row_build(muxgl_handle* h, muxgl_row_state** pst, int64_t cb, int64_t ce, int ch) {
   if (!*pst) *pst = new muxgl_row_state();
   muxgl_row_state* st = *pst;
   dev_free(&st->d_chunk_pos);  // (derived from the chunk tables: rebuilt on first use)
-  if (plan_build_chunks(h, st, cb, ce, ch, stagger)) return 1;
+  if (plan_build_chunks(h, st, cb, ce, ch)) return 1;
   if (!st->d_kmap) {
     if (dev_alloc(h, &st->d_kmap, 256)) return 1;
     hipLaunchKernelGGL(row_kmap_kernel, dim3(1), dim3(64), 0, h->stream, st->d_kmap);

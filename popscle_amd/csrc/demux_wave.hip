@@ -754,7 +754,7 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const bool gen_only = use_lin && nblk == 1;
   // the ring kernel walks a unit's other entries too, with the same accumulators: one write of the slab
   // (MUXGL_FLAG_SPLIT_GENERAL_SWEEP: launches of their own on top of it, as in round 3 -- lets tests compare the two)
-  const bool ring_gen = use_lin && !(h->flags & MUXGL_FLAG_SPLIT_GENERAL_SWEEP);
+  const bool ring_gen = use_lin && !(h->flags & MUXGL_FLAG_SPLIT_GENERAL_SWEEP) && h->gp_min_sum >= 0.35;
   // ... and then nobody but its loader reads the table, record by record in the order of the stream: rows by record (a
   // quarter of the entry-indexed table: 10 GB instead of 41 at configs[2]; allocating those 41 GB was most of a first
   // call's extra second)

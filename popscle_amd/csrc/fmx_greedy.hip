@@ -1020,7 +1020,9 @@ __device__ __forceinline__ bool greedy_xcd_barrier(unsigned* bar, greedy_xbar& X
       __hip_atomic_fetch_add(bar + GBAR_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       wait_for(bar + GBAR_TOP, X.epoch * X.nx);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(bar + GBAR_GEN + 16 * X.x, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the generation word releases this XCD's waiters: only when the other XCDs have arrived -- after a timeout they
+      // leave through bar[1] (raised above, polled in wait_for) instead of running on with states nobody wrote back
+      if (ok) __hip_atomic_store(bar + GBAR_GEN + 16 * X.x, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       wait_for(bar + GBAR_GEN + 16 * X.x, X.epoch);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

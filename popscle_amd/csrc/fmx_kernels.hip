@@ -1145,7 +1145,7 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   // (the chunk tables of the quad E-step are its own: demuxlet's oct kernel cuts cells into longer chunks, and a sharded
   //  run must cut a cell exactly as the whole-pileup run does)
   if (nc > 0 && K <= 16 && !h->fqrow && h->qrow && !(h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_FORCE_ROW_KERNEL)) &&
-      demux_row_build(h, &h->fqrow, 0, h->C, fmx_oct_chunk(), oct_stagger(0)))
+      demux_row_build(h, &h->fqrow, 0, h->C, fmx_oct_chunk()))
     return 1;
   if (nc > 0) qrc = fmx_oct_estep_launch(h, h->fqrow, c0, nc);  // K <= 16: eight lanes per entry
   if (nc > 0 && qrc < 0) qrc = fmx_row2_estep_launch(h, st, c0, nc);  // 16 < K <= 32: two clusters per lane
@@ -1264,7 +1264,7 @@ int muxgl_fmx_set_shard(muxgl_handle* h, int64_t c0, int64_t c1, int64_t s0, int
   demux_row_release(&h->fqrow);
   if (c0 != 0 || c1 != h->C) {  // chunk tables of the cell shard for the row / quad E-step
     if (demux_row_build(h, &h->frow, c0, c1, MUXGL_ROW_CH)) return 1;
-    if (demux_row_build(h, &h->fqrow, c0, c1, fmx_oct_chunk(), oct_stagger(0))) return 1;
+    if (demux_row_build(h, &h->fqrow, c0, c1, fmx_oct_chunk())) return 1;
   }
   return 0;
 }

@@ -23,40 +23,7 @@ using namespace oct;
 
 namespace {
 
-#ifndef FO_INTERLEAVE
-#define FO_INTERLEAVE 0  // unit_of_block's G (common.hpp); MUXGL_OCT_G overrides
-#endif
-constexpr int FO_LPAD = 3, FO_GPAD = 3;
-
-// Streams (records, likelihoods: read once) and partials (written once) with the non-temporal hint, so that they do not
-// push the posterior rows -- the only data with reuse -- out of the XCD's L2.  -DFO_NT=0 turns it off (timing).
-#ifndef FO_NT
-#define FO_NT 1
-#endif
-typedef double fo_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 ld_stream(const double2* p) {
-#if FO_NT
-  const fo_d2 v = __builtin_nontemporal_load(reinterpret_cast<const fo_d2*>(p));
-  return double2{v.x, v.y};
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) {
-#if FO_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-template <class T>
-__device__ __forceinline__ void st_stream(T* p, T v) {
-#if FO_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}  // neutral steps behind a unit's longest list (the loops read ahead)
+constexpr int FO_LPAD = 3, FO_GPAD = 3;  // neutral steps behind a unit's longest list (the loops read ahead)
 
 // E = g1 + 2 g2 of the cluster posteriors, (E_p, E_p+8) adjacent: [S + 1][8][2].  Clusters >= K and the neutral row S: 0.
 __global__ void __launch_bounds__(256) fmx_ceo_kernel(int64_t S, int K, const double* __restrict__ cgp, double* __restrict__ ceo) {
@@ -157,12 +124,12 @@ __global__ void __launch_bounds__(64, FO_WAVES)
                          const double2* __restrict__ lc,
                          const int32_t* __restrict__ gsteps, const int64_t* __restrict__ gptr,
                          const uint32_t* __restrict__ goff, const double* __restrict__ ggl, const double* __restrict__ cgpo,
-                         const double* __restrict__ ceo, double* __restrict__ part_m, int32_t* __restrict__ part_e, int G) {
+                         const double* __restrict__ ceo, double* __restrict__ part_m, int32_t* __restrict__ part_e) {
   const int lane = threadIdx.x;
   const int p = (lane >> 1) & 7;                    // position: clusters p and p + 8
   const int slot = ((lane >> 4) << 1) | (lane & 1);  // 8 entry streams per wave
   const uint32_t p16 = (uint32_t)p * 16u;
-  const int unit = unit_of_block(blockIdx.x, gridDim.x, G);
+  const int unit = xcd_swizzle(blockIdx.x, gridDim.x >> 3);
   const int wq = unit * SLOTS + slot;
   const int q = wq < n_chunks ? (order ? order[wq] : wq) : n_chunks;
 
@@ -220,8 +187,8 @@ __global__ void __launch_bounds__(64, FO_WAVES)
     // entry i: row Rc, (c0, c1) in cc; o0 held its row offset (free), o2 holds that of i + 2; cn receives i + 1's (c0, c1)
     auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const double2& cc, double2& cn, uint32_t& o0, uint32_t o2) {
       load_rowl(Rnn, o2);
-      cn = ld_stream(lcs + (size_t)(i + 1) * SLOTS);
-      o0 = ld_stream(lo + (size_t)(i + 3) * SLOTS);
+      cn = lcs[(size_t)(i + 1) * SLOTS];
+      o0 = lo[(size_t)(i + 3) * SLOTS];
       __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
       sweepL(Rc, cc);
       __builtin_amdgcn_sched_barrier(0);
@@ -272,7 +239,7 @@ __global__ void __launch_bounds__(64, FO_WAVES)
     const double* gg = ggl + (gptr[unit] + slot) * 6;
     auto fetch_gl = [&](gl_t& g, int i) {
       const double2* src = reinterpret_cast<const double2*>(gg + (size_t)i * SLOTS * 6);
-      const double2 x0 = ld_stream(src), x1 = ld_stream(src + 1), x2 = ld_stream(src + 2);
+      const double2 x0 = src[0], x1 = src[1], x2 = src[2];
       g.v[0] = x0.x, g.v[1] = x0.y, g.v[2] = x1.x, g.v[3] = x1.y, g.v[4] = x2.x, g.v[5] = x2.y;
     };
     auto sweep = [&](const row_t& R, const gl_t& g) {
@@ -323,7 +290,7 @@ __global__ void __launch_bounds__(64, FO_WAVES)
     auto step = [&](int i, const row_t& Rc, row_t& Rnn, const gl_t& gc, gl_t& gn, uint32_t& o0, uint32_t o2) {
       load_row(Rnn, o2);
       fetch_gl(gn, i + 1);
-      o0 = ld_stream(go + (size_t)(i + 3) * SLOTS);
+      o0 = go[(size_t)(i + 3) * SLOTS];
       __builtin_amdgcn_sched_barrier(0);
       sweep(Rc, gc);
       __builtin_amdgcn_sched_barrier(0);
@@ -355,8 +322,8 @@ __global__ void __launch_bounds__(64, FO_WAVES)
   if (q < n_chunks) {
 #pragma unroll
     for (int a = 0; a < N_ACC; ++a) {
-      st_stream(part_m + ((size_t)q * N_ACC + a) * 8 + p, acc[a]);
-      st_stream(part_e + ((size_t)q * N_ACC + a) * 8 + p, ex[a]);
+      part_m[((size_t)q * N_ACC + a) * 8 + p] = acc[a];
+      part_e[((size_t)q * N_ACC + a) * 8 + p] = ex[a];
     }
   }
 }
@@ -425,9 +392,7 @@ int fmx_oct_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64
     if (dev_alloc(h, &st->d_part_e, need)) return 1;
     st->part_e_cap = need;
   }
-  if (!st->d_fq_nlin) st->oct_G = oct_interleave(FO_INTERLEAVE);  // fixed with the unit tables below
-  const unsigned gq = (unsigned)(st->oct_G > 0 ? st->oct_G : 8);
-  const unsigned blocks = (unsigned)((((st->n_chunks + SLOTS - 1) / SLOTS) + gq - 1) / gq * gq);  // units (a multiple of G for unit_of_block)
+  const unsigned blocks = (unsigned)((((st->n_chunks + SLOTS - 1) / SLOTS) + 7) / 8 * 8);  // units (multiple of 8 for xcd_swizzle)
   const bool use_lin = h->d_flin && h->nnz > 0 && !(h->flags & MUXGL_FLAG_NO_LINEAR_ENTRIES);
   if (!st->d_fq_nlin && st->n_chunks) {  // once per muxgl_fmx_prepare and chunk table: the units' entries, step-major
     const uint32_t* flin = use_lin ? h->d_flin : nullptr;
@@ -473,7 +438,7 @@ int fmx_oct_estep_launch(muxgl_handle* h, muxgl_row_state* st, int64_t c0, int64
   if (blocks)
     hipLaunchKernelGGL(fmx_estep_oct_kernel, dim3(blocks), dim3(64), 0, h->stream, (int)st->n_chunks, st->d_fq_order,
                        st->d_fo_lsteps, st->d_fo_lptr, st->d_fo_loff, st->d_fo_lc, st->d_fo_gsteps,
-                       st->d_fo_gptr, st->d_fo_goff, st->d_fo_ggl, h->d_cgpq, h->d_ceq, st->d_part, st->d_part_e, st->oct_G);
+                       st->d_fo_gptr, st->d_fo_goff, st->d_fo_ggl, h->d_cgpq, h->d_ceq, st->d_part, st->d_part_e);
   toc(h, MUXGL_T_FMX_ESTEP_SWEEP);
   if (nc > 0)
     hipLaunchKernelGGL(fmx_oct_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,

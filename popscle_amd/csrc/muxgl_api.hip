@@ -323,6 +323,19 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
     dev_free(&h->qrow->d_unit_ptr);
     dev_free(&h->qrow->d_quad_order);
   }
+  h->gp_min_sum = 1.0;
+  if (V > 32 && h->S > 0) {
+    // smallest triple sum: the one-kernel sweep of demux_ring.hip multiplies g_j x pG x g_k into its products directly and
+    // renormalises them on a budget of 37 bits per entry, which holds while every factor is >= 1.1e-11, i.e. for sums
+    // >= ~0.35; posteriors scaled further down than that (nothing the loaders produce) take the split sweep instead
+    double mn = 1.0;
+    for (int64_t s = 0; s < h->S; ++s) {
+      if (!has_gp[s]) continue;
+      const double* row = gp + (size_t)s * V * 3;
+      for (int j = 0; j < V; ++j) mn = std::fmin(mn, (row[3 * j] + row[3 * j + 1]) + row[3 * j + 2]);
+    }
+    h->gp_min_sum = mn;
+  }
   if (V <= 32 && h->S > 0) {
     const int P = V <= 16 ? 8 : 16;  // lanes per entry of the oct tiling (demux_oct.hip): lane p owns samples p and p + P
     // Do all triples sum to 1 within 4 ulp?  (Hard calls through the reference's error mixing do, sc_drop_seq.cpp:287-315;

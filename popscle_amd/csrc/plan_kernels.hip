@@ -94,49 +94,37 @@ __global__ void __launch_bounds__(256)
     snp_cell[p] = entry_cell[snp_entry[p]];
 }
 
-// chunk geometry of a cell with n entries: nch chunks of `step` entries (the last one shorter).  `first` = entries of the
-// first chunk: `step`, or -- stagger -- a per-cell fraction of it (a multiple of 4), so that the chunk boundaries of
-// different cells do not coincide: every cell starts at the first SNPs of the axis, and with equal cuts the first SNPs of
-// all chunks cluster at a few values; staggered, they spread over the whole axis and the launch order (ascending first
-// SNP) becomes a window that slides along it (unit_of_block, common.hpp).
-__device__ __forceinline__ void chunk_geom(int64_t n, int ch, int64_t c, int stagger, int64_t& nch, int64_t& step, int64_t& first) {
+// chunk geometry of a cell with n entries: nch chunks of `step` entries (the last one shorter)
+__device__ __forceinline__ void chunk_geom(int64_t n, int ch, int64_t& nch, int64_t& step) {
   nch = (n + ch - 1) / ch;
   step = nch ? ((n + nch - 1) / nch + 3) / 4 * 4 : 0;
   if (step > ch) step = ch;
-  first = step;
-  if (stagger && nch > 1) {
-    const uint32_t hsh = (uint32_t)c * 2654435769u;  // golden-ratio sequence: consecutive cells far apart
-    int64_t f = (int64_t)(((uint64_t)hsh * (uint64_t)(step / 4)) >> 32) * 4 + 4;  // 4 .. step
-    if (f > step) f = step;
-    first = f;
-    nch = 1 + (n - f + step - 1) / step;
-  }
 }
 
 __global__ void __launch_bounds__(256)
-    chunk_count_kernel(int64_t C, int64_t cb, int64_t ce, int ch, int stagger, const int64_t* __restrict__ cell_ptr,
+    chunk_count_kernel(int64_t C, int64_t cb, int64_t ce, int ch, const int64_t* __restrict__ cell_ptr,
                        int64_t* __restrict__ cnt) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c > C) return;
-  int64_t nch = 0, step = 0, first = 0;
-  if (c >= cb && c < ce) chunk_geom(cell_ptr[c + 1] - cell_ptr[c], ch, c, stagger, nch, step, first);
+  int64_t nch = 0, step = 0;
+  if (c >= cb && c < ce) chunk_geom(cell_ptr[c + 1] - cell_ptr[c], ch, nch, step);
   cnt[c] = nch;  // cnt[C] = 0: the exclusive scan then ends with the total
 }
 
 __global__ void __launch_bounds__(256)
-    chunk_fill_kernel(int64_t cb, int64_t ce, int ch, int stagger, const int64_t* __restrict__ cell_ptr,
+    chunk_fill_kernel(int64_t cb, int64_t ce, int ch, const int64_t* __restrict__ cell_ptr,
                       const int32_t* __restrict__ entry_snp, const int64_t* __restrict__ chunk_ptr,
                       row_chunk* __restrict__ nat, int32_t* __restrict__ key, int32_t* __restrict__ iota) {
   const int64_t c = cb + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ce) return;
   const int64_t e0 = cell_ptr[c], e1 = cell_ptr[c + 1];
-  int64_t nch, step, first;
-  chunk_geom(e1 - e0, ch, c, stagger, nch, step, first);
+  int64_t nch, step;
+  chunk_geom(e1 - e0, ch, nch, step);
   int64_t o = chunk_ptr[c];
-  for (int64_t e = e0, w = first; e < e1; e += w, w = step, ++o) {
+  for (int64_t e = e0; e < e1; e += step, ++o) {
     row_chunk r;
     r.e0 = e;
-    r.len = (int32_t)(e1 - e < w ? e1 - e : w);
+    r.len = (int32_t)(e1 - e < step ? e1 - e : step);
     r.cell = (int32_t)c;
     nat[o] = r;
     key[o] = entry_snp[e];
@@ -302,7 +290,7 @@ int plan_build_snp_major(muxgl_handle* h) {
 
 // chunk tables of the cells [cb, ce) for chunks of <= ch entries; see the header comment.  n_chunks comes back to the
 // host (one 8-byte copy); everything else stays on the device.
-int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch, int stagger) {
+int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t ce, int ch) {
   const int64_t C = h->C;
   if (dev_alloc(h, &st->d_cell_chunk_ptr, (size_t)C + 1)) return 1;
   int64_t* d_cnt = nullptr;
@@ -324,7 +312,7 @@ int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t 
     MUXGL_FAIL(h, "chunk tables: %s", hipGetErrorString(e));
   };
   if (dev_alloc(h, &d_cnt, (size_t)C + 1)) return 1;
-  hipLaunchKernelGGL(chunk_count_kernel, dim3((unsigned)((C + 1 + 255) / 256)), dim3(256), 0, h->stream, C, cb, ce, ch, stagger,
+  hipLaunchKernelGGL(chunk_count_kernel, dim3((unsigned)((C + 1 + 255) / 256)), dim3(256), 0, h->stream, C, cb, ce, ch,
                      h->d_cell_ptr, d_cnt);
   size_t tmp_bytes = 0;
   hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt, st->d_cell_chunk_ptr, (int64_t)0, (size_t)C + 1,
@@ -355,7 +343,7 @@ int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t 
       cleanup();
       return 1;
     }
-    hipLaunchKernelGGL(chunk_fill_kernel, dim3((unsigned)((ce - cb + 255) / 256)), dim3(256), 0, h->stream, cb, ce, ch, stagger,
+    hipLaunchKernelGGL(chunk_fill_kernel, dim3((unsigned)((ce - cb + 255) / 256)), dim3(256), 0, h->stream, cb, ce, ch,
                        h->d_cell_ptr, h->d_entry_snp, st->d_cell_chunk_ptr, d_nat, d_key, d_iota);
     unsigned bits = 1;
     while (bits < 31 && ((int64_t)1 << bits) < h->S) ++bits;

@@ -301,6 +301,19 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const do
   vc.close();
 }
 
+// snps_observed[v] = 1 for every marker some droplet covers (cmd_cram_freemux2.cpp:279-288).  Threads over the entries;
+// the flags are accessed with relaxed atomics (several threads may store the same 1), and a set flag is only read, so that
+// its cache line stays shared between the threads.
+static void mark_observed_snps(const Pileup& p, std::vector<uint8_t>& snps_observed) {
+  const int64_t nnz = p.nnz(), grain = 1 << 20;
+  const int32_t* es = p.entry_snp.data();
+  uint8_t* so = snps_observed.data();
+  parallel_for((nnz + grain - 1) / grain, plp_threads(), [&](int64_t b) {
+    for (int64_t e = b * grain, e1 = std::min(nnz, (b + 1) * grain); e < e1; ++e)
+      if (!__atomic_load_n(so + es[e], __ATOMIC_RELAXED)) __atomic_store_n(so + es[e], (uint8_t)1, __ATOMIC_RELAXED);
+  });
+}
+
 int cmd_freemuxlet(int argc, char** argv) {
   CommonFlags cf;
   std::string initClusterFile;
@@ -424,15 +437,7 @@ int cmd_freemuxlet(int argc, char** argv) {
     for (int64_t i = 0; i < C; ++i) wc0.printf("%d\t%s\t%d\n", (int)i, p.bcs[(size_t)i].c_str(), clusts[(size_t)i]);
   }
   std::vector<uint8_t> snps_observed((size_t)S, 0);  // :279-288
-  {  // (every writer stores 1; a set flag is only read, so that its cache line stays shared between the threads)
-    const int64_t nnz = p.nnz(), grain = 1 << 20;
-    const int32_t* es = p.entry_snp.data();
-    uint8_t* so = snps_observed.data();
-    parallel_for((nnz + grain - 1) / grain, plp_threads(), [&](int64_t b) {
-      for (int64_t e = b * grain, e1 = std::min(nnz, (b + 1) * grain); e < e1; ++e)
-        if (!so[es[e]]) so[es[e]] = 1;
-    });
-  }
+  mark_observed_snps(p, snps_observed);
   check(h, muxgl_fmx_set_clusters(h, K, clusts.data()), "muxgl_fmx_set_clusters");
   time_t now = std::time(nullptr);
   tm* ltm = localtime(&now);
@@ -673,15 +678,7 @@ int cmd_freemuxlet_old(int argc, char** argv) {
     for (int64_t i = 0; i < C; ++i) wc0.printf("%d\t%s\t%d\n", (int)i, p.bcs[(size_t)i].c_str(), clusts[(size_t)i]);
   }
   std::vector<uint8_t> snps_observed((size_t)S, 0);  // :367-376
-  {  // (every writer stores 1; a set flag is only read, so that its cache line stays shared between the threads)
-    const int64_t nnz = p.nnz(), grain = 1 << 20;
-    const int32_t* es = p.entry_snp.data();
-    uint8_t* so = snps_observed.data();
-    parallel_for((nnz + grain - 1) / grain, plp_threads(), [&](int64_t b) {
-      for (int64_t e = b * grain, e1 = std::min(nnz, (b + 1) * grain); e < e1; ++e)
-        if (!so[es[e]]) so[es[e]] = 1;
-    });
-  }
+  mark_observed_snps(p, snps_observed);
   check(h, muxgl_fmx_set_clusters(h, K, clusts.data()), "muxgl_fmx_set_clusters");
   time_t now = std::time(nullptr);
   tm* ltm = localtime(&now);

@@ -46,6 +46,16 @@ class PlpReadVec {
   const PlpRead* end() const { return p_ + n_; }
   PlpRead& operator[](size_t i) { return p_[i]; }
   const PlpRead& operator[](size_t i) const { return p_[i]; }
+  // a size HINT: like reserve(), but gives up quietly (the list then grows on demand) where the allocation is refused --
+  // strict overcommit, a cgroup limit -- since a hint from the file size overshoots what a filtered load keeps
+  bool try_reserve(size_t c) {
+    if (c <= cap_) return true;
+    void* probe = malloc(c * sizeof(PlpRead));
+    if (!probe) return false;
+    free(probe);
+    reserve(c);
+    return true;
+  }
   void reserve(size_t c) {
     if (c <= cap_) return;
     PlpRead* q = (PlpRead*)malloc(c * sizeof(PlpRead));
@@ -453,7 +463,7 @@ inline uint64_t parse_plp_gz(const std::string& prefix, const PlpParseOptions& p
       const uint64_t fsize = (uint64_t)ftell(f) + 4;
       uint64_t isize = 0;
       if (fread(t, 1, 4, f) == 4) isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
-      rds.reserve(rds.size() + (size_t)std::max<uint64_t>(isize / 9, fsize / 4 + (fsize >> 5)));
+      (void)rds.try_reserve(rds.size() + (size_t)std::max<uint64_t>(isize / 9, fsize / 4 + (fsize >> 5)));
     }
     if (f) fclose(f);
   }

@@ -332,3 +332,17 @@ def test_full_size_sample_permutation_equivariance(eng, full_cfg):
     a = np.sort(np.stack([inv[cells[pick]["dBest1"][dbl]], inv[cells[pick]["dBest2"][dbl]]]), axis=0)
     b = np.sort(np.stack([got["dBest1"][dbl], got["dBest2"][dbl]]), axis=0)
     assert np.array_equal(a, b)
+
+
+def test_scaled_down_posteriors_beyond_32_samples():
+    """genotype triples that sum to 0.2 instead of 1 (muxgl_demux_set_gp takes what it is given): the one-kernel sweep of
+    the ring kernel renormalises its products on a bit budget that assumes sums >= 0.35, so such a tensor takes the split
+    sweep -- and the log-likelihoods are the oracle's either way"""
+    V, alphas = 40, (0.0, 0.3, 0.5)
+    p = synth.make_pileup(12, 4000, V, seed=4040, mean_entries=1500, min_entries=800, reads_lambda=1.5)
+    p.gp = p.gp * 0.2
+    want, want_ll = ob.demux(p, alphas, full_ll=True, nthreads=4)
+    with muxgl.Engine(0) as en:
+        got, full = run_gpu(en, p, alphas, full=True)
+    rep = parity.compare_demux(got, want, alphas, want_full=want_ll)
+    assert rep["max_abs_ll_diff"] < 1e-6 and np.isfinite(full[:, parity.needed_ll_mask(V, alphas)]).all()

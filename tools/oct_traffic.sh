@@ -1,13 +1,13 @@
 #!/bin/bash
-# Runs on the GPU box: step time and fabric traffic (FETCH_SIZE / WRITE_SIZE passes) of the oct kernels of configs[1] and
-# configs[3] for interleave factors G of unit_of_block (common.hpp).  usage: bash tools/oct_g_probe.sh "0 8 16 24 32 48"
+# Runs on the GPU box: step time and fabric traffic (FETCH_SIZE / WRITE_SIZE passes, raw counter units / 1e6) of the oct
+# kernels of configs[3] and configs[1] under the current environment (MUXGL_FMX_CH, MUXGL_OCT_CH, MUXGL_LIB ...), once per
+# label given.  usage: bash tools/oct_traffic.sh "label"
 cd /root/repo; export TMPDIR=/tmp
-GS=${1:-"0 8 16 24 32 48"}
+GS=${1:-"run"}
 O=/root/repo/gpurun_out/octg; rm -rf $O; mkdir -p $O
 for cfg in 3 1; do
   pat=$([ $cfg = 3 ] && echo fmx_estep_oct_kernel || echo demux_oct_kernel)
   for g in $GS; do
-    export MUXGL_OCT_G=$g
     python bench.py --config $cfg --steps $([ $cfg = 3 ] && echo 60 || echo 600) --warmup 20 --no-cpu-baseline --no-fmx-leg 2>/dev/null | tail -1 > $O/c${cfg}_g$g.json
     for ctr in FETCH_SIZE WRITE_SIZE; do
       (cd /tmp && timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $O/c${cfg}_g${g}_$ctr -- python /root/repo/bench.py --config $cfg --no-cpu-baseline --no-fmx-leg --steps 3 --warmup 1 --ramp-seconds 0 > $O/c${cfg}_g${g}_$ctr.log 2>&1)
