@@ -9,7 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
+#include <unordered_set>
 
 #include "../../include/muxgl.h"
 
@@ -89,6 +93,8 @@ struct fmx_grec {  // any other entry: its index and SNP
   int32_t snp, pad;
 };
 struct muxgl_handle {
+  std::multimap<size_t, void*> pool;   // cached device blocks by size (dev_alloc / dev_free below)
+  size_t pool_bytes = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = true;
@@ -119,6 +125,8 @@ struct muxgl_handle {
   int64_t n_lin_rec = -1;
   uint2* d_ring_rec = nullptr;      // demux_ring.hip: {snp, table row} of the linear entries, in stream order
   double* d_ring_lut = nullptr;     // ... and the table of (A, Bl, Bm) rows of the current launch
+  double* d_call_alpha = nullptr;   // muxgl_call::call_alpha of the run, for the ring kernel's own call (demux_ring.hip)
+  bool ring_called = false;         // the last sweep made the calls of the whole cells itself: the call kernel takes the cut cells only
   int64_t ring_rec_n = -1;
   uint32_t* d_flin = nullptr;       // [ceil(nnz/32)] freemuxlet: additionally, no clamp fired (checked on the values)
   // The wave E-step's two streams (fmx_wave.hip, built on first use): a cell's linear entries as 24-byte records
@@ -245,21 +253,49 @@ struct host_timer {
                                      __FILE__, __LINE__);                                       \
   } while (0)
 
-template <typename T>
-static inline int dev_alloc(muxgl_handle* h, T** p, size_t n) {
-  if (*p) {
-    (void)hipFree(*p);
-    *p = nullptr;
-  }
-  if (n == 0) n = 1;
-  HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
-  return 0;
+// ---- device memory: dev_alloc / dev_free with a per-handle cache of large blocks -----------------------------------------
+// The phases of a run allocate and free tens of GB each (entry likelihoods, the greedy start's tables, cluster pileups);
+// hipMalloc of memory that was in use before costs ~30 ms per GB on these boxes (the driver clears it) and hipFree drains
+// the device.  Blocks of DEV_POOL_MIN bytes or more therefore go back to a cache of the handle that allocated them and
+// are handed out again to a request they fit (best fit, at most a quarter + 16 MB larger than asked for); the stream of
+// the handle is drained before a cached block is reused, which is what hipFree would have done when it was released.
+// A failed hipMalloc empties every cache of the process and tries again; muxgl_destroy empties the handle's.
+// MUXGL_NO_POOL=1 turns the cache off.
+constexpr size_t DEV_POOL_MIN = (size_t)8 << 20;
+struct dev_block_info {
+  size_t bytes;
+  muxgl_handle* owner;  // NULL once its handle is gone: the block is then freed for good
+};
+struct dev_registry {
+  std::mutex mu;
+  std::unordered_map<void*, dev_block_info> blocks;   // live and cached blocks of at least DEV_POOL_MIN bytes
+  std::unordered_set<muxgl_handle*> handles;          // handles with a cache
+};
+inline dev_registry& dev_reg() {
+  static dev_registry r;
+  return r;
 }
+inline bool dev_pool_on() {
+  static const bool on = getenv("MUXGL_NO_POOL") == nullptr;
+  return on;
+}
+void dev_pool_release(muxgl_handle* h, bool forget_owner);  // muxgl_api.hip
+void dev_pool_release_all();
+
+int dev_alloc_bytes(muxgl_handle* h, void** p, size_t bytes);  // muxgl_api.hip
+void dev_free_bytes(void* p);
 
 template <typename T>
 static inline void dev_free(T** p) {
-  if (*p) (void)hipFree(*p);
+  if (*p) dev_free_bytes((void*)*p);
   *p = nullptr;
+}
+
+template <typename T>
+static inline int dev_alloc(muxgl_handle* h, T** p, size_t n) {
+  dev_free(p);
+  if (n == 0) n = 1;
+  return dev_alloc_bytes(h, (void**)p, n * sizeof(T));
 }
 
 static inline bool timing_off() {  // MUXGL_NO_EVENTS=1: no hipEvent records around the kernels (launch-gap experiments)
@@ -408,6 +444,7 @@ struct wave_item {
   int64_t e0, e1;  // entries
   int64_t slab;    // result slab (in units of one cell's slabs)
   int64_t cell;
+  int64_t whole;   // 1: the unit is the cell's only one (the ring kernel may make its call itself)
 };
 struct wave_cut {
   int64_t cell, first, count;  // overflow slabs [first, first + count)
@@ -424,8 +461,8 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream = false,
                           bool by_record = false);
 int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
-                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt = nullptr,
-                          bool pg_by_record = false);
+                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt,
+                          bool pg_by_record, bool fuse_call);
 void demux_ring_release(muxgl_handle* h);
 int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable

@@ -55,8 +55,9 @@ __global__ void __launch_bounds__(64)
 // with the position-aware insertion, the evidence sums do not depend on the order.
 __global__ void __launch_bounds__(64)
     demux_call_wave_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
-                           double doublet_prior, const double* __restrict__ llw, muxgl_demux_cell* __restrict__ out) {
-  const int64_t i = blockIdx.x;
+                           double doublet_prior, const double* __restrict__ llw, muxgl_demux_cell* __restrict__ out,
+                           const wave_cut* __restrict__ only /* NULL: every cell; else the cells of these cuts */) {
+  const int64_t i = only ? only[blockIdx.x].cell : (int64_t)blockIdx.x;
   const int j = threadIdx.x;
   const bool live = j < nv;
   const double* in = llw + (size_t)i * nAlpha * 4096;
@@ -114,8 +115,17 @@ __global__ void __launch_bounds__(64)
 
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const call_alpha al = make_call_alpha(p, h->V);
-  hipLaunchKernelGGL(demux_call_wave_kernel, dim3((unsigned)h->C), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
-                     p->n_alpha, al, p->doublet_prior, h->d_llw, h->d_dcells);
+  const wave_cut* only = nullptr;
+  int64_t n = h->C;
+  if (h->ring_called) {  // the sweep made the calls of the cells it walked whole (demux_ring.hip): the cut cells are left
+    const wave_item* items;
+    int64_t n_items, n_cuts, n_over;
+    if (demux_wave_items(h, &items, &n_items, &only, &n_cuts, &n_over)) return 1;
+    n = n_cuts;
+    if (n == 0) return 0;
+  }
+  hipLaunchKernelGGL(demux_call_wave_kernel, dim3((unsigned)n), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
+                     p->n_alpha, al, p->doublet_prior, h->d_llw, h->d_dcells, only);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -198,7 +198,10 @@ __global__ void __launch_bounds__(256)
 // relative error of 1e-4 where a genotype no sample carries has probability 0.1 * 1e-10 / V after the mixing -- tried,
 // and caught by the test with qualities up to 93.)
 template <int P, bool UNIT_S>
-__global__ void __launch_bounds__(64, P == 8 ? 3 : 2)
+#ifndef OCT_WAVES
+#define OCT_WAVES 3  // waves per SIMD the P = 8 kernel is allocated for (timing experiments: 4, 5)
+#endif
+__global__ void __launch_bounds__(64, P == 8 ? OCT_WAVES : 2)
     demux_oct_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const quad_entry* __restrict__ qent,
                      const uint2* __restrict__ orec, const int64_t* __restrict__ unit_ptr,
                      const int32_t* __restrict__ chunk_nlin,

@@ -10,6 +10,101 @@
 
 thread_local std::string g_muxgl_create_error;
 
+// ---- device memory cache (common.hpp) -----------------------------------------------------------------------------------
+int dev_alloc_bytes(muxgl_handle* h, void** p, size_t bytes) {
+  *p = nullptr;
+  dev_registry& R = dev_reg();
+  const bool pooled = dev_pool_on() && h && bytes >= DEV_POOL_MIN;
+  if (pooled) {
+    void* hit = nullptr;
+    {
+      std::lock_guard<std::mutex> g(R.mu);
+      auto it = h->pool.lower_bound(bytes);
+      if (it != h->pool.end() && it->first <= bytes + bytes / 4 + ((size_t)16 << 20)) {
+        hit = it->second;
+        h->pool_bytes -= it->first;
+        h->pool.erase(it);
+      }
+    }
+    if (hit) {
+      // whatever still reads or writes the block was enqueued on this handle's stream (or has completed): drain it, as
+      // the hipFree this replaces would have drained the device
+      if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+      *p = hit;
+      return 0;
+    }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {  // give the cached blocks back to the driver and try once more
+    (void)hipGetLastError();
+    dev_pool_release_all();
+    e = hipMalloc(p, bytes);
+  }
+  if (e != hipSuccess) {
+    *p = nullptr;
+    if (h) MUXGL_FAIL(h, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return 1;
+  }
+  if (pooled) {
+    std::lock_guard<std::mutex> g(R.mu);
+    R.blocks[*p] = dev_block_info{bytes, h};
+    R.handles.insert(h);
+  }
+  return 0;
+}
+
+void dev_free_bytes(void* p) {
+  if (!p) return;
+  dev_registry& R = dev_reg();
+  {
+    std::lock_guard<std::mutex> g(R.mu);
+    auto it = R.blocks.find(p);
+    if (it != R.blocks.end()) {
+      muxgl_handle* o = it->second.owner;
+      if (o && dev_pool_on()) {
+        o->pool.emplace(it->second.bytes, p);
+        o->pool_bytes += it->second.bytes;
+        return;
+      }
+      R.blocks.erase(it);
+    }
+  }
+  (void)hipFree(p);
+}
+
+// frees the cached blocks of h; forget_owner: h is going away -- its blocks that are still in use lose their owner and are
+// freed for good when they are released
+void dev_pool_release(muxgl_handle* h, bool forget_owner) {
+  dev_registry& R = dev_reg();
+  std::vector<void*> out;
+  {
+    std::lock_guard<std::mutex> g(R.mu);
+    for (auto& kv : h->pool) {
+      out.push_back(kv.second);
+      R.blocks.erase(kv.second);
+    }
+    h->pool.clear();
+    h->pool_bytes = 0;
+    if (forget_owner) {
+      for (auto& kv : R.blocks)
+        if (kv.second.owner == h) kv.second.owner = nullptr;
+      R.handles.erase(h);
+    }
+  }
+  for (void* q : out) (void)hipFree(q);
+}
+
+void dev_pool_release_all() {
+  dev_registry& R = dev_reg();
+  std::vector<muxgl_handle*> hs;
+  {
+    std::lock_guard<std::mutex> g(R.mu);
+    hs.assign(R.handles.begin(), R.handles.end());
+  }
+  for (muxgl_handle* h : hs) dev_pool_release(h, false);
+}
+
+
 // One handle on one device.  shared_stream != nullptr: the handle launches on that stream and does not own it (the
 // column slab of a slabbed handle shares its parent's stream, so the phases of an EM iteration stay in stream order).
 int muxgl_handle_create(int dev, int32_t flags, hipStream_t shared_stream, muxgl_handle** out, std::string* errp) {
@@ -289,6 +384,7 @@ void muxgl_destroy(muxgl_handle* h) {
   if (h->ev_stat) (void)hipEventDestroy(h->ev_stat);
   for (int i = 0; i < 2 * MUXGL_T_COUNT; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  dev_pool_release(h, true);  // the cached blocks go back to the driver; blocks still out lose their owner
   if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
