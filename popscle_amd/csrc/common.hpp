@@ -125,8 +125,6 @@ struct muxgl_handle {
   int64_t n_lin_rec = -1;
   uint2* d_ring_rec = nullptr;      // demux_ring.hip: {snp, table row} of the linear entries, in stream order
   double* d_ring_lut = nullptr;     // ... and the table of (A, Bl, Bm) rows of the current launch
-  double* d_call_alpha = nullptr;   // muxgl_call::call_alpha of the run, for the ring kernel's own call (demux_ring.hip)
-  bool ring_called = false;         // the last sweep made the calls of the whole cells itself: the call kernel takes the cut cells only
   int64_t ring_rec_n = -1;
   uint32_t* d_flin = nullptr;       // [ceil(nnz/32)] freemuxlet: additionally, no clamp fired (checked on the values)
   // The wave E-step's two streams (fmx_wave.hip, built on first use): a cell's linear entries as 24-byte records
@@ -356,7 +354,41 @@ __device__ __forceinline__ void prodacc_renorm(double& m, int32_t& e) {
   m = frexp(m, &ex);
   e += ex;
 }
+// log of a positive finite double for the end of a product accumulator (round 5).  The library log costs 98 vector
+// instructions for special cases a product of positive likelihoods does not have; at 64 samples and six alphas a cell has
+// 18 208 hypotheses, one log each: 3 % of the sweep's instructions.  Here: x = f 2^k with f in [sqrt(1/2), sqrt(2)),
+// log f = 2 atanh(z), z = (f - 1) / (f + 1), |z| <= 0.1716, as the odd series up to z^21 (truncation 2e-17 relative to z);
+// ~30 instructions, absolute error <= 2e-16 + 1 ulp of the result.  x = 0 gives -inf (the series' own result would be
+// meaningless there), as log does.
+__device__ __forceinline__ double pos_log(double x, double k0) {
+  int ee;
+  double f = frexp(x, &ee);  // [0.5, 1)
+  const bool lo = f < 0.70710678118654752440;
+  f = lo ? f + f : f;
+  const double k = (double)(ee - (lo ? 1 : 0)) + k0;
+  const double z = (f - 1.0) / (f + 1.0);
+  const double w = z * z;
+  double p = 1.0 / 21.0;
+  p = fma(p, w, 1.0 / 19.0);
+  p = fma(p, w, 1.0 / 17.0);
+  p = fma(p, w, 1.0 / 15.0);
+  p = fma(p, w, 1.0 / 13.0);
+  p = fma(p, w, 1.0 / 11.0);
+  p = fma(p, w, 1.0 / 9.0);
+  p = fma(p, w, 1.0 / 7.0);
+  p = fma(p, w, 1.0 / 5.0);
+  p = fma(p, w, 1.0 / 3.0);
+  const double zz = z + z;
+  const double r = fma(zz * w, p, zz);  // 2 atanh(z)
+  // k ln 2 in two pieces (the high one exact for |k| < 2^21), smallest terms first
+  const double v = fma(k, 6.93147180369123816490e-01, fma(k, 1.90821492927058770002e-10, r));
+  return x > 0.0 ? v : -__builtin_huge_val();
+}
+#ifdef MUXGL_LIBRARY_LOG  // (timing experiments: the library log in place of pos_log)
 __device__ __forceinline__ double prodacc_log(double m, int32_t e) { return log(m) + (double)e * 0.6931471805599453094; }
+#else
+__device__ __forceinline__ double prodacc_log(double m, int32_t e) { return pos_log(m, (double)e); }
+#endif
 
 // ---- the ring of partner values of the wave kernels (demux_wave.hip, fmx_wave.hip) ----
 // One 8-byte read per lane from the ring in LDS, at an immediate offset from the lane's slot.  As an opaque instruction
@@ -444,7 +476,6 @@ struct wave_item {
   int64_t e0, e1;  // entries
   int64_t slab;    // result slab (in units of one cell's slabs)
   int64_t cell;
-  int64_t whole;   // 1: the unit is the cell's only one (the ring kernel may make its call itself)
 };
 struct wave_cut {
   int64_t cell, first, count;  // overflow slabs [first, first + count)
@@ -461,8 +492,8 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p);
 int demux_entry_pg_launch(muxgl_handle* h, const muxgl_demux_params* p, double* d_pg, bool gen_stream = false,
                           bool by_record = false);
 int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
-                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt,
-                          bool pg_by_record, bool fuse_call);
+                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt = nullptr,
+                          bool pg_by_record = false);
 void demux_ring_release(muxgl_handle* h);
 int demux_row_plan(muxgl_handle* h);
 int demux_row_launch(muxgl_handle* h, const muxgl_demux_params* p);  // -1: not applicable

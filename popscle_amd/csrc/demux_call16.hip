@@ -55,9 +55,8 @@ __global__ void __launch_bounds__(64)
 // with the position-aware insertion, the evidence sums do not depend on the order.
 __global__ void __launch_bounds__(64)
     demux_call_wave_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv, int nAlpha, call_alpha al,
-                           double doublet_prior, const double* __restrict__ llw, muxgl_demux_cell* __restrict__ out,
-                           const wave_cut* __restrict__ only /* NULL: every cell; else the cells of these cuts */) {
-  const int64_t i = only ? only[blockIdx.x].cell : (int64_t)blockIdx.x;
+                           double doublet_prior, const double* __restrict__ llw, muxgl_demux_cell* __restrict__ out) {
+  const int64_t i = blockIdx.x;
   const int j = threadIdx.x;
   const bool live = j < nv;
   const double* in = llw + (size_t)i * nAlpha * 4096;
@@ -75,35 +74,33 @@ __global__ void __launch_bounds__(64)
       sterm = s + log_single_prior;
       rowmax = sterm;
     }
-    // pass 1: scans, and the largest evidence term of the row
+    // ONE pass over the row's hypotheses (round 5; two passes -- the maximum, then the terms relative to it -- read the
+    // 196 KB of a 64-sample, six-alpha cell twice, and the slab is 19.6 GB at configs[2]): scans, and the evidence as a
+    // running (maximum, sum relative to it) that is rescaled when a larger term turns up, which after the first few
+    // elements it rarely does
+    if (rowmax > NEG_INF) racc = 1.0;  // the singlet term itself
     for (int n = 1; n < nAlpha; ++n) {
       const bool sym = al.a[n] == 0.5;
+      const double prior = sym ? log_doublet_prior2 : log_doublet_prior1;
       int k = j;
-      for (int t = 0; t < 63; ++t) {
-        k = __builtin_amdgcn_mov_dpp(k, 0x13C, 0xF, 0xF, false);
-        if (!live || k >= nv) continue;
-        const double v = in[((size_t)n * 64 + t) * 64 + j];
-        if (sym) {
-          if (k < j) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
-        } else {
-          rowmax = fmax(rowmax, v + log_doublet_prior1);
-        }
-        top2_insert(dbl, v, (j * nv + k) * nAlpha + n);
-      }
-    }
-    // pass 2: the row's evidence terms relative to that maximum
-    if (rowmax > NEG_INF) racc = exp(sterm - rowmax);
-    for (int n = 1; n < nAlpha; ++n) {
-      const bool sym = al.a[n] == 0.5;
-      int k = j;
-      for (int t = 0; t < 63; ++t) {
-        k = __builtin_amdgcn_mov_dpp(k, 0x13C, 0xF, 0xF, false);
-        if (!live || k >= nv || !(rowmax > NEG_INF)) continue;
-        const double v = in[((size_t)n * 64 + t) * 64 + j];
-        if (sym) {
-          if (k < j) racc += exp(v + log_doublet_prior2 - rowmax);
-        } else {
-          racc += exp(v + log_doublet_prior1 - rowmax);
+      for (int t0 = 0; t0 < 63; t0 += 9) {  // nine loads in flight (every slot of the slab exists: unconditional)
+        double vv[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) vv[u] = in[((size_t)n * 64 + t0 + u) * 64 + j];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          k = __builtin_amdgcn_mov_dpp(k, 0x13C, 0xF, 0xF, false);
+          if (!live || k >= nv) continue;
+          const double v = vv[u];
+          top2_insert(dbl, v, (j * nv + k) * nAlpha + n);
+          if (sym && k > j) continue;  // :812-815: an alpha = 0.5 pair counts once
+          const double term = v + prior;
+          if (term > rowmax) {
+            racc = racc * exp_nonpos(rowmax - term) + 1.0;  // (rowmax = -inf: racc is 0 and exp_nonpos gives 0)
+            rowmax = term;
+          } else {
+            racc += exp_nonpos(term - rowmax);
+          }
         }
       }
     }
@@ -115,17 +112,8 @@ __global__ void __launch_bounds__(64)
 
 int demux_call_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   const call_alpha al = make_call_alpha(p, h->V);
-  const wave_cut* only = nullptr;
-  int64_t n = h->C;
-  if (h->ring_called) {  // the sweep made the calls of the cells it walked whole (demux_ring.hip): the cut cells are left
-    const wave_item* items;
-    int64_t n_items, n_cuts, n_over;
-    if (demux_wave_items(h, &items, &n_items, &only, &n_cuts, &n_over)) return 1;
-    n = n_cuts;
-    if (n == 0) return 0;
-  }
-  hipLaunchKernelGGL(demux_call_wave_kernel, dim3((unsigned)n), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
-                     p->n_alpha, al, p->doublet_prior, h->d_llw, h->d_dcells, only);
+  hipLaunchKernelGGL(demux_call_wave_kernel, dim3((unsigned)h->C), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
+                     p->n_alpha, al, p->doublet_prior, h->d_llw, h->d_dcells);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -724,7 +724,7 @@ __device__ __forceinline__ bool oct_decode(int idx, const int32_t* __restrict__ 
 
 // log(m 2^e), spelled with an explicit fma: the reduce kernel and the finish kernel must give the same bits, and whether
 // "a + b * c" is contracted is the compiler's choice per site
-__device__ __forceinline__ double oct_log(double m, int64_t e) { return fma((double)e, 0.6931471805599453094, log(m)); }
+__device__ __forceinline__ double oct_log(double m, int64_t e) { return pos_log(m, (double)e); }
 
 // Multiplies the chunk partials of one cell in chunk order: ONE log per hypothesis.  A chunk's partials sit at the chunk's
 // position ci in its cell's list (the sweep writes them there, oct_chunk_pos_kernel), so a cell's are consecutive and a

@@ -28,7 +28,6 @@
 // Results go to the wave layout llw[cell][block][alpha][step][lane] of demux_wave.hip, whose EM_GENERAL launches add the
 // other entries on top.
 #include "common.hpp"
-#include "demux_call_body.hpp"
 #include "demux_entry.hpp"
 
 namespace {
@@ -115,21 +114,13 @@ __global__ void __launch_bounds__(256)
 // (tells the compiler that the three values, requested by opaque ds_read statements, are defined from here on)
 __device__ __forceinline__ void ring_landed(double (&v)[3]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
 
-// CALL (round 5): the launch covers every hypothesis of the run (one block of the pair matrix, all alphas, GEN), so a
-// workgroup that has walked a WHOLE cell holds everything the call needs: instead of writing the cell's 24 576 logarithms
-// to the slab for demux_call_wave_kernel to read back (19.6 GB each way at configs[2]), the lanes scan their own
-// hypotheses -- top-two lists under (value descending, scan position ascending), evidence terms relative to their
-// maximum (demux_call_body.hpp) --, the waves merge, and one lane makes the decision and writes the record.  Parts of a
-// cut cell still go through the slab (wave_combine_kernel, then the call kernel over the cut cells only).
-template <int NA, bool SYM, bool GEN, bool CALL = false>
+template <int NA, bool SYM, bool GEN>
 __global__ void __launch_bounds__(256, 2)
     demux_ring_lin_kernel(const wave_item* __restrict__ items, int64_t n_items, const uint32_t* __restrict__ lin,
                           const int64_t* __restrict__ lin_rank, const uint2* __restrict__ rrec,
                           const double* __restrict__ lutg, const double* __restrict__ gm, int V, int nAlpha, ring_sel sel,
                           const fmx_grec* __restrict__ gen_rec, const double* __restrict__ gp,
-                          const double* __restrict__ pgt, int pg_by_record, double* __restrict__ ll,
-                          const muxgl_call::call_alpha* __restrict__ cal = nullptr,
-                          muxgl_demux_cell* __restrict__ dcells = nullptr) {
+                          const double* __restrict__ pgt, int pg_by_record, double* __restrict__ ll) {
   constexpr int NS = NA > 0 ? 16 : 0, NSY = SYM ? 8 : 0, NACC = NA * NS + NSY;
   constexpr int NXL = NACC / 2, NXV = NACC - NXL;  // exponents in LDS / in registers (GEN: 36 KB + the 44 KB stage = 80 KB per workgroup)
   constexpr int GN = NS / 4, GS = NSY / 4, GT = GN + GS;  // groups of four ring reads per entry
@@ -357,10 +348,18 @@ __global__ void __launch_bounds__(256, 2)
       const int n0 = lh == 0 ? 0 : sel.n[2], n1 = lh == 0 ? sel.n[0] : sel.n[3], n2 = lh == 0 ? sel.n[1] : sel.nsym;
       double gl[3], hs[3], q[3][9];
       bool gin = false;
+      // the record {entry, snp} of the wave's entry of the NEXT load, requested a batch before the rows that hang off it
+      // (round 5: record -> genotype row was a chain of two dependent loads inside one batch of two entries; the record is
+      // wave-uniform, so holding one more costs scalar registers only)
+      fmx_grec rec_pf = gr[le < ng ? le : ng - 1];
       auto gload = [&](int b) {
         const int64_t i = (int64_t)b * RG_B + le;
         gin = i < ng;
-        const fmx_grec r = gr[gin ? i : ng - 1];  // (a valid record behind the end; its values are not used)
+        const fmx_grec r = rec_pf;  // (behind the end: a valid record whose values are not used)
+        {
+          const int64_t inx = i + RG_B;
+          rec_pf = gr[inx < ng ? inx : ng - 1];
+        }
         const double* row = gp + (size_t)r.snp * V3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) gl[k] = row[jo + k];
@@ -507,28 +506,19 @@ __global__ void __launch_bounds__(256, 2)
   __syncthreads();
   const double logW = stage[0][0][j];
   const uint32_t rb = base0 + rboff, rs = base0 + rsoff;
-  const bool fused = CALL && it.whole != 0;  // (uniform over the workgroup)
-  const double NEG_INF = -__builtin_huge_val();
-  // the hypotheses' logarithms take their accumulators' places (fused: scanned below; else: stored)
   wave_for<0, NS>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
-    if (16 * w + t >= 63) {
-      if (CALL) {
-#pragma unroll
-        for (int a = 0; a < NA; ++a) acc[a * NS + t] = NEG_INF;
-      }
-      return;
-    }
+    if (16 * w + t >= 63) return;
     double lw = wave_ring_rd<(15 - t) * 8>(rb);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
     lw += logW;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
+      constexpr int x = 0;
+      (void)x;
       const int xi = a * NS + t;
       const int32_t e = xi < NXV ? ex[xi < NXV ? xi : 0] : exs[xi < NXV ? 0 : xi - NXV][j];
-      const double v = prodacc_log(acc[xi], e) + lw;
-      if (!fused) out[((size_t)sel.n[a] * 64 + 16 * w + t) * 64 + j] = v;
-      if (CALL) acc[xi] = v;
+      out[((size_t)sel.n[a] * 64 + 16 * w + t) * 64 + j] = prodacc_log(acc[xi], e) + lw;
     }
   });
   wave_for<0, NSY>([&](auto tc) {
@@ -538,114 +528,29 @@ __global__ void __launch_bounds__(256, 2)
     const int tt = 8 * w + t, kk = (j - tt - 1) & 63;
     const int32_t e = xi < NXV ? ex[xi < NXV ? xi : 0] : exs[xi < NXV ? 0 : xi - NXV][j];
     const double v = prodacc_log(acc[xi], e) + lw + logW;
-    const bool writer = tt < 31 || j > kk;  // distance 32 meets every unordered pair from both ends: one writer
-    if (writer && !fused) {
+    if (tt < 31 || j > kk) {  // distance 32 meets every unordered pair from both ends: one writer
       out[((size_t)sel.nsym * 64 + tt) * 64 + j] = v;
       out[((size_t)sel.nsym * 64 + (62 - tt)) * 64 + kk] = v;
     }
-    if (CALL) acc[xi] = writer ? v : NEG_INF;
   });
-  if (w == 0 && sel.with_singlet && !fused) out[j] = lx;  // llw[c][0][0][j]
-
-  if constexpr (CALL) {
-    if (fused) {
-      using namespace muxgl_call;
-      const call_alpha& al = *cal;
-      const double lsp = al.log_single_prior, lp1 = al.log_doublet_prior1, lp2 = al.log_doublet_prior2;
-      top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
-      double M = NEG_INF, Ms = NEG_INF;
-      // pass 1: the lane's hypotheses into the top-two lists (order-independent insertion; an alpha = 0.5 pair stands at both
-      // of its scan positions with the one value), and the largest evidence term
-      if (w == 0 && live) {  // the singlet of sample j (:806,828-837)
-        top2_insert(sng, lx, j);
-        Ms = lx + lsp;
-        M = Ms;
-      }
-      wave_for<0, NS>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int k = (j - (16 * w + t) - 1) & 63;
-        const bool ok = live && k < V && 16 * w + t < 63;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-          const int xi = a * NS + t;
-          if (!ok) acc[xi] = NEG_INF;
-          const double v = acc[xi];
-          if (ok) top2_insert(dbl, v, (j * V + k) * nAlpha + sel.n[a]);
-          M = fmax(M, v + lp1);
-        }
-      });
-      wave_for<0, NSY>([&](auto tc) {
-        constexpr int t = decltype(tc)::value, xi = NA * NS + t;
-        const int kk = (j - (8 * w + t) - 1) & 63;
-        const bool ok = live && kk < V && acc[xi] > NEG_INF;
-        if (!ok) acc[xi] = NEG_INF;
-        const double v = acc[xi];
-        if (ok) {
-          top2_insert(dbl, v, (j * V + kk) * nAlpha + sel.nsym);
-          top2_insert(dbl, v, (kk * V + j) * nAlpha + sel.nsym);
-        }
-        M = fmax(M, v + lp2);  // (:812-815: the pair counts once, with the doubled prior)
-      });
-      // pass 2: the evidence terms relative to that maximum
-      double S = 0.0, Ss = 0.0;
-      if (w == 0 && live) {
-        S = exp_nonpos(Ms - M);
-        Ss = 1.0;
-      }
-      wave_for<0, NS>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) S += exp_nonpos(acc[a * NS + t] + lp1 - M);
-      });
-      wave_for<0, NSY>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        S += exp_nonpos(acc[NA * NS + t] + lp2 - M);
-      });
-      const call_partial cw = demux_call_merge<64>(sng, dbl, Ms, M, S, Ss);
-      __syncthreads();  // (the ring of log sums in the stage has been read by every wave)
-      call_partial* cps = reinterpret_cast<call_partial*>(stage_all);
-      if (j == 0) cps[w] = cw;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        call_partial c = cps[0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-          const call_partial o = cps[q];
-          c.sng = top2_merge(c.sng, o.sng);
-          c.dbl = top2_merge(c.dbl, o.dbl);
-          const double Mn = fmax(c.M, o.M), Msn = fmax(c.Ms, o.Ms);
-          c.S = (c.S > 0.0 ? c.S * exp_nonpos(c.M - Mn) : 0.0) + (o.S > 0.0 ? o.S * exp_nonpos(o.M - Mn) : 0.0);
-          c.Ss = (c.Ss > 0.0 ? c.Ss * exp_nonpos(c.Ms - Msn) : 0.0) + (o.Ss > 0.0 ? o.Ss * exp_nonpos(o.Ms - Msn) : 0.0);
-          c.M = Mn;
-          c.Ms = Msn;
-        }
-        demux_call_decide(c, (int32_t)(it.e1 - it.e0), V, nAlpha, al, dcells + it.cell);
-      }
-    }
-  }
+  if (w == 0 && sel.with_singlet) out[j] = lx;  // llw[c][0][0][j]
 }
 
 template <int NA, bool SYM>
 void ring_launch(muxgl_handle* h, const wave_item* items, int64_t n_items, const double* lut, const double* gm, int A,
-                 const ring_sel& sel, const double* pgt, bool pg_by_record, double* llw, const muxgl_call::call_alpha* cal) {
-  if (pgt && cal)
-    hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, true, true>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items,
-                       n_items, h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt,
-                       pg_by_record ? 1 : 0, llw, cal, h->d_dcells);
-  else if (pgt)
+                 const ring_sel& sel, const double* pgt, bool pg_by_record, double* llw) {
+  if (pgt)
     hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, true>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items,
                        h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt,
-                       pg_by_record ? 1 : 0, llw, nullptr, nullptr);
+                       pg_by_record ? 1 : 0, llw);
   else
     hipLaunchKernelGGL((demux_ring_lin_kernel<NA, SYM, false>), dim3((unsigned)n_items), dim3(256), 0, h->stream, items, n_items,
-                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, 0, llw,
-                       nullptr, nullptr);
+                       h->d_lin, h->d_lin_rank, h->d_ring_rec, lut, gm, h->V, A, sel, h->d_gen_rec, h->d_gp, pgt, 0, llw);
 }
 
 }  // namespace
 
 void demux_ring_release(muxgl_handle* h) {
-  dev_free(&h->d_call_alpha);
   dev_free(&h->d_ring_rec);
   dev_free(&h->d_ring_lut);
   h->ring_rec_n = -1;
@@ -656,8 +561,7 @@ void demux_ring_release(muxgl_handle* h) {
 // pgt: the table of per-entry likelihoods [entry][alpha][9] -- the launch then also walks the units' other entries (GEN) and the
 // slab it writes is final; NULL: the linear entries only (the caller adds the others with demux_wave.hip's EM_GENERAL).
 int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wave_item* items, int64_t n_items,
-                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt, bool pg_by_record,
-                          bool fuse_call) {
+                          const double* gm, int na, const ring_sel& sel, double* llw, const double* pgt, bool pg_by_record) {
   if (h->ring_rec_n != h->n_lin_rec || !h->d_ring_rec) {  // per pileup and genotype set (rows of markers without genotypes)
     if (dev_alloc(h, &h->d_ring_rec, (size_t)h->n_lin_rec + RL_PAD)) return 1;
     const int64_t nr = h->n_lin_rec + RL_PAD;
@@ -673,15 +577,7 @@ int demux_ring_lin_launch(muxgl_handle* h, const muxgl_demux_params* p, const wa
   al.a[5] = sel.nsym > 0 ? p->alpha[sel.nsym] : p->alpha[0];
   hipLaunchKernelGGL(ring_lut_kernel, dim3(RL_NLUT), dim3(64), 0, h->stream, al, h->d_lut, h->d_ring_lut);
   const bool sym = sel.nsym > 0;
-  const muxgl_call::call_alpha* cal = nullptr;
-  if (fuse_call && pgt) {  // the priors and the grid of the call, in device memory (152 bytes)
-    if (!h->d_call_alpha && dev_alloc(h, &h->d_call_alpha, sizeof(muxgl_call::call_alpha) / sizeof(double))) return 1;
-    const muxgl_call::call_alpha ca = muxgl_call::make_call_alpha(p, h->V);
-    HIPCHK(h, hipMemcpyAsync(h->d_call_alpha, &ca, sizeof(ca), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // (ca is a stack object)
-    cal = reinterpret_cast<const muxgl_call::call_alpha*>(h->d_call_alpha);
-  }
-#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, pgt, pg_by_record, llw, cal)
+#define RING(NA, SY) ring_launch<NA, SY>(h, items, n_items, h->d_ring_lut, gm, p->n_alpha, sel, pgt, pg_by_record, llw)
   if (na == 4) sym ? RING(4, true) : RING(4, false);
   else if (na == 2) sym ? RING(2, true) : RING(2, false);
   else if (na == 1) sym ? RING(1, true) : RING(1, false);

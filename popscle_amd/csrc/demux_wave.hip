@@ -700,8 +700,7 @@ int demux_wave_plan(muxgl_handle* h, const int64_t* cell_ptr) {
     const int64_t parts = n > WAVE_ITEM ? (n + WAVE_ITEM - 1) / WAVE_ITEM : 1;
     if (parts > 1) cuts.push_back(wave_cut{c, h->C + n_over, parts - 1});
     for (int64_t q = 0; q < parts; ++q)
-      items.push_back(wave_item{b + n * q / parts, b + n * (q + 1) / parts, q == 0 ? c : h->C + n_over + q - 1, c,
-                                parts == 1 ? 1 : 0});
+      items.push_back(wave_item{b + n * q / parts, b + n * (q + 1) / parts, q == 0 ? c : h->C + n_over + q - 1, c});
     n_over += parts - 1;
   }
   std::stable_sort(items.begin(), items.end(),
@@ -760,14 +759,6 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   // quarter of the entry-indexed table: 10 GB instead of 41 at configs[2]; allocating those 41 GB was most of a first
   // call's extra second)
   const bool pg_by_record = ring_gen && gen_only;
-  // ONE ring launch covers the run (one block of the pair matrix, at most four other alphas in a launch of their own
-  // size and at most one alpha of 0.5): it then makes the calls of the cells it walks whole (demux_ring.hip: CALL)
-  int n_sym = 0, n_plain = 0;
-  for (int n = 1; n < A; ++n) (p->alpha[n] == 0.5 ? n_sym : n_plain)++;
-  const bool ring_call = ring_gen && gen_only && !h->want_full_ll && n_sym <= 1 &&
-                         (n_plain == 4 || n_plain == 2 || n_plain == 1 || (n_plain == 0 && n_sym == 1)) &&
-                         !getenv("MUXGL_NO_RING_CALL");
-  h->ring_called = false;
   if (pg_by_record) need = (size_t)(h->nnz - h->n_lin_rec) * A * 9;
   if (need > st->pg_cap) {
     if (dev_alloc(h, &st->d_pg, need ? need : 1)) return 1;
@@ -866,9 +857,8 @@ int demux_wave_launch(muxgl_handle* h, const muxgl_demux_params* p) {
         rs.nsym = nsym;
         rs.with_singlet = first ? 1 : 0;
         rs.jbase = 64 * X, rs.blk = wb.blk, rs.nblk2 = nblk2;
-        if (ring_call) h->ring_called = true;
         return demux_ring_lin_launch(h, p, st->d_items, st->n_items, st->d_gm, na, rs, h->d_llw, ring_gen ? st->d_pg : nullptr,
-                                     pg_by_record, ring_call);
+                                     pg_by_record);
       };
       while (plain.size() - done >= 4) {
         wave_sel sel = {{plain[done], plain[done + 1], plain[done + 2], plain[done + 3]}};

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "demux_call_body.hpp"
 
 namespace {
 
@@ -472,10 +473,10 @@ __global__ void __launch_bounds__(64)
       while ((jj + 1) * (jj + 2) / 2 <= p) ++jj;
       const double v = llks[p];
       if (p - jj * (jj + 1) / 2 == jj) {
-        sall += exp(v + log_single_prior - mall);
-        ssng += exp(v - msng);
+        sall += muxgl_call::exp_nonpos(v + log_single_prior - mall);  // (arguments <= 0: ~20 instructions against the
+        ssng += muxgl_call::exp_nonpos(v - msng);                     //  library exp's 250; this loop was 8 of configs[4]'s 9 ms)
       } else {
-        sall += exp(v + log_double_prior - mall);
+        sall += muxgl_call::exp_nonpos(v + log_double_prior - mall);
       }
     }
     sall = fmx_wave_sum(sall);
@@ -494,7 +495,22 @@ __global__ void __launch_bounds__(64)
     if (td.p1 != 0x7fffffff) dBest1 = row_of(td.p1), dBest2 = td.p1 - dBest1 * (dBest1 + 1) / 2, dblBestLLK = td.v1;
     if (td.p2 != 0x7fffffff) dNext1 = row_of(td.p2), dNext2 = td.p2 - dNext1 * (dNext1 + 1) / 2, dblNextLLK = td.v2;
   } else {
-  for (int j = 0; j < nSamples; ++j) {  // :469-497
+  // one lane per cell: the reference's scans as written (:469-497); its evidence chain -- logAdd per hypothesis, a library
+  // exp and log each, 400 of them per cell at K = 16: nine tenths of this kernel's instructions -- as a running
+  // (largest term, sum of the terms relative to it), rescaled when a larger term turns up: independent exponentials of
+  // non-positive arguments and one log per sum, the same value to ~1e-16 relative (the sums start at -1e300 in the
+  // reference, :466-467, which logAdd absorbs exactly)
+  const double NEG_INF = -__builtin_huge_val();
+  double mall = NEG_INF, sall = 0.0, msng = NEG_INF, ssng = 0.0;
+  auto evid = [](double t, double& m, double& sacc) {
+    if (t > m) {
+      sacc = sacc * muxgl_call::exp_nonpos(m - t) + 1.0;
+      m = t;
+    } else {
+      sacc += muxgl_call::exp_nonpos(t - m);
+    }
+  };
+  for (int j = 0; j < nSamples; ++j) {
     for (int k = 0; k < j; ++k) {
       const double v = llks[j * (j + 1) / 2 + k];
       if (v > dblBestLLK) {
@@ -509,7 +525,7 @@ __global__ void __launch_bounds__(64)
         dNext2 = k;
         dblNextLLK = v;
       }
-      sumLLK = dev_logadd(sumLLK, v + log_double_prior);
+      evid(v + log_double_prior, mall, sall);
     }
     const double v = llks[j * (j + 1) / 2 + j];
     if (v > sngBestLLK) {
@@ -521,9 +537,11 @@ __global__ void __launch_bounds__(64)
       sNext = j;
       sngNextLLK = v;
     }
-    sumLLK = dev_logadd(sumLLK, v + log_single_prior);
-    sngLLK = dev_logadd(sngLLK, v + log_single_prior);
+    evid(v + log_single_prior, mall, sall);
+    evid(v + log_single_prior, msng, ssng);
   }
+  if (sall > 0.0) sumLLK = mall + log(sall);
+  if (ssng > 0.0) sngLLK = msng + log(ssng);
   }
   muxgl_fmx_cell c = cells[i];
   c.sBest = sBest;

@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(192)
     }
   }
   const int hi = j > k ? j : k, lo = j > k ? k : j;
-  fll[(size_t)c * npairs + hi * (hi + 1) / 2 + lo] = (c0 == c1) ? 0.0 : log(m) + (double)e * 0.6931471805599453094;
+  fll[(size_t)c * npairs + hi * (hi + 1) / 2 + lo] = (c0 == c1) ? 0.0 : pos_log(m, (double)e);
 }
 
 // prefix sums of 8 x steps (host: a few thousand units, once per muxgl_fmx_prepare)
