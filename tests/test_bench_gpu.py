@@ -79,12 +79,19 @@ def test_single_gpu_line():
     assert "error" not in d2, d2
     assert d2["config"]["cells_per_gpu"] == 100000 and d2["config"]["samples"] == 64 and d2["config"]["snps"] == 200000
     assert d2["config"]["alphas"] == [0.0, 0.1, 0.2, 0.3, 0.4, 0.5] and d2["steps"] == 3 and d2["scaling"] == "weak"
-    assert d2["config"]["entries_per_gpu"] > 90_000_000 and d2["roofline"]["kernel"] == "demux_wave_kernel"
+    assert d2["config"]["entries_per_gpu"] > 90_000_000 and d2["roofline"]["kernel"] == "demux_ring_lin_kernel"
     assert abs(d2["value"] - 100000 * (64 + 64 * 63 * 5) / (d2["ms_per_step"] * 1e-3)) / d2["value"] < 1e-9
     assert d2["ms_per_step"] < 60e3  # the north_star's "< 60 s" with room to spare
     assert 0 < d2["roofline"]["frac"] <= 1.0 and d2["cpu_baseline"]["parity_max_abs_ll_diff"] < 1e-5
     assert d2["roofline"]["floor"]["hypotheses_per_entry"] == 18208 and 0.3 < d2["roofline"]["floor"]["frac_of_floor"] <= 1.0
     assert 0.2 < fx["roofline"]["floor"]["frac_of_floor"] <= 1.0 and fx["roofline"]["floor"]["hypotheses_per_entry"] == 136
+    # the E-step legs quote the floor's fraction as THE fraction; the counter traffic stands beside it with its ratio to
+    # the compulsory bytes (it is L2-side fabric traffic: re-read posterior rows, not bytes the kernel must move)
+    for leg in (fx, d["freemuxlet_config4"]):
+        rl = leg["roofline"]
+        assert abs(rl["frac"] - rl["floor"]["frac_of_floor"]) < 1e-9 and rl["bound"] in ("fp64_valu", "hbm")
+        assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
+        assert rl["traffic"] is None or rl["hbm"]["traffic_over_compulsory"] > 1.0
     # ... and configs[4] (freemuxlet 500 k x 500 k, K = 64)
     f4 = d["freemuxlet_config4"]
     assert "error" not in f4, f4

@@ -30,6 +30,20 @@ def eng(request):
     e.close()
 
 
+_ORACLE_CACHE = {}
+
+
+def oracle_demux(key, p, alphas, **kw):
+    """ob.demux memoised per input: every case of this module runs on four kernel selections (the `eng` fixture) with the
+    same seeded input, and the oracle is what takes the time"""
+    k = (key, tuple(alphas), tuple(sorted(kw.items())))
+    if k not in _ORACLE_CACHE:
+        if len(_ORACLE_CACHE) > 6:
+            _ORACLE_CACHE.clear()
+        _ORACLE_CACHE[k] = ob.demux(p, alphas=alphas, **kw)
+    return _ORACLE_CACHE[k]
+
+
 def run_gpu(eng, p, alphas, doublet_prior=0.5, full=False):
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.demux_set_gp(p.gp, p.has_gp)
@@ -81,7 +95,7 @@ def test_golden(eng, name):
 def test_random_vs_oracle(eng, V, alphas, C, S, ment):
     p = synth.make_pileup(C, S, V, seed=1000 + V * 7 + len(alphas), mean_entries=ment, min_entries=20,
                           missing_gp_frac=0.03)
-    want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
+    want, wfull = oracle_demux(("random", V, C, S, ment), p, alphas, full_ll=True, nthreads=4)
     got, gfull = run_gpu(eng, p, alphas, full=True)
     rep = parity.compare_demux(got, want, alphas, want_full=wfull)
     worst = parity.compare_full_ll(gfull, wfull, V, alphas)
@@ -289,7 +303,7 @@ def test_full_size_every_cell_and_how_many_need_an_excuse(full_cfg):
     the two samples of a mirrored alpha = 0.5 pair are named (about half of the cells: the reference's own order is
     decided by the last ulp of two transposed sums, cmd_cram_demuxlet.cpp:738-746)."""
     p, alphas, cells, full = full_cfg
-    want = ob.demux(p, alphas=alphas, nthreads=min(32, os.cpu_count() or 1))
+    want = oracle_demux("configs1-full", p, alphas, nthreads=min(32, os.cpu_count() or 1))
     rep = parity.compare_demux(cells, want, alphas)
     print("configs[1] full size:", rep["cells"], "cells, max |dLL|", rep["max_abs_ll_diff"], rep["excuses_used"])
     assert rep["cells"] == p.C and rep["max_abs_ll_diff"] < 1e-8
