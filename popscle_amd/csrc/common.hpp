@@ -193,6 +193,8 @@ struct muxgl_handle {
   int32_t* d_snp_cell = nullptr;  // [nnz] cell id of the same SNP-major element
   double* d_segls = nullptr;      // [nnz][9] entry likelihoods in SNP-major order (freemuxlet-old's kernels)
   double* d_segls6 = nullptr;     // [nnz][6] their six distinct values {00,11,22,01,02,12}: the ordered M-step streams them
+  uint16_t* d_scode = nullptr;    // [nnz] SNP-major: read byte of an entry with at most one usable read, 0x100 otherwise (fmx_scode_kernel)
+  double* d_mtab = nullptr;       // [256][6] the six values of a one-read entry by its read byte (fmx_mstep.hip)
   double* d_egls6 = nullptr;      // (unused since round 4: the oct E-step's streams are repacked from d_egls)
   int32_t* d_secnt = nullptr;     // [nnz][3] entry counts in SNP-major order
   bool fmx_prepared = false;

@@ -684,6 +684,27 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Code of every element of the SNP-major view for the M-step's stream (fmx_mstep.hip): the byte of the entry's one usable
+// read (0xFF: none -- a read byte is never 0xFF, that is the "other" allele) when it has at most one, 0x100 otherwise.
+// "Other" reads do not enter the likelihoods (sc_drop_seq.cpp:470), so an entry's six values are then those of a one-read
+// entry with that byte: row `code` of the table fmx_entry_kernel makes of the 256 one-read entries.
+__global__ void __launch_bounds__(256)
+    fmx_scode_kernel(int64_t nnz, const int64_t* __restrict__ snp_entry, const int64_t* __restrict__ entry_rptr,
+                     const uint8_t* __restrict__ reads, uint16_t* __restrict__ scode) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = snp_entry[p];
+    uint32_t code = 0xFF;
+    int n = 0;
+    for (int64_t r = entry_rptr[e], r1 = entry_rptr[e + 1]; r < r1 && n < 2; ++r) {
+      const uint8_t b = reads[r];
+      if (b == MUXGL_READ_OTHER) continue;
+      code = b;
+      ++n;
+    }
+    scode[p] = (uint16_t)(n <= 1 ? code : 0x100u);
+  }
+}
+
 // one-time gather of the entry likelihoods and counts into SNP-major order
 __global__ void __launch_bounds__(256)
     fmx_snp_major_kernel(int64_t nnz, const int64_t* __restrict__ snp_entry, const double* __restrict__ egls,
@@ -864,6 +885,41 @@ static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm, bool keep_segls6
     hipLaunchKernelGGL(fmx_snp_major_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
                        h->d_egls, h->d_ecnt, (double*)nullptr, h->d_segls6, (int32_t*)nullptr);
     HIPCHK(h, hipGetLastError());
+    // the codes of the stream's elements and the table behind them: the entry kernel on 256 one-read entries, read byte
+    // = entry number (entry 255's read is the "other" allele: no usable read)
+    dev_free(&h->d_scode);
+    dev_free(&h->d_mtab);
+    static const bool no_codes = getenv("MUXGL_MSTEP_NO_CODES") != nullptr;  // (timing / tests: every row from the stream)
+    if (!no_codes) {
+      int64_t* d_rp = nullptr;
+      uint8_t* d_rd = nullptr;
+      double* d_g9 = nullptr;
+      int32_t* d_cn = nullptr;
+      std::vector<int64_t> rp(257);
+      std::vector<uint8_t> rd(256);
+      for (int i = 0; i < 257; ++i) rp[(size_t)i] = i;
+      for (int i = 0; i < 256; ++i) rd[(size_t)i] = (uint8_t)i;
+      int rc = dev_alloc(h, &h->d_scode, (size_t)nnz) || dev_alloc(h, &h->d_mtab, (size_t)256 * 6) || dev_alloc(h, &d_rp, 257) ||
+               dev_alloc(h, &d_rd, 256) || dev_alloc(h, &d_g9, (size_t)256 * 9) || dev_alloc(h, &d_cn, (size_t)256 * 3);
+      hipError_t e = hipSuccess;
+      if (!rc) e = hipMemcpyAsync(d_rp, rp.data(), sizeof(int64_t) * 257, hipMemcpyHostToDevice, h->stream);
+      if (!rc && e == hipSuccess) e = hipMemcpyAsync(d_rd, rd.data(), 256, hipMemcpyHostToDevice, h->stream);
+      if (!rc && e == hipSuccess) {
+        hipLaunchKernelGGL(fmx_entry_kernel, dim3(1), dim3(256), 0, h->stream, (int64_t)256, d_rp, d_rd, (const int32_t*)nullptr,
+                           (const double*)nullptr, h->d_lut, d_g9, h->d_mtab, d_cn, (double*)nullptr, (double*)nullptr,
+                           (uint32_t*)nullptr);
+        hipLaunchKernelGGL(fmx_scode_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry,
+                           h->d_entry_rptr, h->d_reads, h->d_scode);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (rp / rd are host vectors)
+      dev_free(&d_rp);
+      dev_free(&d_rd);
+      dev_free(&d_g9);
+      dev_free(&d_cn);
+      if (rc) return 1;
+      if (e != hipSuccess) MUXGL_FAIL(h, "M-step codes: %s", hipGetErrorString(e));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   tm.lap("fmx_prepare: SNP-major gather of likelihoods");
@@ -981,6 +1037,8 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
     }
     dev_free(&h->d_segls);
     dev_free(&h->d_segls6);
+    dev_free(&h->d_scode);
+    dev_free(&h->d_mtab);
     dev_free(&h->d_secnt);
   } else if (fmx_build_snp_major(h, tm, true)) {
     return 1;

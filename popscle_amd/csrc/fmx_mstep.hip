@@ -63,7 +63,13 @@ template <int G, int NB, int W, bool TAB>
 __global__ void __launch_bounds__(64 * W)
     fmx_mstep_stream_kernel(int64_t S, int64_t s0, int64_t s1, int K, int64_t C, const int64_t* __restrict__ snp_ptr,
                             const int32_t* __restrict__ snp_cell, const uint8_t* __restrict__ clust8,
-                            const double* __restrict__ segls6, double* __restrict__ cgls) {
+                            const double* __restrict__ segls6, double* __restrict__ cgls,
+                            const uint16_t* __restrict__ scode, const double* __restrict__ mtab) {
+  // scode / mtab (round 5): three quarters of the elements are entries with at most one usable read, whose six
+  // likelihoods are a function of that read's byte alone -- one of 256 rows of mtab (fmx_mstep_codes: made by the entry
+  // kernel itself, so the bits are those of segls6).  Such an element's row is read from the 12 KB table (cache hits)
+  // instead of from its 48 bytes of the stream: 5 + 0.26 x 48 bytes per element instead of 52.  The loads stay
+  // unconditional: the code only selects the address.
   constexpr int BS = G * NB, NG = 64 / G;
   using mask_t = typename mask_of<BS>::type;
   // rows of the batch, one array per matrix element (a lane's write and the reads of a round are then 8 bytes apart
@@ -98,30 +104,33 @@ __global__ void __launch_bounds__(64 * W)
   // pipeline: cell ids two batches ahead, assignments and rows one batch ahead, ONE set of row registers (the loads of
   // the next batch are issued as soon as the current one is parked in LDS, and land while its rounds run); all loads
   // are unconditional from clamped positions (a load under a lane mask makes the compiler wait for it on the spot)
-  auto load_ids = [&](int32_t (&c)[NB], int64_t base) {
+  auto load_ids = [&](int32_t (&c)[NB], uint32_t (&cd)[NB], int64_t base) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int64_t q = base + j * G + k;
       c[j] = snp_cell[q < p1 ? q : plast];
+      cd[j] = scode ? (uint32_t)scode[q < p1 ? q : plast] : 0x100u;
     }
   };
   int32_t kk[NB];
   double2 r[NB][3];
-  auto load_data = [&](const int32_t (&c)[NB], int64_t base) {
+  auto load_data = [&](const int32_t (&c)[NB], const uint32_t (&cd)[NB], int64_t base) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int64_t q = base + j * G + k;
       const uint32_t x = TAB ? tab[c[j]] : clust8[c[j]];
       kk[j] = (q < p1 && x < (uint32_t)G) ? (int32_t)x : G;
-      const double2* o = reinterpret_cast<const double2*>(segls6 + (size_t)(q < p1 ? q : plast) * 6);
+      const double2* o = reinterpret_cast<const double2*>(cd[j] < 0x100u ? mtab + (size_t)cd[j] * 6
+                                                                         : segls6 + (size_t)(q < p1 ? q : plast) * 6);
 #pragma unroll
       for (int i = 0; i < 3; ++i) r[j][i] = o[i];
     }
   };
   int32_t cn[NB], cnn[NB];
-  load_ids(cn, p);
-  load_data(cn, p);
-  load_ids(cn, p + BS);
+  uint32_t dn[NB], dnn[NB];
+  load_ids(cn, dn, p);
+  load_data(cn, dn, p);
+  load_ids(cn, dn, p + BS);
   while (__any(p < p1)) {
     // park the batch: rows by position, one bit per element in its cluster's mask
 #pragma unroll
@@ -134,10 +143,10 @@ __global__ void __launch_bounds__(64 * W)
     wave_lds_sync();
     mask_t m = masks[k];
     masks[k] = 0;
-    load_ids(cnn, p + 2 * BS);
-    load_data(cn, p + BS);
+    load_ids(cnn, dnn, p + 2 * BS);
+    load_data(cn, dn, p + BS);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) cn[j] = cnn[j];
+    for (int j = 0; j < NB; ++j) cn[j] = cnn[j], dn[j] = dnn[j];
     while (m != 0) {  // (a divergent loop: lanes leave as their masks run out, the state is updated under the exec mask)
       const int j = (sizeof(mask_t) == 8) ? __builtin_ctzll((unsigned long long)m) : __builtin_ctz((uint32_t)m);
       m &= m - 1;
@@ -190,12 +199,12 @@ int mstep_go(muxgl_handle* h, int64_t ns) {
     HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const int64_t per = (int64_t)NG * MS_W;
     hipLaunchKernelGGL(kern, dim3((unsigned)((ns + per - 1) / per)), dim3(64 * MS_W), dyn, h->stream, h->S, h->fs0, h->fs1,
-                       h->K, C, h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls);
+                       h->K, C, h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls, h->d_scode, h->d_mtab);
   } else {
     auto kern = fmx_mstep_stream_kernel<G, NB, MS_WG, false>;  // MS_WG independent waves per workgroup
     const int64_t per = (int64_t)NG * MS_WG;
     hipLaunchKernelGGL(kern, dim3((unsigned)((ns + per - 1) / per)), dim3(64 * MS_WG), 0, h->stream, h->S, h->fs0, h->fs1, h->K,
-                       C, h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls);
+                       C, h->d_snp_ptr, h->d_snp_cell, h->d_clust8, h->d_segls6, h->d_cgls, h->d_scode, h->d_mtab);
   }
   HIPCHK(h, hipGetLastError());
   return 0;

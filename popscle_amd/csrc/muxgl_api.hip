@@ -371,6 +371,8 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_snp_cell);
   dev_free(&h->d_segls);
   dev_free(&h->d_segls6);
+  dev_free(&h->d_scode);
+  dev_free(&h->d_mtab);
   dev_free(&h->d_egls6);
   dev_free(&h->d_cgpq);
   dev_free(&h->d_ceq);
