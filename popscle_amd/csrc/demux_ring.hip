@@ -114,6 +114,8 @@ __global__ void __launch_bounds__(256)
 // (tells the compiler that the three values, requested by opaque ds_read statements, are defined from here on)
 __device__ __forceinline__ void ring_landed(double (&v)[3]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
 
+__device__ __forceinline__ void ring_sgpr_landed(double& a, double& b, double& c) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c)); }
+
 template <int NA, bool SYM, bool GEN>
 __global__ void __launch_bounds__(256, 2)
     demux_ring_lin_kernel(const wave_item* __restrict__ items, int64_t n_items, const uint32_t* __restrict__ lin,
@@ -227,6 +229,20 @@ __global__ void __launch_bounds__(256, 2)
       if (used) lA[p][s] = L[s * 3], lB[p][s] = L[s * 3 + 1], lM[p][s] = L[s * 3 + 2];
     }
   };
+  // The table row of the NEXT entry is requested while the current entry's first group is swept and must not be waited
+  // for there: scalar loads and LDS reads share one counter that scalar loads leave out of order, so the wait the
+  // compiler puts in front of the row's first use is lgkmcnt(0) -- placed right behind the request it exposed the scalar
+  // cache's latency twice per entry with the next group's ring reads in flight.  lut_landed names the row's first use:
+  // at the top of the entry's last group, a whole entry's sweep behind the request, where the only LDS reads in flight
+  // are the ones that group waits for anyway.
+  auto lut_landed = [&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+#pragma unroll
+    for (int s = 1; s < 6; ++s) {
+      const bool used = s <= 4 ? s - 1 < NA : SYM;
+      if (used) ring_sgpr_landed(lA[p][s], lB[p][s], lM[p][s]);
+    }
+  };
   load_lut(std::integral_constant<int, 0>{}, rcl[0]);
 
   int cnt = 0, bits = 0;
@@ -261,6 +277,9 @@ __global__ void __launch_bounds__(256, 2)
         constexpr int g = decltype(gc)::value;
         constexpr bool last = g + 1 == GT;
         constexpr bool more = !last || k + 1 < RL_B;
+#ifndef RING_NO_LUT_LANDING
+        if constexpr (last) lut_landed(std::integral_constant<int, 1 - p>{});
+#endif
         if constexpr (!last) issue(kc, std::integral_constant<int, g + 1>{});
         else if constexpr (k + 1 < RL_B) issue(std::integral_constant<int, k + 1>{}, std::integral_constant<int, 0>{});
         constexpr int ahead = more ? (last ? 6 : 4) : 0;  // younger reads: they may stay in flight
