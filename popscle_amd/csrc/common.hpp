@@ -403,6 +403,15 @@ __device__ __forceinline__ double wave_ring_rd(uint32_t a) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
   return v;
 }
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+// ... and 16 bytes (two doubles at a 16-byte aligned address): 4 LDS cycles, and one DS instruction where two 8-byte reads
+// are two
+template <int OFF>
+__device__ __forceinline__ dbl2 wave_ring_rd128(uint32_t a) {
+  dbl2 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void wave_for(F&& f) {  // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
   if constexpr (I < N) {

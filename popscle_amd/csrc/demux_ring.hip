@@ -30,6 +30,28 @@
 #include "common.hpp"
 #include "demux_entry.hpp"
 
+// timing experiments only (the results are wrong): a walk without its waits / its barrier
+#ifdef RING_T_NOWAIT_LIN
+#define RING_T_WAIT_LIN(a, b) b
+#else
+#define RING_T_WAIT_LIN(a, b) a
+#endif
+#ifdef RING_T_NOWAIT_GEN
+#define RING_T_WAIT_GEN(a, b) b
+#else
+#define RING_T_WAIT_GEN(a, b) a
+#endif
+#ifdef RING_T_NOBARRIER_LIN
+#define RING_T_BARRIER_LIN() ((void)0)
+#else
+#define RING_T_BARRIER_LIN() __syncthreads()
+#endif
+#ifdef RING_T_NOBARRIER_GEN
+#define RING_T_BARRIER_GEN() ((void)0)
+#else
+#define RING_T_BARRIER_GEN() __syncthreads()
+#endif
+
 namespace {
 
 constexpr int RL_B = 8;       // entries per staged batch
@@ -112,7 +134,8 @@ __global__ void __launch_bounds__(256)
 // formed once per workgroup instead of once per wave) and the partners' triples from there and carry no scalar
 // operands at all.
 // (tells the compiler that the three values, requested by opaque ds_read statements, are defined from here on)
-__device__ __forceinline__ void ring_landed(double (&v)[3]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
+__device__ __forceinline__ void ring_landed(dbl2& a, double& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void ring_landed(dbl2& a) { asm volatile("" : "+v"(a)); }
 
 __device__ __forceinline__ void ring_sgpr_landed(double& a, double& b, double& c) { asm volatile("" : "+s"(a), "+s"(b), "+s"(c)); }
 
@@ -147,7 +170,11 @@ __global__ void __launch_bounds__(256, 2)
   int64_t i0, i1;
   wave_stream_range<EM_LINEAR>(lin, lin_rank, it.e0, it.e1, i0, i1);
   const int64_t n = i1 - i0;
+#ifdef RING_TIMING_SKIP_LIN  // (timing experiments only: the results are wrong)
+  const int nb = 0;
+#else
   const int nb = (int)((n + RL_B - 1) / RL_B);
+#endif
   const uint2* rr = rrec + i0;
   const double* grow = gm + (size_t)(live ? sel.jbase + j : V - 1) * 2;
 
@@ -284,7 +311,7 @@ __global__ void __launch_bounds__(256, 2)
         else if constexpr (k + 1 < RL_B) issue(std::integral_constant<int, k + 1>{}, std::integral_constant<int, 0>{});
         constexpr int ahead = more ? (last ? 6 : 4) : 0;  // younger reads: they may stay in flight
         if constexpr (g == 0) {
-          asm volatile("s_waitcnt lgkmcnt(%6)"
+          asm volatile(RING_T_WAIT_LIN("s_waitcnt lgkmcnt(%6)", "; %6")
                        : "+v"(rd[0][0]), "+v"(rd[0][1]), "+v"(rd[0][2]), "+v"(rd[0][3]), "+v"(ow[p][0]), "+v"(ow[p][1])
                        : "n"(ahead));
           // the entry's factors of the lane
@@ -297,7 +324,7 @@ __global__ void __launch_bounds__(256, 2)
           if constexpr (k + 1 < RL_B) load_lut(std::integral_constant<int, 1 - p>{}, rcl[k + 1]);
           else load_lut(std::integral_constant<int, 1 - p>{}, rnl[0]);
         } else {
-          asm volatile("s_waitcnt lgkmcnt(%4)"
+          asm volatile(RING_T_WAIT_LIN("s_waitcnt lgkmcnt(%4)", "; %4")
                        : "+v"(rd[g & 1][0]), "+v"(rd[g & 1][1]), "+v"(rd[g & 1][2]), "+v"(rd[g & 1][3])
                        : "n"(ahead));
         }
@@ -343,7 +370,7 @@ __global__ void __launch_bounds__(256, 2)
       }
     }
     store_rows((b + 1) & 1, b + 1);
-    __syncthreads();
+    RING_T_BARRIER_LIN();
 #pragma unroll
     for (int k = 0; k < RL_B; ++k) rcs[k] = rns[k], rcl[k] = rnl[k];
   }
@@ -354,7 +381,11 @@ __global__ void __launch_bounds__(256, 2)
   if constexpr (GEN) {
     int64_t gi0, gi1;
     wave_stream_range<EM_GENERAL>(lin, lin_rank, it.e0, it.e1, gi0, gi1);
+#ifdef RING_TIMING_SKIP_GEN
+    const int64_t ng = 0;
+#else
     const int64_t ng = gi1 - gi0;
+#endif
     if (ng > 0) {  // (workgroup-uniform)
       const fmx_grec* gr = gen_rec + gi0;
       const int nbg = (int)((ng + RG_B - 1) / RG_B);
@@ -401,26 +432,35 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
           for (int a = 0; a < 3; ++a) uu[a][0] = 1.0, uu[a][1] = 0.0, uu[a][2] = 0.0;
         }
-        double* u = base + 448;
+        // Layout of a staged row (RG_ROW doubles): the ring of (g0, g1) pairs twice over [128][2], the ring of g2 twice over
+        // [128], then the lane's own sixteen values as eight 16-byte pairs P[8][64][2] -- value v = 3 a + m is u[a][m]
+        // (a = 0 .. 3: the launch's alphas, 4: the symmetric one), v = 15 the singlet factor; pair v / 2, half v % 2.  One
+        // ds_read_b128 then brings two values (round 5: what a DS instruction costs the sweep is per instruction, not per
+        // byte -- tools/fp64_ilp_probe.hip -- and a general entry took 88 of them per wave; now 56).
+        dbl2* r01 = reinterpret_cast<dbl2*>(base);
+        dbl2* P = reinterpret_cast<dbl2*>(base + 384);
         if (lh == 0) {
-          base[j] = g0, base[j + 64] = g0;
-          base[128 + j] = g1, base[192 + j] = g1;
+          r01[j] = dbl2{g0, g1}, r01[j + 64] = dbl2{g0, g1};
           base[256 + j] = g2, base[320 + j] = g2;
-          base[384 + j] = gin ? fma(hs[2], uu[0][2], fma(hs[1], uu[0][1], hs[0] * uu[0][0])) : 1.0;
-#pragma unroll
-          for (int m = 0; m < 3; ++m) u[(0 * 3 + m) * 64 + j] = uu[1][m], u[(1 * 3 + m) * 64 + j] = uu[2][m];
+          P[0 * 64 + j] = dbl2{uu[1][0], uu[1][1]};
+          P[1 * 64 + j] = dbl2{uu[1][2], uu[2][0]};
+          P[2 * 64 + j] = dbl2{uu[2][1], uu[2][2]};
+          base[384 + (7 * 64 + j) * 2 + 1] = gin ? fma(hs[2], uu[0][2], fma(hs[1], uu[0][1], hs[0] * uu[0][0])) : 1.0;
         } else {
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-            u[(2 * 3 + m) * 64 + j] = uu[0][m], u[(3 * 3 + m) * 64 + j] = uu[1][m], u[(4 * 3 + m) * 64 + j] = uu[2][m];
+          P[3 * 64 + j] = dbl2{uu[0][0], uu[0][1]};
+          P[4 * 64 + j] = dbl2{uu[0][2], uu[1][0]};
+          P[5 * 64 + j] = dbl2{uu[1][1], uu[1][2]};
+          P[6 * 64 + j] = dbl2{uu[2][0], uu[2][1]};
+          base[384 + (7 * 64 + j) * 2] = uu[2][2];
         }
       };
       __syncthreads();  // (the linear walk's last batch has been read by every wave)
       gload(0);
       gstore(0);
       __syncthreads();
-      const uint32_t gown = base0 + (uint32_t)j * 8u;
-      const uint32_t grb = base0 + (uint32_t)(j + 64 - 16 * w - 16) * 8u, grs = base0 + (uint32_t)(j + 64 - 8 * w - 8) * 8u;
+      const uint32_t gown = base0 + 3072u + (uint32_t)j * 16u;
+      const uint32_t grb2 = base0 + (uint32_t)(j + 64 - 16 * w - 16) * 8u, grs2 = base0 + (uint32_t)(j + 64 - 8 * w - 8) * 8u;
+      const uint32_t grb01 = 2u * grb2 - base0, grs01 = 2u * grs2 - base0;
       // Bits since the last renormalisation: the linear walk leaves at most RL_BUDGET + 8 * 35 = 880 behind; a general entry
       // costs < 37 (every factor >= 1.1e-11): renormalising once more than 870 are counted keeps a product above
       // 2^-(870 + 2 * 37) -- and above 2^-(880 + 74) in the first batch.  (A renormalisation block of its own in front of
@@ -431,37 +471,29 @@ __global__ void __launch_bounds__(256, 2)
         gload(b + 1);
         wave_for<0, RG_B>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
-          // the lane's factors (and the singlet factor) of entry k
-          double ug[NA1][3], us[3], svk;
-          wave_for<0, NA>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
-            ug[a][0] = wave_ring_rd<k * ROWGB + (448 + (a * 3 + 0) * 64) * 8>(gown + bo);
-            ug[a][1] = wave_ring_rd<k * ROWGB + (448 + (a * 3 + 1) * 64) * 8>(gown + bo);
-            ug[a][2] = wave_ring_rd<k * ROWGB + (448 + (a * 3 + 2) * 64) * 8>(gown + bo);
+          // the lane's factors (and the singlet factor) of entry k: pairs P[q] that hold a value this launch uses
+          dbl2 pv[8];
+          wave_for<0, 8>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr bool need = (q < 6 && (2 * q) / 3 < NA) || (q < 6 && (2 * q + 1) / 3 < NA) || (q >= 6 && SYM) || q == 7;
+            if constexpr (need) pv[q] = wave_ring_rd128<k * ROWGB + q * 1024>(gown + bo);
           });
-          if (SYM) {
-            us[0] = wave_ring_rd<k * ROWGB + (448 + 12 * 64) * 8>(gown + bo);
-            us[1] = wave_ring_rd<k * ROWGB + (448 + 13 * 64) * 8>(gown + bo);
-            us[2] = wave_ring_rd<k * ROWGB + (448 + 14 * 64) * 8>(gown + bo);
-          }
-          svk = wave_ring_rd<k * ROWGB + 384 * 8>(gown + bo);
-          // partner triples GS_ steps at a time, a group ahead of their use
+          // partner triples GS_ steps at a time, a group ahead of their use: (g0, g1) as one 16-byte read, g2
           constexpr int GS_ = RG_G, NGN = NS / GS_, NGS = NSY / GS_, NGT = NGN + NGS;
-          double rd[2][GS_][3];
+          dbl2 rd01[2][GS_];
+          double rd2[2][GS_];
           auto issue = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             wave_for<0, GS_>([&](auto ic) {
               constexpr int i = decltype(ic)::value;
               if constexpr (g < NGN) {
-                constexpr int off = k * ROWGB + (15 - (GS_ * g + i)) * 8;
-                rd[g & 1][i][0] = wave_ring_rd<off>(grb + bo);
-                rd[g & 1][i][1] = wave_ring_rd<off + 1024>(grb + bo);
-                rd[g & 1][i][2] = wave_ring_rd<off + 2048>(grb + bo);
+                constexpr int x = 15 - (GS_ * g + i);
+                rd01[g & 1][i] = wave_ring_rd128<k * ROWGB + x * 16>(grb01 + bo);
+                rd2[g & 1][i] = wave_ring_rd<k * ROWGB + 2048 + x * 8>(grb2 + bo);
               } else {
-                constexpr int off = k * ROWGB + (7 - (GS_ * (g - NGN) + i)) * 8;
-                rd[g & 1][i][0] = wave_ring_rd<off>(grs + bo);
-                rd[g & 1][i][1] = wave_ring_rd<off + 1024>(grs + bo);
-                rd[g & 1][i][2] = wave_ring_rd<off + 2048>(grs + bo);
+                constexpr int x = 7 - (GS_ * (g - NGN) + i);
+                rd01[g & 1][i] = wave_ring_rd128<k * ROWGB + x * 16>(grs01 + bo);
+                rd2[g & 1][i] = wave_ring_rd<k * ROWGB + 2048 + x * 8>(grs2 + bo);
               }
             });
           };
@@ -470,27 +502,37 @@ __global__ void __launch_bounds__(256, 2)
             constexpr int g = decltype(gc)::value;
             constexpr bool lastg = g + 1 == NGT;
             if constexpr (!lastg) issue(std::integral_constant<int, g + 1>{});
-            // (the u reads were issued in front of group 0's ring reads: waiting for these waits for them)
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(lastg ? 0 : 3 * GS_) : "memory");
-            wave_for<0, GS_>([&](auto ic) { ring_landed(rd[g & 1][decltype(ic)::value]); });
+            // (the lane's own pairs were requested in front of group 0's ring reads: waiting for these waits for them)
+            asm volatile(RING_T_WAIT_GEN("s_waitcnt lgkmcnt(%0)", "; %0") ::"n"(lastg ? 0 : 2 * GS_) : "memory");
+            wave_for<0, GS_>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              ring_landed(rd01[g & 1][i], rd2[g & 1][i]);
+            });
             if constexpr (g == 0) {
               // the lane's factors were requested by opaque statements too: nothing that uses them may be scheduled
               // in front of the wait above (a "memory" clobber does not order register-only instructions)
-              asm volatile("" : "+v"(svk));
-              wave_for<0, NA>([&](auto ac) { ring_landed(ug[decltype(ac)::value]); });
-              if (SYM) ring_landed(us);
-              if (w == 0) accX *= svk;
+              wave_for<0, 8>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr bool need = (q < 6 && (2 * q) / 3 < NA) || (q < 6 && (2 * q + 1) / 3 < NA) || (q >= 6 && SYM) || q == 7;
+                if constexpr (need) ring_landed(pv[q]);
+              });
+              if (w == 0) accX *= pv[7].y;
             }
             wave_for<0, GS_>([&](auto ic) {
               constexpr int i = decltype(ic)::value;
-              const double r0 = rd[g & 1][i][0], r1 = rd[g & 1][i][1], r2 = rd[g & 1][i][2];
+              const double r0 = rd01[g & 1][i].x, r1 = rd01[g & 1][i].y, r2 = rd2[g & 1][i];
               if constexpr (g < NGN) {
                 constexpr int t = GS_ * g + i;
-#pragma unroll
-                for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(r2, ug[a][2], fma(r1, ug[a][1], r0 * ug[a][0]));  // :738-746
+                wave_for<0, NA>([&](auto ac) {
+                  constexpr int a = decltype(ac)::value;
+                  constexpr int v0 = 3 * a, v1 = 3 * a + 1, v2 = 3 * a + 2;
+                  const double u0_ = (v0 & 1) ? pv[v0 / 2].y : pv[v0 / 2].x, u1_ = (v1 & 1) ? pv[v1 / 2].y : pv[v1 / 2].x,
+                               u2_ = (v2 & 1) ? pv[v2 / 2].y : pv[v2 / 2].x;
+                  acc[a * NS + t] *= fma(r2, u2_, fma(r1, u1_, r0 * u0_));  // :738-746
+                });
               } else {
                 constexpr int t = GS_ * (g - NGN) + i;
-                acc[NA * NS + t] *= fma(r2, us[2], fma(r1, us[1], r0 * us[0]));
+                acc[NA * NS + t] *= fma(r2, pv[7].x, fma(r1, pv[6].y, r0 * pv[6].x));
               }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -512,7 +554,7 @@ __global__ void __launch_bounds__(256, 2)
           prodacc_renorm(accX, exX);
         }
         gstore((b + 1) & 1);
-        __syncthreads();
+        RING_T_BARRIER_GEN();
       }
     }
   }

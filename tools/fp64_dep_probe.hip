@@ -69,6 +69,34 @@ __global__ void __launch_bounds__(64) kd(double* out, int iters, double b, doubl
   out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
+// the general entries' hypothesis: t = r0 * u0; t = fma(r1, u1, t); t = fma(r2, u2, t); acc *= t -- a chain of four on one
+// temporary (IL = 1, the order hipcc emits under register pressure) against IL hypotheses advanced in lock step (IL temps)
+template <int IL>
+__global__ void __launch_bounds__(64) kg(double* out, int iters, double u0, double u1, double u2) {
+  double acc[16], r[3];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 1.0 + 1e-9 * threadIdx.x;
+  for (int i = 0; i < 3; ++i) r[i] = 0.3 + 1e-9 * (i + threadIdx.x);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; i += IL) {
+      double t[IL];
+#pragma unroll
+      for (int q = 0; q < IL; ++q) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t[q]) : "v"(r[0]), "v"(u0));
+#pragma unroll
+      for (int q = 0; q < IL; ++q) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(t[q]) : "v"(r[1]), "v"(u1));
+#pragma unroll
+      for (int q = 0; q < IL; ++q) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(t[q]) : "v"(r[2]), "v"(u2));
+#pragma unroll
+      for (int q = 0; q < IL; ++q) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(acc[i + q]) : "v"(t[q]));
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+
 template <class F>
 void time_it(const char* name, int wps, int iters, double instr_per_iter, F launch) {
   const int blocks = 256 * 4 * wps;
@@ -101,6 +129,13 @@ void run(const char* name, int wps) {
     hipLaunchKernelGGL((k<DIST>), dim3(blocks), dim3(64), lds, 0, d, iters, 1e-3, 1.0);
   });
 }
+template <int IL>
+void rung(const char* name, int wps) {
+  const int lds = 160 * 1024 / (4 * wps) - 1024;
+  time_it(name, wps, 40000 / wps, 64.0, [&](int blocks, double* d, int iters) {
+    hipLaunchKernelGGL((kg<IL>), dim3(blocks), dim3(64), lds, 0, d, iters, 0.9, 0.8, 0.7);
+  });
+}
 template <int MODE>
 void rund(const char* name, int wps) {
   const int lds = 160 * 1024 / (4 * wps) - 1024;
@@ -116,6 +151,10 @@ int main() {
     run<2>("fma two pairs ahead", wps);
     run<4>("fma four pairs ahead", wps);
     run<8>("fma eight pairs ahead", wps);
+    rung<1>("mul-fma-fma-mul chain, one at a time", wps);
+    rung<2>("mul-fma-fma-mul, two in lock step", wps);
+    rung<4>("mul-fma-fma-mul, four in lock step", wps);
+    rung<8>("mul-fma-fma-mul, eight in lock step", wps);
     rund<1>("independent fma stream (16 chains)", wps);
     rund<0>("2 x mov_dpp -> fma back to back", wps);
   }

@@ -1,6 +1,7 @@
-# A/B of two builds of the library on one box: configs[2] bench leg (popscle_amd/lib/var/libmuxgl_old.so = the build before the change)
+# A/B of builds of the library on one box: configs[2] bench leg (popscle_amd/lib/var/libmuxgl_<name>.so, tools/build_variant.sh)
 cd /root/repo
 run() { python bench.py --config $1 --no-cpu-baseline --no-legs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d.get('kernel_ms') or d.get('kernel_ms_rank0_last_iteration'); print('$2 c$1', round(d['ms_per_step'],3), {x: round(v,3) for x,v in k.items()})"; }
-for i in 1 2; do
-  run 2 new; MUXGL_LIB=$PWD/popscle_amd/lib/var/libmuxgl_old.so run 2 old
+for i in ${ROUNDS:-1 2}; do
+  run 2 new
+  for v in "$@"; do MUXGL_LIB=$PWD/popscle_amd/lib/var/libmuxgl_$v.so run 2 $v; done
 done
