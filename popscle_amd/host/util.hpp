@@ -281,6 +281,16 @@ class OutFile {
   }
 
  private:
+  // deflate level of the blocks: zlib's 6, which is htslib's default; POPSCLE_AMD_GZ_LEVEL = 1 .. 9 for something else (the
+  // content is the same at any level; the writers' time is mostly number formatting, not deflate: level 4 measured ±0)
+  static int gz_level() {
+    static const int lvl = [] {
+      const char* e = getenv("POPSCLE_AMD_GZ_LEVEL");
+      const int v = e ? atoi(e) : 6;
+      return v >= 1 && v <= 9 ? v : 6;
+    }();
+    return lvl;
+  }
   static constexpr size_t kBlock = 0xff00;   // input bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
   static constexpr size_t kBatch = 4u << 20;
   // deflates whole blocks of buf_ (all of it when `all`), keeps the tail
@@ -295,7 +305,7 @@ class OutFile {
       dst.resize(18 + compressBound((uLong)len) + 8);
       z_stream zs;
       memset(&zs, 0, sizeof(zs));
-      if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+      if (deflateInit2(&zs, gz_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
         bad = true;
         return;
       }
