@@ -280,8 +280,35 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const do
       int32_t gq = old_clust0 ? (int32_t)(-0.1 * log10(1 - pps[bestG] + 1e-100))
                               : (int32_t)(-10 * log10(1.0 - pps[bestG] + 1e-100));
       if (gq > 255) gq = 255;
-      appendf(o, "\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg", bestG == 2 ? 1 : 0, bestG > 0 ? 1 : 0, gq, c[0], c[1],
-              c[2], pls[0], pls[1], pls[2], pps[0], pps[1], pps[2]);
+      // "\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg" (cmd_cram_freemux2.cpp:650-652), digit for digit (util.hpp:
+      // fmt_int, fmt_g3_or_printf -- the latter hands any value it is not sure of to printf itself)
+      char fb[192];
+      int k = 0;
+      fb[k++] = '\t';
+      fb[k++] = bestG == 2 ? '1' : '0';
+      fb[k++] = '/';
+      fb[k++] = bestG > 0 ? '1' : '0';
+      fb[k++] = ':';
+      k += fmt_int(gq, fb + k);
+      fb[k++] = ':';
+      k += fmt_int(c[0], fb + k);
+      fb[k++] = ':';
+      k += fmt_int(c[1], fb + k);
+      fb[k++] = ',';
+      k += fmt_int(c[2], fb + k);
+      fb[k++] = ':';
+      k += fmt_int(pls[0], fb + k);
+      fb[k++] = ',';
+      k += fmt_int(pls[1], fb + k);
+      fb[k++] = ',';
+      k += fmt_int(pls[2], fb + k);
+      fb[k++] = ':';
+      k += fmt_g3_or_printf(pps[0], fb + k);
+      fb[k++] = ',';
+      k += fmt_g3_or_printf(pps[1], fb + k);
+      fb[k++] = ',';
+      k += fmt_g3_or_printf(pps[2], fb + k);
+      o.append(fb, (size_t)k);
     }
     o.push_back('\n');
   };
@@ -820,6 +847,60 @@ int cmd_dump_plp(int argc, char** argv) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ selftest-fmt
+// fmt_g3 / fmt_int against printf on N random values plus the hard ones (exact ties of the third digit and their
+// neighbours, powers of ten, both ends of the "%e" / "%f" switch); prints the counts, exit status 1 on any difference
+int cmd_selftest_fmt(int argc, char** argv) {
+  const long N = argc > 0 ? atol(argv[0]) : 1000000;
+  uint64_t st = 0x9e3779b97f4a7c15ull;
+  auto rnd = [&]() {  // xorshift64*
+    st ^= st >> 12, st ^= st << 25, st ^= st >> 27;
+    return st * 2685821657736338717ull;
+  };
+  auto unif = [&]() { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); };
+  long n = 0, declined = 0, bad = 0;
+  char a[64], b[64];
+  auto check = [&](double x) {
+    ++n;
+    const int k = fmt_g3(x, a);
+    if (k < 0) {
+      ++declined;
+      return;
+    }
+    a[k] = 0;
+    snprintf(b, sizeof(b), "%.3lg", x);
+    if (strcmp(a, b)) {
+      if (bad++ < 20) fprintf(stderr, "fmt_g3 %.17g: %s, printf: %s\n", x, a, b);
+    }
+  };
+  for (long i = 0; i < N; ++i) {
+    const double u = unif();
+    check(u);
+    check(u * pow(10.0, -(double)(rnd() % 20)));
+    check(pow(10.0, -100.0 * unif()) * (1 + u));
+    const int D = 100 + (int)(rnd() % 900), E = -(int)(rnd() % 12);
+    const double t = (D + 0.5) * pow(10.0, E - 2), r = D * pow(10.0, E - 2);
+    check(t), check(nextafter(t, 0)), check(nextafter(t, 1e9));
+    check(r), check(nextafter(r, 0)), check(nextafter(r, 1e9));
+    const int32_t v = (int32_t)rnd();
+    const int k = fmt_int(v, a);
+    a[k] = 0;
+    snprintf(b, sizeof(b), "%d", v);
+    if (strcmp(a, b)) ++bad;
+  }
+  for (double x : {1.0, 0.9995, 0.99949999999999994, 0.9996, 1e-5, 9.995e-5, 9.9949999e-5, 1e-4, 0.0001235, 0.5, 0.125, 1e-100,
+                   1e-99, 9.99e-100, 2.5e-7, 999.4, 999.5, 12.35, 100.0, 1e-290, 0.0, -1.0, 1e3, 1e-300})
+    check(x);
+  for (int32_t v : {0, 1, -1, 9, 10, 255, INT32_MAX, INT32_MIN}) {
+    const int k = fmt_int(v, a);
+    a[k] = 0;
+    snprintf(b, sizeof(b), "%d", v);
+    if (strcmp(a, b)) ++bad;
+  }
+  printf("%ld values, %ld left to printf, %ld differences\n", n, declined, bad);
+  return bad != 0;
+}
+
 // ------------------------------------------------------------------------------------------------ bgzf
 // writer-only command for the CPU tests: copies a file through the BGZF writer of util.hpp (line by line, as the
 // commands' printf calls do)
@@ -855,6 +936,7 @@ int main(int argc, char** argv) {
     if (cmd == "freemuxlet-old") return cmd_freemuxlet_old(argc - 2, argv + 2);
     if (cmd == "dump-plp") return cmd_dump_plp(argc - 2, argv + 2);
     if (cmd == "bgzf") return cmd_bgzf(argc - 2, argv + 2);
+    if (cmd == "selftest-fmt") return cmd_selftest_fmt(argc - 2, argv + 2);
     if (cmd == "synth-plp") return cmd_synth_plp(argc - 2, argv + 2);
     fprintf(stderr, "Cannot recognize the command %s\n", argv[1]);
     return 1;

@@ -480,3 +480,11 @@ def test_errors_next_to_the_vcf_thread_exit_cleanly(exe, tmp_path):
     assert r.returncode == 1 and "has 3 fields" in r.stderr, (r.returncode, r.stderr)
     r = run("--field", "GP")  # both stages fail: the VCF's error is the one the reference would meet first
     assert r.returncode == 1 and "Cannot parse posterior probability" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_writer_number_formatting_is_printf(exe):
+    """The cluster VCF's sample fields are formatted without printf (util.hpp: fmt_int, fmt_g3): the binary's own
+    comparison against "%d" / "%.3lg" over random values, exact ties of the third digit and their neighbours."""
+    r = subprocess.run([exe, "selftest-fmt", "200000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 differences" in r.stdout
