@@ -366,8 +366,15 @@ __global__ void __launch_bounds__(64, P == 8 ? OCT_WAVES : 2)
       } else {
         rc0 = lr[(i + 3) * O_SLOTS];
       }
+#ifdef OCT_OLD_LOAD_ORDER
       load_rowl(Rnn, rc2.x);
       abn = ab_of(rc1);
+#else
+      // (issue order = completion order: the gathered row, which nobody reads for two sweeps, goes last, so that the
+      //  sweep's wait for the next entry's {A, B, 2B} leaves it in flight -- fmx_oct.hip has the measurement)
+      abn = ab_of(rc1);
+      load_rowl(Rnn, rc2.x);
+#endif
       __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
       sweepL(Rc, abc);
       __builtin_amdgcn_sched_barrier(0);
