@@ -247,6 +247,8 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const do
     const int n = snprintf(buf, sizeof(buf), fmt, args...);
     o.append(buf, (size_t)(n < (int)sizeof(buf) ? n : (int)sizeof(buf) - 1));
   };
+  std::atomic<int> checked(0);
+  static const bool check_all = getenv("POPSCLE_AMD_CHECK_FORMAT") != nullptr;
   auto format_snp = [&](int64_t v, std::string& o) {
     const SnpInfo& s = p.snps[(size_t)v];
     appendf(o, "%s\t%d\t.\t%c\t%c\t.\tPASS\tAF=%.5lf\tGT:GQ:DP:AD:PL:GP", p.rid2chr[(size_t)s.rid].c_str(), s.pos,
@@ -308,6 +310,18 @@ void write_cluster_vcf(const std::string& path, const Pileup& p, int K, const do
       k += fmt_g3_or_printf(pps[1], fb + k);
       fb[k++] = ',';
       k += fmt_g3_or_printf(pps[2], fb + k);
+      // the reference's own conversion specification stays the authority: the first fields of every file (and every
+      // field with POPSCLE_AMD_CHECK_FORMAT=1) are also printed with it and compared
+      if (check_all || checked.load(std::memory_order_relaxed) < 4096) {
+        checked.fetch_add(1, std::memory_order_relaxed);
+        char ref[192];
+        const int n = snprintf(ref, sizeof(ref), "\t%d/%d:%d:%d:%d,%d:%d,%d,%d:%.3lg,%.3lg,%.3lg", bestG == 2 ? 1 : 0,
+                               bestG > 0 ? 1 : 0, gq, c[0], c[1], c[2], pls[0], pls[1], pls[2], pps[0], pps[1], pps[2]);
+        if (n != k || memcmp(ref, fb, (size_t)k) != 0) {
+          fb[k] = 0;
+          fatal("cluster VCF: the fast number formatting wrote '%s' where printf writes '%s'", fb + 1, ref + 1);
+        }
+      }
       o.append(fb, (size_t)k);
     }
     o.push_back('\n');

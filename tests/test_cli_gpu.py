@@ -102,7 +102,10 @@ def test_freemuxlet_cli(tmp_path):
     prefix = str(tmp_path / "plp")
     plpio.write_plp(prefix, p, seed=8)
     out = str(tmp_path / "out")
+    # (POPSCLE_AMD_CHECK_FORMAT: every sample field of the cluster VCF is also printed with the reference's own
+    #  conversion specification and compared with what the writer's fast formatting produced)
     r = subprocess.run([BIN, "freemuxlet", "--plp", prefix, "--nsample", str(K), "--out", out, "--seed", "1"],
+                       env=dict(os.environ, POPSCLE_AMD_CHECK_FORMAT="1"),
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     d = pyplp.load(prefix)
