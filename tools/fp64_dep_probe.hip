@@ -1,6 +1,9 @@
 // FP64 dependent-issue probe: what does an fma -> mul pair on ONE temporary (the order hipcc emits for
 // `acc[i] *= fma(B, P[i], X)` under register pressure) cost against the same instructions with the dependent pair
 // D instructions apart, at 1 / 2 / 4 waves per SIMD?  Also a DPP mov feeding an fma.
+// NB (round 5): hipcc puts an s_nop between two asm statements when the second reads a register the first wrote, so the
+// variants below that are written as separate statements also measure those; tools/fp64_ilp_probe.hip keeps every
+// variant's instructions in ONE asm block and is the probe DESIGN.md quotes.
 //   hipcc --offload-arch=gfx950 -O3 tools/fp64_dep_probe.hip -o tools/bin/fp64_dep_probe && tools/bin/fp64_dep_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
