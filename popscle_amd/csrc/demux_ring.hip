@@ -9,10 +9,11 @@
 // file replaced spent 55 of 183 vector instructions per (wave, entry) around the sweep: every wave fetched the marker's
 // row and the entry's (A, Bl, Bm) table row for itself through a register pipeline two entries deep, wrote a ring of its
 // own, and the symmetric alpha walked all entries again in a launch of its own.  Here:
-//   * workgroup = work unit (a cell, or a part of a long one: wave_item), four waves; wave w owns the rotation steps
-//     16 w + 1 .. 16 w + 16 of up to four non-symmetric alphas AND the distances 8 w + 1 .. 8 w + 8 of the symmetric one
-//     (alpha = 0.5 meets every unordered pair within 32 steps): 72 product accumulators per lane, all five pair alphas of
-//     the north_star grid in ONE walk;
+//   * workgroup = work unit (a cell, or a part of a long one: wave_item), four waves; wave w owns sixteen rotation
+//     steps of up to four non-symmetric alphas -- partners at distances 8 w + 1 .. 8 w + 8 and 32 + 8 w + 1 .. 32 + 8 w + 8 --
+//     AND the distances 8 w + 1 .. 8 w + 8 of the symmetric one (alpha = 0.5 meets every unordered pair within 32 steps),
+//     whose partners are those of its first eight steps (round 5: they used to be read a second time): 72 product
+//     accumulators per lane, all five pair alphas of the north_star grid in ONE walk;
 //   * the marker rows (s, rho per sample: wave_gm_kernel) are STAGED: the entries of a unit are taken in batches of
 //     eight; each wave fetches two rows of the next batch (one 16-byte load per lane and row) while the current batch is
 //     swept and leaves them in LDS -- rho twice over, so that the staged row IS the ring all four waves read their
@@ -148,7 +149,12 @@ __global__ void __launch_bounds__(256, 2)
                           const double* __restrict__ pgt, int pg_by_record, double* __restrict__ ll) {
   constexpr int NS = NA > 0 ? 16 : 0, NSY = SYM ? 8 : 0, NACC = NA * NS + NSY;
   constexpr int NXL = NACC / 2, NXV = NACC - NXL;  // exponents in LDS / in registers (GEN: 36 KB + the 44 KB stage = 80 KB per workgroup)
-  constexpr int GN = NS / 4, GS = NSY / 4, GT = GN + GS;  // groups of four ring reads per entry
+  // SHARE (round 5): with both kinds of alphas in the launch, wave w owns the rotation steps 8 w .. 8 w + 7 and
+  // 32 + 8 w .. 39 + 8 w (slots t = 0 .. 7 and 8 .. 15) -- so that the partners of its symmetric distances 8 w + 1 .. 8 w + 8
+  // are the partners of its first eight steps, and the symmetric alpha needs no ring reads of its own: 16 partner values
+  // per wave and entry instead of 24 (what an LDS read costs the sweep is the bytes it returns).
+  constexpr bool SHARE = NA > 0 && SYM;
+  constexpr int GN = NS / 4, GS = SHARE ? 0 : NSY / 4, GT = GN + GS;  // groups of four ring reads per entry
   constexpr int NA1 = NA > 0 ? NA : 1;
   static_assert(GT % 2 == 0 && GT > 0, "the read buffers alternate per group");
   constexpr int RG_B = 2;        // general entries per staged batch
@@ -193,7 +199,9 @@ __global__ void __launch_bounds__(256, 2)
   const uint32_t base0 = (uint32_t)(uintptr_t)&stage[0][0][0];
   constexpr uint32_t ROWB = RL_ROW * 8, BUFB = RL_B * ROWB;
   const uint32_t ownoff = (uint32_t)j * 8u, own2off = (uint32_t)((w == 0 ? 192 : 128) + j) * 8u;
-  const uint32_t rboff = (uint32_t)(j + 64 - 16 * w - 16) * 8u, rsoff = (uint32_t)(j + 64 - 8 * w - 8) * 8u;
+  // ring reads: slot t < 8 is step 8 w + t, read at [j + 63 - 8 w - t] = rsoff + (7 - t) -- which is also the symmetric
+  // distance 8 w + t + 1; slot t >= 8 is step 24 + 8 w + t, read at [j + 39 - 8 w - t] = rboff + (15 - t)
+  const uint32_t rboff = (uint32_t)(j + 24 - 8 * w) * 8u, rsoff = (uint32_t)(j + 64 - 8 * w - 8) * 8u;
 
   // ---- loader: rows of the entries w and w + 4 of a batch
   uint32_t rcs[RL_B], rcl[RL_B], rns[RL_B], rnl[RL_B];  // records of the current / next batch: snp, table row offset
@@ -293,7 +301,8 @@ __global__ void __launch_bounds__(256, 2)
       }
       wave_for<0, 4>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (g < GN) rd[g & 1][i] = wave_ring_rd<k * ROWB + (15 - (4 * g + i)) * 8>(rb);
+        if constexpr (g < GN && 4 * g + i >= 8) rd[g & 1][i] = wave_ring_rd<k * ROWB + (15 - (4 * g + i)) * 8>(rb);
+        else if constexpr (g < GN) rd[g & 1][i] = wave_ring_rd<k * ROWB + (7 - (4 * g + i)) * 8>(rs);
         else rd[g & 1][i] = wave_ring_rd<k * ROWB + (7 - (4 * (g - GN) + i)) * 8>(rs);
       });
     };
@@ -334,6 +343,7 @@ __global__ void __launch_bounds__(256, 2)
             constexpr int t = 4 * g + i;
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[a * NS + t] *= fma(lM[p][a + 1], rd[g & 1][i], u0[a]);
+            if constexpr (SHARE && t < 8) acc[NA * NS + t] *= fma(lM[p][5], rd[g & 1][i], u0s);
           } else {
             constexpr int t = 4 * (g - GN) + i;
             acc[NA * NS + t] *= fma(lM[p][5], rd[g & 1][i], u0s);
@@ -459,7 +469,7 @@ __global__ void __launch_bounds__(256, 2)
       gstore(0);
       __syncthreads();
       const uint32_t gown = base0 + 3072u + (uint32_t)j * 16u;
-      const uint32_t grb2 = base0 + (uint32_t)(j + 64 - 16 * w - 16) * 8u, grs2 = base0 + (uint32_t)(j + 64 - 8 * w - 8) * 8u;
+      const uint32_t grb2 = base0 + rboff, grs2 = base0 + rsoff;  // (the same slots as the linear walk's)
       const uint32_t grb01 = 2u * grb2 - base0, grs01 = 2u * grs2 - base0;
       // Bits since the last renormalisation: the linear walk leaves at most RL_BUDGET + 8 * 35 = 880 behind; a general entry
       // costs < 37 (every factor >= 1.1e-11): renormalising once more than 870 are counted keeps a product above
@@ -479,17 +489,21 @@ __global__ void __launch_bounds__(256, 2)
             if constexpr (need) pv[q] = wave_ring_rd128<k * ROWGB + q * 1024>(gown + bo);
           });
           // partner triples GS_ steps at a time, a group ahead of their use: (g0, g1) as one 16-byte read, g2
-          constexpr int GS_ = RG_G, NGN = NS / GS_, NGS = NSY / GS_, NGT = NGN + NGS;
+          constexpr int GS_ = RG_G, NGN = NS / GS_, NGS = SHARE ? 0 : NSY / GS_, NGT = NGN + NGS;
           dbl2 rd01[2][GS_];
           double rd2[2][GS_];
           auto issue = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             wave_for<0, GS_>([&](auto ic) {
               constexpr int i = decltype(ic)::value;
-              if constexpr (g < NGN) {
+              if constexpr (g < NGN && GS_ * g + i >= 8) {
                 constexpr int x = 15 - (GS_ * g + i);
                 rd01[g & 1][i] = wave_ring_rd128<k * ROWGB + x * 16>(grb01 + bo);
                 rd2[g & 1][i] = wave_ring_rd<k * ROWGB + 2048 + x * 8>(grb2 + bo);
+              } else if constexpr (g < NGN) {
+                constexpr int x = 7 - (GS_ * g + i);
+                rd01[g & 1][i] = wave_ring_rd128<k * ROWGB + x * 16>(grs01 + bo);
+                rd2[g & 1][i] = wave_ring_rd<k * ROWGB + 2048 + x * 8>(grs2 + bo);
               } else {
                 constexpr int x = 7 - (GS_ * (g - NGN) + i);
                 rd01[g & 1][i] = wave_ring_rd128<k * ROWGB + x * 16>(grs01 + bo);
@@ -530,6 +544,7 @@ __global__ void __launch_bounds__(256, 2)
                                u2_ = (v2 & 1) ? pv[v2 / 2].y : pv[v2 / 2].x;
                   acc[a * NS + t] *= fma(r2, u2_, fma(r1, u1_, r0 * u0_));  // :738-746
                 });
+                if constexpr (SHARE && t < 8) acc[NA * NS + t] *= fma(r2, pv[7].x, fma(r1, pv[6].y, r0 * pv[6].x));
               } else {
                 constexpr int t = GS_ * (g - NGN) + i;
                 acc[NA * NS + t] *= fma(r2, pv[7].x, fma(r1, pv[6].y, r0 * pv[6].x));
@@ -569,17 +584,16 @@ __global__ void __launch_bounds__(256, 2)
   const uint32_t rb = base0 + rboff, rs = base0 + rsoff;
   wave_for<0, NS>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
-    if (16 * w + t >= 63) return;
-    double lw = wave_ring_rd<(15 - t) * 8>(rb);
+    const int T = t < 8 ? 8 * w + t : 24 + 8 * w + t;  // the slot's rotation step (see SHARE)
+    if (T >= 63) return;                               // (the lane itself; wave-uniform)
+    double lw = t < 8 ? wave_ring_rd<(7 - (t < 8 ? t : 0)) * 8>(rs) : wave_ring_rd<(15 - (t < 8 ? 8 : t)) * 8>(rb);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lw));
     lw += logW;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-      constexpr int x = 0;
-      (void)x;
       const int xi = a * NS + t;
       const int32_t e = xi < NXV ? ex[xi < NXV ? xi : 0] : exs[xi < NXV ? 0 : xi - NXV][j];
-      out[((size_t)sel.n[a] * 64 + 16 * w + t) * 64 + j] = prodacc_log(acc[xi], e) + lw;
+      out[((size_t)sel.n[a] * 64 + T) * 64 + j] = prodacc_log(acc[xi], e) + lw;
     }
   });
   wave_for<0, NSY>([&](auto tc) {
