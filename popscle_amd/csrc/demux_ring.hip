@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256)
 // other two and of the symmetric one -- and leave them in LDS; the sweeping waves read their u (15 numbers per lane,
 // formed once per workgroup instead of once per wave) and the partners' triples from there and carry no scalar
 // operands at all.
-// (tells the compiler that the three values, requested by opaque ds_read statements, are defined from here on)
+// (tells the compiler that the values, requested by opaque ds_read statements, are defined from here on)
 __device__ __forceinline__ void ring_landed(dbl2& a, double& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void ring_landed(dbl2& a) { asm volatile("" : "+v"(a)); }
 
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, 2)
 #define RING_GEN_G 1
 #endif
   constexpr int RG_G = RING_GEN_G;  // rotation steps per group of ring reads in the general walk
-  constexpr int RG_ROW = 1408;   // doubles per staged general entry: ring[3][128], singlet factor[64], u[5][3][64]
+  constexpr int RG_ROW = 1408;   // doubles per staged general entry: ring of (g0, g1) [128][2], ring of g2 [128], own pairs [8][64][2] (gstore)
   constexpr int STAGE_N = (GEN && 2 * RG_B * RG_ROW > 2 * RL_B * RL_ROW) ? 2 * RG_B * RG_ROW : 2 * RL_B * RL_ROW;
   __shared__ double stage_all[STAGE_N];
   double (*stage)[RL_B][RL_ROW] = reinterpret_cast<double (*)[RL_B][RL_ROW]>(stage_all);
@@ -194,8 +194,7 @@ __global__ void __launch_bounds__(256, 2)
   }
 
   // LDS byte addresses inside a staged row: own rho at [j]; second own value: the singlet factor [192 + j] (wave 0) or the
-  // sum s [128 + j]; ring reads of the non-symmetric steps relative to [j + 64 - 16 w - 16], of the symmetric distances
-  // relative to [j + 64 - 8 w - 8]
+  // sum s [128 + j]; the ring reads: below
   const uint32_t base0 = (uint32_t)(uintptr_t)&stage[0][0][0];
   constexpr uint32_t ROWB = RL_ROW * 8, BUFB = RL_B * ROWB;
   const uint32_t ownoff = (uint32_t)j * 8u, own2off = (uint32_t)((w == 0 ? 192 : 128) + j) * 8u;
