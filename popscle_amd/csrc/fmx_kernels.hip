@@ -1202,10 +1202,14 @@ int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p) {
   return 0;
 }
 
-static int fmx_oct_chunk() {  // entries per chunk of the oct E-step (MUXGL_FMX_CH: tuning)
+// entries per chunk of the oct E-step (MUXGL_FMX_CH: tuning).  256 since the end of round 5: with the sweep moving bytes
+// as fast as the fabric gives them, fewer chunk partials for the sweep to write and the reduce to read
+// beat the shorter tail of 192-entry chunks (configs[3]: 2.05-2.08 -> 2.01-2.02 ms an iteration; 320 level, 384 +0.5 %,
+// 128 +7 %); demuxlet's oct sweep keeps MUXGL_QUAD_CH
+static int fmx_oct_chunk() {
   static const int ch = [] {
     const char* ev = getenv("MUXGL_FMX_CH");
-    return ev && atoi(ev) >= 16 ? atoi(ev) / 4 * 4 : MUXGL_QUAD_CH;
+    return ev && atoi(ev) >= 16 ? atoi(ev) / 4 * 4 : 256;
   }();
   return ch;
 }
