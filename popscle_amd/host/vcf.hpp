@@ -161,17 +161,33 @@ class VcfReader {
     const int fi = fmt_index(field);
     if (fi < 0) return false;
     if (field == "PL") return parse_likelihoods(fi, nalleles, ngenos);
-    // GP (or any float FORMAT key) as posterior (:414-459)
+    // GP (or any float FORMAT key) as posterior (:417-459), float arithmetic throughout
+    std::vector<float> gpSums((size_t)ngenos, 0.f);
+    for (int i = 0; i < nalleles; ++i)
+      for (int j = 0; j <= i; ++j) gpSums[(size_t)((i + 1) * i / 2 + j)] = (float)(((i == j) ? 1.0 : 2.0) / (float)(nalleles * nalleles));
     for (int i = 0; i < ns; ++i) {
       std::vector<std::string> v = split_char(sample_field(i, fi), ',');
       float* o = &gps[(size_t)i * ngenos];
       float sumgp = 0;
       for (int j = 0; j < ngenos; ++j) {
+        // a missing value is htslib's bcf_float_missing / vector_end, both NaN bit patterns
         o[j] = (j < (int)v.size() && v[(size_t)j] != ".") ? (float)strtod(v[(size_t)j].c_str(), nullptr) : NAN;
         sumgp += o[j];
       }
-      for (int j = 0; j < ngenos; ++j) o[j] /= sumgp;
+      for (int j = 0; j < ngenos; ++j) {
+        o[j] /= sumgp;
+        gpSums[(size_t)j] += o[j];
+      }
     }
+    for (int j = 0; j < ngenos; ++j) gpSums[(size_t)j] /= (int32_t)(ns + 1.0);
+    // :452-457 with gt_error = 0: (1-0)*gp + 0*gpSums changes nothing -- unless gpSums is NaN (a sample of this record
+    // had a missing value), which 0*NaN spreads to every sample, as in the reference
+    const double gt_error = 0.0;
+    for (int i = 0; i < ns; ++i)
+      for (int j = 0; j < ngenos; ++j) {
+        float& x = gps[(size_t)i * ngenos + j];
+        x = (float)((1.0 - gt_error) * x + gt_error * gpSums[(size_t)j]);
+      }
     return true;
   }
 

@@ -5,8 +5,9 @@ cmd_cram_demuxlet.cpp / cmd_cram_freemux2.cpp and sc_drop_seq.cpp's per-entry ar
 into oracle/_ref/libscdrop_ref.so (oracle/Makefile, oracle/ref_hot.cpp.in: verbatim line ranges, no stand-ins), fed the
 packed inputs in packed order (tests/ref_binding.py RefScl.from_packed).  The generator also requires the CPU oracle
 (oracle/muxgl_oracle.c) to reproduce every array bit for bit before it writes a file, and records `source` in it.
-fmxold_k4.npz (freemuxlet-old's initial clustering, out of scope per SURVEY section 2 row 2b) remains a regression
-vector of the oracle.  Inputs come from popscle_amd.synth with fixed seeds; each .npz holds the packed inputs and the
+fmxold_k4.npz: its initial clustering part (cmd_cram_freemuxlet.cpp:176-346, out of scope per SURVEY section 2 row 2b)
+remains a regression vector of the oracle; its EM part (em_* arrays) is the reference's own cmd_cram_freemuxlet.cpp:456-653
+run from those clusters (scref_freemuxlet_old).  Inputs come from popscle_amd.synth with fixed seeds; each .npz holds the packed inputs and the
 expected outputs, so the GPU box can check the HIP path against the reference's numbers without /root/reference.
 
     python tests/golden/make_golden.py
@@ -98,11 +99,31 @@ def fmxold_case(name, C, S, K, seed, **kw):
         jit = rng.integers(0, 2**31, (C, K)) / 2.0**31 / 1000.0
         cl, ch, _ = ob.fmxold_vote_refine(C, K, dd, orand, jit, cl, thres, keep_init_missing=(it == 0))
         orands.append(orand), jits.append(jit), clusts.append(cl), changed.append(ch)
+    # the EM loop from those clusters: THE REFERENCE'S OWN cmd_cram_freemuxlet.cpp:107-161,359-370,432-653 (compiled as
+    # verbatim ranges, oracle/ref_hot.cpp.in scref_freemuxlet_old); ten iterations, geno_error in the last one only
+    em_ge, em_dp = 0.05, 0.5
+    ref = rb.RefScl.from_packed(p).freemuxlet_old(K, cl, em_dp, em_ge, full_ll=True, cluster_pileups=True)
+    assert ref["n_iter"] == 10
+    cplp = ob.fmx_build_cluster_pileup(p, e, K, cl)
+    cells = ob.fmx_init_cells(cl)
+    for it in range(10):
+        nsng, namb, _, full = ob.fmx_iterate(p, e, K, cplp, cells, em_dp, em_ge if it == 9 else 0.0, full_ll=True)
+        assert (nsng, namb) == tuple(ref["counters"][it]), "oracle != reference"
+        for f in cells.dtype.names:
+            if f not in ("clust", "_pad"):
+                assert cells[f].tobytes() == ref["cells"][it][f].tobytes(), ("oracle != reference", it, f)
+        assert np.array_equal(full, ref["full_ll"][it]) and cplp.tobytes() == ref["cplp"][it].tobytes()
+    fin = ref["cplp"][9]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), C=p.C, S=p.S, K=K, cell_ptr=p.cell_ptr,
                         entry_snp=p.entry_snp, entry_rptr=p.entry_rptr, reads=p.reads, af=p.af, bf_thres=thres,
                         frac_init_clust=frac, order=order, dropd=dd, jitter0=jit0, clust0=clust0, ccounts0=cc0,
                         orands=np.array(orands), jitters=np.array(jits), clusts=np.array(clusts),
-                        changed=np.array(changed))
+                        changed=np.array(changed),
+                        em_geno_error=em_ge, em_doublet_prior=em_dp, em_counters=ref["counters"], em_cells=ref["cells"],
+                        em_full_ll_first=ref["full_ll"][0], em_full_ll_last=ref["full_ll"][9],
+                        em_cluster_gls=fin["gls"], em_cluster_cnt=np.stack([fin["nreads"], fin["nref"], fin["nalt"]], axis=-1),
+                        em_source="reference: oracle/_ref/libscdrop_ref.so scref_freemuxlet_old "
+                                  "(cmd_cram_freemuxlet.cpp:107-108,113-161,359-370,432-453,456-653)")
     print(name, "cells", p.C, "pairs", dd.size, "first pass", np.bincount(clust0[clust0 >= 0], minlength=K), "changed",
           changed)
 

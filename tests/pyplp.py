@@ -19,6 +19,141 @@ def _lines(path):
             yield t
 
 
+PL_MISSING = -2**31  # bcf_int32_missing: toProb() takes it as uint32 > 255 -> phred2Prob[255] (PhredHelper.h:40)
+
+
+def _toprob(pl):
+    """phredConv.toProb (PhredHelper.h:40, table PhredHelper.cpp:31)"""
+    pl = pl & 0xFFFFFFFF
+    return math.pow(0.1, (255 if pl > 255 else pl) * 0.1)
+
+
+def pl_em(pls, nal, ploidies=None):
+    """BCFFilteredReader::parse_likelihoods, bcf_filtered_reader.cpp:261-324: pls[n][ngenos] of the selected samples ->
+    (float32 gps[n][ngenos], acs[nal] (allele counts), an)"""
+    n = len(pls)
+    ng = nal * (nal + 1) // 2
+    ploidies = [2] * n if ploidies is None else list(ploidies)
+    gps = np.zeros((n, ng), dtype=np.float32)
+    acs = [1.0 / nal] * nal
+    gp = [0.0] * ng
+    an = 0
+    for it in range(10):
+        newacs = [0.0] * nal
+        an = 0
+        for v in range(n):
+            if ploidies[v] == 2:
+                sumgp = 0.0
+                l = 0
+                for j in range(nal):
+                    for k in range(j + 1):
+                        gp[l] = (1 if j == k else 2) * acs[j] * acs[k] * _toprob(int(pls[v][l]))
+                        sumgp += gp[l]
+                        l += 1
+                l = 0
+                for j in range(nal):
+                    for k in range(j + 1):
+                        gp[l] /= sumgp
+                        newacs[j] += gp[l]
+                        newacs[k] += gp[l]
+                        l += 1
+                an += 2
+            elif ploidies[v] == 1:
+                gp = [0.0] * ng
+                sumgp = 0.0
+                for j in range(nal):
+                    l = (j + 1) * (j + 2) // 2 - 1
+                    gp[l] = acs[j] * _toprob(int(pls[v][l]))
+                    sumgp += gp[l]
+                for j in range(nal):
+                    l = (j + 1) * (j + 2) // 2 - 1
+                    gp[l] /= sumgp
+                    newacs[j] += gp[l]
+                an += 1
+            if it == 9:
+                for l in range(ng):
+                    gps[v, l] = np.float32(gp[l])
+        acs = [x / an for x in newacs]
+    return gps, [a * an for a in acs], an
+
+
+def gp_normalise(vals, nal, gt_error=0.0):
+    """parse_posteriors, GP branch, bcf_filtered_reader.cpp:422-457: float arithmetic; each sample divided by its own
+    float sum; then (1-gt_error)*gp + gt_error*gpSums in double, stored as float.  With gt_error == 0 (the only value
+    load_from_plp passes) the second step changes nothing -- unless gpSums is NaN (a sample with a missing value), which
+    0*NaN spreads to every sample of the record."""
+    f32 = np.float32
+    n = len(vals)
+    ng = nal * (nal + 1) // 2
+    g = np.array(vals, dtype=np.float32).reshape(n, ng)
+    sums = np.zeros(ng, dtype=np.float32)
+    for i in range(nal):
+        for j in range(i + 1):
+            sums[(i + 1) * i // 2 + j] = f32((1.0 if i == j else 2.0) / float(f32(nal * nal)))
+    with np.errstate(all="ignore"):
+        for v in range(n):
+            s = f32(0)
+            for j in range(ng):
+                s = f32(s + g[v, j])
+            for j in range(ng):
+                g[v, j] = f32(g[v, j] / s)
+                sums[j] = f32(sums[j] + g[v, j])
+        for j in range(ng):
+            sums[j] = f32(sums[j] / f32(int(n + 1.0)))
+        for v in range(n):
+            for j in range(ng):
+                g[v, j] = f32((1.0 - gt_error) * float(g[v, j]) + gt_error * float(sums[j]))
+    return g
+
+
+def gt_posteriors(gidx, acs, an, nal, gt_error=0.0, ploidies=None):
+    """parse_posteriors, GT branch, bcf_filtered_reader.cpp:385-409 (samples in consecutive columns): one-hot of the
+    genotype index, a missing genotype -> HWE from the allele counts with pseudo-counts, all through float"""
+    f32 = np.float32
+    n = len(gidx)
+    ng = nal * (nal + 1) // 2
+    ploidies = [2] * n if ploidies is None else list(ploidies)
+    out = np.zeros((n + 1) * ng, dtype=np.float32)
+    for v in range(n):
+        g = gidx[v]
+        o = v * ng
+        if g < 0:
+            if ploidies[v] == 2:
+                l = 0
+                for j in range(nal):
+                    for k in range(j + 1):
+                        out[o + l] = f32((1.0 if j == k else 2.0) * (acs[j] + 1.0 / nal) / (an + 1.0) * (acs[k] + 1.0 / nal) / (an + 1.0))
+                        l += 1
+            elif ploidies[v] == 1:
+                out[o:o + 2 * ng] = 0  # :401 clears ngenos * sizeof(double) bytes of a float array: the next column too
+                for j in range(nal):
+                    out[o + (j + 1) * (j + 2) // 2 - 1] = f32((acs[j] + 1.0 / nal) / (an + 1.0))
+        else:
+            for j in range(ng):
+                out[o + j] = f32(1.0 - gt_error) if g == j else f32(gt_error / (ng - 1.0))
+    return out[:n * ng].reshape(n, ng)
+
+
+def gp_row(float_gp, geno_error_offset=0.1, geno_error_coeff=0.0, r2=None):
+    """load_from_plp, sc_drop_seq.cpp:287-315: the double row handed to add_snp from the reader's float posteriors"""
+    g = np.asarray(float_gp, dtype=np.float32).astype(np.float64).reshape(-1)
+    avg = [1e-10, 1e-10, 1e-10]
+    for i in range(g.size):
+        avg[i % 3] += g[i]
+    s = avg[0] + avg[1] + avg[2]
+    avg = [a / s for a in avg]
+    err = geno_error_offset
+    if geno_error_coeff > 0:
+        err += (1 - geno_error_offset) * float(np.float32(1) - np.float32(r2)) * geno_error_coeff  # `1-r2flts[0]` is a float expression
+    if err > 0.999:
+        err = 0.999
+    if err < 0:
+        err = 0
+    if err > 0:
+        g = np.array([(1 - err) * g[i] + err * avg[i % 3] for i in range(g.size)])
+    return g
+
+
 def vcf_records(path, field, min_mac=1, min_callrate=0.5, max_alleles=2):
     """yield (rid, pos, ref0, alt0, float32 gps[nv*3], info dict) for records passing the variant filter"""
     contigs = {}
@@ -61,55 +196,18 @@ def vcf_records(path, field, min_mac=1, min_callrate=0.5, max_alleles=2):
             if ac < min_mac or an - ac < min_mac:
                 continue
             nal = len(alleles)
-            gps = np.zeros(nv * 3, dtype=np.float32)
             if field == "GT":
-                for v, (a1, a2) in enumerate(gts):
-                    if a1 < 0 or a2 < 0:
-                        l = 0
-                        for j in range(nal):
-                            for k in range(j + 1):
-                                gps[v * 3 + l] = np.float32((1.0 if j == k else 2.0) * (acs[j] + 1.0 / nal) / (an + 1.0) *
-                                                            (acs[k] + 1.0 / nal) / (an + 1.0))
-                                l += 1
-                    else:
-                        lo, hi = min(a1, a2), max(a1, a2)
-                        gps[v * 3 + hi * (hi + 1) // 2 + lo] = 1.0
+                gidx = [(-1 if (a1 < 0 or a2 < 0) else max(a1, a2) * (max(a1, a2) + 1) // 2 + min(a1, a2)) for a1, a2 in gts]
+                gps = gt_posteriors(gidx, acs, an, nal).reshape(-1)
             elif field == "PL":
                 fi = keys.index("PL")
-                pls = [[int(x) for x in t[9 + v].split(":")[fi].split(",")] for v in range(nv)]
-                af = [1.0 / nal] * nal
-                gp = [0.0] * 3
-                for it in range(10):
-                    newacs = [0.0] * nal
-                    an2 = 0
-                    for v in range(nv):
-                        sumgp = 0.0
-                        l = 0
-                        for j in range(nal):
-                            for k in range(j + 1):
-                                gp[l] = (1 if j == k else 2) * af[j] * af[k] * math.pow(0.1, pls[v][l] * 0.1)
-                                sumgp += gp[l]
-                                l += 1
-                        l = 0
-                        for j in range(nal):
-                            for k in range(j + 1):
-                                gp[l] /= sumgp
-                                newacs[j] += gp[l]
-                                newacs[k] += gp[l]
-                                l += 1
-                        an2 += 2
-                        if it == 9:
-                            for l in range(3):
-                                gps[v * 3 + l] = np.float32(gp[l])
-                    af = [x / an2 for x in newacs]
+                pls = [[(PL_MISSING if x == "." else int(x)) for x in t[9 + v].split(":")[fi].split(",")] for v in range(nv)]
+                gps = pl_em(pls, nal)[0].reshape(-1)
             else:
                 fi = keys.index(field)
-                for v in range(nv):
-                    vals = np.array([np.float32(float(x)) for x in t[9 + v].split(":")[fi].split(",")], dtype=np.float32)
-                    s = np.float32(0)
-                    for x in vals:
-                        s = np.float32(s + x)
-                    gps[v * 3:v * 3 + 3] = vals / s
+                vals = [[(np.float32(np.nan) if x == "." else np.float32(float(x))) for x in t[9 + v].split(":")[fi].split(",")]
+                        for v in range(nv)]
+                gps = gp_normalise(vals, nal).reshape(-1)
             info = dict(kv.split("=") for kv in t[7].split(";") if "=" in kv)
             yield rid, pos, alleles[0][0], (alleles[1][0] if len(alleles) > 1 else "."), gps, info
 
@@ -158,18 +256,8 @@ def load(prefix, vcf=None, field="GP", min_bq=13, cap_bq=20, geno_error_offset=0
                 if cur[1] == pos:
                     if cur[2] != ref or cur[3] != alt:
                         break
-                    g = cur[4].astype(np.float64)
-                    avg = [1e-10, 1e-10, 1e-10]
-                    for i in range(nv * 3):
-                        avg[i % 3] += g[i]
-                    s = avg[0] + avg[1] + avg[2]
-                    avg = [a / s for a in avg]
-                    err = geno_error_offset
-                    if geno_error_coeff > 0:
-                        err += (1 - geno_error_offset) * (1 - float(np.float32(float(cur[5][r2])))) * geno_error_coeff
-                    err = min(max(err, 0.0), 0.999)
-                    if err > 0:
-                        g = np.array([(1 - err) * g[i] + err * avg[i % 3] for i in range(nv * 3)])
+                    g = gp_row(cur[4], geno_error_offset, geno_error_coeff,
+                               float(cur[5][r2]) if geno_error_coeff > 0 else None)
                     row = g
                     break
             cur = next(recs, None)

@@ -181,3 +181,94 @@ class RefScl:
         assert rc == 0
         res["n_iter"] = n_iter.value
         return res
+
+
+def _freemuxlet_old(self, K, init_clust, doublet_prior=0.5, geno_error=0.0, full_ll=False, cluster_pileups=False):
+    """cmdCramFreemuxlet's EM (cmd_cram_freemuxlet.cpp:107-161,359-370,432-653 compiled as verbatim ranges) from given
+    initial clusters; always ten iterations (no early stop)."""
+    Cn, S = self.C, self.S
+    res = dict(llk0=np.zeros(Cn), llk2=np.zeros(Cn), nsnps=np.zeros(Cn, dtype=np.int32),
+               nreads=np.zeros(Cn, dtype=np.int32), cplp0=np.zeros((K, S), dtype=ob.PLP),
+               cells=np.zeros((10, Cn), dtype=ob.FMX_CELL), counters=np.zeros((10, 2), dtype=np.int32),
+               full_ll=np.zeros((10, Cn, K * (K + 1) // 2)) if full_ll else None,
+               cplp=np.zeros((10, K, S), dtype=ob.PLP) if cluster_pileups else None)
+    ic = np.ascontiguousarray(init_clust, dtype=np.int32)
+    assert ic.size == Cn
+    n_iter = C.c_int32()
+    f = lib().scref_freemuxlet_old
+    f.restype = C.c_int32
+    rc = f(self.h, C.c_int32(K), C.c_double(doublet_prior), C.c_double(geno_error), _p(ic), _p(res["llk0"]),
+           _p(res["llk2"]), _p(res["nsnps"]), _p(res["nreads"]), _p(res["cplp0"]), _p(res["cells"]),
+           _p(res["counters"]), _p(res["full_ll"]), _p(res["cplp"]), C.byref(n_iter))
+    assert rc == 0
+    res["n_iter"] = n_iter.value
+    return res
+
+
+RefScl.freemuxlet_old = _freemuxlet_old
+
+
+# ---- the VCF -> GP arithmetic of bcf_filtered_reader.cpp / sc_drop_seq.cpp:287-315 (oracle/ref_vcf.cpp.in) -----------
+PL_MISSING = -2**31  # bcf_int32_missing
+
+
+def _sel(nsamples, sel_cols):
+    sel = np.arange(nsamples, dtype=np.int32) if sel_cols is None else np.ascontiguousarray(sel_cols, dtype=np.int32)
+    return sel
+
+
+def vcf_pl(pls, nalleles=2, sel_cols=None, ploidies=None):
+    """parse_likelihoods' EM.  pls [nsamples][ngenos] int32 (all VCF columns).  Returns (float32 gps of the SELECTED
+    samples [nsel][ngenos], acs[nalleles], an)."""
+    pls = np.ascontiguousarray(pls, dtype=np.int32)
+    ns, ng = pls.shape
+    sel = _sel(ns, sel_cols)
+    pl8 = np.full(sel.size, 2, dtype=np.int8) if ploidies is None else np.ascontiguousarray(ploidies, dtype=np.int8)
+    gps = np.zeros((ns, ng), dtype=np.float32)
+    acs = np.zeros(nalleles)
+    an = C.c_int32()
+    f = lib().scref_vcf_pl
+    f.restype = C.c_int32
+    assert f(C.c_int32(nalleles), C.c_int32(ns), C.c_int32(sel.size), _p(sel), _p(pl8), _p(pls), _p(gps), _p(acs),
+             C.byref(an)) == 0
+    return gps[sel], acs, an.value
+
+
+def vcf_gp(vals, nalleles=2, sel_cols=None, gt_error=0.0):
+    """parse_posteriors' GP branch.  vals [nsamples][ngenos] float32 as bcf_get_format_float leaves them."""
+    g = np.array(vals, dtype=np.float32)
+    ns, ng = g.shape
+    sel = _sel(ns, sel_cols)
+    f = lib().scref_vcf_gp
+    f.restype = C.c_int32
+    assert f(C.c_int32(nalleles), C.c_int32(ns), C.c_int32(sel.size), _p(sel), C.c_double(gt_error), _p(g)) == 0
+    return g[sel]
+
+
+def vcf_gt(gidx, acs, an, nalleles=2, nsamples=None, sel_cols=None, ploidies=None, gt_error=0.0):
+    """parse_posteriors' GT branch given get_genotype_at(i) of every selected sample and parse_genotypes' acs / an.
+    Returns the whole [nsamples][ngenos] buffer (columns no selected sample wrote stay 0)."""
+    gidx = np.ascontiguousarray(gidx, dtype=np.int32)
+    ns = gidx.size if nsamples is None else nsamples
+    sel = _sel(ns, sel_cols)
+    assert sel.size == gidx.size
+    ng = nalleles * (nalleles + 1) // 2
+    pl8 = np.full(sel.size, 2, dtype=np.int8) if ploidies is None else np.ascontiguousarray(ploidies, dtype=np.int8)
+    acs = np.ascontiguousarray(acs, dtype=np.float64)
+    out = np.zeros((ns, ng), dtype=np.float32)
+    f = lib().scref_vcf_gt
+    f.restype = C.c_int32
+    assert f(C.c_int32(nalleles), C.c_int32(ns), C.c_int32(sel.size), _p(sel), _p(pl8), _p(gidx), _p(acs),
+             C.c_int32(an), C.c_double(gt_error), _p(out)) == 0
+    return out
+
+
+def gp_row(float_gp, geno_error_offset=0.1, geno_error_coeff=0.0, r2=0.0):
+    """load_from_plp's row construction, sc_drop_seq.cpp:287-315"""
+    g = np.ascontiguousarray(float_gp, dtype=np.float32).reshape(-1)
+    nv = g.size // 3
+    out = np.zeros(nv * 3)
+    f = lib().scref_gp_row
+    f.restype = C.c_int32
+    assert f(C.c_int32(nv), _p(g), C.c_double(geno_error_offset), C.c_double(geno_error_coeff), C.c_float(r2), _p(out)) == 0
+    return out

@@ -187,7 +187,8 @@ def test_private_random_r_state_equals_rand():
 
 
 def test_oracle_reproduces_golden_fmxold():
-    """tests/golden/fmxold_k4.npz (regression vectors of the restatement, tests/golden/make_golden.py)"""
+    """tests/golden/fmxold_k4.npz: initial clustering = regression vectors of the restatement; EM = the reference's own run
+    (tests/golden/make_golden.py)"""
     import os
 
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fmxold_k4.npz"))
@@ -201,3 +202,18 @@ def test_oracle_reproduces_golden_fmxold():
     for it in range(3):
         cl, ch, _ = ob.fmxold_vote_refine(p.C, K, dd, g["orands"][it], g["jitters"][it], cl, thres, it == 0)
         assert np.array_equal(cl, g["clusts"][it]) and ch == g["changed"][it]
+    # the EM part of the fixture is the REFERENCE's run (cmd_cram_freemuxlet.cpp:456-653, see make_golden.py)
+    cplp = ob.fmx_build_cluster_pileup(p, e, K, cl)
+    cells = ob.fmx_init_cells(cl)
+    ge, dp = float(g["em_geno_error"]), float(g["em_doublet_prior"])
+    for it in range(10):
+        nsng, namb, _, full = ob.fmx_iterate(p, e, K, cplp, cells, dp, ge if it == 9 else 0.0, full_ll=True)
+        assert (nsng, namb) == tuple(g["em_counters"][it])
+        for f in cells.dtype.names:
+            if f not in ("clust", "_pad"):
+                assert cells[f].tobytes() == g["em_cells"][it][f].tobytes(), (it, f)
+        if it == 0:
+            assert np.array_equal(full, g["em_full_ll_first"])
+    assert np.array_equal(full, g["em_full_ll_last"])
+    assert np.array_equal(cplp["gls"], g["em_cluster_gls"])
+    assert np.array_equal(np.stack([cplp["nreads"], cplp["nref"], cplp["nalt"]], axis=-1), g["em_cluster_cnt"])

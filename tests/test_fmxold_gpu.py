@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
+import parity
 import pyplp
 from popscle_amd import muxgl, plpio, synth
 from test_cli_gpu import BIN, TYPES, as_pileup, assert_rows_match
@@ -113,6 +114,26 @@ def test_golden(eng):
     for it in range(3):
         cl, ch, _ = eng.fmxold_vote_refine(K, g["orands"][it], g["jitters"][it], cl, it == 0)
         assert np.array_equal(cl, g["clusts"][it]) and ch == g["changed"][it]
+    # the EM loop from those clusters against THE REFERENCE'S OWN run of cmd_cram_freemuxlet.cpp:456-653 (em_* arrays,
+    # tests/golden/make_golden.py): driven the way popscle-amd freemuxlet-old drives the C-ABI (host/main.cpp): ten
+    # iterations, geno_error only in the last, no early stop
+    eng.fmx_set_clusters(K, cl)
+    ge, dp = float(g["em_geno_error"]), float(g["em_doublet_prior"])
+    worst = 0.0
+    for it in range(10):
+        cells, stats, full = eng.fmx_iterate(dp, ge if it == 9 else 0.0, want_full_ll=True)
+        assert stats[:2] == tuple(g["em_counters"][it]), it
+        want = g["em_cells"][it].copy()
+        want["clust"] = np.where(want["type"] == 0, want["jBest"], -1)   # the old loop has no clusts update (row c1)
+        rep = parity.compare_fmx(cells, want, want_full=g["em_full_ll_last"] if it == 9 else None)
+        assert rep["cells_needing_an_excuse"] == 0, (it, rep)
+        worst = max(worst, rep["max_abs_ll_diff"])
+        if it == 0:
+            assert np.abs(full - g["em_full_ll_first"]).max() < 1e-7
+    assert np.abs(full - g["em_full_ll_last"]).max() < 1e-7 and worst < 1e-7
+    gls, cnt = eng.fmx_cluster_pileup()
+    assert np.array_equal(cnt, g["em_cluster_cnt"])
+    assert np.allclose(gls, g["em_cluster_gls"], rtol=1e-11, atol=1e-300)
 
 
 def jitters(rng, n, K, mode):

@@ -311,6 +311,277 @@ def test_freemux2_runs_ten_iterations_without_convergence():
     assert {0, 2} <= types or {0, 1} <= types
 
 
+# ------------------------------------------------------------------ freemuxlet-old: the EM loop of the file north_star names
+def oracle_freemuxlet_old(q, K, init_clust, doublet_prior=0.5, geno_error=0.0):
+    """the oracle driven the way cmdCramFreemuxlet runs its EM (and the way popscle-amd freemuxlet-old drives the C-ABI,
+    popscle_amd/host/main.cpp): always ten iterations, geno_error only in the last one (:485,500), no early stop"""
+    e = ob.fmx_entry_pileup(q)
+    llk0, llk2, ns, nr = ob.fmx_cell_scores(q, e)
+    clust0 = np.ascontiguousarray(init_clust, dtype=np.int32)
+    cplp = ob.fmx_build_cluster_pileup(q, e, K, clust0)
+    cplp0 = cplp.copy()
+    cells = ob.fmx_init_cells(clust0)
+    iters = []
+    for it in range(10):
+        nsng, namb, _, full = ob.fmx_iterate(q, e, K, cplp, cells, doublet_prior, geno_error if it == 9 else 0.0,
+                                             full_ll=True)
+        iters.append((cells.copy(), (nsng, namb), full, cplp.copy()))
+    return dict(e=e, llk0=llk0, llk2=llk2, nsnps=ns, nreads=nr, cplp0=cplp0, iters=iters)
+
+
+FMXOLD_FIELDS_NOT_COMPARED = {"clust"}   # cmdCramFreemuxlet never updates clusts in its loop; freemux2 does (:545,568)
+
+FMXOLD_CASES = [
+    # C, S, K, doublet_prior, geno_error, fraction of droplets without an initial cluster
+    (300, 1500, 4, 0.5, 0.0, 0.0),
+    (200, 1500, 8, 0.5, 0.1, 0.0),
+    (250, 1200, 3, 0.1, 0.05, 0.3),
+    (150, 1000, 16, 0.5, 0.1, 0.1),
+    (150, 1000, 2, 0.5, 0.0, 0.0),
+]
+
+
+@pytest.mark.parametrize("C,S,K,dp,ge,unassigned", FMXOLD_CASES)
+def test_freemuxlet_old_em_is_the_references(C, S, K, dp, ge, unassigned):
+    """cmd_cram_freemuxlet.cpp:107-161,359-370,432-653 compiled as verbatim ranges (scref_freemuxlet_old) against the
+    oracle's iteration driven with freemuxlet-old's loop control: bit for bit, every iteration."""
+    p, raw = deep_pileup(C, S, K, seed=170 + K, with_gp=False, mean_entries=90)
+    r = rb.RefScl.from_pileup(p, raw_bq=raw, min_bq=1, cap_bq=60)   # sc_drop_seq.h:181: freemuxlet-old's loader defaults
+    q, _, _ = r.export()
+    rng = np.random.default_rng(K)
+    # a plausible start: the greedy clusters of freemux2 with some droplets moved and some left out
+    e = ob.fmx_entry_pileup(q)
+    llk0, llk2, _, _ = ob.fmx_cell_scores(q, e)
+    init = ob.fmx_greedy_init(q, e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
+    move = rng.random(q.C) < 0.15
+    init[move] = rng.integers(0, K, int(move.sum()))
+    init[rng.random(q.C) < unassigned] = -1
+    want = r.freemuxlet_old(K, init, dp, ge, full_ll=True, cluster_pileups=True)
+    got = oracle_freemuxlet_old(q, K, init, dp, ge)
+    assert want["n_iter"] == 10
+    assert got["e"].tobytes() == r.entry_pileup(q.nnz).tobytes()
+    for k in ("llk0", "llk2", "nsnps", "nreads"):
+        assert np.array_equal(got[k], want[k]), k
+    assert got["cplp0"].tobytes() == want["cplp0"].tobytes()
+    for it, (cells, counters, full, cplp) in enumerate(got["iters"]):
+        assert counters == tuple(want["counters"][it]), it
+        bad = [f for f in same_records(cells, want["cells"][it]) if f not in FMXOLD_FIELDS_NOT_COMPARED]
+        assert bad == [], (it, bad)
+        assert np.array_equal(want["cells"][it]["clust"], init)
+        assert np.array_equal(full, want["full_ll"][it]), it
+        assert cplp.tobytes() == want["cplp"][it].tobytes(), it
+    if ge > 0:
+        # the genotype error acts in iteration 10 only: iteration 9 -> 10 changes every LL although the clusters settled
+        assert not np.array_equal(want["full_ll"][9], want["full_ll"][8])
+    types = np.bincount(want["cells"][9]["type"], minlength=3)
+    assert types[0] > 0 and types[1] + types[2] > 0
+
+
+def test_freemuxlet_old_differs_from_freemux2_where_the_survey_says():
+    """row c1: with geno_error > 0 the two commands' first iteration already differs (freemux2 mixes in every iteration,
+    cmd_cram_freemux2.cpp:410-415; the old loop only when iter + 1 == max_iter), and the old loop runs on after
+    nchanged == 0"""
+    p, raw = deep_pileup(200, 1200, 4, seed=33, with_gp=False, mean_entries=90)
+    r = rb.RefScl.from_pileup(p, raw_bq=raw)
+    q, _, _ = r.export()
+    e = ob.fmx_entry_pileup(q)
+    llk0, llk2, _, _ = ob.fmx_cell_scores(q, e)
+    init = ob.fmx_greedy_init(q, e, 4, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
+    new = r.freemux2(4, geno_error=0.1, init_clust=init, full_ll=True)
+    old = r.freemuxlet_old(4, init, 0.5, 0.1, full_ll=True)
+    assert new["n_iter"] < 10 and old["n_iter"] == 10
+    assert not np.array_equal(new["full_ll"][0], old["full_ll"][0])
+    new0 = r.freemux2(4, geno_error=0.0, init_clust=init, full_ll=True)
+    old0 = r.freemuxlet_old(4, init, 0.5, 0.0, full_ll=True)
+    assert np.array_equal(new0["full_ll"][0], old0["full_ll"][0])   # same arithmetic without the mixing
+
+
+# ------------------------------------------------------------------ VCF -> genotype posteriors (SURVEY 8 row f2)
+def _rand_pls(rng, ns, nal, missing=0.1):
+    ng = nal * (nal + 1) // 2
+    pls = rng.integers(0, 120, (ns, ng)).astype(np.int32)
+    pls[np.arange(ns), rng.integers(0, ng, ns)] = 0            # a called genotype has PL 0
+    pls[rng.random(ns) < 0.1] = rng.integers(200, 400, ng)     # beyond the table's 255 (toProb clamps)
+    miss = rng.random(ns) < missing
+    pls[miss] = rb.PL_MISSING                                  # "." -> bcf_int32_missing -> toProb(255)
+    return pls
+
+
+@pytest.mark.parametrize("nal", [2, 3])
+def test_pl_em_is_the_references(nal):
+    """bcf_filtered_reader.cpp:262-324 (the 10-iteration EM of parse_likelihoods) vs tests/pyplp.pl_em: float outputs and
+    allele counts bit for bit; all samples, a subset in arbitrary column order, haploid columns, missing PLs"""
+    import pyplp
+    rng = np.random.default_rng(nal)
+    for trial in range(60):
+        ns = int(rng.integers(1, 12))
+        pls = _rand_pls(rng, ns, nal)
+        sel = None
+        if trial % 3 == 1:
+            sel = rng.permutation(ns)[:max(1, ns // 2)].astype(np.int32)
+        nsel = ns if sel is None else sel.size
+        ploidy = None if trial % 4 else rng.integers(1, 3, nsel).astype(np.int8)
+        want, wacs, wan = rb.vcf_pl(pls, nal, sel, ploidy)
+        rows = pls if sel is None else pls[sel]
+        got, gacs, gan = pyplp.pl_em(rows.tolist(), nal, None if ploidy is None else ploidy.tolist())
+        assert got.dtype == np.float32 and want.dtype == np.float32
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), trial
+        assert gan == wan and np.array_equal(np.array(gacs), wacs), trial
+
+
+@pytest.mark.parametrize("nal", [2, 3])
+def test_gp_branch_is_the_references(nal):
+    """bcf_filtered_reader.cpp:422-457 vs tests/pyplp.gp_normalise, incl. a missing value (NaN) in one sample, which the
+    reference's `gt_error*gpSums[j]` term spreads to every sample of the record even at gt_error == 0"""
+    import pyplp
+    rng = np.random.default_rng(10 + nal)
+    ng = nal * (nal + 1) // 2
+    for trial in range(80):
+        ns = int(rng.integers(1, 12))
+        vals = rng.dirichlet([0.4] * ng, ns).astype(np.float32)
+        if trial % 5 == 0:
+            vals = np.round(vals, 3).astype(np.float32)        # as printed with three decimals: sums != 1
+        if trial % 7 == 3:
+            vals[rng.integers(0, ns)] = np.float32(np.nan)
+        sel = None if trial % 3 else rng.permutation(ns)[:max(1, ns // 2)].astype(np.int32)
+        gt_error = 0.0 if trial % 4 else 0.01
+        want = rb.vcf_gp(vals, nal, sel, gt_error)
+        got = pyplp.gp_normalise((vals if sel is None else vals[sel]).tolist(), nal, gt_error)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), trial
+        if trial % 7 == 3 and (sel is None or np.isnan(vals[sel]).any()):
+            assert np.isnan(want).all()
+
+
+def test_gt_branch_is_the_references():
+    """bcf_filtered_reader.cpp:385-409 given the genotype indices and allele counts vs tests/pyplp.gt_posteriors"""
+    import pyplp
+    rng = np.random.default_rng(5)
+    for trial in range(80):
+        nal = 2 if trial % 3 else 3
+        ng = nal * (nal + 1) // 2
+        ns = int(rng.integers(1, 12))
+        gidx = rng.integers(-1, ng, ns).astype(np.int32)
+        an = int(rng.integers(0, 2 * ns + 1))
+        acs = rng.multinomial(an, [1.0 / nal] * nal).astype(np.float64)
+        gt_error = 0.0 if trial % 4 else 0.02
+        ploidy = None if trial % 5 else rng.integers(1, 3, ns).astype(np.int8)
+        want = rb.vcf_gt(gidx, acs, an, nal, ploidies=ploidy, gt_error=gt_error)
+        got = pyplp.gt_posteriors(gidx.tolist(), acs.tolist(), an, nal, gt_error, None if ploidy is None else ploidy.tolist())
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), trial
+
+
+def test_gp_row_mixing_is_the_references():
+    """sc_drop_seq.cpp:287-315 (float posteriors -> the double row of add_snp: avgGP with 1e-10 pseudo-counts, error =
+    offset + (1-offset)(1-R2)coeff clipped to [0, 0.999]) vs tests/pyplp.gp_row"""
+    import pyplp
+    rng = np.random.default_rng(6)
+    for trial in range(100):
+        nv = int(rng.integers(1, 20))
+        g = rng.dirichlet([0.3, 0.3, 0.3], nv).astype(np.float32)
+        if trial % 3 == 0:
+            g = np.eye(3, dtype=np.float32)[rng.integers(0, 3, nv)]
+        off = [0.1, 0.0, 0.05, 1.5, -0.2][trial % 5]
+        coeff = [0.0, 0.5, 2.0][trial % 3]
+        r2 = np.float32(rng.random())
+        want = rb.gp_row(g, off, coeff, float(r2))
+        got = pyplp.gp_row(g, off, coeff, float(r2))
+        assert np.array_equal(got, want), trial
+
+
+def _vcf_columns(path):
+    """(sample ids, [(pos, FORMAT keys, per-sample field strings)]) of a small VCF, parsed independently of pyplp"""
+    import gzip
+    ids, recs = None, []
+    with gzip.open(path, "rt") as f:
+        for line in f:
+            t = line.rstrip("\n").split("\t")
+            if line.startswith("#CHROM"):
+                ids = t[9:]
+            elif not line.startswith("#"):
+                recs.append((int(t[1]), t[8].split(":"), [c.split(":") for c in t[9:]], t[7]))
+    return ids, recs
+
+
+@pytest.mark.parametrize("field,subset", [("PL", False), ("PL", True), ("GP", False), ("GP", True), ("GT", False)])
+def test_product_loader_vcf_fields_vs_reference_arithmetic(tmp_path, field, subset):
+    """`popscle-amd dump-plp --vcf V --field PL|GP|GT` (popscle_amd/host/vcf.hpp) against the reference's own arithmetic:
+    the text of each record is split here, the numbers go through scref_vcf_pl / scref_vcf_gp / scref_vcf_gt and
+    scref_gp_row, and the loader's GP tensor must equal the result bit for bit.  (What stays unpinned: text -> number
+    conversion and allele counting, which live in htslib.)"""
+    if not os.path.exists(BIN):
+        pytest.skip("popscle-amd not built")
+    V = 6
+    p = synth.make_pileup(8, 70, V, seed=21, mean_entries=20, min_entries=4)
+    G = p.truth["G"].astype(np.int64)
+    rng = np.random.default_rng(3)
+    gp = rng.dirichlet([0.3, 0.3, 0.3], size=G.shape)
+    pl = _rand_pls(rng, G.size, 2, missing=0.0).reshape(G.shape + (3,))
+    pl = np.where(pl > 255, 255, pl)
+    prefix = str(tmp_path / "plp")
+    plpio.write_plp(prefix, p, seed=21)
+    vcf = str(tmp_path / "g.vcf.gz")
+    plpio.write_vcf(vcf, p, G, field=field, missing_frac=0.08, gp=gp, pl=pl)
+    poisoned = None
+    if field == "GP":
+        # one sample of one record without a value: htslib hands out NaN bit patterns, and the reference's
+        # `gt_error*gpSums[j]` term turns the whole record NaN (bcf_filtered_reader.cpp:444,455)
+        import gzip
+        lines = gzip.open(vcf, "rt").read().split("\n")
+        poisoned = set()
+        for k in [i for i, ln in enumerate(lines) if ln and not ln.startswith("#")][5::9]:
+            t = lines[k].split("\t")
+            poisoned.add(int(t[1]))
+            t[9 + 4] = t[9 + 4].split(":")[0] + ":."
+            lines[k] = "\t".join(t)
+        with gzip.open(vcf, "wt") as f:
+            f.write("\n".join(lines))
+    extra = []
+    if subset:
+        extra = ["--sm", "S4", "--sm", "S1", "--sm", "S5"]       # numbered in sorted-ID order: S1, S4, S5
+    out = str(tmp_path / "d.bin")
+    r = subprocess.run([BIN, "dump-plp", "--plp", prefix, "--out", out, "--vcf", vcf, "--field", field,
+                        "--geno-error-offset", "0.07", "--geno-error-coeff", "0.3", *extra], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = plpio.read_dump(out)
+    ids, recs = _vcf_columns(vcf)
+    sel = np.array([1, 4, 5] if subset else range(V), dtype=np.int32)
+    assert got["sample_ids"] == [ids[i] for i in sel]
+    by_pos = {rec[0]: rec for rec in recs}
+    checked = seen_poisoned = 0
+    for s in range(p.S):
+        if not got["has_gp"][s]:
+            continue
+        _, keys, cols, info = by_pos[1000 + 10 * s]
+        if field == "PL":
+            fi = keys.index("PL")
+            pls = np.array([[int(x) for x in c[fi].split(",")] for c in cols], dtype=np.int32)
+            fgp, _, _ = rb.vcf_pl(pls, 2, sel)
+        elif field == "GP":
+            fi = keys.index("GP")
+            vals = np.array([([np.float32(float(x)) for x in c[fi].split(",")] if c[fi] != "." else [np.nan] * 3)
+                             for c in cols], dtype=np.float32)
+            fgp = rb.vcf_gp(vals, 2, sel, 0.0)
+        else:
+            al = [[(-1 if a == "." else int(a)) for a in c[0].replace("|", "/").split("/")] for c in cols]
+            acs, an = np.zeros(2), 0
+            for i in sel:                              # parse_genotypes counts over the selected samples (:225-247)
+                for a in al[i]:
+                    if a >= 0:
+                        acs[a] += 1
+                        an += 1
+            gidx = [(-1 if min(al[i]) < 0 else max(al[i]) * (max(al[i]) + 1) // 2 + min(al[i])) for i in sel]
+            fgp = rb.vcf_gt(gidx, acs, an, 2, nsamples=V, sel_cols=sel)[sel]
+        r2 = np.float32(float(info.split("R2=")[1]))
+        want = rb.gp_row(fgp, 0.07, 0.3, float(r2)).reshape(sel.size, 3)
+        assert np.array_equal(got["gp"][s], want, equal_nan=True), (field, s)
+        if poisoned and 1000 + 10 * s in poisoned:
+            assert np.isnan(want).all()
+            seen_poisoned += 1
+        checked += 1
+    assert poisoned is None or seen_poisoned >= 2
+    assert checked > 30
+
+
 # ------------------------------------------------- the synthetic generator's packed pileups, as the bench feeds them
 def test_packed_synthetic_pileup_through_the_reference():
     """a slice of BASELINE configs[1] (10 k x 16 x 50 k shape) handed to the reference in packed order"""
