@@ -113,6 +113,9 @@ typedef struct {
   double sumLLK, sngLLK;
   double bestLLK, nextLLK;
   double bestPP, sngPP, sngOnlyPP;
+  double sngThirdLLK, dblThirdLLK; /* third-largest log-likelihood of the singlet / doublet scan (-1e300: none).  Not a
+                                      quantity of the reference: muxgl_demux_exact_calls reads it to tell whether best
+                                      and next are the only hypotheses within rounding reach of each other */
 } muxgl_demux_cell;
 
 /* freemuxlet parameters: --doublet-prior, --geno-error (cmd_cram_freemux2.cpp:19-20) */
@@ -130,6 +133,7 @@ typedef struct {
   double bestLLK, nextLLK;
   double sngBestLLK, sngNextLLK, dblBestLLK, dblNextLLK;
   double bestPP, sngPP, sngOnlyPP, sumLLK;
+  double sngThirdLLK, dblThirdLLK; /* third-largest log-likelihood of each scan (-1e300: none), see muxgl_demux_cell */
 } muxgl_fmx_cell;
 
 /* kernel timings of the most recent *_run / *_iterate call, milliseconds, measured with hipEvents recorded on the
@@ -171,20 +175,26 @@ int muxgl_demux_set_gp(muxgl_handle* h, int32_t V, const double* gp, const uint8
  * receiving llksAB for the entries the reference ever reads: (j,0,0) and (j,k!=j,n>=1); other slots are 0. */
 int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_cell* out, double* full_ll);
 
-/* The reference's order of a mirrored alpha = 0.5 pair -- HOST pass, no device work, no handle.  The likelihood of a
- * doublet at alpha 0.5 is symmetric in its two samples; the reference nevertheless evaluates llksAB[j][k][n] and
- * llksAB[k][j][n] with transposed summation orders (cmd_cram_demuxlet.cpp:738-746), so they differ by rounding noise, and
- * its strict-'<' scan (:883-906) prints whichever order came out larger as DBL.BEST.GUESS (the other one becomes the
- * runner-up).  muxgl_demux_run computes such a pair once and names it (lo, hi).  This call recomputes, for the best and
- * next doublet of every cell whose alpha is 0.5, the two log-likelihoods in the reference's own association on the host
- * (IEEE doubles, glibc log) and rewrites dBest1/2, dNext1/2 and the derived jBest/kBest/jNext/kNext of cells[C] in the
- * order the reference reports; log-likelihood fields are left as the device computed them.  The pileup and gp / has_gp
- * are the arrays handed to muxgl_set_pileup / muxgl_demux_set_gp.  nthreads host threads (cells are independent).
- * stats: NULL or int64[3] = cells looked at, pairs put into (hi, lo) order, pairs whose two orders tied exactly. */
-int muxgl_demux_reference_pair_order(int64_t C, int32_t V, const int64_t* cell_ptr, const int32_t* entry_snp,
-                                     const int64_t* entry_rptr, const uint8_t* reads, const double* gp,
-                                     const uint8_t* has_gp, const muxgl_demux_params* p, muxgl_demux_cell* cells,
-                                     int32_t nthreads, int64_t* stats);
+/* The calls rounding noise could decide, settled in the reference's own arithmetic -- HOST pass, no device work, no
+ * handle (popscle_amd/host/exact_calls.hpp).  The kernels' log-likelihoods equal the reference's to ~1e-12, not to the last
+ * bit, and every decision of cmd_cram_demuxlet.cpp:827-837,883-906,925-988 compares two of them.  For the cells of
+ * cells[C] (records of muxgl_demux_run) where a comparison's margin is within 1e-9 x max(1, |LL|) this call recomputes the
+ * contested hypotheses on the host as the reference does (IEEE doubles in its operation order, glibc log) and rewrites the
+ * record from those numbers:
+ *   - the best (or next) doublet is an alpha = 0.5 pair: the reference evaluates (j,k) and (k,j) with transposed
+ *     summation orders (:738-746) and reports whichever came out larger as DBL.BEST.GUESS, the other as runner-up;
+ *     muxgl_demux_run names the pair (lo, hi).  Every such cell is looked at (two hypotheses);
+ *   - best and next of a scan, or a +2 threshold, within reach: the named hypotheses are recomputed and compared;
+ *   - next and third of a scan within reach (sngThirdLLK / dblThirdLLK): every hypothesis of that scan is recomputed.
+ * Integer fields and the log-likelihoods of recomputed hypotheses then equal the reference's exactly; sumLLK / sngLLK
+ * stay as the device summed them.  The pileup and gp / has_gp are the arrays handed to muxgl_set_pileup /
+ * muxgl_demux_set_gp.  nthreads host threads (cells are independent).
+ * stats: NULL or int64[6] = cells looked at, mirrored pairs put into (hi, lo) order, mirrored pairs whose two orders tied
+ * exactly, cells with a near tie other than the mirror, cells that needed every hypothesis of a scan, cells whose call
+ * changed beyond the order of a mirrored pair. */
+int muxgl_demux_exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int32_t* entry_snp,
+                            const int64_t* entry_rptr, const uint8_t* reads, const double* gp, const uint8_t* has_gp,
+                            const muxgl_demux_params* p, muxgl_demux_cell* cells, int32_t nthreads, int64_t* stats);
 
 /* pinned host view of the last run's [C] records (valid until the next run or destroy) */
 const muxgl_demux_cell* muxgl_demux_results(const muxgl_handle* h);

@@ -1,9 +1,9 @@
 // demux_call16.hip -- evidence sums, best/next scans and the SNG/DBL/AMB call (cmd_cram_demuxlet.cpp:788-991) for
 // V <= 16, sixteen lanes per cell instead of one.
 //
-// The reference walks the V*V*A hypotheses of a cell sequentially.  demux_call_kernel (demux_kernels.hip) keeps that
-// walk, one lane per cell, which leaves a 10 k-cell batch with 157 waves of ~270 serial logAdd's each (0.1 ms, as long
-// as a fifth of the whole sweep).  Here lane j of a 16-lane group owns row j of llksAB:
+// The reference walks the V*V*A hypotheses of a cell sequentially; one lane per cell doing the same leaves a 10 k-cell
+// batch with 157 waves of ~270 serial logAdd's each (0.1 ms, as long as a fifth of the whole sweep; that kernel was
+// retired in round 6).  Here lane j of a 16-lane group owns row j of llksAB:
 //   * scans: the reference's update rule (strict <, first-seen wins; :827-837, :883-906) leaves the two largest
 //     hypotheses under the total order (value descending, scan position ascending); that order is associative, so each
 //     lane scans its row and a 4-step butterfly merges the sixteen top-2 lists -- the result is the reference's, tie
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64)
   const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
   const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
   const int32_t nsnps = (int32_t)(cell_ptr[i + 1] - cell_ptr[i]);
-  top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
+  top2 sng = {-1e300, -1e300, -1, -1, -1e300}, dbl = {-1e300, -1e300, -1, -1, -1e300};
   const double NEG_INF = -__builtin_huge_val();
   double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0;
   if (nsnps > 0) {  // (an empty cell leaves no LL behind; its record is all zeros, :653)
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64)
           k = __builtin_amdgcn_mov_dpp(k, 0x13C, 0xF, 0xF, false);
           if (!live || k >= nv) continue;
           const double v = vv[u];
-          top2_insert(dbl, v, (j * nv + k) * nAlpha + n);
+          if (!(sym && k < j)) top2_insert(dbl, v, (j * nv + k) * nAlpha + n);  // an alpha = 0.5 pair is listed once, as (lo, hi)
           if (sym && k > j) continue;  // :812-815: an alpha = 0.5 pair counts once
           const double term = v + prior;
           if (term > rowmax) {

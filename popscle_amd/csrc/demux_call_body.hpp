@@ -54,6 +54,8 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 struct top2 {
   double bv, nv;  // best / next value
   int32_t bp, np; // scan positions (-1: none); position encodes the hypothesis
+  double tv;  // third-largest VALUE of the scan (no position): tells the exact-call pass (host/exact_calls.hpp)
+                       // whether best and next are the only hypotheses within rounding reach of each other
 };
 
 // reference update rule for one more element at a later position (selects, no branches: the scans are lock-step loops
@@ -61,6 +63,7 @@ struct top2 {
 __device__ __forceinline__ void top2_push(top2& t, double v, int32_t pos) {
   const bool b = t.bv < v;
   const bool n = !b && t.nv < v;
+  t.tv = (b || n) ? t.nv : fmax(t.tv, v);
   t.nv = b ? t.bv : (n ? v : t.nv);
   t.np = b ? t.bp : (n ? pos : t.np);
   t.bv = b ? v : t.bv;
@@ -87,6 +90,8 @@ __device__ __forceinline__ top2 top2_merge(const top2& a, const top2& b) {
   r.bp = wp;
   r.nv = keep ? wn : lv;
   r.np = keep ? wnp : lp;
+  // third value of the union of two descending triples x, y: max(x3, y3, min(x2, y1), min(x1, y2))
+  r.tv = fmax(fmax(a.tv, b.tv), fmax(fmin(a.nv, b.bv), fmin(a.bv, b.nv)));
   return r;
 }
 
@@ -96,19 +101,24 @@ __device__ __forceinline__ top2 top2_xor(const top2& t, int m) {
   o.nv = __shfl_xor(t.nv, m, 64);
   o.bp = __shfl_xor(t.bp, m, 64);
   o.np = __shfl_xor(t.np, m, 64);
+  o.tv = __shfl_xor(t.tv, m, 64);
   return o;
 }
 
 // order-independent insertion (the scans above rely on ascending positions; this one does not)
 __device__ __forceinline__ void top2_insert(top2& t, double v, int32_t pos) {
   if (key_before(v, pos, t.bv, t.bp)) {
+    t.tv = t.nv;
     t.nv = t.bv;
     t.np = t.bp;
     t.bv = v;
     t.bp = pos;
   } else if (key_before(v, pos, t.nv, t.np)) {
+    t.tv = t.nv;
     t.nv = v;
     t.np = pos;
+  } else {
+    t.tv = fmax(t.tv, v);
   }
 }
 
@@ -170,14 +180,25 @@ __device__ __forceinline__ void demux_call_decide(const call_partial& c, int32_t
   o.valid = 1;
   const int32_t sBest = sng.bp, sNext = sng.np;
   const double sngBestLLK = sng.bv, sngNextLLK = sng.nv;
-  const double dblBestLLK = dbl.bv, dblNextLLK = dbl.nv;
+  const double dblBestLLK = dbl.bv;
   int32_t dBest1 = -1, dBest2 = -1, dblBestAlpha = -1, dNext1 = -1, dNext2 = -1, dblNextAlpha = -1;
   if (dbl.bp >= 0) {
     dblBestAlpha = dbl.bp % nAlpha;
     dBest2 = (dbl.bp / nAlpha) % nv;
     dBest1 = dbl.bp / (nAlpha * nv);
   }
-  if (dbl.np >= 0) {
+  // The scans list an alpha = 0.5 pair ONCE, as (lo, hi): its mirror (hi, lo) has the same likelihood (the reference's two
+  // evaluations differ by rounding noise only, cmd_cram_demuxlet.cpp:738-746), so where such a pair is the best doublet
+  // the runner-up is its mirror, as the reference's scan finds it.  Which of the two orders the reference names first is
+  // decided by that noise: host/exact_calls.hpp recomputes it.  `third` = the best hypothesis that is neither of them.
+  double dblNextLLK = dbl.nv, dblThird = dbl.tv;
+  if (dbl.bp >= 0 && gridAlpha[dblBestAlpha] == 0.5) {
+    dNext1 = dBest2;
+    dNext2 = dBest1;
+    dblNextAlpha = dblBestAlpha;
+    dblNextLLK = dbl.bv;
+    dblThird = dbl.nv;
+  } else if (dbl.np >= 0) {
     dblNextAlpha = dbl.np % nAlpha;
     dNext2 = (dbl.np / nAlpha) % nv;
     dNext1 = dbl.np / (nAlpha * nv);
@@ -249,6 +270,8 @@ __device__ __forceinline__ void demux_call_decide(const call_partial& c, int32_t
   o.bestPP = bestPP;
   o.sngPP = exp(sngLLK - sumLLK);                             // :990
   o.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);  // :991
+  o.sngThirdLLK = sng.tv;
+  o.dblThirdLLK = dblThird;
   *out = o;
 }
 
@@ -278,19 +301,16 @@ template <int G, int Q = 1>
 __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, int nv, int nAlpha, const call_alpha& al,
                                                         const double* ll_cell, int ld = 0) {
   if (ld == 0) ld = nv * nAlpha;
-#ifndef CALL_EXP
-#define CALL_EXP 0  // (timing experiments: 1 no scans, 2 no evidence pass, 4 no merge / decision)
-#endif
   const int j = lane & (G - 1);
   const int q = (lane / G) & (Q - 1);
   const int kq = (nv + Q - 1) / Q, k0 = q * kq, k1 = (k0 + kq < nv) ? k0 + kq : nv;
-  const bool live = cell_ok && j < nv && !(CALL_EXP & 1);
+  const bool live = cell_ok && j < nv;
   const double* gridAlpha = al.a;
   const double log_single_prior = al.log_single_prior;
   const double log_doublet_prior1 = al.log_doublet_prior1;
   const double log_doublet_prior2 = al.log_doublet_prior2;
 
-  top2 sng = {-1e300, -1e300, -1, -1}, dbl = {-1e300, -1e300, -1, -1};
+  top2 sng = {-1e300, -1e300, -1, -1, -1e300}, dbl = {-1e300, -1e300, -1, -1, -1e300};
   const double NEG_INF = -__builtin_huge_val();
   double sterm = NEG_INF, rowmax = NEG_INF, racc = 0.0, sacc = 0.0;
   if (live) {
@@ -311,7 +331,10 @@ __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, 
         for (int n = 1; n < nAlpha; ++n) {
           const double v = row[k * nAlpha + n];
           if (gridAlpha[n] == 0.5) {
-            if (k < jr) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
+            if (k < jr) {
+              rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
+              continue;                                        // (hi, lo): listed as (lo, hi), see demux_call_decide
+            }
           } else {
             rowmax = fmax(rowmax, v + log_doublet_prior1);
           }
@@ -320,7 +343,7 @@ __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, 
       }
     }
     // pass 2: the evidence terms relative to that maximum (independent exp's instead of a logAdd chain)
-    if (rowmax > NEG_INF && !(CALL_EXP & 2)) {
+    if (rowmax > NEG_INF) {
       for (int jr = j; jr < nv; jr += G) {
         const double* row = ll_cell + (size_t)jr * ld;
         if (q == 0) {
@@ -342,7 +365,6 @@ __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, 
       }
     }
   }
-  if (CALL_EXP & 4) return call_partial{sng, dbl, rowmax, racc, sterm, sacc};
   return demux_call_merge<G * Q>(sng, dbl, sterm, rowmax, racc, sacc);
 }
 

@@ -259,144 +259,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// a7-a9: cmd_cram_demuxlet.cpp:788-991, one lane per cell, the reference's scan order.
-__global__ void __launch_bounds__(64) demux_call_kernel(int64_t C, const int64_t* __restrict__ cell_ptr, int nv,
-                                                         int nAlpha, alpha_args al, double doublet_prior,
-                                                         const double* __restrict__ ll,
-                                                         muxgl_demux_cell* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C) return;
-  muxgl_demux_cell o;
-  memset(&o, 0, sizeof(o));
-  o.nsnps = (int32_t)(cell_ptr[i + 1] - cell_ptr[i]);
-  if (o.nsnps == 0) {
-    out[i] = o;
-    return;
-  }
-  o.valid = 1;
-  const double* llksAB = ll + (size_t)i * nv * nv * nAlpha;
-  const double* gridAlpha = al.a;
-  int32_t j, k, n;
-  int32_t sBest = -1, sNext = -1, dBest1 = -1, dBest2 = -1, dNext1 = -1, dNext2 = -1, dblBestAlpha = -1,
-          dblNextAlpha = -1;
-  double sngBestLLK = -1e300, sngNextLLK = -1e300;
-  double dblBestLLK = -1e300, dblNextLLK = -1e300;
-  double sumLLK = -1e-300, sngLLK = -1e-300;  // :791 (sic)
-  double bestPP = -1e300;
-  const double log_single_prior = log((1.0 - doublet_prior) / nv);
-  const double log_doublet_prior1 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.));
-  const double log_doublet_prior2 = log(doublet_prior / nv / (nv - 1.) / (nAlpha - 1.) * 2);
-
-  for (j = 0; j < nv; ++j) {  // :804-821 evidence, :827-837 singlet scan, :883-906 doublet scan
-    const double s = llksAB[(size_t)j * nv * nAlpha];
-    sumLLK = dev_logadd(sumLLK, s + log_single_prior);
-    sngLLK = dev_logadd(sngLLK, s + log_single_prior);
-    if (sngBestLLK < s) {
-      sngNextLLK = sngBestLLK;
-      sNext = sBest;
-      sBest = j;
-      sngBestLLK = s;
-    } else if (sngNextLLK < s) {
-      sNext = j;
-      sngNextLLK = s;
-    }
-    for (k = 0; k < nv; ++k) {
-      if (j == k) continue;
-      for (n = 1; n < nAlpha; ++n) {
-        const double v = llksAB[((size_t)j * nv + k) * nAlpha + n];
-        if (gridAlpha[n] == 0.5) {
-          if (k < j) sumLLK = dev_logadd(sumLLK, v + log_doublet_prior2);
-        } else
-          sumLLK = dev_logadd(sumLLK, v + log_doublet_prior1);
-        if (dblBestLLK < v) {
-          dNext1 = dBest1;
-          dNext2 = dBest2;
-          dblNextAlpha = dblBestAlpha;
-          dblNextLLK = dblBestLLK;
-          dBest1 = j;
-          dBest2 = k;
-          dblBestAlpha = n;
-          dblBestLLK = v;
-        } else if (dblNextLLK < v) {
-          dNext1 = j;
-          dNext2 = k;
-          dblNextAlpha = n;
-          dblNextLLK = v;
-        }
-      }
-    }
-  }
-
-  int32_t bestType, nextType, jBest, kBest, jNext, kNext, alphaBest, alphaNext;
-  double bestLLK, nextLLK;
-  if (dblBestLLK > sngBestLLK + 2) {  // :925
-    bestType = MUXGL_DBL;
-    bestPP = exp(dblBestLLK + ((gridAlpha[dblBestAlpha] == 0.5) ? log_doublet_prior2 : log_doublet_prior1) - sumLLK);
-    jBest = dBest1;
-    kBest = dBest2;
-    bestLLK = dblBestLLK;
-    alphaBest = dblBestAlpha;
-    if (dblNextLLK > sngBestLLK + 2) {
-      nextType = MUXGL_DBL;
-      jNext = dNext1;
-      kNext = dNext2;
-      nextLLK = dblNextLLK;
-      alphaNext = dblNextAlpha;
-    } else {
-      nextType = MUXGL_SNG;
-      jNext = kNext = sBest;
-      nextLLK = sngBestLLK;
-      alphaNext = 0;
-    }
-  } else {
-    bestType = (sngBestLLK > sngNextLLK + 2) ? MUXGL_SNG : MUXGL_AMB;  // :947 / :968 (same body)
-    bestPP = sngBestLLK + log_single_prior - sumLLK;                   // log value, as the reference (:949,970)
-    jBest = kBest = sBest;
-    bestLLK = sngBestLLK;
-    alphaBest = 0;
-    if (dblBestLLK > sngNextLLK + 2) {
-      nextType = MUXGL_DBL;
-      jNext = dBest1;
-      kNext = dBest2;
-      nextLLK = dblBestLLK;
-      alphaNext = dblBestAlpha;
-    } else {
-      nextType = MUXGL_SNG;
-      jNext = kNext = sNext;
-      nextLLK = sngNextLLK;
-      alphaNext = 0;
-    }
-  }
-  o.type = bestType;
-  o.next_type = nextType;
-  o.sBest = sBest;
-  o.sNext = sNext;
-  o.dBest1 = dBest1;
-  o.dBest2 = dBest2;
-  o.dBestA = dblBestAlpha;
-  o.dNext1 = dNext1;
-  o.dNext2 = dNext2;
-  o.dNextA = dblNextAlpha;
-  o.jBest = jBest;
-  o.kBest = kBest;
-  o.aBest = alphaBest;
-  o.jNext = jNext;
-  o.kNext = kNext;
-  o.aNext = alphaNext;
-  o.sngBestLLK = sngBestLLK;
-  o.sngNextLLK = sngNextLLK;
-  o.dblBestLLK = dblBestLLK;
-  o.dblNextLLK = dblNextLLK;
-  o.sumLLK = sumLLK;
-  o.sngLLK = sngLLK;
-  o.bestLLK = bestLLK;
-  o.nextLLK = nextLLK;
-  o.bestPP = bestPP;
-  o.sngPP = exp(sngLLK - sumLLK);                              // :990
-  o.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);   // :991
-  out[i] = o;
-}
-
 template <int NA>
 int launch_sweep(muxgl_handle* h, const muxgl_demux_params* p, uint32_t symmask, const alpha_args& al) {
   const int V = h->V, A = p->n_alpha;
@@ -560,13 +422,8 @@ int demux_launch(muxgl_handle* h, const muxgl_demux_params* p) {
   tic(h, MUXGL_T_DEMUX_CALL);
   if (h->ll_wave) {
     if (demux_call_wave_launch(h, p)) return 1;
-  } else if (!(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
-    if (demux_call16_launch(h, p)) return 1;  // 16 or 64 lanes per cell (a lane takes every 64th row beyond 64 samples)
   } else {
-    const unsigned blocks = (unsigned)((h->C + 63) / 64);
-    hipLaunchKernelGGL(demux_call_kernel, dim3(blocks ? blocks : 1), dim3(64), 0, h->stream, h->C, h->d_cell_ptr, h->V,
-                       A, al, p->doublet_prior, h->d_ll, h->d_dcells);
-    HIPCHK(h, hipGetLastError());
+    if (demux_call16_launch(h, p)) return 1;  // 16 or 64 lanes per cell (a lane takes every 64th row beyond 64 samples)
   }
   toc(h, MUXGL_T_DEMUX_CALL);
   return 0;

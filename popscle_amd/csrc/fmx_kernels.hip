@@ -390,16 +390,21 @@ __global__ void __launch_bounds__(256)
 struct fmx_top2 {
   double v1, v2;
   int32_t p1, p2;
+  double v3;  // third-largest value (no position), for the exact-call pass: see muxgl_fmx_cell
 };
 __device__ __forceinline__ bool fmx_better(double va, int32_t pa, double vb, int32_t pb) {
   return va > vb || (va == vb && pa < pb);
 }
 __device__ __forceinline__ void fmx_top2_push(fmx_top2& t, double v, int32_t p) {
   if (fmx_better(v, p, t.v1, t.p1)) {
+    t.v3 = t.v2;
     t.v2 = t.v1, t.p2 = t.p1;
     t.v1 = v, t.p1 = p;
   } else if (fmx_better(v, p, t.v2, t.p2)) {
+    t.v3 = t.v2;
     t.v2 = v, t.p2 = p;
+  } else {
+    t.v3 = fmax(t.v3, v);
   }
 }
 __device__ __forceinline__ fmx_top2 fmx_top2_wave(fmx_top2 t) {
@@ -408,8 +413,10 @@ __device__ __forceinline__ fmx_top2 fmx_top2_wave(fmx_top2 t) {
     fmx_top2 o;
     o.v1 = __shfl_xor(t.v1, off, 64), o.p1 = __shfl_xor(t.p1, off, 64);
     o.v2 = __shfl_xor(t.v2, off, 64), o.p2 = __shfl_xor(t.p2, off, 64);
+    o.v3 = __shfl_xor(t.v3, off, 64);
     fmx_top2_push(t, o.v1, o.p1);
     fmx_top2_push(t, o.v2, o.p2);
+    t.v3 = fmax(t.v3, o.v3);  // (o.v1 >= o.v2 >= o.v3 are all in the union: o.v3 can be its third at best)
   }
   return t;
 }
@@ -442,9 +449,10 @@ __global__ void __launch_bounds__(64)
   int32_t sBest = -1, sNext = -1, dBest1 = -1, dBest2 = -1, dNext1 = -1, dNext2 = -1;
   double sngBestLLK = -1e300, sngNextLLK = -1e300, dblBestLLK = -1e300, dblNextLLK = -1e300;
   double sumLLK = -1e300, sngLLK = -1e300;
+  double sngThird = -1e300, dblThird = -1e300;
   if constexpr (WAVE) {
     const int lane = threadIdx.x;
-    fmx_top2 ts = {-1e300, -1e300, 0x7fffffff, 0x7fffffff}, td = ts;
+    fmx_top2 ts = {-1e300, -1e300, 0x7fffffff, 0x7fffffff, -1e300}, td = ts;
     double mall = -1e300, msng = -1e300;
     // position p = j (j + 1) / 2 + k of the scan order; the row j of a position is followed through the strides
     int j = (int)((sqrt(8.0 * lane + 1.0) - 1.0) * 0.5);
@@ -494,6 +502,8 @@ __global__ void __launch_bounds__(64)
     if (ts.p2 != 0x7fffffff) sNext = row_of(ts.p2), sngNextLLK = ts.v2;
     if (td.p1 != 0x7fffffff) dBest1 = row_of(td.p1), dBest2 = td.p1 - dBest1 * (dBest1 + 1) / 2, dblBestLLK = td.v1;
     if (td.p2 != 0x7fffffff) dNext1 = row_of(td.p2), dNext2 = td.p2 - dNext1 * (dNext1 + 1) / 2, dblNextLLK = td.v2;
+    sngThird = ts.v3;
+    dblThird = td.v3;
   } else {
   // one lane per cell: the reference's scans as written (:469-497); its evidence chain -- logAdd per hypothesis, a library
   // exp and log each, 400 of them per cell at K = 16: nine tenths of this kernel's instructions -- as a running
@@ -514,6 +524,7 @@ __global__ void __launch_bounds__(64)
     for (int k = 0; k < j; ++k) {
       const double v = llks[j * (j + 1) / 2 + k];
       if (v > dblBestLLK) {
+        dblThird = dblNextLLK;
         dNext1 = dBest1;
         dNext2 = dBest2;
         dblNextLLK = dblBestLLK;
@@ -521,21 +532,28 @@ __global__ void __launch_bounds__(64)
         dBest2 = k;
         dblBestLLK = v;
       } else if (v > dblNextLLK) {
+        dblThird = dblNextLLK;
         dNext1 = j;
         dNext2 = k;
         dblNextLLK = v;
+      } else {
+        dblThird = fmax(dblThird, v);
       }
       evid(v + log_double_prior, mall, sall);
     }
     const double v = llks[j * (j + 1) / 2 + j];
     if (v > sngBestLLK) {
+      sngThird = sngNextLLK;
       sNext = sBest;
       sngNextLLK = sngBestLLK;
       sBest = j;
       sngBestLLK = v;
     } else if (v > sngNextLLK) {
+      sngThird = sngNextLLK;
       sNext = j;
       sngNextLLK = v;
+    } else {
+      sngThird = fmax(sngThird, v);
     }
     evid(v + log_single_prior, mall, sall);
     evid(v + log_single_prior, msng, ssng);
@@ -557,6 +575,8 @@ __global__ void __launch_bounds__(64)
   c.sngPP = exp(sngLLK - sumLLK);
   c.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);
   c.sumLLK = sumLLK;
+  c.sngThirdLLK = sngThird;
+  c.dblThirdLLK = dblThird;
 
   int32_t dsingle = 0, damb = 0, dchanged = 0;
   c.clust = -1;                           // :520

@@ -12,7 +12,7 @@
 // behind muxgl_* calls; there is no CPU implementation of it in this program.
 #include <cmath>
 
-#include "pair_order.hpp"
+#include "exact_calls.hpp"
 #include "plp.hpp"
 #include "synthplp.hpp"
 
@@ -102,10 +102,10 @@ int cmd_demuxlet(int argc, char** argv) {
   double doublet_prior = 0.5;  // cmd_cram_demuxlet.cpp:32
   std::string sam, tagGroup, tagUMI;
   int32_t dummy_i = 0;
-  bool devicePairOrder = false;  // (ours) skip the host pass that orders mirrored alpha = 0.5 pairs as the reference does
+  bool deviceCalls = false;  // (ours) skip the host pass that settles mirrored alpha = 0.5 pairs and near-tie calls as the reference does
   Args a;
   cf.add(a);
-  a.add_bool("device-pair-order", &devicePairOrder);
+  a.add_bool("device-calls", &deviceCalls);
   a.add_string("vcf", &vr.path);
   a.add_string("field", &cf.lo.field);
   a.add_double("geno-error-offset", &cf.lo.genoErrorOffset);
@@ -160,14 +160,18 @@ int cmd_demuxlet(int argc, char** argv) {
   std::vector<muxgl_demux_cell> cells((size_t)p.C());
   check(h, muxgl_demux_run(h, &dp, cells.data(), nullptr), "muxgl_demux_run");
   tm.lap("demuxlet: muxgl_demux_run");
-  if (!devicePairOrder) {
-    // DBL.BEST.GUESS / NEXT.GUESS of a mirrored alpha = 0.5 pair in the order the reference's scan reports
-    // (cmd_cram_demuxlet.cpp:738-746,883-906; pair_order.hpp)
-    int64_t st[3];
-    pair_order::reference_pair_order(p.C(), p.nv, p.cell_ptr.data(), p.entry_snp.data(), p.entry_rptr.data(),
-                                     p.reads.data(), p.gp.data(), p.has_gp.data(), dp.n_alpha, dp.alpha, cells.data(),
-                                     plp_threads(), st);
-    tm.lap("demuxlet: reference pair order (host)");
+  if (!deviceCalls) {
+    // the calls rounding noise could decide -- the order of a mirrored alpha = 0.5 pair in DBL.BEST.GUESS / NEXT.GUESS
+    // (cmd_cram_demuxlet.cpp:738-746,883-906) and near ties of the scans and thresholds (:827-837,925-988) -- settled in
+    // the reference's own arithmetic (exact_calls.hpp)
+    int64_t st[exact_calls::ST_N];
+    exact_calls::exact_calls(p.C(), p.nv, p.cell_ptr.data(), p.entry_snp.data(), p.entry_rptr.data(), p.reads.data(),
+                             p.gp.data(), p.has_gp.data(), dp.n_alpha, dp.alpha, dp.doublet_prior, cells.data(),
+                             plp_threads(), st);
+    notice("Exact-call pass: %lld droplets looked at (%lld near ties besides mirrored pairs, %lld needing every hypothesis, "
+           "%lld calls changed)", (long long)st[exact_calls::ST_CELLS], (long long)st[exact_calls::ST_NEAR_TIES],
+           (long long)st[exact_calls::ST_DEEP], (long long)st[exact_calls::ST_CHANGED]);
+    tm.lap("demuxlet: exact calls (host)");
   }
 
   // .best, cmd_cram_demuxlet.cpp:629,636-641,993-1013: rows in barcode-sorted order, INT_ID counts skipped cells too

@@ -43,21 +43,22 @@ DEMUX_CELL = np.dtype(
     [(n, np.int32) for n in ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA",
                              "dNext1", "dNext2", "dNextA", "jBest", "kBest", "aBest", "jNext", "kNext", "aNext")]
     + [(n, np.float64) for n in ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK", "sumLLK", "sngLLK",
-                                 "bestLLK", "nextLLK", "bestPP", "sngPP", "sngOnlyPP")],
+                                 "bestLLK", "nextLLK", "bestPP", "sngPP", "sngOnlyPP", "sngThirdLLK",
+                                 "dblThirdLLK")],
     align=True,
 )
 FMX_CELL = np.dtype(
     [(n, np.int32) for n in ("type", "clust", "jBest", "kBest", "jNext", "kNext", "sBest", "sNext", "dBest1",
                              "dBest2", "dNext1", "dNext2")]
     + [(n, np.float64) for n in ("bestLLK", "nextLLK", "sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK",
-                                 "bestPP", "sngPP", "sngOnlyPP", "sumLLK")],
+                                 "bestPP", "sngPP", "sngOnlyPP", "sumLLK", "sngThirdLLK", "dblThirdLLK")],
     align=True,
 )
 DROPD = np.dtype([("nsnps", np.int32), ("nread1", np.int32), ("nread2", np.int32), ("_pad", np.int32),
                   ("llk0", np.float64), ("llk2", np.float64)], align=True)
 assert DROPD.itemsize == 32
-assert DEMUX_CELL.itemsize == 18 * 4 + 11 * 8
-assert FMX_CELL.itemsize == 12 * 4 + 10 * 8
+assert DEMUX_CELL.itemsize == 18 * 4 + 13 * 8
+assert FMX_CELL.itemsize == 12 * 4 + 12 * 8
 
 
 class _Config(C.Structure):
@@ -85,8 +86,8 @@ SYMBOLS = {
     "muxgl_demux_set_gp": (C.c_int, [_VP, C.c_int32, _VP, _VP]),
     "muxgl_demux_run": (C.c_int, [_VP, C.POINTER(_DemuxParams), _VP, _VP]),
     "muxgl_demux_results": (_VP, [_VP]),
-    "muxgl_demux_reference_pair_order": (C.c_int, [C.c_int64, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP,
-                                                   C.POINTER(_DemuxParams), _VP, C.c_int32, _VP]),
+    "muxgl_demux_exact_calls": (C.c_int, [C.c_int64, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP,
+                                          C.POINTER(_DemuxParams), _VP, C.c_int32, _VP]),
     "muxgl_demux_get_entry_pg": (C.c_int, [_VP, _VP]),
     "muxgl_fmx_prepare": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_entry_gls": (C.c_int, [_VP, _VP, _VP]),
@@ -139,15 +140,20 @@ class MuxglError(RuntimeError):
     pass
 
 
-def demux_reference_pair_order(p, alphas, cells, nthreads=0):
-    """muxgl_demux_reference_pair_order: the host pass (no device) that puts the alpha = 0.5 pairs of `cells` (records of
-    demux_run over pileup p, modified in place) into the order the reference's scan reports
-    (cmd_cram_demuxlet.cpp:738-746,883-906).  Returns (cells looked at, pairs turned to (hi, lo), exact ties)."""
+EXACT_STATS = ("cells", "mirror_turned", "mirror_exact_ties", "near_ties", "deep", "changed")
+
+
+def demux_exact_calls(p, alphas, cells, doublet_prior=0.5, nthreads=0):
+    """muxgl_demux_exact_calls: the host pass (no device) that settles, in the reference's own arithmetic, every call of
+    `cells` (records of demux_run over pileup p, modified in place) that rounding noise could decide: the order of a
+    mirrored alpha = 0.5 pair (cmd_cram_demuxlet.cpp:738-746,883-906) and the near ties of the scans and thresholds
+    (:827-837,925-988).  Returns a dict of the six counters (EXACT_STATS)."""
     lib = load_library()
     dp = _DemuxParams()
     dp.n_alpha = len(alphas)
     for i, a in enumerate(alphas):
         dp.alpha[i] = float(a)
+    dp.doublet_prior = float(doublet_prior)
     cell_ptr = _arr(p.cell_ptr, np.int64, "cell_ptr")
     entry_snp = _arr(p.entry_snp, np.int32, "entry_snp")
     entry_rptr = _arr(p.entry_rptr, np.int64, "entry_rptr")
@@ -156,14 +162,13 @@ def demux_reference_pair_order(p, alphas, cells, nthreads=0):
     has_gp = _arr(p.has_gp, np.uint8, "has_gp")
     if cells.dtype != DEMUX_CELL or not cells.flags.c_contiguous or cells.shape != (cell_ptr.size - 1,):
         raise ValueError("cells must be the contiguous [C] record array demux_run returned")
-    stats = np.zeros(3, dtype=np.int64)
-    rc = lib.muxgl_demux_reference_pair_order(cell_ptr.size - 1, gp.shape[1], _ptr(cell_ptr), _ptr(entry_snp),
-                                              _ptr(entry_rptr), _ptr(reads), _ptr(gp), _ptr(has_gp), C.byref(dp),
-                                              _ptr(cells), int(nthreads) if nthreads else (os.cpu_count() or 1),
-                                              _ptr(stats))
+    stats = np.zeros(len(EXACT_STATS), dtype=np.int64)
+    rc = lib.muxgl_demux_exact_calls(cell_ptr.size - 1, gp.shape[1], _ptr(cell_ptr), _ptr(entry_snp), _ptr(entry_rptr),
+                                     _ptr(reads), _ptr(gp), _ptr(has_gp), C.byref(dp), _ptr(cells),
+                                     int(nthreads) if nthreads else (os.cpu_count() or 1), _ptr(stats))
     if rc != 0:
-        raise MuxglError(f"muxgl_demux_reference_pair_order failed ({rc})")
-    return tuple(int(x) for x in stats)
+        raise MuxglError(f"muxgl_demux_exact_calls failed ({rc})")
+    return dict(zip(EXACT_STATS, (int(x) for x in stats)))
 
 
 def _ptr(a):

@@ -1,10 +1,14 @@
 """Parity comparison helpers shared by the GPU tests, smoke() and bench.py's self-check.
 
 Bar (BASELINE.json north_star): best-sample / doublet calls exact, log-likelihoods within 1e-5 absolute.
-One canonicalisation is applied before comparing calls: at alpha == 0.5 the doublet likelihood is symmetric in the
-two samples, the reference evaluates (j,k) and (k,j) with transposed summation orders and lets the last ulp decide
-which order it reports (cmd_cram_demuxlet.cpp:738-746,883-906) -- a GPU log() cannot reproduce that ulp, so ordered
-pairs at alpha 0.5 are compared as unordered pairs.
+
+"Exact" means exact: every integer field of a record -- droplet type, best / next singlet, best / next doublet in the
+ORDER the reference names its two samples, the derived guesses -- must equal the reference's, with no tie window and no
+canonical pair order.  The kernels' log-likelihoods equal the reference's to ~1e-12, not to the last bit, so the records
+are compared after the product's own exact-call pass (popscle_amd/host/exact_calls.hpp = muxgl_demux_exact_calls, what
+`popscle-amd demuxlet` runs before it writes .best): it recomputes, in the reference's arithmetic, the hypotheses of every
+cell where a comparison's margin is within rounding reach and leaves all other cells untouched -- for those the raw
+device record is what is compared.
 """
 from __future__ import annotations
 
@@ -14,20 +18,8 @@ LL_TOL = 1e-5  # absolute, on log-likelihoods (north_star)
 
 DEMUX_LL_FIELDS = ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK", "sumLLK", "sngLLK", "bestLLK", "nextLLK")
 DEMUX_PP_FIELDS = ("bestPP", "sngPP", "sngOnlyPP")
-
-
-def _canon_pairs(a, b, alpha_idx, alphas):
-    """sort (a,b) where the alpha of the hypothesis is 0.5"""
-    a = a.copy()
-    b = b.copy()
-    al = np.asarray(alphas, dtype=np.float64)
-    idx = np.clip(alpha_idx, 0, al.size - 1)
-    sym = (alpha_idx >= 0) & (al[idx] == 0.5)
-    lo = np.minimum(a, b)
-    hi = np.maximum(a, b)
-    a[sym] = lo[sym]
-    b[sym] = hi[sym]
-    return a, b
+DEMUX_INT_FIELDS = ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA", "dNext1",
+                    "dNext2", "dNextA", "jBest", "kBest", "aBest", "jNext", "kNext", "aNext")
 
 
 def _close(x, y, tol):
@@ -39,30 +31,37 @@ def _close(x, y, tol):
         return same_inf | both_nan | (np.abs(x - y) <= tol)
 
 
-def _ll_of(full, cells, a, b, n):
-    """oracle LL of hypothesis (a,b,n) for each listed cell (-inf where the hypothesis is void)"""
-    out = np.full(cells.size, -np.inf)
-    ok = (a >= 0) & (b >= 0) & (n >= 0)
-    out[ok] = full[cells[ok], a[ok], b[ok], n[ok]]
+def exact(got, alphas, p, doublet_prior=0.5, nthreads=0):
+    """a copy of the raw device records `got` after the product's exact-call pass"""
+    from popscle_amd import muxgl
+
+    out = np.ascontiguousarray(got).copy()
+    muxgl.demux_exact_calls(p, alphas, out, doublet_prior, nthreads=nthreads)
     return out
 
 
-def compare_demux(got, want, alphas, tol=LL_TOL, tie_eps=1e-7, want_full=None):
-    """Compare [C] demux records (numpy structured arrays with the muxgl_demux_cell fields).
+def compare_demux(got, want, alphas, p, tol=LL_TOL, doublet_prior=0.5, nthreads=0):
+    """Compare [C] demux records of muxgl_demux_run over pileup `p` (numpy structured arrays with the muxgl_demux_cell
+    fields; `got` is not modified) with the reference's / oracle's records `want`.
 
-    want_full: optional oracle llksAB [C][V][V][A].  With it, a guess that differs from the oracle's is still accepted
-    when the ORACLE's own LL of the guessed hypothesis equals the oracle's best/next LL within tie_eps, i.e. when the
-    two candidates are tied in the reference arithmetic itself (cells with a handful of entries tie structurally).
-
-    Returns a dict with max LL deviation and the number of call mismatches that are NOT explained by an exact tie
-    (two hypotheses whose oracle LLs differ by < tie_eps).  Raises AssertionError on any violation of the bar.
+    Runs the product's exact-call pass on a copy of `got`, then requires every integer field to be EQUAL and every
+    log-likelihood / posterior within `tol`.  Returns a report: the largest LL deviation, the pass's counters, and how
+    many cells' raw device records differed from the reference before the pass (all of them cells the pass looked at).
+    Raises AssertionError on any violation.
     """
-    assert got.shape == want.shape
-    assert np.array_equal(got["valid"], want["valid"]), "valid flags differ"
-    assert np.array_equal(got["nsnps"], want["nsnps"]), "NUM.SNPS differ"
+    from popscle_amd import muxgl
+
+    assert got.shape == want.shape == (p.C,)
+    raw = got
+    got = np.ascontiguousarray(got).copy()
+    st = muxgl.demux_exact_calls(p, alphas, got, doublet_prior, nthreads=nthreads)
     v = want["valid"] == 1
+    report = {"cells": int(v.sum()), "exact_pass": st}
+    for f in DEMUX_INT_FIELDS:
+        bad = np.flatnonzero(got[f] != want[f])
+        assert bad.size == 0, (f"{f} differs in {bad.size} cells: {bad[:5].tolist()}: got {got[f][bad[:5]].tolist()}, "
+                               f"reference {want[f][bad[:5]].tolist()}")
     g, w = got[v], want[v]
-    report = {"cells": int(v.sum())}
     worst = 0.0
     for f in DEMUX_LL_FIELDS + DEMUX_PP_FIELDS:
         ok = _close(g[f], w[f], tol)
@@ -73,62 +72,13 @@ def compare_demux(got, want, alphas, tol=LL_TOL, tie_eps=1e-7, want_full=None):
             worst = max(worst, float(d.max()))
         assert ok.all(), f"{f}: {int((~ok).sum())} cells beyond {tol}; worst {d.max() if d.size else 'nan'}"
     report["max_abs_ll_diff"] = worst
-
-    # singlet calls: exact unless best and next are tied
-    tie_s = np.abs(w["sngBestLLK"] - w["sngNextLLK"]) < tie_eps
-    bad = (g["sBest"] != w["sBest"]) & ~tie_s
-    assert not bad.any(), f"sBest differs in {int(bad.sum())} cells"
-    # how often each relaxation of "exact" was actually USED (a difference that only a tie or the canonical pair order
-    # excuses): reported so that full-size runs can bound them
-    used = {"singlet_tie": int(((g["sBest"] != w["sBest"]) | (g["sNext"] != w["sNext"])).sum())}
-    # sNext: exact unless the runner-up itself is tied with a third sample (cannot tell from the record): require
-    # equal LL then
-    bad = (g["sNext"] != w["sNext"]) & ~tie_s & ~_close(g["sngNextLLK"], w["sngNextLLK"], 1e-9)
-    assert not bad.any(), f"sNext differs in {int(bad.sum())} cells"
-
-    # doublet calls, unordered at alpha 0.5
-    gb = _canon_pairs(g["dBest1"], g["dBest2"], g["dBestA"], alphas)
-    wb = _canon_pairs(w["dBest1"], w["dBest2"], w["dBestA"], alphas)
-    gn = _canon_pairs(g["dNext1"], g["dNext2"], g["dNextA"], alphas)
-    wn = _canon_pairs(w["dNext1"], w["dNext2"], w["dNextA"], alphas)
-    tie_d = np.abs(w["dblBestLLK"] - w["dblNextLLK"]) < tie_eps
-    same_best = (gb[0] == wb[0]) & (gb[1] == wb[1]) & (g["dBestA"] == w["dBestA"])
-    same_next = (gn[0] == wn[0]) & (gn[1] == wn[1]) & (g["dNextA"] == w["dNextA"])
-    # when best and next are tied (always the case for mirrored alpha-0.5 pairs) the two may swap roles
-    swapped = (gb[0] == wn[0]) & (gb[1] == wn[1]) & (g["dBestA"] == w["dNextA"]) & \
-              (gn[0] == wb[0]) & (gn[1] == wb[1]) & (g["dNextA"] == w["dBestA"])
-    okd = (same_best & same_next) | (tie_d & (swapped | same_best))
-    if want_full is not None and not okd.all():
-        idx = np.nonzero(v)[0]
-        lb = _ll_of(want_full, idx, g["dBest1"], g["dBest2"], g["dBestA"])
-        ln = _ll_of(want_full, idx, g["dNext1"], g["dNext2"], g["dNextA"])
-        okd |= (np.abs(lb - w["dblBestLLK"]) < tie_eps) & (np.abs(ln - w["dblNextLLK"]) < tie_eps)
-    assert okd.all(), f"doublet best/next guesses differ in {int((~okd).sum())} cells"
-    report["doublet_tie_swaps"] = int((tie_d & ~same_best).sum())
-    raw_same = (g["dBest1"] == w["dBest1"]) & (g["dBest2"] == w["dBest2"]) & (g["dNext1"] == w["dNext1"]) & \
-               (g["dNext2"] == w["dNext2"])
-    used["mirrored_pair_order"] = int((same_best & same_next & ~raw_same).sum())  # same pairs, other order at alpha 0.5
-    used["doublet_tie"] = int((~(same_best & same_next)).sum())                    # other pairs, tied in the oracle's numbers
-
-    # droplet type and the derived best/next guesses
-    assert np.array_equal(g["type"], w["type"]), "DROPLET.TYPE differs"
-    assert np.array_equal(g["next_type"], w["next_type"]), "next type differs"
-    gj = _canon_pairs(g["jBest"], g["kBest"], g["aBest"], alphas)
-    wj = _canon_pairs(w["jBest"], w["kBest"], w["aBest"], alphas)
-    okb = ((gj[0] == wj[0]) & (gj[1] == wj[1]) & (g["aBest"] == w["aBest"])) | (tie_d & (g["type"] == 1)) | \
-          (tie_s & (g["type"] != 1))
-    gj =_canon_pairs(g["jNext"], g["kNext"], g["aNext"], alphas)
-    wj = _canon_pairs(w["jNext"], w["kNext"], w["aNext"], alphas)
-    okn = ((gj[0] == wj[0]) & (gj[1] == wj[1]) & (g["aNext"] == w["aNext"])) | tie_d | tie_s
-    if want_full is not None:
-        # structural ties beyond best/next: the guessed hypotheses carry the oracle's LLs
-        okb |= _close(g["bestLLK"], w["bestLLK"], tie_eps)
-        okn |= _close(g["nextLLK"], w["nextLLK"], tie_eps)
-    assert okb.all(), f"BEST.GUESS differs in {int((~okb).sum())} cells"
-    assert okn.all(), f"NEXT.GUESS differs in {int((~okn).sum())} cells"
-    report["excuses_used"] = used
-    report["cells_needing_an_excuse"] = int((((g["sBest"] != w["sBest"]) | (g["sNext"] != w["sNext"])) |
-                                             ~(same_best & same_next) | ~raw_same).sum())
+    differs = np.zeros(got.shape, dtype=bool)
+    for f in DEMUX_INT_FIELDS:
+        differs |= raw[f] != want[f]
+    report["raw_records_differing"] = int(differs.sum())   # the pass's work, seen from outside
+    assert report["raw_records_differing"] <= st["cells"]
+    # kept for the readers of bench lines of earlier rounds: no relaxation exists any more
+    report["excuses_used"] = {"singlet_tie": 0, "doublet_tie": 0, "mirrored_pair_order": 0}
     return report
 
 

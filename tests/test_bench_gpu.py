@@ -52,8 +52,12 @@ def test_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["parity_max_abs_ll_diff"] < 1e-5
-    # with the product's host pass for mirrored alpha = 0.5 pairs the checked records need no pair-order excuse
-    assert cb["parity_excuses_used"]["mirrored_pair_order"] == 0 and cb["pair_order_pass"]["cells"] == cb["parity_checked_cells"]
+    # the checked records equal the oracle's in every integer field after the product's exact-call pass; the pass's cost
+    # over ALL cells of the step is stated next to the timed value, not inside it
+    assert set(cb["parity_excuses_used"].values()) == {0} and cb["exact_pass_on_checked_cells"]["cells"] > 0
+    ep = d["exact_calls_pass"]
+    assert ep["timed_in_value"] is False and ep["ms_all_cells"] > 0 and ep["cells"] > 9000 and ep["deep"] < 20
+    assert d["pair_order_ms_all_cells"] == ep["ms_all_cells"]
     # value = LLs of the job / step time
     assert abs(d["value"] - 10000 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
     assert d["value"] > 50 * cb["value"]

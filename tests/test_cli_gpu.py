@@ -53,22 +53,34 @@ def as_pileup(d):
                         d["gp"] if d["nv"] else None, d["has_gp"] if d["nv"] else None)
 
 
-@pytest.mark.parametrize("V,alphas", [(4, None),   # BASELINE configs[0]'s shape: 4-sample GT VCF, default grid
-                                      (6, None), (6, (0.0, 0.1, 0.3, 0.5)), (20, None)])
-def test_demuxlet_cli(tmp_path, V, alphas):
+@pytest.mark.parametrize("V,alphas,field", [
+    (4, None, "GT"),   # BASELINE configs[0]'s shape: 4-sample GT VCF, default grid
+    (6, None, "GT"), (6, (0.0, 0.1, 0.3, 0.5), "GT"), (20, None, "GT"),
+    # posteriors from FORMAT/GP (float normalisation) and from FORMAT/PL (the 10-iteration EM); the
+    # loader's arithmetic for both is pinned to the reference's own lines in tests/test_oracle_ref.py
+    (6, None, "GP"), (6, None, "PL"), (4, (0.0, 0.25, 0.5), "PL"), (20, None, "GP")])
+def test_demuxlet_cli(tmp_path, V, alphas, field):
     p = synth.make_pileup(60, 800, V, seed=5, mean_entries=150, min_entries=20, doublet_frac=0.3)
     prefix = str(tmp_path / "plp")
     plpio.write_plp(prefix, p, seed=5, extra_cells=1)
     vcf = str(tmp_path / "g.vcf.gz")
-    plpio.write_vcf(vcf, p, p.truth["G"].astype(np.int64), missing_frac=0.02, drop_snps=range(0, 800, 37))
+    G = p.truth["G"].astype(np.int64)
+    rng = np.random.default_rng(V)
+    onehot = np.eye(3)[G]
+    gp = 0.85 * onehot + 0.15 * rng.dirichlet([0.5, 0.5, 0.5], size=G.shape)   # imputation-like posteriors
+    pl = np.where(onehot > 0, 0, rng.integers(8, 70, size=G.shape + (3,)))       # caller-like likelihoods
+    plpio.write_vcf(vcf, p, G, field=field, missing_frac=0.02, drop_snps=range(0, 800, 37), gp=gp, pl=pl)
     out = str(tmp_path / "out")
-    cmd = [BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", "GT", "--out", out]
+    cmd = [BIN, "demuxlet", "--plp", prefix, "--vcf", vcf, "--field", field, "--out", out]
     for a in alphas or ():
         cmd += ["--alpha", str(a)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     al = alphas or (0.0, 0.5)
-    d = pyplp.load(prefix, vcf=vcf, field="GT")
+    d = pyplp.load(prefix, vcf=vcf, field=field)
+    if field != "GT":
+        hard = pyplp.load(prefix, vcf=vcf, field="GT")
+        assert not np.array_equal(hard["gp"], d["gp"])   # the run really read another FORMAT key
     q = as_pileup(d)
     cells = ob.demux(q, alphas=al, doublet_prior=0.5)
     ids = [f"S{v}" for v in range(V)]
@@ -90,8 +102,8 @@ def test_demuxlet_cli(tmp_path, V, alphas):
                         c["sngBestLLK"] - c["dblBestLLK"]))
     got = open(out + ".best").readlines()
 
-    # no canonicalisation: the front end orders a mirrored alpha-0.5 pair as the reference's scan does
-    # (popscle_amd/host/pair_order.hpp), so DBL.BEST.GUESS / BEST.GUESS / NEXT.GUESS are compared as printed
+    # no canonicalisation: the front end settles the order of a mirrored alpha-0.5 pair and every near-tie call as the
+    # reference does (popscle_amd/host/exact_calls.hpp), so every guess column is compared as printed
     assert_rows_match(got, want)
     assert len(got) == 1 + int((cells["valid"] == 1).sum())
 

@@ -57,7 +57,7 @@ def test_golden(eng, name):
                      z["gp"], z["has_gp"])
     alphas = tuple(z["alphas"])
     got, full = run_gpu(eng, p, alphas, float(z["doublet_prior"]), full=True)
-    rep = parity.compare_demux(got, z["cells"], alphas, want_full=z["full_ll"])
+    rep = parity.compare_demux(got, z["cells"], alphas, p, doublet_prior=float(z["doublet_prior"]))
     worst = parity.compare_full_ll(full, z["full_ll"], p.gp.shape[1], alphas)
     assert rep["max_abs_ll_diff"] < 1e-8 and worst < 1e-8  # expected ~1e-11; the bar is 1e-5
 
@@ -97,7 +97,7 @@ def test_random_vs_oracle(eng, V, alphas, C, S, ment):
                           missing_gp_frac=0.03)
     want, wfull = oracle_demux(("random", V, C, S, ment), p, alphas, full_ll=True, nthreads=4)
     got, gfull = run_gpu(eng, p, alphas, full=True)
-    rep = parity.compare_demux(got, want, alphas, want_full=wfull)
+    rep = parity.compare_demux(got, want, alphas, p)
     worst = parity.compare_full_ll(gfull, wfull, V, alphas)
     assert rep["max_abs_ll_diff"] < 1e-7 and worst < 1e-7
     # slots the reference never reads stay 0 in the returned tensor
@@ -112,7 +112,7 @@ def test_long_alpha_grids(eng, V, nalpha, C, S, ment):
     p = synth.make_pileup(C, S, V, seed=2000 + V, mean_entries=ment, min_entries=20)
     want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
     got, gfull = run_gpu(eng, p, alphas, full=True)
-    rep = parity.compare_demux(got, want, alphas, want_full=wfull)
+    rep = parity.compare_demux(got, want, alphas, p)
     assert rep["max_abs_ll_diff"] < 1e-7 and parity.compare_full_ll(gfull, wfull, V, alphas) < 1e-7
 
 
@@ -126,10 +126,10 @@ def test_deep_pileups_per_entry(eng, V):
     alphas = (0.0, 0.3, 0.5)
     want, wfull = ob.demux(p, alphas=alphas, full_ll=True, nthreads=4)
     got, gfull = run_gpu(eng, p, alphas, full=True)
-    rep = parity.compare_demux(got, want, alphas, want_full=wfull)
+    rep = parity.compare_demux(got, want, alphas, p)
     assert rep["max_abs_ll_diff"] < 1e-7 and parity.compare_full_ll(gfull, wfull, V, alphas) < 1e-7
     got2 = run_gpu(eng, p, (0.0, 0.5))
-    parity.compare_demux(got2, ob.demux(p, alphas=(0.0, 0.5), nthreads=4), (0.0, 0.5))
+    parity.compare_demux(got2, ob.demux(p, alphas=(0.0, 0.5), nthreads=4), (0.0, 0.5), p)
 
 
 @pytest.mark.parametrize("V", [8, 16, 17, 19, 22, 24, 27, 32, 48])
@@ -141,7 +141,7 @@ def test_records_do_not_depend_on_the_tensor_request(eng, V):
     with_tensor, _ = run_gpu(eng, p, alphas, full=True)
     without = run_gpu(eng, p, alphas)
     assert without.tobytes() == with_tensor.tobytes()
-    parity.compare_demux(without, ob.demux(p, alphas=alphas, nthreads=4), alphas)
+    parity.compare_demux(without, ob.demux(p, alphas=alphas, nthreads=4), alphas, p)
 
 
 def test_entry_pg_vs_oracle(eng):
@@ -181,7 +181,7 @@ def test_ragged_and_edge_inputs(eng, V):
     for alphas in [(0.0, 0.5), GRID6]:
         want, wfull = ob.demux(p, alphas=alphas, full_ll=True)
         got, gfull = run_gpu(eng, p, alphas, full=True)
-        parity.compare_demux(got, want, alphas, want_full=wfull)
+        parity.compare_demux(got, want, alphas, p)
         parity.compare_full_ll(gfull, wfull, V, alphas)
         assert got["valid"].tolist() == [0, 1, 1, 1, 0, 1, 0]
         assert run_gpu(eng, p, alphas).tobytes() == got.tobytes()  # the call made in LDS (no tensor requested)
@@ -207,8 +207,8 @@ def test_one_sweep_for_all_entries_matches_the_split_sweeps(V, alphas):
         b, bfull = run_gpu(new, p, alphas, full=True)
         for _ in range(3):
             assert run_gpu(new, p, alphas).tobytes() == b.tobytes()
-    parity.compare_demux(b, want, alphas, want_full=wfull)
-    parity.compare_demux(a, want, alphas, want_full=wfull)
+    parity.compare_demux(b, want, alphas, p)
+    parity.compare_demux(a, want, alphas, p)
     assert parity.compare_full_ll(bfull, wfull, V, alphas) < 1e-7
     assert b["valid"].tolist() == (lens > 0).astype(int).tolist()
     # the two sweeps accumulate in different associations (one product over all entries / a sum of two logarithms)
@@ -258,7 +258,7 @@ def test_zero_cells_and_reuse_of_handle(eng):
     b = run_gpu(eng, p, GRID6)
     c = run_gpu(eng, p, (0.0, 0.5))
     assert a.tobytes() == c.tobytes()
-    parity.compare_demux(b, ob.demux(p, alphas=GRID6), GRID6)
+    parity.compare_demux(b, ob.demux(p, alphas=GRID6), GRID6, p)
 
 
 def test_error_paths(eng):
@@ -293,23 +293,25 @@ def test_full_size_oracle_subsample(full_cfg):
     pick = np.sort(rng.choice(p.C, 64, replace=False))
     sub = p.subset_cells(pick)
     want, wfull = ob.demux(sub, alphas=alphas, full_ll=True, nthreads=4)
-    parity.compare_demux(cells[pick], want, alphas, want_full=wfull)
+    parity.compare_demux(cells[pick], want, alphas, sub)
     parity.compare_full_ll(full[pick], wfull, p.gp.shape[1], alphas)
 
 
-def test_full_size_every_cell_and_how_many_need_an_excuse(full_cfg):
-    """ALL 10 000 cells of configs[1] against the oracle, and the count of cells whose calls agree only through one of
-    parity.py's relaxations: a tie in the oracle's own numbers (none expected on this workload) or the order in which
-    the two samples of a mirrored alpha = 0.5 pair are named (about half of the cells: the reference's own order is
-    decided by the last ulp of two transposed sums, cmd_cram_demuxlet.cpp:738-746)."""
+def test_full_size_every_cell_exact(full_cfg):
+    """ALL 10 000 cells of configs[1] against the oracle: every integer field equal -- no tie window, no canonical pair
+    order -- after the product's exact-call pass (which `popscle-amd demuxlet` runs before it writes .best).  About every
+    cell is looked at by the pass here: with the grid {0, 0.5} every best doublet is a mirrored pair whose printed order
+    the reference decides in the last ulp of two transposed sums (cmd_cram_demuxlet.cpp:738-746)."""
     p, alphas, cells, full = full_cfg
     want = oracle_demux("configs1-full", p, alphas, nthreads=min(32, os.cpu_count() or 1))
-    rep = parity.compare_demux(cells, want, alphas)
-    print("configs[1] full size:", rep["cells"], "cells, max |dLL|", rep["max_abs_ll_diff"], rep["excuses_used"])
+    rep = parity.compare_demux(cells, want, alphas, p)
+    print("configs[1] full size:", rep["cells"], "cells, max |dLL|", rep["max_abs_ll_diff"], rep["exact_pass"],
+          "raw records differing:", rep["raw_records_differing"])
     assert rep["cells"] == p.C and rep["max_abs_ll_diff"] < 1e-8
-    used = rep["excuses_used"]
-    assert used["singlet_tie"] == 0 and used["doublet_tie"] <= 3, used
-    assert used["mirrored_pair_order"] < 0.75 * p.C
+    st = rep["exact_pass"]
+    assert st["cells"] > 0.9 * p.C and 0.2 * p.C < st["mirror_turned"] < 0.8 * p.C
+    # near ties proper are rare on this workload, and none of them needs more than the named hypotheses
+    assert st["near_ties"] < 0.01 * p.C, st
 
 
 def test_full_size_mirror_symmetry(full_cfg):
@@ -358,5 +360,5 @@ def test_scaled_down_posteriors_beyond_32_samples():
     want, want_ll = ob.demux(p, alphas, full_ll=True, nthreads=4)
     with muxgl.Engine(0) as en:
         got, full = run_gpu(en, p, alphas, full=True)
-    rep = parity.compare_demux(got, want, alphas, want_full=want_ll)
+    rep = parity.compare_demux(got, want, alphas, p)
     assert rep["max_abs_ll_diff"] < 1e-6 and np.isfinite(full[:, parity.needed_ll_mask(V, alphas)]).all()
