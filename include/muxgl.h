@@ -244,6 +244,17 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust);
 int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
                       int32_t* nchanged, double* full_ll);
 
+/* Near-tie calls of the EM iterations since muxgl_fmx_set_clusters.  The kernels' log-likelihoods equal the reference's to
+ * ~1e-12, not to the last bit; a cell where a comparison of cmd_cram_freemux2.cpp:469-497,521-584 has a margin within
+ * 1e-9 x max(1, |LL|) is therefore not decided by them: muxgl_fmx_iterate recomputes its contested hypotheses in the
+ * reference's own arithmetic (cluster states as ordered clamped chains from the read bytes, IEEE operations in the
+ * reference's order on the device, glibc log on the host: fmx_exact.hip), patches the record, the assignment and the
+ * counters, and runs the M-step again when an assignment changed.  near_tie_cells = cells that went through that path,
+ * calls_changed = how many of them it decided differently from the kernels.  The sharded phases (muxgl_fmx_iter_*) and
+ * device groups only count such cells (a rank holds neither the other ranks' entries nor their previous assignments):
+ * unresolved.  Any pointer may be NULL. */
+int muxgl_fmx_exact_stats(const muxgl_handle* h, int64_t* near_tie_cells, int64_t* calls_changed, int64_t* unresolved);
+
 /* cluster pileups for the .clust1.vcf.gz writer (cmd_cram_freemux2.cpp:608-658): gls[K][S][9], counts[K][S][3] */
 int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
 

@@ -186,7 +186,12 @@ struct muxgl_handle {
   muxgl_fmx_cell* d_fcells = nullptr;
   muxgl_fmx_cell* h_fcells = nullptr;  // pinned
   double* d_fll = nullptr;        // [C][K(K+1)/2]
-  int32_t* d_fstat = nullptr;     // nsingle, namb, nchanged
+  int32_t* d_fstat = nullptr;     // nsingle, namb, nchanged, cells listed for the exact-call path
+  // near-tie calls (fmx_exact.hip): what fmx_call_kernel keeps aside for the exact path
+  int32_t* d_prev_clust = nullptr;  // [C] the assignments the cluster pileups of the running iteration were built from
+  int32_t* d_prev_state = nullptr;  // [C] (type, jBest, kBest) before the running iteration, a byte each
+  int32_t* d_flagged = nullptr;     // [C] cells whose call is within rounding reach, d_fstat[3] of them
+  int64_t fmx_exact_cells = 0, fmx_exact_changed = 0, fmx_exact_unresolved = 0;  // since muxgl_fmx_set_clusters
   // SNP-major (CSC) view of the entries, cells ascending inside each SNP: M-step walks it
   int64_t* d_snp_ptr = nullptr;   // [S+1]
   int64_t* d_snp_entry = nullptr; // [nnz] entry index
@@ -552,6 +557,7 @@ int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_mstep(muxgl_handle* h);
 int fmx_mstep_stream_launch(muxgl_handle* h);  // K <= 64 (fmx_mstep.hip); -1: not applicable
+int fmx_exact_resolve(muxgl_handle* h, const muxgl_fmx_params* p, int32_t nflag, bool* reassigned);  // fmx_exact.hip
 
 // device groups (muxgl_group.hip): every entry point of the C-ABI forwards here when h->group is set
 int group_create(const muxgl_config* cfg, muxgl_handle** out, std::string* err);
@@ -569,6 +575,7 @@ int group_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust);
 int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
                       int32_t* nchanged, double* full_ll);
 int group_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
+void group_fmx_exact_unresolved(const muxgl_handle* h, int64_t* unresolved);
 int group_get_timing(const muxgl_handle* h, float* ms);
 #define MUXGL_NOT_FOR_GROUPS(h, who) \
   if ((h)->group) MUXGL_FAIL(h, who ": not available on a device group (use a one-device handle)")

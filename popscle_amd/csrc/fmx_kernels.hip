@@ -438,7 +438,8 @@ __device__ __forceinline__ double fmx_wave_sum(double v) {
 template <bool WAVE>
 __global__ void __launch_bounds__(64)
     fmx_call_kernel(int64_t c0, int64_t c1, int K, double doublet_prior, const double* __restrict__ fll,
-                    muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat) {
+                    muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat,
+                    int32_t* __restrict__ prev_clust, int32_t* __restrict__ prev_state, int32_t* __restrict__ flagged) {
   const int64_t i = WAVE ? c0 + (int64_t)blockIdx.x : c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c1) return;
   const int nSamples = K;
@@ -562,6 +563,7 @@ __global__ void __launch_bounds__(64)
   if (ssng > 0.0) sngLLK = msng + log(ssng);
   }
   muxgl_fmx_cell c = cells[i];
+  const int32_t prev_type = c.type, prev_j = c.jBest, prev_k = c.kBest;
   c.sBest = sBest;
   c.sngBestLLK = sngBestLLK;
   c.sNext = sNext;
@@ -626,6 +628,25 @@ __global__ void __launch_bounds__(64)
       c.jNext = c.kNext = sNext;
       c.nextLLK = sngNextLLK;
     }
+  }
+  // (round 6) a decision whose margin is within rounding reach of the kernels' numbers -- best / next of a scan, next /
+  // third, one of the four +2 thresholds -- is not this kernel's to make: the cell goes on the list fmx_exact.hip settles
+  // in the reference's own arithmetic.  What that needs of the state BEFORE this iteration is kept aside: the
+  // assignment the cluster pileups were built from, and the previous (type, jBest, kBest) of the nchanged rules.
+  if (prev_clust) {
+    prev_clust[i] = clust[i];
+    prev_state[i] = (prev_type & 0xff) | ((prev_j & 0xff) << 8) | ((prev_k & 0xff) << 16);
+    double mag = 1.0;
+    if (sngBestLLK > -1e299) mag = fmax(mag, fabs(sngBestLLK));
+    if (dblBestLLK > -1e299) mag = fmax(mag, fabs(dblBestLLK));
+    if (sngNextLLK > -1e299) mag = fmax(mag, fabs(sngNextLLK));
+    if (dblNextLLK > -1e299) mag = fmax(mag, fabs(dblNextLLK));
+    const double eps = 1e-9 * mag;
+    auto near = [eps](double a, double b) { return a > -1e299 && b > -1e299 && fabs(a - b) <= eps; };
+    if (near(sngBestLLK, sngNextLLK) || near(sngNextLLK, sngThird) || near(dblBestLLK, dblNextLLK) ||
+        near(dblNextLLK, dblThird) || near(dblBestLLK, sngBestLLK + 2) || near(dblNextLLK, sngBestLLK + 2) ||
+        near(sngBestLLK, sngNextLLK + 2) || near(dblBestLLK, sngNextLLK + 2))
+      flagged[atomicAdd(&stat[3], 1)] = (int32_t)i;
   }
   cells[i] = c;
   clust[i] = c.clust;
@@ -1189,6 +1210,10 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   }
   if (h->col && CT)
     HIPCHK(h, hipMemcpyAsync(m->d_clust, cl.data(), sizeof(int32_t) * CT, hipMemcpyHostToDevice, h->stream));
+  if (dev_alloc(h, &h->d_prev_clust, (size_t)(C ? C : 1)) || dev_alloc(h, &h->d_prev_state, (size_t)(C ? C : 1)) ||
+      dev_alloc(h, &h->d_flagged, (size_t)(C ? C : 1)))
+    return 1;
+  h->fmx_exact_cells = h->fmx_exact_changed = h->fmx_exact_unresolved = 0;
   clear_timing(h);
   tic(h, MUXGL_T_FMX_MSTEP);
   if (fmx_mstep_launch(m)) {  // :277-288: every assigned cell, ascending cell id
@@ -1279,10 +1304,11 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
     if ((h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP) || K <= 24)  // (few hypotheses per cell: a wave per cell is mostly overhead,
                                                              //  0.54 against 0.13 ms at configs[3])
       hipLaunchKernelGGL(fmx_call_kernel<false>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, c0, c1, K,
-                         p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+                         p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_clust, h->d_prev_state,
+                         h->d_flagged);
     else
       hipLaunchKernelGGL(fmx_call_kernel<true>, dim3((unsigned)nc), dim3(64), 0, h->stream, c0, c1, K, p->doublet_prior,
-                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat);
+                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_clust, h->d_prev_state, h->d_flagged);
   }
   toc(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipGetLastError());
@@ -1325,6 +1351,8 @@ static int fmx_phase_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingl
   if (nsingle) *nsingle = h->h_fstat[0];
   if (namb) *namb = h->h_fstat[1];
   if (nchanged) *nchanged = h->h_fstat[2];
+  h->fmx_exact_unresolved += h->h_fstat[3];  // (muxgl_fmx_iterate settled its listed cells before it came here: 0)
+  h->h_fstat[3] = 0;
   if (full_ll && C) HIPCHK(h, hipMemcpy(full_ll, h->d_fll, sizeof(double) * (size_t)C * npairs, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1341,8 +1369,27 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
   clear_timing(h);
   if (fmx_phase_gp(h, p) || fmx_phase_estep(h, p) || fmx_phase_mstep(h)) return 1;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->h_fstat[3] > 0) {  // calls within rounding reach: settled in the reference's arithmetic (fmx_exact.hip)
+    bool reassigned = false;
+    if (fmx_exact_resolve(h, p, h->h_fstat[3], &reassigned)) return 1;
+    h->h_fstat[3] = 0;
+    if (reassigned) {  // the ordered M-step again, from the corrected assignments
+      if (fmx_phase_mstep(h)) return 1;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+  }
   if (fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll)) return 1;
   collect_timing(h);
+  return 0;
+}
+
+int muxgl_fmx_exact_stats(const muxgl_handle* h, int64_t* near_tie_cells, int64_t* calls_changed, int64_t* unresolved) {
+  if (!h) return 1;
+  int64_t a = h->fmx_exact_cells, b = h->fmx_exact_changed, c = h->fmx_exact_unresolved;
+  if (h->group) group_fmx_exact_unresolved(h, &c);
+  if (near_tie_cells) *near_tie_cells = a;
+  if (calls_changed) *calls_changed = b;
+  if (unresolved) *unresolved = c;
   return 0;
 }
 

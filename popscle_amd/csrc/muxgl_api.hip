@@ -366,6 +366,9 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_fcells);
   dev_free(&h->d_fll);
   dev_free(&h->d_fstat);
+  dev_free(&h->d_prev_clust);
+  dev_free(&h->d_prev_state);
+  dev_free(&h->d_flagged);
   dev_free(&h->d_snp_ptr);
   dev_free(&h->d_snp_entry);
   dev_free(&h->d_snp_cell);

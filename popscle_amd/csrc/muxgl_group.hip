@@ -307,6 +307,12 @@ int group_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
   });
 }
 
+void group_fmx_exact_unresolved(const muxgl_handle* h, int64_t* unresolved) {
+  int64_t n = 0;
+  for (muxgl_handle* m : h->group->m) n += m->fmx_exact_unresolved;
+  *unresolved = n;
+}
+
 int group_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   muxgl_group* g = h->group;
   if (!g->prepared) MUXGL_FAIL(h, "muxgl_fmx_set_clusters: call muxgl_fmx_prepare first");
@@ -386,6 +392,8 @@ int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
     collect_timing(m);
     if (out && nc) memcpy(out + c0, m->h_fcells, sizeof(muxgl_fmx_cell) * (size_t)nc);
     for (int i = 0; i < 3; ++i) st[i] += m->h_fstat[i];
+    m->fmx_exact_unresolved += m->h_fstat[3];  // near-tie calls a member lists but cannot settle alone (fmx_exact.hip)
+    m->h_fstat[3] = 0;
     if (full_ll && nc)
       GCHK(m, hipMemcpy(full_ll + (size_t)c0 * npairs, m->d_fll, sizeof(double) * (size_t)nc * npairs, hipMemcpyDeviceToHost));
   }

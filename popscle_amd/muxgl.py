@@ -96,6 +96,7 @@ SYMBOLS = {
     "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_fmx_exact_stats": (C.c_int, [_VP, _VP, _VP, _VP]),
     "muxgl_fmxold_pair_dist": (C.c_int, [_VP, C.c_double, _VP]),
     "muxgl_fmxold_get_signs": (C.c_int, [_VP, _VP]),
     "muxgl_fmxold_vote_init": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_double, _VP, _VP]),
@@ -419,6 +420,12 @@ class Engine:
 
     def memcpy_dev(self, dst_ptr, src_ptr, nbytes):
         self._check(self.lib.muxgl_memcpy_dev(self.h, _VP(dst_ptr), _VP(src_ptr), int(nbytes)))
+
+    def fmx_exact_stats(self):
+        """(near-tie cells settled by the exact path, calls it changed, near-tie cells left unresolved) since set_clusters"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.muxgl_fmx_exact_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def fmx_cluster_pileup(self):
         gls = np.zeros((self.K, self.S, 9))

@@ -108,11 +108,36 @@ FMX_INT_FIELDS = ("type", "clust", "jBest", "kBest", "jNext", "kNext", "sBest", 
                   "dNext2")
 
 
-def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7, want_full=None):
-    """want_full: the oracle's packed LL triangle [C][K(K+1)/2] (optional).  With it, a different runner-up doublet is
-    accepted where the pair the GPU names is tied with the oracle's runner-up IN THE ORACLE'S OWN NUMBERS (clusters
-    without cells have identical posteriors, so their pairs tie exactly in the reference, which then keeps the first
-    in scan order; the kernels evaluate the two tied pairs in different associations)."""
+def fmx_near_tie_mask(rec):
+    """cells of [C] muxgl_fmx_cell records whose call is within rounding reach of the kernels' numbers: the rule of
+    fmx_call_kernel (popscle_amd/csrc/fmx_kernels.hip), restated on the record's own fields"""
+    def some(v):
+        return v > -1e299
+
+    mag = np.ones(rec.shape)
+    for f in ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK"):
+        mag = np.where(some(rec[f]), np.maximum(mag, np.abs(rec[f])), mag)
+    eps = 1e-9 * mag
+
+    def near(a, b):
+        with np.errstate(invalid="ignore", over="ignore"):
+            return some(a) & some(b) & (np.abs(a - b) <= eps)
+
+    sB, sN, s3 = rec["sngBestLLK"], rec["sngNextLLK"], rec["sngThirdLLK"]
+    dB, dN, d3 = rec["dblBestLLK"], rec["dblNextLLK"], rec["dblThirdLLK"]
+    return (near(sB, sN) | near(sN, s3) | near(dB, dN) | near(dN, d3) | near(dB, sB + 2) | near(dN, sB + 2) |
+            near(sB, sN + 2) | near(dB, sN + 2))
+
+
+def compare_fmx(got, want, tol=LL_TOL, resolved=True):
+    """[C] freemuxlet records of the library against the reference's / oracle's.  Every log-likelihood and posterior
+    within `tol`; every integer field EQUAL -- no tie window.
+
+    resolved=True (muxgl_fmx_iterate on one device): the library settled its near-tie calls itself in the reference's
+    arithmetic (fmx_exact.hip), so there is nothing to excuse.  resolved=False (the sharded phases and device groups,
+    which only COUNT such cells): a cell the record itself shows to be within rounding reach (fmx_near_tie_mask) may
+    differ; the report says how many did.
+    """
     assert got.shape == want.shape
     worst = 0.0
     for f in FMX_LL_FIELDS:
@@ -123,24 +148,18 @@ def compare_fmx(got, want, tol=LL_TOL, tie_eps=1e-7, want_full=None):
         if d.size:
             worst = max(worst, float(d.max()))
         assert ok.all(), f"{f}: {int((~ok).sum())} cells beyond {tol}"
-    tie = (np.abs(want["sngBestLLK"] - want["sngNextLLK"]) < tie_eps) | \
-          (np.abs(want["dblBestLLK"] - want["dblNextLLK"]) < tie_eps)
-    next_tie = np.zeros(got.shape, dtype=bool)
-    if want_full is not None:
-        hi = np.maximum(got["dNext1"], got["dNext2"]).astype(np.int64)
-        lo = np.minimum(got["dNext1"], got["dNext2"]).astype(np.int64)
-        ok_idx = (lo >= 0) & (hi * (hi + 1) // 2 + lo < want_full.shape[1])
-        named = want_full[np.arange(got.size), np.where(ok_idx, hi * (hi + 1) // 2 + lo, 0)]
-        next_tie = ok_idx & (np.abs(named - want["dblNextLLK"]) < tie_eps)
+    near = fmx_near_tie_mask(got) if "sngThirdLLK" in (got.dtype.names or ()) else np.zeros(got.shape, dtype=bool)
     differs = np.zeros(got.shape, dtype=bool)
     for f in FMX_INT_FIELDS:
-        excused = tie | (next_tie if f in ("dNext1", "dNext2") else False)
-        bad = (got[f] != want[f]) & ~excused
-        assert not bad.any(), f"{f} differs in {int(bad.sum())} cells"
         differs |= got[f] != want[f]
-    # "ties": cells whose oracle numbers tie (an excuse was AVAILABLE); "cells_needing_an_excuse": where one was USED
-    return {"cells": int(got.size), "max_abs_ll_diff": worst, "ties": int(tie.sum()),
-            "cells_needing_an_excuse": int(differs.sum())}
+    bad = differs if resolved else differs & ~near
+    if bad.any():
+        i = int(np.flatnonzero(bad)[0])
+        assert False, (f"{int(bad.sum())} cells differ in an integer field; first: cell {i}: "
+                       f"got {[(f, int(got[f][i])) for f in FMX_INT_FIELDS]}, reference {[(f, int(want[f][i])) for f in FMX_INT_FIELDS]}")
+    return {"cells": int(got.size), "max_abs_ll_diff": worst, "near_tie_cells": int(near.sum()),
+            "unresolved_near_ties_differing": int(differs.sum()) if not resolved else 0,
+            "cells_needing_an_excuse": 0 if resolved else int(differs.sum())}
 
 
 SUM_FIELDS = ("sumLLK", "sngLLK", "bestPP", "sngPP", "sngOnlyPP")

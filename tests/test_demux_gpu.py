@@ -309,7 +309,10 @@ def test_full_size_every_cell_exact(full_cfg):
           "raw records differing:", rep["raw_records_differing"])
     assert rep["cells"] == p.C and rep["max_abs_ll_diff"] < 1e-8
     st = rep["exact_pass"]
-    assert st["cells"] > 0.9 * p.C and 0.2 * p.C < st["mirror_turned"] < 0.8 * p.C
+    # (the two orders of a mirrored pair come out EQUAL in the reference for most cells -- the scan then keeps (lo, hi) --
+    #  and (hi, lo) wins for the rest: SURVEY measured 8.3 % of cells printing j > k)
+    assert st["cells"] > 0.9 * p.C and 0.02 * p.C < st["mirror_turned"] < 0.3 * p.C
+    assert rep["raw_records_differing"] == st["mirror_turned"] + st["changed"]
     # near ties proper are rare on this workload, and none of them needs more than the named hypotheses
     assert st["near_ties"] < 0.01 * p.C, st
 

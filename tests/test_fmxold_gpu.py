@@ -125,7 +125,7 @@ def test_golden(eng):
         assert stats[:2] == tuple(g["em_counters"][it]), it
         want = g["em_cells"][it].copy()
         want["clust"] = np.where(want["type"] == 0, want["jBest"], -1)   # the old loop has no clusts update (row c1)
-        rep = parity.compare_fmx(cells, want, want_full=g["em_full_ll_last"] if it == 9 else None)
+        rep = parity.compare_fmx(cells, want)
         assert rep["cells_needing_an_excuse"] == 0, (it, rep)
         worst = max(worst, rep["max_abs_ll_diff"])
         if it == 0:

@@ -188,7 +188,7 @@ def test_device_group_against_oracle():
             ostats = ob.fmx_iterate(p, e, K, cplp, ocells, 0.5, 0.1)
             gcells, gstats = g.fmx_iterate(0.5, 0.1)
             assert tuple(gstats) == tuple(ostats)
-            assert parity.compare_fmx(gcells, ocells)["max_abs_ll_diff"] < 1e-7
+            assert parity.compare_fmx(gcells, ocells, resolved=False)["max_abs_ll_diff"] < 1e-7   # (a group only counts near ties)
 
 
 def test_group_create_errors():

@@ -134,7 +134,7 @@ def test_config4_full_size_freemuxlet_eight_ranks():
     del gls0, cnt0
     ocells = ob.fmx_init_cells(np.ascontiguousarray(clust0[cells_s]))
     ob.fmx_iterate(sub, se, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
-    rep = parity.compare_fmx(its[0][0][cells_s], ocells)
+    rep = parity.compare_fmx(its[0][0][cells_s], ocells, resolved=False)   # a group counts near ties, and the checker starts from the device's pileups
     assert rep["max_abs_ll_diff"] < 1e-6
     del cplp
     # the one-device, whole-pileup run of the same job: bit-identical records and counters
@@ -185,7 +185,7 @@ def test_config3_full_size_freemuxlet_oracle_sample():
             cells, stats = e.fmx_iterate(0.5, 0.1)
             ocells = ob.fmx_init_cells(np.ascontiguousarray(clust[pick]))
             ob.fmx_iterate(sub, se, K, cplp, ocells, 0.5, 0.1, nthreads=NT)
-            rep = parity.compare_fmx(cells[pick], ocells)
+            rep = parity.compare_fmx(cells[pick], ocells, resolved=False)   # (the checker starts from the device's own pileups)
             assert rep["max_abs_ll_diff"] < 1e-6, (it, rep)
             clust = np.where(cells["type"] == 0, cells["clust"], -1).astype(np.int32)  # only singlets merge (:590-596)
     ok = (cells["type"] == 0) & ~p.truth["is_doublet"]

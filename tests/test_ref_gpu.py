@@ -63,7 +63,7 @@ def test_freemuxlet_vs_reference_library(eng, K, C, S, ment):
         cells, st, full = eng.fmx_iterate(0.5, 0.1, want_full_ll=True)
         assert tuple(st) == tuple(ref["counters"][it]), (it, st, ref["counters"][it])
         assert np.max(np.abs(full - ref["full_ll"][it])) < 1e-7
-        parity.compare_fmx(cells, ref["cells"][it], want_full=ref["full_ll"][it])
+        parity.compare_fmx(cells, ref["cells"][it])   # the reference library itself: every integer field equal
         g, c = eng.fmx_cluster_pileup()
         w = ref["cplp"][it]
         assert np.array_equal(c, np.stack([w["nreads"], w["nref"], w["nalt"]], axis=-1))
