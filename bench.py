@@ -742,20 +742,10 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
         fl = fmx_floor(K, my_entries, frac_lin, S, est_s * 1e3)
         rf = out["roofline"]
         rf["floor"] = fl
-        # The E-step's headline fraction is the floor's: what the algorithm as built must issue / move against
-        # the kernel's time.  The counter-based "hbm" fraction stays beside it under rf["hbm"], with what it really is: fabric
-        # traffic of the L2 (posterior-row gathers that miss the 4 MB L2 and hit the Infinity Cache count), NOT bytes the
-        # kernel must move -- traffic_over_compulsory says how much of it is re-reads.
-        if fl["frac_of_floor"] is not None:
-            by_valu = fl["valu_ms"] >= fl["hbm_ms"]
-            rf["bound"] = "fp64_valu" if by_valu else "hbm"
-            # (the floor's own clock and issue width, so that frac IS frac_of_floor: 64 lanes x 2 flop per 4 cycles on 1024 SIMDs
-            #  at 2.4 GHz = 78.64 TFLOP/s, the guide's 78.6)
-            rf["peak"], rf["unit"] = (FP64_PEAK_TFLOPS, "TFLOP/s") if by_valu else (HBM_PEAK_GBS, "GB/s")
-            rf["frac"] = fl["frac_of_floor"]
-            rf["achieved"] = rf["frac"] * rf["peak"]
-            rf["frac_is"] = ("floor of the algorithm as built (roofline.floor): FP64 lane-instructions x 2 at the 78.6 TFLOP/s vector "
-                             "roof" if by_valu else "compulsory bytes at 8 TB/s")
+        # roofline.frac means the same in every leg of this line: FP64 flops ISSUED (PMC SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64,
+        # FMA counted twice) / kernel time / 78.6 TFLOP/s, or counter bytes / time / 8 TB/s when that is larger
+        # (roofline.fp64.source says whether the counters or, without a current PMC record, the instruction model supplied the
+        # flops).  The fraction of the recomputable floor of the algorithm as built is its own key: roofline.floor.frac_of_floor.
         if rf.get("traffic"):
             rf["hbm"]["traffic_over_compulsory"] = rf["traffic"] / fl["compulsory_bytes"]
             rf["hbm"]["note"] = ("traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch: L2-side fabric requests, Infinity-Cache hits "

@@ -89,13 +89,15 @@ def test_single_gpu_line():
     assert 0 < d2["roofline"]["frac"] <= 1.0 and d2["cpu_baseline"]["parity_max_abs_ll_diff"] < 1e-5
     assert d2["roofline"]["floor"]["hypotheses_per_entry"] == 18208 and 0.3 < d2["roofline"]["floor"]["frac_of_floor"] <= 1.0
     assert 0.2 < fx["roofline"]["floor"]["frac_of_floor"] <= 1.0 and fx["roofline"]["floor"]["hypotheses_per_entry"] == 136
-    # the E-step legs quote the floor's fraction as THE fraction; the counter traffic stands beside it with its ratio to
-    # the compulsory bytes (it is L2-side fabric traffic: re-read posterior rows, not bytes the kernel must move)
-    for leg in (fx, d["freemuxlet_config4"]):
+    # one key, one meaning: in EVERY leg roofline.frac = achieved / peak of the binding roof from issued FP64 flops or counter
+    # bytes (fp64.source names counters or model); the fraction of the algorithm's own floor is roofline.floor.frac_of_floor
+    for leg in (d, d2, fx, d["freemuxlet_config4"]):
         rl = leg["roofline"]
-        assert abs(rl["frac"] - rl["floor"]["frac_of_floor"]) < 1e-9 and rl["bound"] in ("fp64_valu", "hbm")
-        assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
-        assert rl["traffic"] is None or rl["hbm"]["traffic_over_compulsory"] > 1.0
+        assert rl["bound"] in ("fp64_valu", "hbm") and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
+        top = rl["fp64"] if rl["bound"] == "fp64_valu" else rl["hbm"]
+        assert rl["frac"] == top["frac"] and rl["achieved"] == top["achieved"] and "frac_is" not in rl
+        assert rl["fp64"]["source"].startswith(("pmc", "model")) and 0 < rl["floor"]["frac_of_floor"] <= 1.0
+        assert rl["traffic"] is None or "traffic_over_compulsory" not in rl["hbm"] or rl["hbm"]["traffic_over_compulsory"] > 1.0
     # ... and configs[4] (freemuxlet 500 k x 500 k, K = 64)
     f4 = d["freemuxlet_config4"]
     assert "error" not in f4, f4
