@@ -246,14 +246,35 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
 
 /* Near-tie calls of the EM iterations since muxgl_fmx_set_clusters.  The kernels' log-likelihoods equal the reference's to
  * ~1e-12, not to the last bit; a cell where a comparison of cmd_cram_freemux2.cpp:469-497,521-584 has a margin within
- * 1e-9 x max(1, |LL|) is therefore not decided by them: muxgl_fmx_iterate recomputes its contested hypotheses in the
+ * 1e-9 x max(1, |LL|) is therefore not decided by them but listed, and its contested hypotheses are recomputed in the
  * reference's own arithmetic (cluster states as ordered clamped chains from the read bytes, IEEE operations in the
- * reference's order on the device, glibc log on the host: fmx_exact.hip), patches the record, the assignment and the
- * counters, and runs the M-step again when an assignment changed.  near_tie_cells = cells that went through that path,
- * calls_changed = how many of them it decided differently from the kernels.  The sharded phases (muxgl_fmx_iter_*) and
- * device groups only count such cells (a rank holds neither the other ranks' entries nor their previous assignments):
- * unresolved.  Any pointer may be NULL. */
+ * reference's order on the device, glibc log on the host: fmx_exact.hip); record, assignment and counters are patched
+ * and the M-step runs again when an assignment changed.  muxgl_fmx_iterate does all of that itself, on one device and on a
+ * device group.  near_tie_cells = cells that went through that path, calls_changed = how many of them it decided
+ * differently from the kernels, unresolved = listed cells a caller of the sharded phases left open (see below).  Any
+ * pointer may be NULL. */
 int muxgl_fmx_exact_stats(const muxgl_handle* h, int64_t* near_tie_cells, int64_t* calls_changed, int64_t* unresolved);
+
+/* The same for the sharded phases (muxgl_fmx_iter_*): a listed cell's SNPs are spread over the ranks' M-step ranges, so the
+ * caller carries two small exchanges in the iterations where the job-wide count of listed cells (the fourth counter of
+ * MUXGL_BUF_STAT after the all-reduce, or the sum of muxgl_fmx_exact_pending over the ranks) is not zero -- after
+ * muxgl_fmx_iter_estep + muxgl_fmx_iter_fetch and BEFORE anything overwrites the assignments of the previous iteration
+ * the chains are built from (the library keeps its own copy, taken when the E-step started):
+ *   1. muxgl_fmx_exact_snps on every rank: the SNPs its listed cells cover (call with out = NULL for the count, then
+ *      with room); the caller unites the lists (ascending, unique);
+ *   2. muxgl_fmx_exact_rows on every rank with the united list: rows[n][K][3] and owned[n] are filled for the SNPs of the
+ *      rank's own M-step range; the caller gathers every row from its owner;
+ *   3. muxgl_fmx_exact_finish on every rank with the complete rows: settles the rank's listed cells, patches records,
+ *      assignments (also in MUXGL_BUF_CLUST) and the rank's counters; deltas[3] = what it added to (nsingle, namb,
+ *      nchanged), *reassigned != 0: an assignment changed.
+ * Then the assignments are exchanged again and, if any rank reports a reassignment, muxgl_fmx_iter_mstep is repeated on
+ * all.  popscle_amd/freemuxlet.py run_em is the reference driver. */
+int muxgl_fmx_exact_pending(const muxgl_handle* h, int64_t* cells);
+int muxgl_fmx_exact_snps(muxgl_handle* h, int32_t* out, int64_t cap, int64_t* n);
+int muxgl_fmx_exact_rows(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, double* rows,
+                         uint8_t* owned);
+int muxgl_fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, const double* rows,
+                           int64_t* deltas, int32_t* reassigned);
 
 /* cluster pileups for the .clust1.vcf.gz writer (cmd_cram_freemux2.cpp:608-658): gls[K][S][9], counts[K][S][3] */
 int muxgl_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);

@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -188,10 +189,15 @@ struct muxgl_handle {
   double* d_fll = nullptr;        // [C][K(K+1)/2]
   int32_t* d_fstat = nullptr;     // nsingle, namb, nchanged, cells listed for the exact-call path
   // near-tie calls (fmx_exact.hip): what fmx_call_kernel keeps aside for the exact path
-  int32_t* d_prev_clust = nullptr;  // [C] the assignments the cluster pileups of the running iteration were built from
+  int32_t* d_prev_clust = nullptr;  // the assignments the cluster pileups of the running iteration were built from: a copy
+                                    // of d_clust taken before the call kernel runs, on the handle that runs the M-step
   int32_t* d_prev_state = nullptr;  // [C] (type, jBest, kBest) before the running iteration, a byte each
   int32_t* d_flagged = nullptr;     // [C] cells whose call is within rounding reach, d_fstat[3] of them
   int64_t fmx_exact_cells = 0, fmx_exact_changed = 0, fmx_exact_unresolved = 0;  // since muxgl_fmx_set_clusters
+  struct fmx_exact_state* xs = nullptr;  // between steps A and C of the exact path (fmx_exact.hip)
+  int32_t fmx_listed = 0;                // cells the last fetch of a sharded phase found listed and left open
+  std::vector<int32_t> xs_snps;          // muxgl_fmx_exact_snps: the list between the size query and the copy
+  bool xs_snps_valid = false;
   // SNP-major (CSC) view of the entries, cells ascending inside each SNP: M-step walks it
   int64_t* d_snp_ptr = nullptr;   // [S+1]
   int64_t* d_snp_entry = nullptr; // [nnz] entry index
@@ -389,13 +395,11 @@ __device__ __forceinline__ double pos_log(double x, double k0) {
   const double r = fma(zz * w, p, zz);  // 2 atanh(z)
   // k ln 2 in two pieces (the high one exact for |k| < 2^21), smallest terms first
   const double v = fma(k, 6.93147180369123816490e-01, fma(k, 1.90821492927058770002e-10, r));
-  return x > 0.0 ? v : -__builtin_huge_val();
+  // log's own conventions outside the domain: 0 -> -inf; a negative or NaN product (a corrupt genotype tensor) stays NaN
+  // instead of turning into a -inf score that later sums would absorb
+  return x > 0.0 ? v : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
 }
-#ifdef MUXGL_LIBRARY_LOG  // (timing experiments: the library log in place of pos_log)
-__device__ __forceinline__ double prodacc_log(double m, int32_t e) { return log(m) + (double)e * 0.6931471805599453094; }
-#else
 __device__ __forceinline__ double prodacc_log(double m, int32_t e) { return pos_log(m, (double)e); }
-#endif
 
 // ---- the ring of partner values of the wave kernels (demux_wave.hip, fmx_wave.hip) ----
 // One 8-byte read per lane from the ring in LDS, at an immediate offset from the lane's slot.  As an opaque instruction
@@ -557,7 +561,13 @@ int fmx_phase_gp(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p);
 int fmx_phase_mstep(muxgl_handle* h);
 int fmx_mstep_stream_launch(muxgl_handle* h);  // K <= 64 (fmx_mstep.hip); -1: not applicable
-int fmx_exact_resolve(muxgl_handle* h, const muxgl_fmx_params* p, int32_t nflag, bool* reassigned);  // fmx_exact.hip
+// fmx_exact.hip: near-tie calls settled in the reference's arithmetic (steps A, B, C; all three on one handle)
+int fmx_exact_snps(muxgl_handle* h, std::vector<int32_t>* snps);
+int fmx_exact_rows(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, double* rows, uint8_t* owned);
+int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, const double* rows,
+                     int64_t* deltas, int32_t* reassigned);
+int fmx_exact_resolve(muxgl_handle* h, const muxgl_fmx_params* p, bool* reassigned);
+void fmx_exact_release(muxgl_handle* h);
 
 // device groups (muxgl_group.hip): every entry point of the C-ABI forwards here when h->group is set
 int group_create(const muxgl_config* cfg, muxgl_handle** out, std::string* err);
@@ -575,7 +585,7 @@ int group_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust);
 int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell* out, int32_t* nsingle, int32_t* namb,
                       int32_t* nchanged, double* full_ll);
 int group_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
-void group_fmx_exact_unresolved(const muxgl_handle* h, int64_t* unresolved);
+void group_fmx_exact_stats(const muxgl_handle* h, int64_t* cells, int64_t* changed, int64_t* unresolved);
 int group_get_timing(const muxgl_handle* h, float* ms);
 #define MUXGL_NOT_FOR_GROUPS(h, who) \
   if ((h)->group) MUXGL_FAIL(h, who ": not available on a device group (use a one-device handle)")

@@ -42,9 +42,6 @@
 
 namespace {
 
-#ifndef OCT_EXP
-#define OCT_EXP 0  // timing experiments (tools/gpu_quadx.sh): 1 no nine-term loop, 2 no linear loop
-#endif
 constexpr int O_NLUT = 129;        // {A, B, 2B} by (allele << 6 | base quality <= 63), and one neutral entry
 constexpr int O_LPAD = 3;          // steps of neutral records behind a unit's longest linear list (the loop reads ahead)
 
@@ -260,8 +257,8 @@ __global__ void __launch_bounds__(64, P == 8 ? OCT_WAVES : 2)
   // first, by a loop of their own (below), the others by the nine-term loop.  Trip counts of the wave = the longest
   // run of either kind among its chunks.
   const int nl = (chunk_nlin && q < n_chunks) ? chunk_nlin[q] : 0;
-  const int nLmax = (OCT_EXP & 2) ? 0 : wave_max_i32(nl);
-  const int ngmax = (OCT_EXP & 1) ? 0 : wave_max_i32(len - nl);
+  const int nLmax = wave_max_i32(nl);
+  const int ngmax = wave_max_i32(len - nl);
   const int nb = (ngmax + O_BATCH - 1) / O_BATCH;
 
   double acc[ON_ACC];
@@ -328,13 +325,6 @@ __global__ void __launch_bounds__(64, P == 8 ? OCT_WAVES : 2)
     };
     auto sweepL = [&](const rowl_t& R, const ab_t& ab) __attribute__((always_inline)) {
       const double A = ab.A, B = ab.B, B2 = ab.B2;
-      if (OCT_EXP & 128) {  // (experiment) the loads with next to no arithmetic
-        accW[0] *= R.sa;
-        accW[1] *= R.sb;
-        acc[0] *= fma(B2, R.ra, A);
-        acc[1] *= fma(B2, R.rb, A);
-        return;
-      }
       if (!UNIT_S) {
         accW[0] *= R.sa;
         accW[1] *= R.sb;
@@ -361,20 +351,11 @@ __global__ void __launch_bounds__(64, P == 8 ? OCT_WAVES : 2)
     // entry i: its row in Rc and {A, B, 2B} in abc; rc0 held its record (free now), rc1 / rc2 hold those of i + 1 / i + 2
     auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const ab_t& abc, ab_t& abn, uint2& rc0, const uint2& rc1,
                     const uint2& rc2) __attribute__((always_inline)) {
-      if (OCT_EXP & 32) {  // (experiment) no record loads: a cheap pseudo-random record
-        rc0.x = (rc0.x * 1664525u + 1013904223u) & 0x00FFFF00u;
-      } else {
-        rc0 = lr[(i + 3) * O_SLOTS];
-      }
-#ifdef OCT_OLD_LOAD_ORDER
-      load_rowl(Rnn, rc2.x);
-      abn = ab_of(rc1);
-#else
+      rc0 = lr[(i + 3) * O_SLOTS];
       // (issue order = completion order: the gathered row, which nobody reads for two sweeps, goes last, so that the
       //  sweep's wait for the next entry's {A, B, 2B} leaves it in flight -- fmx_oct.hip has the measurement)
       abn = ab_of(rc1);
       load_rowl(Rnn, rc2.x);
-#endif
       __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
       sweepL(Rc, abc);
       __builtin_amdgcn_sched_barrier(0);
@@ -1047,11 +1028,7 @@ int oct_launch_t(muxgl_handle* h, const muxgl_demux_params* p) {
     constexpr int QF_CELLS = P == 8 ? QF_CELLS_N : 1;
     hipLaunchKernelGGL(demux_oct_finish_kernel<P>, dim3((unsigned)((h->C + QF_CELLS - 1) / QF_CELLS)), dim3(256), 0,
                        h->stream, h->C, h->d_cell_ptr, st->d_cell_chunk_ptr, st->d_part, st->d_part_e, st->d_tmap, h->V, al,
-#ifdef FIN_DEV
-                       p->doublet_prior, h->d_dcells);  // (timing experiment: records stay on the device)
-#else
                        p->doublet_prior, h->h_dcells);
-#endif
     h->records_on_host = true;
   }
   HIPCHK(h, hipGetLastError());

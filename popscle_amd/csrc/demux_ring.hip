@@ -31,28 +31,6 @@
 #include "common.hpp"
 #include "demux_entry.hpp"
 
-// timing experiments only (the results are wrong): a walk without its waits / its barrier
-#ifdef RING_T_NOWAIT_LIN
-#define RING_T_WAIT_LIN(a, b) b
-#else
-#define RING_T_WAIT_LIN(a, b) a
-#endif
-#ifdef RING_T_NOWAIT_GEN
-#define RING_T_WAIT_GEN(a, b) b
-#else
-#define RING_T_WAIT_GEN(a, b) a
-#endif
-#ifdef RING_T_NOBARRIER_LIN
-#define RING_T_BARRIER_LIN() ((void)0)
-#else
-#define RING_T_BARRIER_LIN() __syncthreads()
-#endif
-#ifdef RING_T_NOBARRIER_GEN
-#define RING_T_BARRIER_GEN() ((void)0)
-#else
-#define RING_T_BARRIER_GEN() __syncthreads()
-#endif
-
 namespace {
 
 constexpr int RL_B = 8;       // entries per staged batch
@@ -176,11 +154,7 @@ __global__ void __launch_bounds__(256, 2)
   int64_t i0, i1;
   wave_stream_range<EM_LINEAR>(lin, lin_rank, it.e0, it.e1, i0, i1);
   const int64_t n = i1 - i0;
-#ifdef RING_TIMING_SKIP_LIN  // (timing experiments only: the results are wrong)
-  const int nb = 0;
-#else
   const int nb = (int)((n + RL_B - 1) / RL_B);
-#endif
   const uint2* rr = rrec + i0;
   const double* grow = gm + (size_t)(live ? sel.jbase + j : V - 1) * 2;
 
@@ -319,7 +293,7 @@ __global__ void __launch_bounds__(256, 2)
         else if constexpr (k + 1 < RL_B) issue(std::integral_constant<int, k + 1>{}, std::integral_constant<int, 0>{});
         constexpr int ahead = more ? (last ? 6 : 4) : 0;  // younger reads: they may stay in flight
         if constexpr (g == 0) {
-          asm volatile(RING_T_WAIT_LIN("s_waitcnt lgkmcnt(%6)", "; %6")
+          asm volatile("s_waitcnt lgkmcnt(%6)"
                        : "+v"(rd[0][0]), "+v"(rd[0][1]), "+v"(rd[0][2]), "+v"(rd[0][3]), "+v"(ow[p][0]), "+v"(ow[p][1])
                        : "n"(ahead));
           // the entry's factors of the lane
@@ -332,7 +306,7 @@ __global__ void __launch_bounds__(256, 2)
           if constexpr (k + 1 < RL_B) load_lut(std::integral_constant<int, 1 - p>{}, rcl[k + 1]);
           else load_lut(std::integral_constant<int, 1 - p>{}, rnl[0]);
         } else {
-          asm volatile(RING_T_WAIT_LIN("s_waitcnt lgkmcnt(%4)", "; %4")
+          asm volatile("s_waitcnt lgkmcnt(%4)"
                        : "+v"(rd[g & 1][0]), "+v"(rd[g & 1][1]), "+v"(rd[g & 1][2]), "+v"(rd[g & 1][3])
                        : "n"(ahead));
         }
@@ -361,11 +335,7 @@ __global__ void __launch_bounds__(256, 2)
       cnt = 0;
       prodacc_renorm(accX, exX);
     }
-#ifdef RL_FIXED_RENORM
-    if (cnt == 0) {
-#else
     if (bits > RL_BUDGET) {
-#endif
       bits = 0;
 #pragma unroll
       for (int t = 0; t < NACC; ++t) {
@@ -379,7 +349,7 @@ __global__ void __launch_bounds__(256, 2)
       }
     }
     store_rows((b + 1) & 1, b + 1);
-    RING_T_BARRIER_LIN();
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RL_B; ++k) rcs[k] = rns[k], rcl[k] = rnl[k];
   }
@@ -390,11 +360,7 @@ __global__ void __launch_bounds__(256, 2)
   if constexpr (GEN) {
     int64_t gi0, gi1;
     wave_stream_range<EM_GENERAL>(lin, lin_rank, it.e0, it.e1, gi0, gi1);
-#ifdef RING_TIMING_SKIP_GEN
-    const int64_t ng = 0;
-#else
     const int64_t ng = gi1 - gi0;
-#endif
     if (ng > 0) {  // (workgroup-uniform)
       const fmx_grec* gr = gen_rec + gi0;
       const int nbg = (int)((ng + RG_B - 1) / RG_B);
@@ -516,7 +482,7 @@ __global__ void __launch_bounds__(256, 2)
             constexpr bool lastg = g + 1 == NGT;
             if constexpr (!lastg) issue(std::integral_constant<int, g + 1>{});
             // (the lane's own pairs were requested in front of group 0's ring reads: waiting for these waits for them)
-            asm volatile(RING_T_WAIT_GEN("s_waitcnt lgkmcnt(%0)", "; %0") ::"n"(lastg ? 0 : 2 * GS_) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(lastg ? 0 : 2 * GS_) : "memory");
             wave_for<0, GS_>([&](auto ic) {
               constexpr int i = decltype(ic)::value;
               ring_landed(rd01[g & 1][i], rd2[g & 1][i]);
@@ -568,7 +534,7 @@ __global__ void __launch_bounds__(256, 2)
           prodacc_renorm(accX, exX);
         }
         gstore((b + 1) & 1);
-        RING_T_BARRIER_GEN();
+        __syncthreads();
       }
     }
   }

@@ -528,8 +528,8 @@ __device__ __forceinline__ void greedy_load9(double (&o)[9], const double* __res
 // What one workgroup of greedy_batches_kernel writes and another reads later in the same launch (MI355X: eight XCDs with
 // private L2s; a compute unit's L1 is never refreshed by another's stores):
 //   * the states (xwg_ld / xwg_st): plain 16-byte accesses under the grid barrier's agent-scope release / acquire.
-//     Measured alternative, kept as a build knob (-DMUXGL_GREEDY_SC1): 8-byte relaxed agent-scope accesses and a barrier
-//     without fences -- slower (configs[3]: 0.154 s against 0.132 s): every read then goes to memory;
+//     (Measured alternative, HISTORY.md: 8-byte relaxed agent-scope accesses and a barrier without fences -- slower,
+//     configs[3] 0.154 s against 0.132 s: every read then goes to memory);
 //   * chunk partials and guesses (sc1_ld / sc1_st): 8-byte relaxed agent-scope accesses (sc1: the store writes through, the
 //     load bypasses L1) handed over point to point -- a tag word stored after the data is drained (chunk partials), or a
 //     word that carries tag and value at once (guesses) -- so that their readers need not wait at a grid barrier.
@@ -551,17 +551,10 @@ __device__ __forceinline__ void sc1_st(int2* p, int2 v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)(uint32_t)v.x | ((unsigned long long)(uint32_t)v.y << 32),
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#ifdef MUXGL_GREEDY_SC1
-template <class V>
-__device__ __forceinline__ V xwg_ld(const V* p) { return sc1_ld(p); }
-template <class V>
-__device__ __forceinline__ void xwg_st(V* p, V v) { sc1_st(p, v); }
-#else
 template <class V>
 __device__ __forceinline__ V xwg_ld(const V* p) { return *p; }
 template <class V>
 __device__ __forceinline__ void xwg_st(V* p, V v) { *p = v; }
-#endif
 
 // the nine values of state (SNP, cluster) out of the two tables; false: no such state yet
 __device__ __forceinline__ bool greedy_state(const double* diag, const double* offd, size_t row, double (&v)[9], double& B) {
@@ -959,10 +952,8 @@ __device__ __forceinline__ bool greedy_grid_barrier(unsigned* bar, unsigned& epo
   __syncthreads();
   ++epoch;
   if (threadIdx.x == 0) {
-#ifndef MUXGL_GREEDY_SC1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = epoch * gridDim.x;
     bool ok = true;
@@ -975,9 +966,7 @@ __device__ __forceinline__ bool greedy_grid_barrier(unsigned* bar, unsigned& epo
       }
       __builtin_amdgcn_s_sleep(2);
     }
-#ifndef MUXGL_GREEDY_SC1
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
     *s_ok = ok;
   }
   __syncthreads();

@@ -439,7 +439,7 @@ template <bool WAVE>
 __global__ void __launch_bounds__(64)
     fmx_call_kernel(int64_t c0, int64_t c1, int K, double doublet_prior, const double* __restrict__ fll,
                     muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat,
-                    int32_t* __restrict__ prev_clust, int32_t* __restrict__ prev_state, int32_t* __restrict__ flagged) {
+                    int32_t* __restrict__ prev_state, int32_t* __restrict__ flagged) {
   const int64_t i = WAVE ? c0 + (int64_t)blockIdx.x : c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c1) return;
   const int nSamples = K;
@@ -631,10 +631,9 @@ __global__ void __launch_bounds__(64)
   }
   // (round 6) a decision whose margin is within rounding reach of the kernels' numbers -- best / next of a scan, next /
   // third, one of the four +2 thresholds -- is not this kernel's to make: the cell goes on the list fmx_exact.hip settles
-  // in the reference's own arithmetic.  What that needs of the state BEFORE this iteration is kept aside: the
-  // assignment the cluster pileups were built from, and the previous (type, jBest, kBest) of the nchanged rules.
-  if (prev_clust) {
-    prev_clust[i] = clust[i];
+  // in the reference's own arithmetic.  What that needs of the state BEFORE this iteration is kept aside: the previous
+  // (type, jBest, kBest) of the nchanged rules here, the assignments the cluster pileups were built from by the launcher.
+  if (prev_state) {
     prev_state[i] = (prev_type & 0xff) | ((prev_j & 0xff) << 8) | ((prev_k & 0xff) << 16);
     double mag = 1.0;
     if (sngBestLLK > -1e299) mag = fmax(mag, fabs(sngBestLLK));
@@ -1210,7 +1209,7 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   }
   if (h->col && CT)
     HIPCHK(h, hipMemcpyAsync(m->d_clust, cl.data(), sizeof(int32_t) * CT, hipMemcpyHostToDevice, h->stream));
-  if (dev_alloc(h, &h->d_prev_clust, (size_t)(C ? C : 1)) || dev_alloc(h, &h->d_prev_state, (size_t)(C ? C : 1)) ||
+  if (dev_alloc(h, &m->d_prev_clust, (size_t)(CT ? CT : 1)) || dev_alloc(h, &h->d_prev_state, (size_t)(C ? C : 1)) ||
       dev_alloc(h, &h->d_flagged, (size_t)(C ? C : 1)))
     return 1;
   h->fmx_exact_cells = h->fmx_exact_changed = h->fmx_exact_unresolved = 0;
@@ -1299,16 +1298,21 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   toc(h, MUXGL_T_FMX_ESTEP);
   tic(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipMemsetAsync(h->d_fstat, 0, 4 * sizeof(int32_t), h->stream));
+  {  // the assignments the running iteration's cluster pileups were built from, for the exact path (fmx_exact.hip)
+    muxgl_handle* m = h->col ? h->col : h;
+    const int64_t CT = h->col ? h->C_total : h->C;
+    if (m->d_prev_clust && CT)
+      HIPCHK(h, hipMemcpyAsync(m->d_prev_clust, m->d_clust, sizeof(int32_t) * (size_t)CT, hipMemcpyDeviceToDevice, h->stream));
+  }
   if (nc > 0)
   {
     if ((h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP) || K <= 24)  // (few hypotheses per cell: a wave per cell is mostly overhead,
                                                              //  0.54 against 0.13 ms at configs[3])
       hipLaunchKernelGGL(fmx_call_kernel<false>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, c0, c1, K,
-                         p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_clust, h->d_prev_state,
-                         h->d_flagged);
+                         p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_state, h->d_flagged);
     else
       hipLaunchKernelGGL(fmx_call_kernel<true>, dim3((unsigned)nc), dim3(64), 0, h->stream, c0, c1, K, p->doublet_prior,
-                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_clust, h->d_prev_state, h->d_flagged);
+                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_state, h->d_flagged);
   }
   toc(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipGetLastError());
@@ -1351,7 +1355,10 @@ static int fmx_phase_fetch(muxgl_handle* h, muxgl_fmx_cell* out, int32_t* nsingl
   if (nsingle) *nsingle = h->h_fstat[0];
   if (namb) *namb = h->h_fstat[1];
   if (nchanged) *nchanged = h->h_fstat[2];
-  h->fmx_exact_unresolved += h->h_fstat[3];  // (muxgl_fmx_iterate settled its listed cells before it came here: 0)
+  // cells listed for the exact path that are still open (muxgl_fmx_iterate settled its own before it came here): counted as
+  // unresolved until muxgl_fmx_exact_finish takes them off again
+  h->fmx_listed = h->h_fstat[3];
+  h->fmx_exact_unresolved += h->h_fstat[3];
   h->h_fstat[3] = 0;
   if (full_ll && C) HIPCHK(h, hipMemcpy(full_ll, h->d_fll, sizeof(double) * (size_t)C * npairs, hipMemcpyDeviceToHost));
   return 0;
@@ -1371,8 +1378,7 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->h_fstat[3] > 0) {  // calls within rounding reach: settled in the reference's arithmetic (fmx_exact.hip)
     bool reassigned = false;
-    if (fmx_exact_resolve(h, p, h->h_fstat[3], &reassigned)) return 1;
-    h->h_fstat[3] = 0;
+    if (fmx_exact_resolve(h, p, &reassigned)) return 1;
     if (reassigned) {  // the ordered M-step again, from the corrected assignments
       if (fmx_phase_mstep(h)) return 1;
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1383,10 +1389,64 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
   return 0;
 }
 
+// The exact path for the sharded phases (see fmx_exact.hip; popscle_amd/freemuxlet.py run_em drives it): after
+// muxgl_fmx_iter_estep + muxgl_fmx_iter_fetch, when the job-wide count of listed cells is not zero.
+int muxgl_fmx_exact_snps(muxgl_handle* h, int32_t* out, int64_t cap, int64_t* n) {
+  if (!h || !n) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_exact_snps");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->xs_snps_valid) {
+    if (h->fmx_listed > h->h_fstat[3]) h->h_fstat[3] = h->fmx_listed;  // (a muxgl_fmx_iter_fetch moved the count there)
+    if (fmx_exact_snps(h, &h->xs_snps)) return 1;
+    h->xs_snps_valid = true;
+  }
+  *n = (int64_t)h->xs_snps.size();
+  if (out) {
+    if (cap < *n) MUXGL_FAIL(h, "muxgl_fmx_exact_snps: room for %lld SNPs, %lld needed", (long long)cap, (long long)*n);
+    memcpy(out, h->xs_snps.data(), sizeof(int32_t) * h->xs_snps.size());
+    h->xs_snps_valid = false;
+    h->xs_snps.clear();
+  }
+  return 0;
+}
+
+int muxgl_fmx_exact_rows(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, double* rows,
+                         uint8_t* owned) {
+  if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_exact_rows");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (fmx_check_iter(h, p, "muxgl_fmx_exact_rows")) return 1;
+  if (n > 0 && (!snps || !rows)) MUXGL_FAIL(h, "muxgl_fmx_exact_rows: NULL argument");
+  return fmx_exact_rows(h, p, snps, n, rows, owned);
+}
+
+int muxgl_fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, const double* rows,
+                           int64_t* deltas, int32_t* reassigned) {
+  if (!h || !deltas || !reassigned) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_exact_finish");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (fmx_check_iter(h, p, "muxgl_fmx_exact_finish")) return 1;
+  if (fmx_exact_finish(h, p, snps, n, rows, deltas, reassigned)) return 1;
+  for (int i = 0; i < 3; ++i) h->h_fstat[i] += (int32_t)deltas[i];  // the rank's own counters, corrected
+  h->h_fstat[3] = 0;
+  h->fmx_exact_unresolved -= h->fmx_listed;
+  h->fmx_listed = 0;
+  HIPCHK(h, hipMemcpy(h->d_fstat, h->h_fstat, 4 * sizeof(int32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// cells of the last muxgl_fmx_iter_fetch that are listed for the exact path and not settled yet
+int muxgl_fmx_exact_pending(const muxgl_handle* h, int64_t* cells) {
+  if (!h || !cells) return 1;
+  *cells = h->group ? 0 : h->fmx_listed;
+  return 0;
+}
+
 int muxgl_fmx_exact_stats(const muxgl_handle* h, int64_t* near_tie_cells, int64_t* calls_changed, int64_t* unresolved) {
   if (!h) return 1;
   int64_t a = h->fmx_exact_cells, b = h->fmx_exact_changed, c = h->fmx_exact_unresolved;
-  if (h->group) group_fmx_exact_unresolved(h, &c);
+  if (h->group) group_fmx_exact_stats(h, &a, &b, &c);
   if (near_tie_cells) *near_tie_cells = a;
   if (calls_changed) *calls_changed = b;
   if (unresolved) *unresolved = c;

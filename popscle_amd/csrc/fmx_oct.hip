@@ -186,11 +186,6 @@ __global__ void __launch_bounds__(64, FO_WAVES)
     };
     // entry i: row Rc, (c0, c1) in cc; o0 held its row offset (free), o2 holds that of i + 2; cn receives i + 1's (c0, c1)
     auto step = [&](int i, const rowl_t& Rc, rowl_t& Rnn, const double2& cc, double2& cn, uint32_t& o0, uint32_t o2) {
-#ifdef FO_OLD_LOAD_ORDER
-      load_rowl(Rnn, o2);
-      cn = lcs[(size_t)(i + 1) * SLOTS];
-      o0 = lo[(size_t)(i + 3) * SLOTS];
-#else
       // Issue order = completion order (vmcnt): the row offset, which the NEXT step's first load needs, goes first and
       // the gathered row, which nobody reads for two sweeps, last -- so that waiting for the offset (vmcnt(2)) and for
       // the next entry's (c0, c1) (vmcnt(4)) leaves the gather in flight.  (Round 5: the gather used to be issued first
@@ -198,7 +193,6 @@ __global__ void __launch_bounds__(64, FO_WAVES)
       o0 = lo[(size_t)(i + 3) * SLOTS];
       cn = lcs[(size_t)(i + 1) * SLOTS];
       load_rowl(Rnn, o2);
-#endif
       __builtin_amdgcn_sched_barrier(0);  // the loads are issued in front of the sweep they hide behind
       sweepL(Rc, cc);
       __builtin_amdgcn_sched_barrier(0);
@@ -298,15 +292,9 @@ __global__ void __launch_bounds__(64, FO_WAVES)
     };
     // entry i: row Rc, likelihoods gc; o0 held its row offset (free), o2 holds that of i + 2; gn receives i + 1's likelihoods
     auto step = [&](int i, const row_t& Rc, row_t& Rnn, const gl_t& gc, gl_t& gn, uint32_t& o0, uint32_t o2) {
-#ifdef FO_OLD_LOAD_ORDER
-      load_row(Rnn, o2);
-      fetch_gl(gn, i + 1);
-      o0 = go[(size_t)(i + 3) * SLOTS];
-#else
       o0 = go[(size_t)(i + 3) * SLOTS];  // (offset first, the gathered rows last: see the linear loop)
       fetch_gl(gn, i + 1);
       load_row(Rnn, o2);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       sweep(Rc, gc);
       __builtin_amdgcn_sched_barrier(0);

@@ -369,6 +369,7 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_prev_clust);
   dev_free(&h->d_prev_state);
   dev_free(&h->d_flagged);
+  fmx_exact_release(h);
   dev_free(&h->d_snp_ptr);
   dev_free(&h->d_snp_entry);
   dev_free(&h->d_snp_cell);

@@ -307,10 +307,13 @@ int group_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
   });
 }
 
-void group_fmx_exact_unresolved(const muxgl_handle* h, int64_t* unresolved) {
-  int64_t n = 0;
-  for (muxgl_handle* m : h->group->m) n += m->fmx_exact_unresolved;
-  *unresolved = n;
+void group_fmx_exact_stats(const muxgl_handle* h, int64_t* cells, int64_t* changed, int64_t* unresolved) {
+  *cells = *changed = *unresolved = 0;
+  for (muxgl_handle* m : h->group->m) {
+    *cells += m->fmx_exact_cells;
+    *changed += m->fmx_exact_changed;
+    *unresolved += m->fmx_exact_unresolved;
+  }
 }
 
 int group_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
@@ -380,6 +383,64 @@ int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
     }
     if (fmx_phase_mstep(m)) return phase_fail(m);
   }
+  // Near-tie calls (fmx_exact.hip): the members' listed cells are settled in the reference's arithmetic -- the SNP lists
+  // united, every row computed by the member whose M-step range holds the SNP, the rows handed to all -- and, when an
+  // assignment changed, the assignments are pulled and the ordered merge is run once more.
+  int64_t listed = 0;
+  for (int r = 0; r < n; ++r) {
+    muxgl_handle* m = g->m[(size_t)r];
+    GCHK(m, hipSetDevice(m->device));
+    GCHK(m, hipStreamSynchronize(m->stream));
+    listed += m->h_fstat[3];
+  }
+  if (listed > 0) {
+    std::vector<int32_t> uni;
+    for (int r = 0; r < n; ++r) {
+      muxgl_handle* m = g->m[(size_t)r];
+      GCHK(m, hipSetDevice(m->device));
+      std::vector<int32_t> sn;
+      if (fmx_exact_snps(m, &sn)) return phase_fail(m);
+      uni.insert(uni.end(), sn.begin(), sn.end());
+    }
+    std::sort(uni.begin(), uni.end());
+    uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+    const int64_t nu = (int64_t)uni.size();
+    std::vector<double> rows((size_t)nu * row);
+    std::vector<uint8_t> owned((size_t)nu, 0);
+    for (int r = 0; r < n; ++r) {
+      muxgl_handle* m = g->m[(size_t)r];
+      GCHK(m, hipSetDevice(m->device));
+      if (fmx_exact_rows(m, p, uni.data(), nu, rows.data(), owned.data())) return phase_fail(m);
+    }
+    for (int64_t i = 0; i < nu; ++i)
+      if (!owned[(size_t)i]) MUXGL_FAIL(h, "device group: no member's M-step range holds SNP %d", uni[(size_t)i]);
+    bool reassigned = false;
+    for (int r = 0; r < n; ++r) {
+      muxgl_handle* m = g->m[(size_t)r];
+      GCHK(m, hipSetDevice(m->device));
+      int64_t dl[3];
+      int32_t re = 0;
+      if (fmx_exact_finish(m, p, uni.data(), nu, rows.data(), dl, &re)) return phase_fail(m);
+      for (int i = 0; i < 3; ++i) m->h_fstat[i] += (int32_t)dl[i];
+      m->h_fstat[3] = 0;
+      reassigned = reassigned || re != 0;
+    }
+    if (reassigned) {
+      for (int r = 0; r < n; ++r) {  // (finish drained every member's stream: no events needed for these pulls)
+        muxgl_handle* m = g->m[(size_t)r];
+        GCHK(m, hipSetDevice(m->device));
+        for (int o = 0; o < n; ++o) {
+          if (o == r) continue;
+          muxgl_handle* src = g->m[(size_t)o];
+          const int64_t c0 = g->cb[(size_t)o], c1 = g->cb[(size_t)o + 1];
+          if (c1 <= c0) continue;
+          GCHK(m, hipMemcpyPeerAsync(m->col->d_clust + c0, m->device, src->col->d_clust + c0, src->device,
+                                     sizeof(int32_t) * (size_t)(c1 - c0), m->stream));
+        }
+        if (fmx_phase_mstep(m)) return phase_fail(m);
+      }
+    }
+  }
   const size_t npairs = (size_t)K * (K + 1) / 2;
   int32_t st[3] = {0, 0, 0};
   for (int r = 0; r < n; ++r) {
@@ -392,8 +453,6 @@ int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
     collect_timing(m);
     if (out && nc) memcpy(out + c0, m->h_fcells, sizeof(muxgl_fmx_cell) * (size_t)nc);
     for (int i = 0; i < 3; ++i) st[i] += m->h_fstat[i];
-    m->fmx_exact_unresolved += m->h_fstat[3];  // near-tie calls a member lists but cannot settle alone (fmx_exact.hip)
-    m->h_fstat[3] = 0;
     if (full_ll && nc)
       GCHK(m, hipMemcpy(full_ll + (size_t)c0 * npairs, m->d_fll, sizeof(double) * (size_t)nc * npairs, hipMemcpyDeviceToHost));
   }

@@ -139,6 +139,34 @@ def load_rank_from_files(eng, exe, plp_prefix, rank, world, scratch, extra=()):
     return eng.fmx_prepare(d["af"]), d
 
 
+def settle_near_ties(engs, gather, doublet_prior, geno_error):
+    """The exact path for the calls rounding noise could decide (include/muxgl.h, csrc/fmx_exact.hip), across ranks:
+    the SNP lists of the ranks' listed cells are united, every cluster-posterior row is recomputed exactly by the rank
+    whose M-step range holds the SNP, all ranks get all rows, and every rank settles its own cells.
+
+    engs: the engines this process drives (one per rank in a real run; several virtual ranks in tests).
+    gather(obj) -> list of obj over ALL ranks of the job (identity-like for a process that drives every rank).
+    Returns True when an assignment changed anywhere (assignments must be exchanged again, the M-step repeated)."""
+    lists = [e.fmx_exact_snps() for e in engs]
+    every = [x for part in gather(lists) for x in part]
+    uni = np.unique(np.concatenate(every)).astype(np.int32) if every else np.zeros(0, dtype=np.int32)
+    K = engs[0].K
+    mine = []
+    for e in engs:
+        rows, owned = e.fmx_exact_rows(uni, doublet_prior, geno_error)
+        mine.append((np.flatnonzero(owned), rows[owned]))
+    full = np.zeros((uni.size, K, 3))
+    seen = np.zeros(uni.size, dtype=bool)
+    for part in gather(mine):
+        for idx, r in part:
+            full[idx] = r
+            seen[idx] = True
+    if not seen.all():
+        raise RuntimeError("near-tie calls: no rank's M-step range holds SNP(s) " + str(uni[~seen][:5].tolist()))
+    re = [e.fmx_exact_finish(uni, full, doublet_prior, geno_error)[1] for e in engs]
+    return any(x for part in gather(re) for x in part)
+
+
 def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early_stop=True, exchange=None,
            exchange_tensor=engine_exchange_tensor, log=None, per=None, timings=None, sync=None, stream_ctx=None):
     """EM loop of cmd_cram_freemux2.cpp:373-605 on a prepared engine.  One rank: a plain engine holding the whole
@@ -201,13 +229,22 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
                 stat_ready.record()
                 eng.fmx_iter_mstep()
                 stat_ready.synchronize()
-                stats = tuple(int(x) for x in stat_host[:3].tolist())
+                stats4 = tuple(int(x) for x in stat_host[:4].tolist())
             else:
-                if multi:
-                    stats = tuple(int(x) for x in t_stat[:3].tolist())
-                else:
-                    _, stats = eng.fmx_iter_fetch(want_cells=False)  # three counters; the records travel once, below
+                stats4 = tuple(int(x) for x in t_stat[:4].tolist())
+            if stats4[3] > 0:
+                # cells whose call is within rounding reach of the kernels' numbers, somewhere in the job: settled in the
+                # reference's arithmetic (two small exchanges, this iteration only), then the assignments and the counters
+                # once more, and the ordered merge from the corrected assignments
+                reassigned = settle_near_ties([eng], ex.gather_objects, doublet_prior, geno_error)
+                ex.allgather_equal(t_clust, per_c)
+                ex.allreduce_sum(t_stat)
+                stats4 = tuple(int(x) for x in t_stat[:4].tolist())
+                if reassigned or not ordered:
+                    eng.fmx_iter_mstep()
+            elif not ordered:
                 eng.fmx_iter_mstep()  # :516-517 + :590-596 for the own SNP range
+            stats = stats4[:3]
             history.append(stats)
             if log:
                 log(f"iter {it + 1}: {stats[0]} singlets, {eng.C_total - stats[0] - stats[1]} doublets, "

@@ -97,6 +97,10 @@ SYMBOLS = {
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
     "muxgl_fmx_exact_stats": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "muxgl_fmx_exact_pending": (C.c_int, [_VP, _VP]),
+    "muxgl_fmx_exact_snps": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
+    "muxgl_fmx_exact_rows": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, C.c_int64, _VP, _VP]),
+    "muxgl_fmx_exact_finish": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, C.c_int64, _VP, _VP, _VP]),
     "muxgl_fmxold_pair_dist": (C.c_int, [_VP, C.c_double, _VP]),
     "muxgl_fmxold_get_signs": (C.c_int, [_VP, _VP]),
     "muxgl_fmxold_vote_init": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_double, _VP, _VP]),
@@ -426,6 +430,37 @@ class Engine:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.muxgl_fmx_exact_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    # ---- the exact path for the sharded phases (include/muxgl.h; freemuxlet.settle_near_ties drives it)
+    def fmx_exact_pending(self):
+        n = C.c_int64()
+        self._check(self.lib.muxgl_fmx_exact_pending(self.h, C.byref(n)))
+        return n.value
+
+    def fmx_exact_snps(self):
+        n = C.c_int64()
+        self._check(self.lib.muxgl_fmx_exact_snps(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.int32)
+        self._check(self.lib.muxgl_fmx_exact_snps(self.h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def fmx_exact_rows(self, snps, doublet_prior=0.5, geno_error=0.1):
+        snps = _arr(snps, np.int32, "snps")
+        p = _FmxParams(float(doublet_prior), float(geno_error))
+        rows = np.zeros((snps.size, self.K, 3))
+        owned = np.zeros(snps.size, dtype=np.uint8)
+        self._check(self.lib.muxgl_fmx_exact_rows(self.h, C.byref(p), _ptr(snps), snps.size, _ptr(rows), _ptr(owned)))
+        return rows, owned.astype(bool)
+
+    def fmx_exact_finish(self, snps, rows, doublet_prior=0.5, geno_error=0.1):
+        snps = _arr(snps, np.int32, "snps")
+        rows = _arr(rows, np.float64, "rows")
+        p = _FmxParams(float(doublet_prior), float(geno_error))
+        deltas = np.zeros(3, dtype=np.int64)
+        re = C.c_int32()
+        self._check(self.lib.muxgl_fmx_exact_finish(self.h, C.byref(p), _ptr(snps), snps.size, _ptr(rows), _ptr(deltas),
+                                                    C.byref(re)))
+        return deltas, bool(re.value)
 
     def fmx_cluster_pileup(self):
         gls = np.zeros((self.K, self.S, 9))

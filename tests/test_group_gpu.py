@@ -188,7 +188,40 @@ def test_device_group_against_oracle():
             ostats = ob.fmx_iterate(p, e, K, cplp, ocells, 0.5, 0.1)
             gcells, gstats = g.fmx_iterate(0.5, 0.1)
             assert tuple(gstats) == tuple(ostats)
-            assert parity.compare_fmx(gcells, ocells, resolved=False)["max_abs_ll_diff"] < 1e-7   # (a group only counts near ties)
+            assert parity.compare_fmx(gcells, ocells)["max_abs_ll_diff"] < 1e-7   # (a group settles its near ties like one device)
+
+
+def test_device_group_settles_near_tie_calls():
+    """clusters without cells and very shallow droplets (exact and near ties in the reference): the group's members unite
+    their lists, compute the rows of their own SNP ranges and settle their own cells -- the same records, counters and
+    cluster pileups as the oracle and as one device, over whole trajectories"""
+    import parity
+
+    K, used = 12, 4
+    p = synth.make_pileup(350, 500, used, seed=21, mean_entries=7, min_entries=1, with_gp=False)
+    rng = np.random.default_rng(2)
+    clust0 = rng.integers(0, used, p.C).astype(np.int32)
+    clust0[rng.random(p.C) < 0.1] = -1
+    e = ob.fmx_entry_pileup(p)
+    cplp = ob.fmx_build_cluster_pileup(p, e, K, clust0)
+    ocells = ob.fmx_init_cells(clust0)
+    with muxgl.Engine([0, 0, 0, 0]) as g, muxgl.Engine(0) as one:
+        for en in (g, one):
+            en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+            en.fmx_prepare(p.af)
+            en.fmx_set_clusters(K, clust0)
+        for it in range(3):
+            ostats = ob.fmx_iterate(p, e, K, cplp, ocells, 0.5, 0.1)
+            gcells, gstats = g.fmx_iterate(0.5, 0.1)
+            ocell1, ostat1 = one.fmx_iterate(0.5, 0.1)
+            assert tuple(gstats) == tuple(ostats) == tuple(ostat1), it
+            parity.compare_fmx(gcells, ocells)
+            assert gcells.tobytes() == ocell1.tobytes()
+        near, changed, unresolved = g.fmx_exact_stats()
+        assert near > 0 and unresolved == 0 and (near, changed) == one.fmx_exact_stats()[:2]
+        gg, gc = g.fmx_cluster_pileup()
+        og, oc = one.fmx_cluster_pileup()
+        assert np.array_equal(gg, og) and np.array_equal(gc, oc)
 
 
 def test_group_create_errors():
