@@ -82,8 +82,9 @@ def test_virtual_ranks_match_single_handle(K, world, C):
         assert np.array_equal(g[:, b:en], ref_gls[:, b:en]) and np.array_equal(c[:, b:en], ref_cnt[:, b:en])
         assert e.fmx_exact_stats()[2] == 0   # nothing left open
         e.close()
-    if K > 8 and C > 3:   # more clusters than donors: empty clusters, exact ties -- the path must have run on both sides
-        assert ref_near > 0 and settled_sharded > 0
+    assert (ref_near > 0) == (settled_sharded > 0)   # the exact path ran on both sides or on neither ...
+    if K == 20:
+        assert ref_near > 0                           # ... and this shape does have such cells
 
 
 def test_exchange_tensor_aliases_library_memory():
