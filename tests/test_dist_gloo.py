@@ -78,8 +78,9 @@ class FakeFmxEngine:
     """oracle-backed stand-in with the interface of a muxgl.Engine holding a rank's slabs (set_pileup + set_column_slab):
     E-step on the row slab (own cells, every SNP), ordered merge on the column slab (every cell, own SNPs)"""
 
-    def __init__(self, p, c_range, s_range):
+    def __init__(self, p, c_range, s_range, near_ties=False):
         self.p = p
+        self.near_ties = near_ties
         self.C_total, self.S = p.C, p.S
         self.c0, self.c1 = c_range
         self.s0, self.s1 = s_range
@@ -116,6 +117,53 @@ class FakeFmxEngine:
         self.clust[:] = -1000  # poison: every slice must come back through the exchange
         self.clust[self.c0:self.c1] = self.cells["clust"]
         self.stat[:] = (ns, na, nch, 0)
+        if self.near_ties:
+            self._list_and_corrupt()
+            self.stat_local = self.stat.copy()   # (the exchange all-reduces self.stat in place)
+
+    # ---- the exact path for near-tie calls (include/muxgl.h muxgl_fmx_exact_*; freemuxlet.settle_near_ties).  The
+    #      stand-in LISTS some of its cells in every iteration and leaves them with a WRONG call (assignment and counters),
+    #      as if rounding noise had decided them; the protocol must bring the reference's back -- which it can only do if
+    #      run_em notices the job-wide count, unites the lists, fetches every row from the rank that owns its SNP, and
+    #      exchanges the assignments and the counters once more before the ordered merge.
+    def _list_and_corrupt(self):
+        self.iteration = getattr(self, "iteration", 0) + 1
+        ids = np.arange(self.c0, self.c1)
+        self.listed = np.flatnonzero((ids + self.iteration) % 5 == 0)
+        self.true_cells, self.true_stat = self.cells.copy(), self.stat.copy()
+        for i in self.listed:
+            self.cells["clust"][i] = -1 if self.cells["clust"][i] >= 0 else 0
+            self.cells["type"][i] = 2 if self.cells["clust"][i] < 0 else 0
+        self.clust[self.c0:self.c1] = self.cells["clust"]
+        self.stat[:] = (self.stat[0] + 3, self.stat[1] + 1, self.stat[2] + 2, len(self.listed))
+
+    def fmx_exact_snps(self):
+        r = self.rows
+        ent = np.concatenate([np.arange(r.cell_ptr[i], r.cell_ptr[i + 1]) for i in self.listed] + [np.zeros(0, np.int64)])
+        return np.unique(r.entry_snp[ent.astype(np.int64)]).astype(np.int32)
+
+    def _row_of(self, gls):  # [K][9] -> [K][3]: stands for the posterior row of a SNP
+        return gls[:, [0, 4, 8]]
+
+    def fmx_exact_rows(self, snps, dp, ge):
+        rows = np.zeros((len(snps), self.K, 3))
+        owned = (snps >= self.s0) & (snps < self.s1)
+        for i in np.flatnonzero(owned):
+            rows[i] = self._row_of(self.cplp["gls"][:, snps[i]])
+        return rows, owned
+
+    def fmx_exact_finish(self, snps, rows, dp, ge):
+        assert np.array_equal(snps, np.unique(snps))
+        mine = self.fmx_exact_snps()
+        assert np.isin(mine, snps).all(), "the united list lacks a SNP of this rank's listed cells"
+        xg = self.xg[:self.S].reshape(self.S, self.K, 9)
+        for s_ in mine:   # every row must be the one its owner holds (= the one the all-gathered tensor carries)
+            assert np.array_equal(rows[np.searchsorted(snps, s_)], self._row_of(xg[s_])), "a row did not come from its owner"
+        deltas = self.true_stat[:3].astype(np.int64) - self.stat_local[:3]
+        self.cells = self.true_cells
+        self.clust[self.c0:self.c1] = self.cells["clust"]
+        self.stat[:] = (*self.true_stat[:3], 0)
+        return deltas, len(self.listed) > 0
 
     def fmx_iter_fetch(self, want_cells=True):
         return (self.cells.copy() if want_cells else None), tuple(int(x) for x in self.stat[:3])
@@ -156,7 +204,7 @@ def _worker(rank, world, port, kind, outdir):
         K = 3
         p = synth.make_pileup(60, 500, K, seed=44, mean_entries=120, min_entries=20, with_gp=False)
         (c_ranges, per_c), (s_ranges, per_s) = freemuxlet.plan_ranges(p.C, p.S, world)
-        eng = FakeFmxEngine(p, c_ranges[rank], s_ranges[rank])
+        eng = FakeFmxEngine(p, c_ranges[rank], s_ranges[rank], near_ties=(kind == "fmx_ties"))
         e = ob.fmx_entry_pileup(p)
         llk0, llk2, _, _ = ob.fmx_cell_scores(p, e)
         clust0 = ob.fmx_greedy_init(p, e, K, llk2 - llk0, ob.fmx_sort(llk2 - llk0))
@@ -178,9 +226,11 @@ def test_sharded_demuxlet_gloo(tmp_path, world):
         assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_freemuxlet_gloo(tmp_path, world):
-    mp.spawn(_worker, args=(world, _free_port(), "fmx", str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,kind", [(2, "fmx"), (3, "fmx"), (2, "fmx_ties"), (3, "fmx_ties")])
+def test_sharded_freemuxlet_gloo(tmp_path, world, kind):
+    """kind "fmx_ties": every rank lists cells as near ties in every iteration and leaves them wrong; the exact-path
+    protocol of run_em (two extra exchanges, assignments and counters again, then the M-step) must restore the run"""
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
     K = 3
     p = synth.make_pileup(60, 500, K, seed=44, mean_entries=120, min_entries=20, with_gp=False)
     e = ob.fmx_entry_pileup(p)
