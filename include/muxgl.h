@@ -64,9 +64,7 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 #define MUXGL_FLAG_NO_PIVOT_SUMS 256 /* freemuxlet E-step beyond 32 clusters: the pair sums of the non-linear entries as the
                                         three-term sums instead of around the lane's smallest term (lets tests compare the
                                         two forms) */
-#define MUXGL_FLAG_MSTEP_LDS_STATES 128 /* freemuxlet M-step for K <= 64 with one lane per marker and the cluster states
-                                           in LDS (fmx_mstep_snp_kernel) instead of one lane per (marker, cluster) chain
-                                           over the marker's list as a stream (lets tests compare the two) */
+/* (128 was MUXGL_FLAG_MSTEP_LDS_STATES until round 6: the M-step variant with the cluster states in LDS is retired) */
 #define MUXGL_FLAG_SPLIT_GENERAL_SWEEP 512 /* demuxlet beyond 32 samples: sweep the entries with more than one usable read in
                                              launches of their own on top of the linear entries' slab (round 3's scheme)
                                              instead of in the same launch with the same accumulators (lets tests

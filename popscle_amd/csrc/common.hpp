@@ -292,6 +292,9 @@ inline bool dev_pool_on() {
 }
 void dev_pool_release(muxgl_handle* h, bool forget_owner);  // muxgl_api.hip
 void dev_pool_release_all();
+// hipMalloc for buffers that do not go through the cache (rocprim temporaries): on failure the cached blocks of every handle
+// go back to the driver and the allocation is tried once more, as dev_alloc does
+hipError_t dev_malloc_retry(void** p, size_t bytes);
 
 int dev_alloc_bytes(muxgl_handle* h, void** p, size_t bytes);  // muxgl_api.hip
 void dev_free_bytes(void* p);

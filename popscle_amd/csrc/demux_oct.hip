@@ -926,7 +926,7 @@ int quad_launch_order(muxgl_handle* h, const row_chunk* d_chunks, const int32_t*
                      d_nlin, d_key, d_iota);
   size_t tmp_bytes = 0;
   hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key, d_key2, d_iota, *order, (size_t)n, 0u, 64u, h->stream);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = dev_malloc_retry((void**)&d_tmp, tmp_bytes ? tmp_bytes : 1);
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_iota, *order, (size_t)n, 0u, 64u, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   cleanup();

@@ -1458,7 +1458,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       while (bbits < 31 && ((int64_t)1 << bbits) < (int64_t)(n / GB + 1)) ++bbits;
       size_t tmp_bytes = 0;
       e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key, d_key2, d_val, d_val2, nP, 0u, 32u + bbits, h->stream);
-      if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+      if (e == hipSuccess) e = dev_malloc_retry((void**)&d_tmp, tmp_bytes ? tmp_bytes : 1);
       if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_val, d_val2, nP, 0u, 32u + bbits, h->stream);
       if (e != hipSuccess) break;
@@ -1476,7 +1476,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
         size_t tb = 0;
         hipError_t er = rocprim::exclusive_scan(nullptr, tb, in, out, (int64_t)0, cnt, rocprim::plus<int64_t>(), h->stream);
         void* tmp = nullptr;
-        if (er == hipSuccess) er = hipMalloc(&tmp, tb ? tb : 1);
+        if (er == hipSuccess) er = dev_malloc_retry((void**)&tmp, tb ? tb : 1);
         if (er == hipSuccess)
           er = rocprim::exclusive_scan(tmp, tb, in, out, (int64_t)0, cnt, rocprim::plus<int64_t>(), h->stream);
         if (er == hipSuccess) er = hipStreamSynchronize(h->stream);

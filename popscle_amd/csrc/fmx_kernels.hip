@@ -9,10 +9,8 @@
 //   fmx_entry_kernel      lane <-> entry: 9 genotype-pair likelihoods + counts + log lk0/lk2 of the entry
 //   fmx_cell_score_kernel wave <-> cell: sums of the entry logs
 //   fmx_cgp_kernel        lane <-> (SNP, cluster): cluster genotype posterior row used by the E-step
-//   fmx_estep_row_kernel  K <= 16: the row-kernel scheme of demux_row.hip (slot of 16 lanes = one chunk of a cell,
-//                         lane = cluster, partner triples by DPP row rotation; the entry's 3x3 likelihood matrix is
-//                         symmetric, so 8 shifts cover all unordered pairs), product accumulators, one log per chunk
-//   fmx_estep_pair_kernel K > 16: workgroup <-> cell, lane <-> cluster pair (general fallback)
+//   fmx_estep_pair_kernel workgroup <-> cell, lane <-> cluster pair: the plain E-step (the shaped ones live in fmx_oct.hip,
+//                         fmx_row2.hip, fmx_wave.hip)
 //   fmx_call_kernel       scans, evidence, re-assignment, change counters: lane <-> cell (K <= 24) or wave <-> cell
 //   fmx_mstep_kernel      lane <-> (SNP, cluster): walks the SNP's entries in ascending cell id (SNP-major view) and
 //                         applies merge() for the cells assigned to the cluster -- the exact sequential order of the
@@ -196,127 +194,6 @@ __global__ void __launch_bounds__(256)
   o[0] = g0;
   o[1] = g1;
   o[2] = g2;
-}
-
-// ------------------------------------------------------------------------------------------------ E-step, K <= 16
-
-__device__ __forceinline__ double dpp_ror1(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x121, 0xF, 0xF, false);  // row_ror:1
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x121, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-
-constexpr int FX_PGS = 10;                    // 9 likelihoods + 1 pad (16-byte aligned rows)
-constexpr int FX_SLOT_STRIDE = 16 * FX_PGS + 4;
-constexpr int FX_NACC = 9;                    // [0] singlet, [1..8] shifts
-
-__global__ void __launch_bounds__(64)
-    fmx_estep_row_kernel(const row_chunk* __restrict__ chunks, int n_chunks, const int32_t* __restrict__ entry_snp,
-                         const double* __restrict__ egls, const double* __restrict__ cgp, int K,
-                         double* __restrict__ part) {
-  __shared__ __align__(16) double gl[4 * FX_SLOT_STRIDE];
-  __shared__ int32_t snps[64];
-  const int lane = threadIdx.x;
-  const int slot = lane >> 4, j = lane & 15;
-  const int q = xcd_swizzle(blockIdx.x, gridDim.x >> 3) * 4 + slot;
-  int64_t e0 = 0;
-  int len = 0;
-  if (q < n_chunks) {
-    e0 = chunks[q].e0;
-    len = chunks[q].len;
-  }
-  const int nb = (wave_max_i32(len) + 15) >> 4;
-  double acc[FX_NACC];
-  int32_t ex[FX_NACC];
-#pragma unroll
-  for (int a = 0; a < FX_NACC; ++a) {
-    acc[a] = 1.0;
-    ex[a] = 0;
-  }
-  const int K3 = K * 3;
-  const bool live = j < K;
-
-  for (int b = 0; b < nb; ++b) {
-    {  // phase 1: lane <-> entry, the 3x3 likelihoods of 64 entries into LDS
-      const int idx = b * 16 + j;
-      double* dst = gl + slot * FX_SLOT_STRIDE + j * FX_PGS;
-      int32_t s = -1;
-      if (idx < len) {
-        const int64_t e = e0 + idx;
-        s = entry_snp[e];
-        const double* src = egls + (size_t)e * 9;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) dst[i] = src[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) dst[i] = 1.0;  // dead entry: with g = (1,0,0) every factor is exactly 1
-      }
-      snps[lane] = s;
-    }
-    __syncthreads();
-    int32_t s_next = snps[slot * 16];
-    double ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-    if (s_next >= 0 && live) {
-      const double* row = cgp + (size_t)s_next * K3 + j * 3;
-      ng0 = row[0], ng1 = row[1], ng2 = row[2];
-    }
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-      const double g0 = ng0, g1 = ng1, g2 = ng2;
-      ng0 = 1.0, ng1 = 0.0, ng2 = 0.0;
-      if (i + 1 < 16) {
-        s_next = snps[slot * 16 + i + 1];
-        if (s_next >= 0 && live) {
-          const double* row = cgp + (size_t)s_next * K3 + j * 3;
-          ng0 = row[0], ng1 = row[1], ng2 = row[2];
-        }
-      }
-      const double* p = gl + slot * FX_SLOT_STRIDE + i * FX_PGS;
-      // singlet: sum_g glis[g,g] * gp_j[g]   (cmd_cram_freemux2.cpp:448-452)
-      acc[0] *= fma(g2, p[8], fma(g1, p[4], g0 * p[0]));
-      // pairs: sum_{g1,g2} glis[g1,g2] gp_j[g1] gp_k[g2]   (:440-446)
-      const double u0 = fma(g2, p[6], fma(g1, p[3], g0 * p[0]));
-      const double u1 = fma(g2, p[7], fma(g1, p[4], g0 * p[1]));
-      const double u2 = fma(g2, p[8], fma(g1, p[5], g0 * p[2]));
-      double r0 = g0, r1 = g1, r2 = g2;
-#pragma unroll
-      for (int t = 1; t <= 8; ++t) {
-        r0 = dpp_ror1(r0);
-        r1 = dpp_ror1(r1);
-        r2 = dpp_ror1(r2);
-        acc[t] *= fma(r2, u2, fma(r1, u1, r0 * u0));
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < FX_NACC; ++a) prodacc_renorm(acc[a], ex[a]);
-    __syncthreads();
-  }
-  if (q < n_chunks) {
-    double* out = part + (size_t)q * FX_NACC * 16;
-#pragma unroll
-    for (int a = 0; a < FX_NACC; ++a) out[a * 16 + j] = prodacc_log(acc[a], ex[a]);  // :454-455 as one log per chunk
-  }
-}
-
-__global__ void __launch_bounds__(192)
-    fmx_estep_row_reduce_kernel(const int64_t* __restrict__ cell_chunk_ptr, const int32_t* __restrict__ cell_chunks,
-                                const double* __restrict__ part, const int32_t* __restrict__ kmap, int K,
-                                int64_t c_off, double* __restrict__ fll) {
-  const int64_t c = c_off + blockIdx.x;
-  const int64_t c0 = cell_chunk_ptr[c], c1 = cell_chunk_ptr[c + 1];
-  const int npairs = K * (K + 1) / 2;
-  const int idx = threadIdx.x;
-  if (idx >= FX_NACC * 16) return;
-  const int a = idx >> 4, j = idx & 15;
-  if (j >= K) return;
-  const int k = (a == 0) ? j : kmap[a * 16 + j];
-  if (k >= K) return;
-  if (a == 8 && j < k) return;  // shift 8 visits every unordered pair twice
-  double s = 0.0;
-  for (int64_t ci = c0; ci < c1; ++ci) s += part[(size_t)cell_chunks[ci] * FX_NACC * 16 + idx];
-  const int hi = j > k ? j : k, lo = j > k ? k : j;
-  fll[(size_t)c * npairs + hi * (hi + 1) / 2 + lo] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ E-step, any K
@@ -771,136 +648,16 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// The same chains with one lane per SNP: the lane walks its SNP's entries once (ascending cell id) and keeps the K
-// cluster states of that SNP in LDS, so every list element costs one merge on a fully populated wave instead of a
-// K-fold masked one.  Loads are software-pipelined one element ahead (entry id and cell are SNP-major and sequential;
-// the assignment lookup and the 72-byte likelihood gather of the next element fly during the current merge).
-// The read counts of the cluster pileups are plain sums and are not needed by the EM: fmx_counts_kernel computes
-// them on demand (muxgl_fmx_get_cluster_pileup).
-// For K > 16 a marker is shared by P = 2 or 4 lanes, each holding KL = K/P (<= 16) of its cluster states: the lanes of a
-// marker read the same list (identical addresses, one fetch) and only the lane that owns the entry's cluster merges.
-// Needs 64*(9*KL+1)*8 B of LDS.
-__global__ void __launch_bounds__(64)
-    fmx_mstep_snp_kernel(int64_t S, int64_t s0, int64_t s1, int K, int P, int KL, const int64_t* __restrict__ snp_ptr,
-                         const int32_t* __restrict__ snp_cell, const int32_t* __restrict__ clust,
-                         const double* __restrict__ segls6, double* __restrict__ cgls) {
-  // The likelihood matrix of an entry is symmetric (calculate_snp_droplet_pileup) and a cluster state starts at all
-  // ones, so every state stays symmetric: six numbers {00, 11, 22, 01, 02, 12} per state and entry instead of nine --
-  // a third fewer LDS bytes per marker (more markers in flight), three 16-byte loads per entry instead of nine 8-byte
-  // ones.  The sums over the nine elements become  d0 + d1 + d2 + 2 (o01 + o02 + o12).
-  extern __shared__ double sm[];
-  const int lane = threadIdx.x;
-  const int STR = KL * 6 + 1;
-  double* st = sm + (size_t)lane * STR;
-  for (int i = 0; i < KL * 6; ++i) st[i] = 1.0;
-  const int per = 64 / P;                       // markers per wave
-  const int part = lane / per;                  // this lane owns clusters [part*KL, part*KL + KL)
-  const int64_t s = s0 + (int64_t)blockIdx.x * per + (lane - part * per);
-  int64_t p = 0, p1 = 0;
-  if (s < s1) {
-    p = snp_ptr[s];
-    p1 = snp_ptr[s + 1];
-  }
-  // Software pipeline in blocks of MU entries, two register sets: while block n is merged (a strictly sequential chain
-  // through the LDS states), the likelihoods and assignments of block n+1 and the cell ids of block n+2 are in flight.
-  // The number of chains in flight is capped by LDS (K*48 B per marker, ~210 markers per CU), so the time per chain
-  // step is what counts: it was one full memory round trip with a single entry of look-ahead.
-  // (all loads are unconditional from clamped positions: a predicated load merged with a default makes the compiler
-  // wait for it on the spot)
-  constexpr int MU = 4;
-  struct blk_t {
-    int32_t k[MU];
-    double g[MU][6];
-  };
-  const int64_t plast = (p1 > p) ? p1 - 1 : 0;
-  auto load_ids = [&](int32_t (&c)[MU], int64_t base) {
-#pragma unroll
-    for (int u = 0; u < MU; ++u) c[u] = snp_cell[(base + u < p1) ? base + u : plast];
-  };
-  auto load_data = [&](blk_t& B, const int32_t (&c)[MU], int64_t base) {
-#pragma unroll
-    for (int u = 0; u < MU; ++u) {
-      const int64_t e = (base + u < p1) ? base + u : plast;
-      B.k[u] = clust[c[u]];
-      const double2* o = reinterpret_cast<const double2*>(segls6 + (size_t)e * 6);  // 48 B, 16-byte aligned
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double2 v = o[i];
-        B.g[u][2 * i] = v.x;
-        B.g[u][2 * i + 1] = v.y;
-      }
-    }
-  };
-  auto merge_blk = [&](const blk_t& B, int64_t base) {
-#pragma unroll
-    for (int u = 0; u < MU; ++u) {
-      const int32_t k = B.k[u] - part * KL;
-      if (base + u < p1 && k >= 0 && k < KL) {  // only cells called singlets carry a cluster (b8, :590-596)
-        double* q = st + k * 6;
-        double v[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = q[i] * B.g[u][i];
-        double inv = fast_rcp(((v[0] + v[1]) + v[2]) + 2.0 * ((v[3] + v[4]) + v[5]));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          v[i] *= inv;
-          if (v[i] < kMinNormGL) v[i] = kMinNormGL;
-        }
-        inv = fast_rcp(((v[0] + v[1]) + v[2]) + 2.0 * ((v[3] + v[4]) + v[5]));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) q[i] = v[i] * inv;
-      }
-    }
-  };
-  blk_t A, B;
-  int32_t ca[MU], cb[MU];
-  load_ids(ca, p);
-  load_ids(cb, p + MU);
-  load_data(A, ca, p);
-  while (__any(p < p1)) {
-    load_data(B, cb, p + MU);
-    load_ids(ca, p + 2 * MU);
-    merge_blk(A, p);
-    p += MU;
-    if (!__any(p < p1)) break;
-    load_data(A, ca, p + MU);
-    load_ids(cb, p + 2 * MU);
-    merge_blk(B, p);
-    p += MU;
-  }
-  if (s < s1) {
-    for (int k = 0; k < KL && part * KL + k < K; ++k) {
-      double* og = cgls + ((size_t)(part * KL + k) * S + s) * 9;
-      const double* q = st + k * 6;
-      og[0] = q[0], og[1] = q[3], og[2] = q[4];
-      og[3] = q[3], og[4] = q[1], og[5] = q[5];
-      og[6] = q[4], og[7] = q[5], og[8] = q[2];
-    }
-  }
-}
-
 }  // namespace
 
 static int fmx_mstep_launch(muxgl_handle* h) {
   const int64_t n = (h->fs1 - h->fs0) * h->K;
   if (n <= 0) return 0;
-  int P = 1;  // lanes per SNP, each holding at most 16 of its cluster states
-  while (P * 16 < h->K) P *= 2;
-  const int KL = (h->K + P - 1) / P;
-  const size_t lds = (size_t)64 * (KL * 6 + 1) * sizeof(double);
-  if (!(h->flags & (MUXGL_FLAG_FORCE_TILE_SWEEP | MUXGL_FLAG_MSTEP_LDS_STATES))) {  // lane = chain, the list as a stream
+  if (!(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // K <= 64: lane = chain, the SNP's list as a stream (fmx_mstep.hip)
     const int rc = fmx_mstep_stream_launch(h);
     if (rc >= 0) return rc;
   }
-  if (P <= 16 && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {  // lane(s) per SNP, cluster states in LDS
-    const int64_t ns = h->fs1 - h->fs0;
-    const int per = 64 / P;
-    HIPCHK(h, hipFuncSetAttribute((const void*)fmx_mstep_snp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fmx_mstep_snp_kernel, dim3((unsigned)((ns + per - 1) / per)), dim3(64), lds, h->stream, h->S,
-                       h->fs0, h->fs1, h->K, P, KL, h->d_snp_ptr, h->d_snp_cell, h->d_clust, h->d_segls6, h->d_cgls);
-    HIPCHK(h, hipGetLastError());
-    return 0;
-  }
+  // beyond 64 clusters (no BASELINE shape), or under MUXGL_FLAG_FORCE_TILE_SWEEP: lane = (SNP, cluster), every chain on its own
   hipLaunchKernelGGL(fmx_mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->fs0, h->fs1,
                      h->K, h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_ecnt, h->d_cgls,
                      h->d_ccnt);
@@ -908,8 +665,6 @@ static int fmx_mstep_launch(muxgl_handle* h) {
   return 0;
 }
 
-// SNP-major view of the entries (cells ascending inside each SNP) and SNP-major copies of the entry likelihoods for the
-// ordered M-step, built on the device
 static int fmx_build_snp_major(muxgl_handle* h, host_timer& tm, bool keep_segls6 = false /* allocated by the caller */) {
   const int64_t nnz = h->nnz;
   if (plan_build_snp_major(h)) return 1;
@@ -1275,25 +1030,12 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   if (nc > 0 && qrc < 0) qrc = fmx_row2_estep_launch(h, st, c0, nc);  // 16 < K <= 32: two clusters per lane
   if (nc > 0 && qrc < 0) qrc = fmx_wave_estep_launch(h, c0, nc);  // 32 < K: one wave per cell (part) and block
   if (qrc > 0) return 1;
-  if (nc > 0 && qrc < 0) {
-    if (K <= 16 && st && !(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) {
-      const size_t need = (size_t)st->n_chunks * FX_NACC * 16;
-      if (need > st->part_cap) {
-        if (dev_alloc(h, &st->d_part, need)) return 1;
-        st->part_cap = need;
-      }
-      const unsigned blocks = (unsigned)((((st->n_chunks + 3) / 4) + 7) / 8 * 8);  // multiple of 8 for xcd_swizzle
-      if (blocks)
-        hipLaunchKernelGGL(fmx_estep_row_kernel, dim3(blocks), dim3(64), 0, h->stream, st->d_chunks, (int)st->n_chunks,
-                           h->d_entry_snp, h->d_egls, h->d_cgp, K, st->d_part);
-      hipLaunchKernelGGL(fmx_estep_row_reduce_kernel, dim3((unsigned)nc), dim3(192), 0, h->stream, st->d_cell_chunk_ptr,
-                         st->d_cell_chunks, st->d_part, st->d_kmap, K, c0, h->d_fll);
-    } else {
-      const int T = 256, PPT = 4;
-      const unsigned tiles = (unsigned)((npairs + T * PPT - 1) / (T * PPT));
-      hipLaunchKernelGGL(fmx_estep_pair_kernel<PPT>, dim3((unsigned)nc, tiles), dim3(T), 0, h->stream, h->d_cell_ptr,
-                         h->d_entry_snp, h->d_egls, h->d_cgp, K, c0, h->d_fll);
-    }
+  if (nc > 0 && qrc < 0) {  // the plain kernel: workgroup <-> (cell, tile of pairs).  K > 255 never happens (muxgl_fmx_set_clusters):
+                            // reached under MUXGL_FLAG_FORCE_TILE_SWEEP / _FORCE_ROW_KERNEL, which tests use to cover it
+    const int T = 256, PPT = 4;
+    const unsigned tiles = (unsigned)((npairs + T * PPT - 1) / (T * PPT));
+    hipLaunchKernelGGL(fmx_estep_pair_kernel<PPT>, dim3((unsigned)nc, tiles), dim3(T), 0, h->stream, h->d_cell_ptr,
+                       h->d_entry_snp, h->d_egls, h->d_cgp, K, c0, h->d_fll);
   }
   toc(h, MUXGL_T_FMX_ESTEP);
   tic(h, MUXGL_T_FMX_CALL);

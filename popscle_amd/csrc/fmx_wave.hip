@@ -522,7 +522,7 @@ static int fmx_wave_streams_build(muxgl_handle* h) {
   void* tmp = nullptr;
   HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, h->d_flin_rank, h->d_flin_rank, (int64_t)0, (size_t)nwords + 1,
                                     rocprim::plus<int64_t>(), h->stream));
-  HIPCHK(h, hipMalloc(&tmp, tb ? tb : 1));
+  HIPCHK(h, dev_malloc_retry((void**)&tmp, tb ? tb : 1));
   hipError_t e = rocprim::exclusive_scan(tmp, tb, h->d_flin_rank, h->d_flin_rank, (int64_t)0, (size_t)nwords + 1,
                                          rocprim::plus<int64_t>(), h->stream);
   int64_t n_lin = 0;

@@ -53,6 +53,27 @@ int dev_alloc_bytes(muxgl_handle* h, void** p, size_t bytes) {
   return 0;
 }
 
+hipError_t dev_malloc_retry(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    dev_pool_release_all();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
+// what a handle's cache may hold: a third of the device's memory (a phase that parks more than that gives the rest back to
+// the driver at once, so that allocations outside the cache keep finding room)
+static size_t dev_pool_cap() {
+  static const size_t cap = [] {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)64 << 30;
+    return tot / 3;
+  }();
+  return cap;
+}
+
 void dev_free_bytes(void* p) {
   if (!p) return;
   dev_registry& R = dev_reg();
@@ -61,7 +82,7 @@ void dev_free_bytes(void* p) {
     auto it = R.blocks.find(p);
     if (it != R.blocks.end()) {
       muxgl_handle* o = it->second.owner;
-      if (o && dev_pool_on()) {
+      if (o && dev_pool_on() && o->pool_bytes + it->second.bytes <= dev_pool_cap()) {
         o->pool.emplace(it->second.bytes, p);
         o->pool_bytes += it->second.bytes;
         return;

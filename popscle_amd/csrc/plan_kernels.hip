@@ -196,7 +196,7 @@ int plan_build_bit_streams(muxgl_handle* h, const uint32_t* bits, int64_t** rank
   size_t tb = 0;
   void* tmp = nullptr;
   HIPCHK(h, rocprim::exclusive_scan(nullptr, tb, *rank, *rank, (int64_t)0, (size_t)nwords + 1, rocprim::plus<int64_t>(), h->stream));
-  HIPCHK(h, hipMalloc(&tmp, tb ? tb : 1));
+  HIPCHK(h, dev_malloc_retry((void**)&tmp, tb ? tb : 1));
   hipError_t e = rocprim::exclusive_scan(tmp, tb, *rank, *rank, (int64_t)0, (size_t)nwords + 1, rocprim::plus<int64_t>(), h->stream);
   int64_t n = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&n, *rank + nwords, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
@@ -271,7 +271,7 @@ int plan_build_snp_major(muxgl_handle* h) {
   size_t tmp_bytes = 0;
   hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->d_entry_snp, d_keys, d_iota, h->d_snp_entry,
                                            (size_t)nnz, 0u, bits, h->stream);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = dev_malloc_retry((void**)&d_tmp, tmp_bytes ? tmp_bytes : 1);
   if (e == hipSuccess)
     e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, h->d_entry_snp, d_keys, d_iota, h->d_snp_entry, (size_t)nnz, 0u,
                                   bits, h->stream);
@@ -317,7 +317,7 @@ int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t 
   size_t tmp_bytes = 0;
   hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt, st->d_cell_chunk_ptr, (int64_t)0, (size_t)C + 1,
                                          rocprim::plus<int64_t>(), h->stream);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+  if (e == hipSuccess) e = dev_malloc_retry((void**)&d_tmp, tmp_bytes ? tmp_bytes : 1);
   if (e == hipSuccess)
     e = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_cnt, st->d_cell_chunk_ptr, (int64_t)0, (size_t)C + 1,
                                 rocprim::plus<int64_t>(), h->stream);
@@ -349,7 +349,7 @@ int plan_build_chunks(muxgl_handle* h, muxgl_row_state* st, int64_t cb, int64_t 
     while (bits < 31 && ((int64_t)1 << bits) < h->S) ++bits;
     tmp_bytes = 0;
     e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_key, d_key2, d_iota, d_ord, (size_t)n, 0u, bits, h->stream);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = dev_malloc_retry((void**)&d_tmp, tmp_bytes ? tmp_bytes : 1);
     if (e == hipSuccess)
       e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_key, d_key2, d_iota, d_ord, (size_t)n, 0u, bits, h->stream);
     if (e == hipSuccess) {

@@ -28,7 +28,6 @@ FLAG_FORCE_BATCHED_GREEDY = 8
 FLAG_DEMUX_ONLY = 16
 FLAG_ASYNC_PHASES = 32
 FLAG_NO_LINEAR_ENTRIES = 64
-FLAG_MSTEP_LDS_STATES = 128
 FLAG_NO_PIVOT_SUMS = 256
 FLAG_SPLIT_GENERAL_SWEEP = 512
 MAX_DEVICES = 16

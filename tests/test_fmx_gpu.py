@@ -378,11 +378,12 @@ def test_greedy_default_run_reports_its_near_ties(geng):
 
 @pytest.mark.parametrize("K,C,S,me", [(3, 2500, 60, 30), (16, 3000, 50, 25), (20, 2500, 40, 20), (32, 4000, 64, 30),
                                       (40, 3000, 48, 24), (64, 6000, 70, 40), (16, 64, 40, 30)])
-def test_mstep_stream_vs_lds_states_and_oracle(K, C, S, me):
+def test_mstep_stream_vs_plain_chains_and_oracle(K, C, S, me):
     """Ordered clamped M-step (sc_drop_seq.h:77-101 driven by cmd_cram_freemux2.cpp:586-597) on markers covered by
     hundreds to thousands of cells -- lists of many batches per chain, clusters of very different sizes, unassigned
-    cells: the stream kernel (lane = (marker, cluster) chain, fmx_mstep.hip) and the kernel with the states in LDS
-    (MUXGL_FLAG_MSTEP_LDS_STATES) agree bit for bit, and with the oracle's cluster pileups to rounding."""
+    cells: the stream kernel (lane = (marker, cluster) chain fed from a staged stream, fmx_mstep.hip) and the plain kernel
+    (every chain walks the list on its own; MUXGL_FLAG_FORCE_TILE_SWEEP) agree to rounding with each other and with the
+    oracle's cluster pileups."""
     p = synth.make_pileup(C, S, min(K, 8), seed=900 + K + C, mean_entries=me, min_entries=5, with_gp=False)
     rng = np.random.default_rng(K * 1000 + C)
     w = rng.dirichlet(np.full(K, 0.6))  # unbalanced clusters: some chains much longer than a batch, some empty
@@ -391,7 +392,7 @@ def test_mstep_stream_vs_lds_states_and_oracle(K, C, S, me):
     e = ob.fmx_entry_pileup(p)
     want = ob.fmx_build_cluster_pileup(p, e, K, clust)
     got = []
-    for flags in (0, muxgl.FLAG_MSTEP_LDS_STATES):
+    for flags in (0, muxgl.FLAG_FORCE_TILE_SWEEP):
         with muxgl.Engine(0, flags) as en:
             en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
             en.fmx_prepare(p.af)
@@ -399,16 +400,18 @@ def test_mstep_stream_vs_lds_states_and_oracle(K, C, S, me):
             g, c = en.fmx_cluster_pileup()
             assert np.array_equal(c, np.stack([want["nreads"], want["nref"], want["nalt"]], axis=-1))
             assert np.allclose(g, want["gls"], rtol=1e-11, atol=1e-300)
-            en.fmx_iterate(0.5, 0.1)  # the M-step behind a re-assignment
+            cells, _ = en.fmx_iterate(0.5, 0.1)  # the M-step behind a re-assignment
             g2, _ = en.fmx_cluster_pileup()
-            got.append((g, g2))
-    assert got[0][0].tobytes() == got[1][0].tobytes() and got[0][1].tobytes() == got[1][1].tobytes()
+            got.append((g, g2, cells))
+    assert np.array_equal(got[0][2]["clust"], got[1][2]["clust"])   # the same assignments went into the second merge
+    assert np.allclose(got[0][0], got[1][0], rtol=1e-11, atol=1e-300) and np.allclose(got[0][1], got[1][1], rtol=1e-11, atol=1e-300)
 
 
 def test_mstep_stream_without_the_lds_table(tmp_path):
     """Beyond ~60 k cells the assignments do not fit next to the staging areas in LDS and the stream M-step gathers them
     from global memory (one wave per workgroup): forced here on small inputs through MUXGL_MSTEP_NO_TABLE in a process
-    of its own (the library reads the variable once), bit-identical to the kernel with the states in LDS."""
+    of its own (the library reads the variable once), bit-identical to the same kernel with the table (run in a second
+    process without the variable)."""
     import subprocess
     import sys
     code = r"""
@@ -420,22 +423,25 @@ for K, C, S, me in [(5, 2000, 40, 20), (16, 3000, 50, 25), (24, 2500, 40, 20), (
     rng = np.random.default_rng(K)
     clust = rng.choice(K, size=p.C, p=rng.dirichlet(np.full(K, 0.6))).astype(np.int32)
     clust[rng.random(p.C) < 0.07] = -1
-    out = []
-    for flags in (0, muxgl.FLAG_MSTEP_LDS_STATES):
-        with muxgl.Engine(0, flags) as en:
-            en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
-            en.fmx_prepare(p.af)
-            en.fmx_set_clusters(K, clust)
-            g, c = en.fmx_cluster_pileup()
-            en.fmx_iterate(0.5, 0.1)
-            g2, _ = en.fmx_cluster_pileup()
-            out.append(g.tobytes() + g2.tobytes())
-    assert out[0] == out[1], K
+    with muxgl.Engine(0) as en:
+        en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        en.fmx_prepare(p.af)
+        en.fmx_set_clusters(K, clust)
+        g, c = en.fmx_cluster_pileup()
+        en.fmx_iterate(0.5, 0.1)
+        g2, _ = en.fmx_cluster_pileup()
+        import hashlib
+        print("digest", K, hashlib.sha256(g.tobytes() + g2.tobytes()).hexdigest())
 print("ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MUXGL_MSTEP_NO_TABLE="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    outs = []
+    for extra in ({"MUXGL_MSTEP_NO_TABLE": "1"}, {}):
+        env = {k: v for k, v in os.environ.items() if k != "MUXGL_MSTEP_NO_TABLE"}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")])
+    assert len(outs[0]) == 4 and outs[0] == outs[1]
 
 
 @pytest.mark.parametrize("K,C,S,me", [(1, 40, 3, 3), (2, 50, 2, 2), (33, 30, 700, 120), (16, 20, 1, 1)])
