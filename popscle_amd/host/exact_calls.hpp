@@ -54,44 +54,89 @@ struct Hyp {
   double ll;
 };
 
-// log-likelihoods of the listed hypotheses over one cell, cmd_cram_demuxlet.cpp:655-747 restricted to those slots
-inline void cell_lls(const Tables& t, int64_t e0, int64_t e1, const int32_t* entry_snp, const int64_t* entry_rptr,
-                     const uint8_t* reads, int32_t V, const double* gp, const uint8_t* has_gp, int32_t nAlpha,
-                     const double* gridAlpha, Hyp* hyps, size_t nh) {
+// pGs[nAlpha * 9] of one entry from its reads [r0, r1): per-read update with division by the running maximum, floor,
+// division by the maximum (cmd_cram_demuxlet.cpp:655-725)
+inline void entry_pgs(const Tables& t, const uint8_t* reads, int64_t r0, int64_t r1, int32_t nAlpha, const double* gridAlpha,
+                      double* pGs) {
 #if defined(__clang__)
 #pragma clang fp contract(off)  // this block only: every a*b+c below is two roundings, as in the reference's build
 #elif defined(__FMA__)
 #error "build exact_calls.hpp without -mfma / -march=native: g++ would contract a*b+c and change the last bit"
 #endif
-  double pGs[MUXGL_MAX_ALPHA * 9];
+  for (int32_t i = 0; i < nAlpha * 9; ++i) pGs[i] = 1.0;
+  for (int64_t r = r0; r < r1; ++r) {  // :659-700
+    const uint8_t b = reads[r];
+    if (b == MUXGL_READ_OTHER) continue;  // al == 2
+    const int al = b >> 7, bq = b & 0x7f;
+    const double pR = (al == 0) ? t.mat[bq] : t.err[bq] / 3.0;
+    const double pA = (al == 1) ? t.mat[bq] : t.err[bq] / 3.0;
+    double maxpG = 0;
+    for (int32_t a = 0; a < nAlpha; ++a)
+      for (int32_t l = 0; l < 3; ++l)
+        for (int32_t m = 0; m < 3; ++m) {
+          const double p = 0.5 * l + (m - l) * 0.5 * gridAlpha[a];
+          double& pG = pGs[a * 9 + l * 3 + m];
+          pG *= (pR * (1.0 - p) + pA * p);
+          if (maxpG < pG) maxpG = pG;
+        }
+    for (int32_t i = 0; i < nAlpha * 9; ++i) pGs[i] /= maxpG;
+  }
+  double maxpG = 0;  // :703-725
+  for (int32_t i = 0; i < nAlpha * 9; ++i) {
+    pGs[i] += 1e-10;
+    if (maxpG < pGs[i]) maxpG = pGs[i];
+  }
+  for (int32_t i = 0; i < nAlpha * 9; ++i) pGs[i] /= maxpG;
+}
+
+// The pGs of an entry with at most one usable read depend on that read's byte alone (three quarters of the entries of a
+// droplet data set): the same operations on the same numbers, done once per byte instead of once per entry.
+// Row 255 (MUXGL_READ_OTHER is never a usable read's byte): no usable read.
+struct OneReadTable {
+  int32_t nAlpha = 0;
+  std::vector<double> rows;  // [256][nAlpha * 9]
+  OneReadTable(const Tables& t, int32_t nA, const double* gridAlpha) : nAlpha(nA), rows((size_t)256 * nA * 9) {
+    for (int b = 0; b < 256; ++b) {
+      const uint8_t byte = (uint8_t)b;
+      entry_pgs(t, &byte, 0, b == MUXGL_READ_OTHER ? 0 : 1, nA, gridAlpha, &rows[(size_t)b * nA * 9]);
+    }
+  }
+  const double* row(uint8_t b) const { return &rows[(size_t)b * nAlpha * 9]; }
+};
+
+// log-likelihoods of the listed hypotheses over one cell, cmd_cram_demuxlet.cpp:655-747 restricted to those slots
+inline void cell_lls(const Tables& t, const OneReadTable& one, int64_t e0, int64_t e1, const int32_t* entry_snp,
+                     const int64_t* entry_rptr, const uint8_t* reads, int32_t V, const double* gp, const uint8_t* has_gp,
+                     int32_t nAlpha, const double* gridAlpha, Hyp* hyps, size_t nh) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  double buf[MUXGL_MAX_ALPHA * 9];
   for (size_t h = 0; h < nh; ++h) hyps[h].ll = 0;
   for (int64_t e = e0; e < e1; ++e) {
-    for (int32_t i = 0; i < nAlpha * 9; ++i) pGs[i] = 1.0;
-    for (int64_t r = entry_rptr[e]; r < entry_rptr[e + 1]; ++r) {  // :659-700
-      const uint8_t b = reads[r];
-      if (b == MUXGL_READ_OTHER) continue;  // al == 2
-      const int al = b >> 7, bq = b & 0x7f;
-      const double pR = (al == 0) ? t.mat[bq] : t.err[bq] / 3.0;
-      const double pA = (al == 1) ? t.mat[bq] : t.err[bq] / 3.0;
-      double maxpG = 0;
-      for (int32_t a = 0; a < nAlpha; ++a)
-        for (int32_t l = 0; l < 3; ++l)
-          for (int32_t m = 0; m < 3; ++m) {
-            const double p = 0.5 * l + (m - l) * 0.5 * gridAlpha[a];
-            double& pG = pGs[a * 9 + l * 3 + m];
-            pG *= (pR * (1.0 - p) + pA * p);
-            if (maxpG < pG) maxpG = pG;
-          }
-      for (int32_t i = 0; i < nAlpha * 9; ++i) pGs[i] /= maxpG;
+    if (e + 8 < e1) {  // the genotype rows of an entry are a random gather from a tensor of tens of MB: ask for them early
+      const double* g8 = gp + (size_t)entry_snp[e + 8] * V * 3;
+      for (size_t h = 0; h < (nh < 4 ? nh : 4); ++h) {
+        __builtin_prefetch(g8 + hyps[h].j * 3);
+        __builtin_prefetch(g8 + hyps[h].k * 3);
+      }
     }
-    double maxpG = 0;  // :703-725
-    for (int32_t i = 0; i < nAlpha * 9; ++i) {
-      pGs[i] += 1e-10;
-      if (maxpG < pGs[i]) maxpG = pGs[i];
-    }
-    for (int32_t i = 0; i < nAlpha * 9; ++i) pGs[i] /= maxpG;
     const int32_t s = entry_snp[e];
-    if (!has_gp[s]) continue;  // :733
+    if (!has_gp[s]) continue;  // :733 (the entry's pGs are formed by the reference, and read by nobody)
+    int usable = 0;
+    uint8_t byte = MUXGL_READ_OTHER;
+    for (int64_t r = entry_rptr[e]; r < entry_rptr[e + 1] && usable < 2; ++r)
+      if (reads[r] != MUXGL_READ_OTHER) {
+        byte = reads[r];
+        ++usable;
+      }
+    const double* pGs;
+    if (usable <= 1) {
+      pGs = one.row(byte);
+    } else {
+      entry_pgs(t, reads, entry_rptr[e], entry_rptr[e + 1], nAlpha, gridAlpha, buf);
+      pGs = buf;
+    }
     const double* g = gp + (size_t)s * V * 3;
     for (size_t h = 0; h < nh; ++h) {
       const double* gj = g + hyps[h].j * 3;
@@ -127,6 +172,7 @@ inline void exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int
                         const double* gridAlpha, double doublet_prior, muxgl_demux_cell* cells, int nthreads,
                         int64_t* stats) {
   static const Tables tables;
+  const OneReadTable one(tables, nAlpha, gridAlpha);
   if (nthreads < 1) nthreads = 1;
   nthreads = (int)std::min<int64_t>(nthreads, std::max<int64_t>(1, C / 16));
   std::vector<int64_t> st((size_t)nthreads * ST_N, 0);
@@ -176,7 +222,7 @@ inline void exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int
           if (x.sNext >= 0) hs.push_back(Hyp{x.sNext, 0, 0, 0.0});
           std::sort(hs.begin(), hs.end(), [](const Hyp& a, const Hyp& b) { return a.j < b.j; });
         }
-        cell_lls(tables, cell_ptr[c], cell_ptr[c + 1], entry_snp, entry_rptr, reads, V, gp, has_gp, nAlpha, gridAlpha,
+        cell_lls(tables, one, cell_ptr[c], cell_ptr[c + 1], entry_snp, entry_rptr, reads, V, gp, has_gp, nAlpha, gridAlpha,
                  hs.data(), hs.size());
         Top2 t;
         for (size_t i = 0; i < hs.size(); ++i) t.push(hs[i].ll, (int32_t)i);
@@ -204,7 +250,7 @@ inline void exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int
             return ((int64_t)a.j * V + a.k) * nAlpha + a.n < ((int64_t)b.j * V + b.k) * nAlpha + b.n;
           });
         }
-        cell_lls(tables, cell_ptr[c], cell_ptr[c + 1], entry_snp, entry_rptr, reads, V, gp, has_gp, nAlpha, gridAlpha,
+        cell_lls(tables, one, cell_ptr[c], cell_ptr[c + 1], entry_snp, entry_rptr, reads, V, gp, has_gp, nAlpha, gridAlpha,
                  hd.data(), hd.size());
         Top2 t;
         for (size_t i = 0; i < hd.size(); ++i) t.push(hd[i].ll, (int32_t)i);

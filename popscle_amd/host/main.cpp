@@ -12,7 +12,6 @@
 // behind muxgl_* calls; there is no CPU implementation of it in this program.
 #include <cmath>
 
-#include "exact_calls.hpp"
 #include "plp.hpp"
 #include "synthplp.hpp"
 
@@ -164,13 +163,12 @@ int cmd_demuxlet(int argc, char** argv) {
     // the calls rounding noise could decide -- the order of a mirrored alpha = 0.5 pair in DBL.BEST.GUESS / NEXT.GUESS
     // (cmd_cram_demuxlet.cpp:738-746,883-906) and near ties of the scans and thresholds (:827-837,925-988) -- settled in
     // the reference's own arithmetic (exact_calls.hpp)
-    int64_t st[exact_calls::ST_N];
-    exact_calls::exact_calls(p.C(), p.nv, p.cell_ptr.data(), p.entry_snp.data(), p.entry_rptr.data(), p.reads.data(),
-                             p.gp.data(), p.has_gp.data(), dp.n_alpha, dp.alpha, dp.doublet_prior, cells.data(),
-                             plp_threads(), st);
+    int64_t st[6];
+    check(h, muxgl_demux_exact_calls(p.C(), p.nv, p.cell_ptr.data(), p.entry_snp.data(), p.entry_rptr.data(), p.reads.data(),
+                                     p.gp.data(), p.has_gp.data(), &dp, cells.data(), compute_threads(), st),
+          "muxgl_demux_exact_calls");
     notice("Exact-call pass: %lld droplets looked at (%lld near ties besides mirrored pairs, %lld needing every hypothesis, "
-           "%lld calls changed)", (long long)st[exact_calls::ST_CELLS], (long long)st[exact_calls::ST_NEAR_TIES],
-           (long long)st[exact_calls::ST_DEEP], (long long)st[exact_calls::ST_CHANGED]);
+           "%lld calls changed)", (long long)st[0], (long long)st[3], (long long)st[4], (long long)st[5]);
     tm.lap("demuxlet: exact calls (host)");
   }
 

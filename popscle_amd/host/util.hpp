@@ -128,6 +128,13 @@ inline int plp_threads() {
   return (int)std::min(16u, std::max(1u, hc));
 }
 
+// threads of a pure compute pass over independent cells (the exact-call pass): no I/O thread to leave room for
+inline int compute_threads() {
+  if (const char* ev = getenv("POPSCLE_AMD_THREADS")) return std::max(1, atoi(ev));
+  const unsigned hc = std::thread::hardware_concurrency();
+  return (int)std::min(64u, std::max(1u, hc));
+}
+
 // fn(i) for i in [0, n), items handed out one at a time to the threads of a persistent pool.  The workers sleep on a
 // condition variable between calls (OpenMP's spinning workers starve the inflating thread when every core is taken;
 // threads spawned per call are not spread over the cores before a 5 ms job is over).
