@@ -768,6 +768,9 @@ def fmx_leg(args, ctx, config, steps, warmup, cpu_baseline=True, cpu_budget_s=10
                 "measured_ms_per_iteration": elapsed / steps * 1e3,
                 "note": "strong scaling: the same job on every rank count; E-step and scans shard by cells, cluster "
                         "posteriors and the ordered M-step by SNPs (DESIGN.md 4.3)"}
+        # near-tie calls of the timed iterations: cells the exact path (csrc/fmx_exact.hip) settled inside the timed region, how
+        # many of them it decided differently from the kernels, and cells left open (0: every path settles its own)
+        out["exact_path"] = dict(zip(("near_tie_cells", "calls_changed", "unresolved"), eng.fmx_exact_stats()))
         if cpu_baseline and ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fmx(p, K, clust0, budget_s=cpu_budget_s)
             out["cpu_baseline"].update(fmx_parity_sample(eng, p, K, cells))

@@ -268,6 +268,12 @@ int muxgl_fmx_exact_stats(const muxgl_handle* h, int64_t* near_tie_cells, int64_
  * Then the assignments are exchanged again and, if any rank reports a reassignment, muxgl_fmx_iter_mstep is repeated on
  * all.  popscle_amd/freemuxlet.py run_em is the reference driver. */
 int muxgl_fmx_exact_pending(const muxgl_handle* h, int64_t* cells);
+/* A settled cell is not listed again while its inputs last: the library keeps the exact scan results per cell and
+ * fmx_call_kernel takes them from there as long as no assignment has changed anywhere since (a converged job pays nothing
+ * for its near ties).  muxgl_fmx_iterate knows that from its own counters; a caller of the phases says so after every
+ * iteration with the JOB-WIDE number of changed cells (after the exact path) -- without this call every E-step starts
+ * afresh, which is always correct. */
+int muxgl_fmx_exact_hint(muxgl_handle* h, int32_t nchanged_jobwide);
 int muxgl_fmx_exact_snps(muxgl_handle* h, int32_t* out, int64_t cap, int64_t* n);
 int muxgl_fmx_exact_rows(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* snps, int64_t n, double* rows,
                          uint8_t* owned);

@@ -93,6 +93,12 @@ struct fmx_grec {  // any other entry: its index and SNP
   int64_t e;
   int32_t snp, pad;
 };
+// exact scan results of a settled near-tie cell (fmx_exact.hip), read back by fmx_call_kernel while the cell's inputs last
+struct fmx_xc {
+  int32_t sBest, sNext, dBest1, dBest2, dNext1, dNext2;
+  double sngBestLLK, sngNextLLK, dblBestLLK, dblNextLLK;
+};
+
 struct muxgl_handle {
   std::multimap<size_t, void*> pool;   // cached device blocks by size (dev_alloc / dev_free below)
   size_t pool_bytes = 0;
@@ -193,6 +199,11 @@ struct muxgl_handle {
                                     // of d_clust taken before the call kernel runs, on the handle that runs the M-step
   int32_t* d_prev_state = nullptr;  // [C] (type, jBest, kBest) before the running iteration, a byte each
   int32_t* d_flagged = nullptr;     // [C] cells whose call is within rounding reach, d_fstat[3] of them
+  int32_t* d_xc_epoch = nullptr;    // [C] epoch a cell's entry of d_xc was written in (0: none)
+  fmx_xc* d_xc = nullptr;           // [C] exact scan results of settled cells
+  int32_t xs_epoch = 1;             // advances whenever the E-step's inputs may have changed
+  bool xs_keep = false, xs_have_p = false;
+  muxgl_fmx_params xs_p{};
   int64_t fmx_exact_cells = 0, fmx_exact_changed = 0, fmx_exact_unresolved = 0;  // since muxgl_fmx_set_clusters
   struct fmx_exact_state* xs = nullptr;  // between steps A and C of the exact path (fmx_exact.hip)
   int32_t fmx_listed = 0;                // cells the last fetch of a sharded phase found listed and left open

@@ -126,14 +126,38 @@ __global__ void __launch_bounds__(256)
   lk_out[i] = lk;
 }
 
-// cells[idx[i]] = rec[i]; the assignment also at its place in the job-wide array the M-step reads (clust_all may be NULL)
+// cells[idx[i]] = rec[i]; the assignment also at its place in the job-wide array the M-step reads (clust_all may be NULL);
+// the exact scan results into the table fmx_call_kernel reads while the cell's inputs last
 __global__ void patch_kernel(int n, const int32_t* __restrict__ idx, const muxgl_fmx_cell* __restrict__ rec,
-                             muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ clust_all) {
+                             muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ clust_all,
+                             fmx_xc* __restrict__ xc, int32_t* __restrict__ xc_epoch, int32_t epoch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  cells[idx[i]] = rec[i];
-  clust[idx[i]] = rec[i].clust;
-  if (clust_all) clust_all[idx[i]] = rec[i].clust;
+  const muxgl_fmx_cell r = rec[i];
+  cells[idx[i]] = r;
+  clust[idx[i]] = r.clust;
+  if (clust_all) clust_all[idx[i]] = r.clust;
+  xc[idx[i]] = fmx_xc{r.sBest, r.sNext, r.dBest1, r.dBest2, r.dNext1, r.dNext2, r.sngBestLLK, r.sngNextLLK, r.dblBestLLK, r.dblNextLLK};
+  xc_epoch[idx[i]] = epoch;
+}
+
+// what the exact path needs of the listed cells, gathered: record, previous state, entry range
+struct cell_info {
+  muxgl_fmx_cell rec;
+  int64_t e0, e1;
+  int32_t prev, pad;
+};
+__global__ void gather_kernel(int n, const int32_t* __restrict__ idx, const muxgl_fmx_cell* __restrict__ cells,
+                              const int32_t* __restrict__ prev_state, const int64_t* __restrict__ cell_ptr,
+                              cell_info* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = idx[i];
+  out[i].rec = cells[c];
+  out[i].e0 = cell_ptr[c];
+  out[i].e1 = cell_ptr[c + 1];
+  out[i].prev = prev_state[c];
+  out[i].pad = 0;
 }
 
 struct hyp {
@@ -166,6 +190,7 @@ int upload(muxgl_handle* h, T** d, const T* v, size_t n) {
 // what step A leaves for step C
 struct fmx_exact_state {
   std::vector<int32_t> cells;   // listed cells (local ids), ascending
+  std::vector<cell_info> info;  // their records, previous states and entry ranges
   std::vector<int64_t> cptr;    // [cells + 1] positions of their entries in ent / esnp
   std::vector<int64_t> ent;     // entry ids
   std::vector<int32_t> esnp;    // their SNPs
@@ -187,11 +212,27 @@ int fmx_exact_snps(muxgl_handle* h, std::vector<int32_t>* snps) {
   xs.cells.resize((size_t)nflag);
   HIPCHK(h, hipMemcpy(xs.cells.data(), h->d_flagged, sizeof(int32_t) * (size_t)nflag, hipMemcpyDeviceToHost));
   std::sort(xs.cells.begin(), xs.cells.end());  // (atomic order -> cell order: nothing may depend on it)
-  std::vector<int64_t> cp((size_t)h->C + 1);
-  HIPCHK(h, hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * ((size_t)h->C + 1), hipMemcpyDeviceToHost));
+  {
+    int32_t* d_idx = nullptr;
+    cell_info* d_info = nullptr;
+    xs.info.resize((size_t)nflag);
+    int rc = upload(h, &d_idx, xs.cells.data(), xs.cells.size()) || dev_alloc(h, &d_info, (size_t)nflag);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+      hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((nflag + 255) / 256)), dim3(256), 0, h->stream, (int)nflag, d_idx, h->d_fcells,
+                         h->d_prev_state, h->d_cell_ptr, d_info);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(xs.info.data(), d_info, sizeof(cell_info) * (size_t)nflag, hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    dev_free(&d_idx);
+    dev_free(&d_info);
+    if (rc) return 1;
+    if (e != hipSuccess) MUXGL_FAIL(h, "fmx_exact_snps: %s", hipGetErrorString(e));
+  }
   xs.cptr.push_back(0);
-  for (int32_t c : xs.cells) {
-    for (int64_t e = cp[(size_t)c]; e < cp[(size_t)c + 1]; ++e) xs.ent.push_back(e);
+  for (const cell_info& ci : xs.info) {
+    for (int64_t e = ci.e0; e < ci.e1; ++e) xs.ent.push_back(e);
     xs.cptr.push_back((int64_t)xs.ent.size());
   }
   xs.esnp.resize(xs.ent.size());
@@ -201,7 +242,7 @@ int fmx_exact_snps(muxgl_handle* h, std::vector<int32_t>* snps) {
     for (size_t t = 0; t < xs.ent.size(); ++t) xs.esnp[t] = es[(size_t)xs.ent[t]];
   } else {
     for (size_t f = 0; f < xs.cells.size(); ++f) {  // a cell's entries are contiguous
-      const int64_t e0 = cp[(size_t)xs.cells[f]], n = xs.cptr[f + 1] - xs.cptr[f];
+      const int64_t e0 = xs.info[f].e0, n = xs.cptr[f + 1] - xs.cptr[f];
       if (n) HIPCHK(h, hipMemcpy(xs.esnp.data() + xs.cptr[f], h->d_entry_snp + e0, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     }
   }
@@ -266,13 +307,8 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
   }
   fmx_exact_state& xs = *h->xs;
   const int K = h->K;
-  const int64_t C = h->C;
   const size_t nf = xs.cells.size();
   const int64_t nT = (int64_t)xs.ent.size();
-  std::vector<muxgl_fmx_cell> all((size_t)C);
-  std::vector<int32_t> prev((size_t)C);
-  HIPCHK(h, hipMemcpy(all.data(), h->d_fcells, sizeof(muxgl_fmx_cell) * (size_t)C, hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(prev.data(), h->d_prev_state, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost));
   const double log_single_prior = log((1.0 - p->doublet_prior) / K);          // :379
   const double log_double_prior = log(p->doublet_prior / K / (K - 1) * 2.0);  // :380
 
@@ -281,7 +317,7 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
   std::vector<item> items;
   std::vector<int64_t> ioff;
   for (size_t f = 0; f < nf; ++f) {
-    const muxgl_fmx_cell& x = all[(size_t)xs.cells[f]];
+    const muxgl_fmx_cell& x = xs.info[f].rec;
     double mag = 1.0;
     for (double v : {x.sngBestLLK, x.sngNextLLK, x.dblBestLLK, x.dblNextLLK})
       if (v > -1e299) mag = std::max(mag, fabs(v));
@@ -360,7 +396,7 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
       for (size_t i = 0; i < s.size(); ++i) s[i].ll += log(q[(size_t)t * nh + i]);
       for (size_t i = 0; i < d.size(); ++i) d[i].ll += log(q[(size_t)t * nh + s.size() + i]);
     }
-    muxgl_fmx_cell c = all[(size_t)ci];
+    muxgl_fmx_cell c = xs.info[f].rec;
     const muxgl_fmx_cell before = c;
     top2 ts, td;
     for (size_t i = 0; i < s.size(); ++i) ts.push(s[i].ll, (int32_t)i);
@@ -374,7 +410,7 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
     c.dNext2 = td.n >= 0 ? d[(size_t)td.n].k : -1;
     c.dblBestLLK = td.bv, c.dblNextLLK = td.nv;
     // state before this iteration (what the nchanged rules compare with, :523,543-544,566)
-    const int32_t ps = prev[(size_t)ci];
+    const int32_t ps = xs.info[f].prev;
     auto byte = [](int32_t v) { return v == 0xff ? -1 : v; };
     const int32_t ptype = (int8_t)(ps & 0xff), pj = byte((ps >> 8) & 0xff), pk = byte((ps >> 16) & 0xff);
     int chg;
@@ -446,7 +482,8 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
     return 1;
   }
   hipLaunchKernelGGL(patch_kernel, dim3((unsigned)((pidx.size() + 255) / 256)), dim3(256), 0, h->stream, (int)pidx.size(), d_idx,
-                     d_rec, h->d_fcells, h->d_clust, h->col ? h->col->d_clust + h->cell_base : nullptr);
+                     d_rec, h->d_fcells, h->d_clust, h->col ? h->col->d_clust + h->cell_base : nullptr, h->d_xc, h->d_xc_epoch,
+                     h->xs_epoch);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   dev_free(&d_idx);

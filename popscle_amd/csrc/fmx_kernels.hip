@@ -314,15 +314,16 @@ __device__ __forceinline__ double fmx_wave_sum(double v) {
 // relative.  !WAVE: one lane per cell, the reference's loop as written (kept behind MUXGL_FLAG_FORCE_TILE_SWEEP).
 template <bool WAVE>
 __global__ void __launch_bounds__(64)
-    fmx_call_kernel(int64_t c0, int64_t c1, int K, double doublet_prior, const double* __restrict__ fll,
+    fmx_call_kernel(int64_t c0, int64_t c1, int K, double log_single_prior, double log_double_prior, const double* __restrict__ fll,
                     muxgl_fmx_cell* __restrict__ cells, int32_t* __restrict__ clust, int32_t* __restrict__ stat,
-                    int32_t* __restrict__ prev_state, int32_t* __restrict__ flagged) {
+                    int32_t* __restrict__ prev_state, int32_t* __restrict__ flagged, const int32_t* __restrict__ xc_epoch,
+                    const fmx_xc* __restrict__ xc, int32_t epoch) {
   const int64_t i = WAVE ? c0 + (int64_t)blockIdx.x : c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c1) return;
   const int nSamples = K;
   const int npairs = K * (K + 1) / 2;
-  const double log_single_prior = log((1.0 - doublet_prior) / nSamples);                // :379
-  const double log_double_prior = log(doublet_prior / nSamples / (nSamples - 1) * 2.0); // :380
+  // (log_single_prior, log_double_prior of :379-380: taken on the host with glibc's log, the reference's own, so that this
+  //  kernel and the host side of the exact path, fmx_exact.hip, add the same two numbers)
   const double* llks = fll + (size_t)i * npairs;
   int32_t sBest = -1, sNext = -1, dBest1 = -1, dBest2 = -1, dNext1 = -1, dNext2 = -1;
   double sngBestLLK = -1e300, sngNextLLK = -1e300, dblBestLLK = -1e300, dblNextLLK = -1e300;
@@ -439,6 +440,37 @@ __global__ void __launch_bounds__(64)
   if (sall > 0.0) sumLLK = mall + log(sall);
   if (ssng > 0.0) sngLLK = msng + log(ssng);
   }
+  // (round 6) A decision whose margin is within rounding reach of the kernels' numbers -- best / next of a scan, next /
+  // third, one of the four +2 thresholds -- is not this kernel's to make: the cell goes on the list fmx_exact.hip settles
+  // in the reference's own arithmetic.  What that needs of the state BEFORE this iteration is kept aside (the previous
+  // (type, jBest, kBest) of the nchanged rules below; the assignments the cluster pileups were built from: the launcher).
+  // A cell settled in an earlier iteration whose inputs have not changed since (no assignment changed anywhere: same
+  // `epoch`) takes the exact scan results from the table instead of being listed again: a converged job pays nothing.
+  bool listed = false;
+  double sngBestDev = -1e300;  // the kernels' own value where the table overrides it (sngOnlyPP stays what a listed cell keeps)
+  bool from_table = false;
+  if (prev_state) {
+    double mag = 1.0;
+    if (sngBestLLK > -1e299) mag = fmax(mag, fabs(sngBestLLK));
+    if (dblBestLLK > -1e299) mag = fmax(mag, fabs(dblBestLLK));
+    if (sngNextLLK > -1e299) mag = fmax(mag, fabs(sngNextLLK));
+    if (dblNextLLK > -1e299) mag = fmax(mag, fabs(dblNextLLK));
+    const double eps = 1e-9 * mag;
+    auto near = [eps](double a, double b) { return a > -1e299 && b > -1e299 && fabs(a - b) <= eps; };
+    if (near(sngBestLLK, sngNextLLK) || near(sngNextLLK, sngThird) || near(dblBestLLK, dblNextLLK) ||
+        near(dblNextLLK, dblThird) || near(dblBestLLK, sngBestLLK + 2) || near(dblNextLLK, sngBestLLK + 2) ||
+        near(sngBestLLK, sngNextLLK + 2) || near(dblBestLLK, sngNextLLK + 2)) {
+      if (xc_epoch && xc_epoch[i] == epoch) {
+        const fmx_xc e = xc[i];
+        sngBestDev = sngBestLLK;
+        from_table = true;
+        sBest = e.sBest, sNext = e.sNext, dBest1 = e.dBest1, dBest2 = e.dBest2, dNext1 = e.dNext1, dNext2 = e.dNext2;
+        sngBestLLK = e.sngBestLLK, sngNextLLK = e.sngNextLLK, dblBestLLK = e.dblBestLLK, dblNextLLK = e.dblNextLLK;
+      } else {
+        listed = true;
+      }
+    }
+  }
   muxgl_fmx_cell c = cells[i];
   const int32_t prev_type = c.type, prev_j = c.jBest, prev_k = c.kBest;
   c.sBest = sBest;
@@ -452,7 +484,7 @@ __global__ void __launch_bounds__(64)
   c.dNext2 = dNext2;
   c.dblNextLLK = dblNextLLK;
   c.sngPP = exp(sngLLK - sumLLK);
-  c.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);
+  c.sngOnlyPP = exp((from_table ? sngBestDev : sngBestLLK) + log_single_prior - sngLLK);
   c.sumLLK = sumLLK;
   c.sngThirdLLK = sngThird;
   c.dblThirdLLK = dblThird;
@@ -506,24 +538,8 @@ __global__ void __launch_bounds__(64)
       c.nextLLK = sngNextLLK;
     }
   }
-  // (round 6) a decision whose margin is within rounding reach of the kernels' numbers -- best / next of a scan, next /
-  // third, one of the four +2 thresholds -- is not this kernel's to make: the cell goes on the list fmx_exact.hip settles
-  // in the reference's own arithmetic.  What that needs of the state BEFORE this iteration is kept aside: the previous
-  // (type, jBest, kBest) of the nchanged rules here, the assignments the cluster pileups were built from by the launcher.
-  if (prev_state) {
-    prev_state[i] = (prev_type & 0xff) | ((prev_j & 0xff) << 8) | ((prev_k & 0xff) << 16);
-    double mag = 1.0;
-    if (sngBestLLK > -1e299) mag = fmax(mag, fabs(sngBestLLK));
-    if (dblBestLLK > -1e299) mag = fmax(mag, fabs(dblBestLLK));
-    if (sngNextLLK > -1e299) mag = fmax(mag, fabs(sngNextLLK));
-    if (dblNextLLK > -1e299) mag = fmax(mag, fabs(dblNextLLK));
-    const double eps = 1e-9 * mag;
-    auto near = [eps](double a, double b) { return a > -1e299 && b > -1e299 && fabs(a - b) <= eps; };
-    if (near(sngBestLLK, sngNextLLK) || near(sngNextLLK, sngThird) || near(dblBestLLK, dblNextLLK) ||
-        near(dblNextLLK, dblThird) || near(dblBestLLK, sngBestLLK + 2) || near(dblNextLLK, sngBestLLK + 2) ||
-        near(sngBestLLK, sngNextLLK + 2) || near(dblBestLLK, sngNextLLK + 2))
-      flagged[atomicAdd(&stat[3], 1)] = (int32_t)i;
-  }
+  if (prev_state) prev_state[i] = (prev_type & 0xff) | ((prev_j & 0xff) << 8) | ((prev_k & 0xff) << 16);
+  if (listed) flagged[atomicAdd(&stat[3], 1)] = (int32_t)i;
   cells[i] = c;
   clust[i] = c.clust;
   if (dsingle) atomicAdd(&stat[0], 1);
@@ -965,8 +981,12 @@ int muxgl_fmx_set_clusters(muxgl_handle* h, int32_t K, const int32_t* clust) {
   if (h->col && CT)
     HIPCHK(h, hipMemcpyAsync(m->d_clust, cl.data(), sizeof(int32_t) * CT, hipMemcpyHostToDevice, h->stream));
   if (dev_alloc(h, &m->d_prev_clust, (size_t)(CT ? CT : 1)) || dev_alloc(h, &h->d_prev_state, (size_t)(C ? C : 1)) ||
-      dev_alloc(h, &h->d_flagged, (size_t)(C ? C : 1)))
+      dev_alloc(h, &h->d_flagged, (size_t)(C ? C : 1)) || dev_alloc(h, &h->d_xc_epoch, (size_t)(C ? C : 1)) ||
+      dev_alloc(h, &h->d_xc, (size_t)(C ? C : 1)))
     return 1;
+  HIPCHK(h, hipMemsetAsync(h->d_xc_epoch, 0, sizeof(int32_t) * (size_t)(C ? C : 1), h->stream));
+  h->xs_epoch = 1;
+  h->xs_keep = false;
   h->fmx_exact_cells = h->fmx_exact_changed = h->fmx_exact_unresolved = 0;
   clear_timing(h);
   tic(h, MUXGL_T_FMX_MSTEP);
@@ -1040,21 +1060,32 @@ int fmx_phase_estep(muxgl_handle* h, const muxgl_fmx_params* p) {
   toc(h, MUXGL_T_FMX_ESTEP);
   tic(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipMemsetAsync(h->d_fstat, 0, 4 * sizeof(int32_t), h->stream));
+  // The table of settled near-tie cells stays valid while the E-step's inputs do: no assignment changed in the previous
+  // iteration (xs_keep: set by muxgl_fmx_iterate / the group from the counters, by muxgl_fmx_exact_hint for callers of the
+  // phases) and the same parameters.
+  if (!h->xs_keep || !h->xs_have_p || h->xs_p.doublet_prior != p->doublet_prior || h->xs_p.geno_error != p->geno_error) ++h->xs_epoch;
+  h->xs_keep = false;
+  h->xs_p = *p;
+  h->xs_have_p = true;
   {  // the assignments the running iteration's cluster pileups were built from, for the exact path (fmx_exact.hip)
     muxgl_handle* m = h->col ? h->col : h;
     const int64_t CT = h->col ? h->C_total : h->C;
     if (m->d_prev_clust && CT)
       HIPCHK(h, hipMemcpyAsync(m->d_prev_clust, m->d_clust, sizeof(int32_t) * (size_t)CT, hipMemcpyDeviceToDevice, h->stream));
   }
+  const double lsp = log((1.0 - p->doublet_prior) / K);          // cmd_cram_freemux2.cpp:379
+  const double ldp = log(p->doublet_prior / K / (K - 1) * 2.0);  // :380
   if (nc > 0)
   {
     if ((h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP) || K <= 24)  // (few hypotheses per cell: a wave per cell is mostly overhead,
                                                              //  0.54 against 0.13 ms at configs[3])
       hipLaunchKernelGGL(fmx_call_kernel<false>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, c0, c1, K,
-                         p->doublet_prior, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_state, h->d_flagged);
+                         lsp, ldp, h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_state, h->d_flagged,
+                         h->d_xc_epoch, h->d_xc, h->xs_epoch);
     else
-      hipLaunchKernelGGL(fmx_call_kernel<true>, dim3((unsigned)nc), dim3(64), 0, h->stream, c0, c1, K, p->doublet_prior,
-                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_state, h->d_flagged);
+      hipLaunchKernelGGL(fmx_call_kernel<true>, dim3((unsigned)nc), dim3(64), 0, h->stream, c0, c1, K, lsp, ldp,
+                         h->d_fll, h->d_fcells, h->d_clust, h->d_fstat, h->d_prev_state, h->d_flagged, h->d_xc_epoch, h->d_xc,
+                         h->xs_epoch);
   }
   toc(h, MUXGL_T_FMX_CALL);
   HIPCHK(h, hipGetLastError());
@@ -1126,8 +1157,18 @@ int muxgl_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
       HIPCHK(h, hipStreamSynchronize(h->stream));
     }
   }
+  h->xs_keep = h->h_fstat[2] == 0;  // no assignment changed: the next E-step sees the same cluster pileups
   if (fmx_phase_fetch(h, out, nsingle, namb, nchanged, full_ll)) return 1;
   collect_timing(h);
+  return 0;
+}
+
+// For callers of the phases: the job-wide number of changed cells of the iteration just finished (after the exact path).
+// 0 keeps the table of settled near-tie cells valid for the next E-step; without this call every E-step starts afresh.
+int muxgl_fmx_exact_hint(muxgl_handle* h, int32_t nchanged_jobwide) {
+  if (!h) return 1;
+  MUXGL_NOT_FOR_GROUPS(h, "muxgl_fmx_exact_hint");
+  h->xs_keep = nchanged_jobwide == 0;
   return 0;
 }
 

@@ -390,6 +390,8 @@ void muxgl_destroy(muxgl_handle* h) {
   dev_free(&h->d_prev_clust);
   dev_free(&h->d_prev_state);
   dev_free(&h->d_flagged);
+  dev_free(&h->d_xc_epoch);
+  dev_free(&h->d_xc);
   fmx_exact_release(h);
   dev_free(&h->d_snp_ptr);
   dev_free(&h->d_snp_entry);

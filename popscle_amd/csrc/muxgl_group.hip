@@ -457,6 +457,7 @@ int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
       GCHK(m, hipMemcpy(full_ll + (size_t)c0 * npairs, m->d_fll, sizeof(double) * (size_t)nc * npairs, hipMemcpyDeviceToHost));
   }
 #undef GCHK
+  for (muxgl_handle* m : g->m) m->xs_keep = st[2] == 0;  // (fmx_exact.hip: the settled cells' table stays valid while nothing moves)
   if (nsingle) *nsingle = st[0];
   if (namb) *namb = st[1];
   if (nchanged) *nchanged = st[2];

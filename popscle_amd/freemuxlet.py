@@ -245,6 +245,8 @@ def run_em(eng, K, clust0, doublet_prior=0.5, geno_error=0.1, max_iter=10, early
             elif not ordered:
                 eng.fmx_iter_mstep()  # :516-517 + :590-596 for the own SNP range
             stats = stats4[:3]
+            if hasattr(eng, "fmx_exact_hint"):
+                eng.fmx_exact_hint(stats[2])  # nothing moved: the cells settled so far need not be listed again
             history.append(stats)
             if log:
                 log(f"iter {it + 1}: {stats[0]} singlets, {eng.C_total - stats[0] - stats[1]} doublets, "

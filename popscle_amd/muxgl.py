@@ -97,6 +97,7 @@ SYMBOLS = {
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
     "muxgl_fmx_exact_stats": (C.c_int, [_VP, _VP, _VP, _VP]),
     "muxgl_fmx_exact_pending": (C.c_int, [_VP, _VP]),
+    "muxgl_fmx_exact_hint": (C.c_int, [_VP, C.c_int32]),
     "muxgl_fmx_exact_snps": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "muxgl_fmx_exact_rows": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, C.c_int64, _VP, _VP]),
     "muxgl_fmx_exact_finish": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, C.c_int64, _VP, _VP, _VP]),
@@ -435,6 +436,9 @@ class Engine:
         n = C.c_int64()
         self._check(self.lib.muxgl_fmx_exact_pending(self.h, C.byref(n)))
         return n.value
+
+    def fmx_exact_hint(self, nchanged_jobwide):
+        self._check(self.lib.muxgl_fmx_exact_hint(self.h, int(nchanged_jobwide)))
 
     def fmx_exact_snps(self):
         n = C.c_int64()
