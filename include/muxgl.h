@@ -64,6 +64,8 @@ enum { MUXGL_SNG = 0, MUXGL_DBL = 1, MUXGL_AMB = 2 };
 #define MUXGL_FLAG_NO_PIVOT_SUMS 256 /* freemuxlet E-step beyond 32 clusters: the pair sums of the non-linear entries as the
                                         three-term sums instead of around the lane's smallest term (lets tests compare the
                                         two forms) */
+#define MUXGL_FLAG_GROUP_PROBE_SELF 1024 /* device group: muxgl_create also walks the pairs of members that share a device when
+                                           it enables peer access (tests: the refusal path on a one-GPU box) */
 /* (128 was MUXGL_FLAG_MSTEP_LDS_STATES until round 6: the M-step variant with the cluster states in LDS is retired) */
 #define MUXGL_FLAG_SPLIT_GENERAL_SWEEP 512 /* demuxlet beyond 32 samples: sweep the entries with more than one usable read in
                                              launches of their own on top of the linear entries' slab (round 3's scheme)
@@ -95,11 +97,17 @@ typedef struct {
   double doublet_prior;
 } muxgl_demux_params;
 
+#define MUXGL_CELL_DEEP_SNG 2
+#define MUXGL_CELL_DEEP_DBL 4
+
 /* per-cell demuxlet result: every quantity cmd_cram_demuxlet.cpp:788-991 derives and :993-1013 prints.
  * Sample indices are positions in the GP tensor's V axis; -1 = none.  valid=0: the cell has no entries and the
  * reference prints no row (:653). */
 typedef struct {
-  int32_t valid;
+  int32_t valid; /* bit 0: the cell has entries (0: the reference prints no row, :653).  muxgl_demux_run also sets
+                    MUXGL_CELL_DEEP_SNG / MUXGL_CELL_DEEP_DBL where the THIRD-largest log-likelihood of the singlet /
+                    doublet scan is within rounding reach of the runner-up (three or more hypotheses contend): read and
+                    cleared by muxgl_demux_exact_calls, which then recomputes every hypothesis of that scan */
   int32_t nsnps;
   int32_t type, next_type;
   int32_t sBest, sNext;
@@ -111,9 +119,6 @@ typedef struct {
   double sumLLK, sngLLK;
   double bestLLK, nextLLK;
   double bestPP, sngPP, sngOnlyPP;
-  double sngThirdLLK, dblThirdLLK; /* third-largest log-likelihood of the singlet / doublet scan (-1e300: none).  Not a
-                                      quantity of the reference: muxgl_demux_exact_calls reads it to tell whether best
-                                      and next are the only hypotheses within rounding reach of each other */
 } muxgl_demux_cell;
 
 /* freemuxlet parameters: --doublet-prior, --geno-error (cmd_cram_freemux2.cpp:19-20) */
@@ -159,6 +164,12 @@ void muxgl_destroy(muxgl_handle* h);
 const char* muxgl_last_error(const muxgl_handle* h);
 int muxgl_version(void);
 
+/* device group: what muxgl_create found when it enabled direct peer copies between its members' devices: out[3] = ordered
+ * pairs of members on distinct devices (with MUXGL_FLAG_GROUP_PROBE_SELF: all ordered pairs), pairs with peer access
+ * enabled, pairs left on the runtime's staged copy (no peer access between the two devices, or MUXGL_GROUP_NO_PEER=1 in
+ * the environment).  Either way the copies are hipMemcpyPeerAsync and the results the same. */
+int muxgl_group_peer_stats(const muxgl_handle* h, int32_t* out);
+
 /* ---- pileup hand-over: replaces the in-memory result of sc_dropseq_lib_t::load_from_plp
  *      (sc_drop_seq.cpp:103-384; containers sc_drop_seq.h:130-184).  Copies to device memory. --------------------- */
 int muxgl_set_pileup(muxgl_handle* h, int64_t C, int64_t S, int64_t nnz, int64_t R, const int64_t* cell_ptr,
@@ -183,7 +194,7 @@ int muxgl_demux_run(muxgl_handle* h, const muxgl_demux_params* p, muxgl_demux_ce
  *     summation orders (:738-746) and reports whichever came out larger as DBL.BEST.GUESS, the other as runner-up;
  *     muxgl_demux_run names the pair (lo, hi).  Every such cell is looked at (two hypotheses);
  *   - best and next of a scan, or a +2 threshold, within reach: the named hypotheses are recomputed and compared;
- *   - next and third of a scan within reach (sngThirdLLK / dblThirdLLK): every hypothesis of that scan is recomputed.
+ *   - next and third of a scan within reach (MUXGL_CELL_DEEP_* in `valid`): every hypothesis of that scan is recomputed.
  * Integer fields and the log-likelihoods of recomputed hypotheses then equal the reference's exactly; sumLLK / sngLLK
  * stay as the device summed them.  The pileup and gp / has_gp are the arrays handed to muxgl_set_pileup /
  * muxgl_demux_set_gp.  nthreads host threads (cells are independent).

@@ -600,6 +600,7 @@ int group_fmx_iterate(muxgl_handle* h, const muxgl_fmx_params* p, muxgl_fmx_cell
                       int32_t* nchanged, double* full_ll);
 int group_fmx_get_cluster_pileup(muxgl_handle* h, double* gls, int32_t* counts);
 void group_fmx_exact_stats(const muxgl_handle* h, int64_t* cells, int64_t* changed, int64_t* unresolved);
+void group_peer_stats(const muxgl_handle* h, int32_t* out);
 int group_get_timing(const muxgl_handle* h, float* ms);
 #define MUXGL_NOT_FOR_GROUPS(h, who) \
   if ((h)->group) MUXGL_FAIL(h, who ": not available on a device group (use a one-device handle)")

@@ -51,6 +51,25 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return ldexp(p, (int)n);
 }
 
+// A lane's partner in step M of a butterfly over a wave.  The merges below are symmetric in their two arguments and every
+// step starts with the merged value uniform over the group it ended with, so any pairing of the two halves does -- and
+// within a row of sixteen lanes a pairing that a DPP modifier can express costs one move per dword (quad permutations for
+// M = 1, 2; the mirrors of eight and of sixteen lanes for M = 4, 8) where a shuffle is a trip through the LDS crossbar
+// (ds_bpermute: an address VGPR, ~100 cycles of latency each, and the finish kernel is nothing but such latencies).
+template <int M>
+__device__ __forceinline__ int32_t lane_partner(int32_t x) {
+  if constexpr (M == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);        // quad_perm [1, 0, 3, 2]
+  else if constexpr (M == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+  else if constexpr (M == 4) return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);  // row_half_mirror: i <-> 7 - i
+  else if constexpr (M == 8) return __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true);  // row_mirror: i <-> 15 - i
+  else return __shfl_xor(x, M, 64);
+}
+template <int M>
+__device__ __forceinline__ double lane_partner(double x) {
+  if constexpr (M >= 16) return __shfl_xor(x, M, 64);
+  return __hiloint2double(lane_partner<M>(__double2hiint(x)), lane_partner<M>(__double2loint(x)));
+}
+
 struct top2 {
   double bv, nv;  // best / next value
   int32_t bp, np; // scan positions (-1: none); position encodes the hypothesis
@@ -60,10 +79,11 @@ struct top2 {
 
 // reference update rule for one more element at a later position (selects, no branches: the scans are lock-step loops
 // over sixteen lanes' rows, and a divergent branch per element serialises them)
+template <bool T3 = true>  // T3: keep the third-largest value along (false: the caller finds it in a pass of its own)
 __device__ __forceinline__ void top2_push(top2& t, double v, int32_t pos) {
   const bool b = t.bv < v;
   const bool n = !b && t.nv < v;
-  t.tv = (b || n) ? t.nv : fmax(t.tv, v);
+  if (T3) t.tv = (b || n) ? t.nv : fmax(t.tv, v);
   t.nv = b ? t.bv : (n ? v : t.nv);
   t.np = b ? t.bp : (n ? pos : t.np);
   t.bv = b ? v : t.bv;
@@ -79,6 +99,7 @@ __device__ __forceinline__ bool key_before(double va, int32_t pa, double vb, int
   return pa < pb;
 }
 
+template <bool T3 = true>
 __device__ __forceinline__ top2 top2_merge(const top2& a, const top2& b) {
   // the best of the two lists, then the better of (the winner's runner-up, the loser's best) -- as selects
   const bool ab = key_before(a.bv, a.bp, b.bv, b.bp);
@@ -91,17 +112,18 @@ __device__ __forceinline__ top2 top2_merge(const top2& a, const top2& b) {
   r.nv = keep ? wn : lv;
   r.np = keep ? wnp : lp;
   // third value of the union of two descending triples x, y: max(x3, y3, min(x2, y1), min(x1, y2))
-  r.tv = fmax(fmax(a.tv, b.tv), fmax(fmin(a.nv, b.bv), fmin(a.bv, b.nv)));
+  r.tv = T3 ? fmax(fmax(a.tv, b.tv), fmax(fmin(a.nv, b.bv), fmin(a.bv, b.nv))) : -1e300;
   return r;
 }
 
-__device__ __forceinline__ top2 top2_xor(const top2& t, int m) {
+template <int M, bool T3 = true>
+__device__ __forceinline__ top2 top2_partner(const top2& t) {
   top2 o;
-  o.bv = __shfl_xor(t.bv, m, 64);
-  o.nv = __shfl_xor(t.nv, m, 64);
-  o.bp = __shfl_xor(t.bp, m, 64);
-  o.np = __shfl_xor(t.np, m, 64);
-  o.tv = __shfl_xor(t.tv, m, 64);
+  o.bv = lane_partner<M>(t.bv);
+  o.nv = lane_partner<M>(t.nv);
+  o.bp = lane_partner<M>(t.bp);
+  o.np = lane_partner<M>(t.np);
+  o.tv = T3 ? lane_partner<M>(t.tv) : -1e300;
   return o;
 }
 
@@ -132,25 +154,27 @@ struct call_partial {
 // merges the per-lane row results (top-2 lists, the largest evidence term rowmax of the lane's rows, their evidence sum
 // racc relative to rowmax, the largest singlet term sterm and the singlet sum sacc relative to it) over the G lanes of
 // the cell; every lane of the group ends with the cell's partial
-template <int G>
+template <int G, bool T3 = true>
 __device__ __forceinline__ call_partial demux_call_merge(top2 sng, top2 dbl, double sterm, double rowmax, double racc,
                                                          double sacc) {
   const double NEG_INF = -__builtin_huge_val();
   double M = rowmax, Ms = sterm;
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    sng = top2_merge(sng, top2_xor(sng, m));
-    dbl = top2_merge(dbl, top2_xor(dbl, m));
-    M = fmax(M, __shfl_xor(M, m, 64));
-    Ms = fmax(Ms, __shfl_xor(Ms, m, 64));
-  }
+  constexpr int STEPS = G <= 1 ? 0 : (G <= 2 ? 1 : (G <= 4 ? 2 : (G <= 8 ? 3 : (G <= 16 ? 4 : (G <= 32 ? 5 : 6)))));
+  static_assert((1 << STEPS) == G, "groups of 2^n lanes");
+  wave_for<0, STEPS>([&](auto sc) {
+    constexpr int m = 1 << decltype(sc)::value;
+    sng = top2_merge<T3>(sng, top2_partner<m, T3>(sng));
+    dbl = top2_merge<T3>(dbl, top2_partner<m, T3>(dbl));
+    M = fmax(M, lane_partner<m>(M));
+    Ms = fmax(Ms, lane_partner<m>(Ms));
+  });
   double S = (racc > 0.0) ? racc * exp_nonpos(rowmax - M) : 0.0;
   double Ss = (sterm > NEG_INF) ? sacc * exp_nonpos(sterm - Ms) : 0.0;
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    S += __shfl_xor(S, m, 64);
-    Ss += __shfl_xor(Ss, m, 64);
-  }
+  wave_for<0, STEPS>([&](auto sc) {
+    constexpr int m = 1 << decltype(sc)::value;
+    S += lane_partner<m>(S);
+    Ss += lane_partner<m>(Ss);
+  });
   return call_partial{sng, dbl, M, S, Ms, Ss};
 }
 
@@ -166,9 +190,19 @@ __device__ __forceinline__ void demux_call_decide(const call_partial& c, int32_t
   const top2& sng = c.sng;
   const top2& dbl = c.dbl;
   // :791 (sic): the reference starts both sums at -1e-300, i.e. with one more term exp(-1e-300)
+  // (This lane's chain of transcendental calls is the finish kernel's critical path -- one lock-step round of workgroups, a
+  //  handful of lanes each -- so it uses the short forms: exp_nonpos for the non-positive arguments all of them have,
+  //  pos_log for the positive ones; ~25 instructions each against the library's 150-250, within 2 ulp, on quantities
+  //  whose bar is 1e-5.)
+  auto logadd = [](double la, double lb) {  // sc_drop_seq.cpp:5-8
+    const double hi = la > lb ? la : lb, lo = la > lb ? lb : la;
+    return hi + pos_log(1.0 + exp_nonpos(lo - hi), 0.0);
+  };
+  // posteriors the writer prints with %.2lg / %.5lf: the library exp only where the short form would flush a denormal
+  auto pp_exp = [](double x) { return x < -700.0 ? exp(x) : exp_nonpos(x); };
   double sumLLK = -1e-300, sngLLK = -1e-300;
-  if (c.S > 0.0) sumLLK = dev_logadd(sumLLK, c.M + log(c.S));
-  if (c.Ss > 0.0) sngLLK = dev_logadd(sngLLK, c.Ms + log(c.Ss));
+  if (c.S > 0.0) sumLLK = logadd(sumLLK, c.M + pos_log(c.S, 0.0));
+  if (c.Ss > 0.0) sngLLK = logadd(sngLLK, c.Ms + pos_log(c.Ss, 0.0));
 
   muxgl_demux_cell o;
   memset(&o, 0, sizeof(o));
@@ -207,7 +241,7 @@ __device__ __forceinline__ void demux_call_decide(const call_partial& c, int32_t
   double bestLLK, nextLLK, bestPP;
   if (dblBestLLK > sngBestLLK + 2) {  // :925
     bestType = MUXGL_DBL;
-    bestPP = exp(dblBestLLK + ((gridAlpha[dblBestAlpha] == 0.5) ? log_doublet_prior2 : log_doublet_prior1) - sumLLK);
+    bestPP = pp_exp(dblBestLLK + ((gridAlpha[dblBestAlpha] == 0.5) ? log_doublet_prior2 : log_doublet_prior1) - sumLLK);
     jBest = dBest1;
     kBest = dBest2;
     bestLLK = dblBestLLK;
@@ -268,10 +302,18 @@ __device__ __forceinline__ void demux_call_decide(const call_partial& c, int32_t
   o.bestLLK = bestLLK;
   o.nextLLK = nextLLK;
   o.bestPP = bestPP;
-  o.sngPP = exp(sngLLK - sumLLK);                             // :990
-  o.sngOnlyPP = exp(sngBestLLK + log_single_prior - sngLLK);  // :991
-  o.sngThirdLLK = sng.tv;
-  o.dblThirdLLK = dblThird;
+  o.sngPP = pp_exp(sngLLK - sumLLK);                             // :990
+  o.sngOnlyPP = pp_exp(sngBestLLK + log_single_prior - sngLLK);  // :991
+  {  // three or more hypotheses of a scan within rounding reach of each other: the exact-call pass must look at all of them
+    double mag = 1.0;
+    if (sngBestLLK > -1e299) mag = fmax(mag, fabs(sngBestLLK));
+    if (sngNextLLK > -1e299) mag = fmax(mag, fabs(sngNextLLK));
+    if (dblBestLLK > -1e299) mag = fmax(mag, fabs(dblBestLLK));
+    if (dblNextLLK > -1e299) mag = fmax(mag, fabs(dblNextLLK));
+    const double eps = 1e-9 * mag;
+    if (sngNextLLK > -1e299 && sng.tv > -1e299 && sngNextLLK - sng.tv <= eps) o.valid |= MUXGL_CELL_DEEP_SNG;
+    if (dblNextLLK > -1e299 && dblThird > -1e299 && dblNextLLK - dblThird <= eps) o.valid |= MUXGL_CELL_DEEP_DBL;
+  }
   *out = o;
 }
 
@@ -321,7 +363,7 @@ __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, 
       const double* row = ll_cell + (size_t)jr * ld;
       if (q == 0) {
         const double s = row[0];  // llksAB[j][0][0]
-        top2_push(sng, s, jr);
+        top2_push<!(G == 16 && Q == 4)>(sng, s, jr);
         const double st = s + log_single_prior;
         sterm = fmax(sterm, st);
         rowmax = fmax(rowmax, st);
@@ -330,15 +372,15 @@ __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, 
         if (k == jr) continue;
         for (int n = 1; n < nAlpha; ++n) {
           const double v = row[k * nAlpha + n];
-          if (gridAlpha[n] == 0.5) {
-            if (k < jr) {
-              rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
-              continue;                                        // (hi, lo): listed as (lo, hi), see demux_call_decide
-            }
+          const bool sym = gridAlpha[n] == 0.5;
+          if (sym) {
+            if (k < jr) rowmax = fmax(rowmax, v + log_doublet_prior2);  // :812-815
           } else {
             rowmax = fmax(rowmax, v + log_doublet_prior1);
           }
-          top2_push(dbl, v, (jr * nv + k) * nAlpha + n);
+          // (hi, lo) of an alpha = 0.5 pair is listed as (lo, hi), see demux_call_decide: pushed as "nothing" -- a select, not
+          // a branch around the push: the lanes of a wave differ in jr and k, and a divergent branch serialises the loop
+          top2_push<!(G == 16 && Q == 4)>(dbl, (sym && k < jr) ? -1e300 : v, (jr * nv + k) * nAlpha + n);
         }
       }
     }
@@ -365,7 +407,37 @@ __device__ __forceinline__ call_partial demux_call_scan(int lane, bool cell_ok, 
       }
     }
   }
-  return demux_call_merge<G * Q>(sng, dbl, sterm, rowmax, racc, sacc);
+  // The third-largest value of each scan (what host/exact_calls.hpp needs to know whether best and next are the only
+  // contenders).  Sixteen lanes x four column ranges (a handful of elements per lane, the tile in LDS): cheaper found
+  // after the merge -- the largest element that is neither best nor next, one max-butterfly per scan -- than carried
+  // through every update and every step of the two merges (the finish kernel of the oct path is one lock-step round of
+  // workgroups: every instruction of it is on the step's critical path).
+  constexpr bool T3 = !(G == 16 && Q == 4);
+  call_partial cp = demux_call_merge<G * Q, T3>(sng, dbl, sterm, rowmax, racc, sacc);
+  if (!T3) {
+    double s3 = -1e300, d3 = -1e300;
+    if (live) {
+      for (int jr = j; jr < nv; jr += G) {
+        const double* row = ll_cell + (size_t)jr * ld;
+        s3 = fmax(s3, (q == 0 && jr != cp.sng.bp && jr != cp.sng.np) ? row[0] : -1e300);
+        for (int k = k0; k < k1; ++k) {
+          for (int n = 1; n < nAlpha; ++n) {
+            const int32_t pos = (jr * nv + k) * nAlpha + n;
+            const bool out = k == jr || (gridAlpha[n] == 0.5 && k < jr) || pos == cp.dbl.bp || pos == cp.dbl.np;
+            d3 = fmax(d3, out ? -1e300 : row[k * nAlpha + n]);
+          }
+        }
+      }
+    }
+    wave_for<0, 6>([&](auto sc) {
+      constexpr int m = 1 << decltype(sc)::value;
+      s3 = fmax(s3, lane_partner<m>(s3));
+      d3 = fmax(d3, lane_partner<m>(d3));
+    });
+    cp.sng.tv = s3;
+    cp.dbl.tv = d3;
+  }
+  return cp;
 }
 
 template <int G, int Q = 1>

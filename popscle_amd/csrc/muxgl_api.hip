@@ -320,6 +320,13 @@ int muxgl_set_pileup_role(muxgl_handle* h, int role, int64_t C, int64_t S, int64
 
 extern "C" {
 
+int muxgl_group_peer_stats(const muxgl_handle* h, int32_t* out) {
+  if (!h || !out) return 1;
+  out[0] = out[1] = out[2] = 0;
+  if (h->group) group_peer_stats(h, out);
+  return 0;
+}
+
 int muxgl_version(void) { return MUXGL_VERSION; }
 
 const char* muxgl_last_error(const muxgl_handle* h) { return h ? h->err.c_str() : g_muxgl_create_error.c_str(); }

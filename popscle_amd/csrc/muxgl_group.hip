@@ -30,6 +30,7 @@ struct muxgl_group {
   muxgl_demux_cell* h_dcells = nullptr;  // [C] records of the last demuxlet run, in cell order
   std::vector<hipEvent_t> ev_gp, ev_es;  // per member: posterior rows ready / assignments ready
   float ms[MUXGL_T_COUNT] = {};
+  int32_t peer_pairs = 0, peer_enabled = 0, peer_refused = 0;  // of group_create's walk over the member pairs
 };
 
 namespace {
@@ -90,15 +91,30 @@ int group_create(const muxgl_config* cfg, muxgl_handle** out, std::string* err) 
     }
     g->m.push_back(m);
   }
-  // direct peer copies between distinct devices (a failure leaves hipMemcpyPeerAsync on its staged path, still correct)
+  // Direct peer copies between distinct devices.  Whatever goes wrong here -- no peer access between two devices, access
+  // already enabled by another handle -- leaves hipMemcpyPeerAsync on its staged path, which is still correct, and must
+  // not leave a sticky error behind for the next HIP call.  MUXGL_GROUP_NO_PEER=1 skips the enabling altogether (the
+  // staged path on a box that does have peer access); MUXGL_FLAG_GROUP_PROBE_SELF also walks the pairs of members that
+  // share a device (virtual ranks on one GPU: hipDeviceEnablePeerAccess(self) fails -- the error path, on any box).
+  g->peer_pairs = g->peer_enabled = g->peer_refused = 0;
+  const bool no_peer = getenv("MUXGL_GROUP_NO_PEER") != nullptr;
+  const bool probe_self = (cfg->flags & MUXGL_FLAG_GROUP_PROBE_SELF) != 0;
   for (int a = 0; a < g->n; ++a)
     for (int b = 0; b < g->n; ++b) {
       const int da = g->m[(size_t)a]->device, db = g->m[(size_t)b]->device;
-      if (da == db) continue;
+      if (a == b || (da == db && !probe_self)) continue;
+      ++g->peer_pairs;
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can && hipSetDevice(da) == hipSuccess) {
-        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      hipError_t e = hipDeviceCanAccessPeer(&can, da, db);
+      if (e != hipSuccess) (void)hipGetLastError();
+      if (e == hipSuccess && da == db) can = 1;  // (probe: the runtime answers 0 for a device and itself; ask it to enable anyway)
+      if (e == hipSuccess && can && !no_peer && hipSetDevice(da) == hipSuccess) {
+        e = hipDeviceEnablePeerAccess(db, 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ++g->peer_enabled;
+        else ++g->peer_refused;
+        if (e != hipSuccess) (void)hipGetLastError();
+      } else {
+        ++g->peer_refused;
       }
     }
   g->ev_gp.assign((size_t)g->n, nullptr);
@@ -305,6 +321,10 @@ int group_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts) {
     const size_t e0 = (size_t)g->eb[(size_t)r];
     return muxgl_fmx_get_entry_gls(g->m[(size_t)r], gls ? gls + e0 * 9 : nullptr, counts ? counts + e0 * 3 : nullptr);
   });
+}
+
+void group_peer_stats(const muxgl_handle* h, int32_t* out) {
+  out[0] = h->group->peer_pairs, out[1] = h->group->peer_enabled, out[2] = h->group->peer_refused;
 }
 
 void group_fmx_exact_stats(const muxgl_handle* h, int64_t* cells, int64_t* changed, int64_t* unresolved) {

@@ -4,8 +4,8 @@
 // bookkeeping and one log per hypothesis instead of a sum of logs): equal to ~1e-12, not to the last bit.  Every decision
 // of cmd_cram_demuxlet.cpp:827-837 (best/next singlet), :883-906 (best/next doublet) and :925-988 (the +2 thresholds
 // between them) is a comparison of two such numbers, so a comparison whose margin is within EPS = 1e-9 x max(1, |LL|)
-// is not the kernels' to make.  This pass finds those cells from the records (muxgl_demux_cell carries the third-largest
-// value of each scan next to best and next), recomputes the contested hypotheses exactly as the reference does --
+// is not the kernels' to make.  This pass finds those cells from the records (next to best and next the call kernel leaves
+// two bits in `valid`: the third-largest value of a scan is in reach of the runner-up), recomputes the contested hypotheses exactly as the reference does --
 // IEEE doubles in the reference's operation order with nothing contracted, glibc's log; per-read update, floor and
 // normalisation of :655-725 over the whole alpha grid -- and makes the scans and the call on those numbers:
 //
@@ -190,7 +190,7 @@ inline void exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int
     std::vector<Hyp> hs, hd;
     for (int64_t c = c0; c < c1; ++c) {
       muxgl_demux_cell& x = cells[c];
-      if (!x.valid) continue;
+      if (!(x.valid & 1)) continue;
       double mag = 1.0;
       for (double v : {x.sngBestLLK, x.sngNextLLK, x.dblBestLLK, x.dblNextLLK})
         if (v > -1e299) mag = std::max(mag, fabs(v));
@@ -200,10 +200,11 @@ inline void exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int
       auto sym = [&](int32_t n) { return n >= 1 && n < nAlpha && gridAlpha[n] == 0.5; };
       const bool mirror = x.dBest1 >= 0 && sym(x.dBestA) && x.dNext1 == x.dBest2 && x.dNext2 == x.dBest1 && x.dNextA == x.dBestA;
       const bool next_sym = !mirror && x.dNext1 >= 0 && sym(x.dNextA);
-      const bool s2 = near(x.sngBestLLK, x.sngNextLLK), s3 = near(x.sngNextLLK, x.sngThirdLLK);
-      // (a mirrored best: `third` is the best hypothesis that is neither order of it, demux_call_body.hpp)
+      const bool s2 = near(x.sngBestLLK, x.sngNextLLK), s3 = (x.valid & MUXGL_CELL_DEEP_SNG) != 0;
+      // (set by the call kernel from the third-largest value of the scan; for a mirrored best: from the best hypothesis that
+      //  is neither order of it, demux_call_body.hpp)
       const bool d2 = !mirror && near(x.dblBestLLK, x.dblNextLLK);
-      const bool d3 = mirror ? near(x.dblBestLLK, x.dblThirdLLK) : near(x.dblNextLLK, x.dblThirdLLK);
+      const bool d3 = (x.valid & MUXGL_CELL_DEEP_DBL) != 0;
       const bool th = near(x.dblBestLLK, x.sngBestLLK + 2) || near(x.dblNextLLK, x.sngBestLLK + 2) ||
                       near(x.sngBestLLK, x.sngNextLLK + 2) || near(x.dblBestLLK, x.sngNextLLK + 2);
       const bool do_s = s2 || s3 || th, do_d = mirror || next_sym || d2 || d3 || th;
@@ -211,6 +212,7 @@ inline void exact_calls(int64_t C, int32_t V, const int64_t* cell_ptr, const int
       ++s[ST_CELLS];
       if (s2 || s3 || d2 || d3 || th) ++s[ST_NEAR_TIES];
       if (s3 || d3) ++s[ST_DEEP];
+      x.valid = 1;
       const muxgl_demux_cell before = x;
 
       if (do_s) {  // singlet scan (:827-837) over the contenders, ascending sample = the reference's scan order

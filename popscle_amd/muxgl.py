@@ -30,6 +30,7 @@ FLAG_ASYNC_PHASES = 32
 FLAG_NO_LINEAR_ENTRIES = 64
 FLAG_NO_PIVOT_SUMS = 256
 FLAG_SPLIT_GENERAL_SWEEP = 512
+FLAG_GROUP_PROBE_SELF = 1024
 MAX_DEVICES = 16
 XCHG_PAD = 64
 T_FMX_ENTRY, T_FMX_GP, T_FMX_ESTEP, T_FMX_CALL, T_FMX_MSTEP = 4, 5, 6, 7, 8
@@ -42,10 +43,10 @@ DEMUX_CELL = np.dtype(
     [(n, np.int32) for n in ("valid", "nsnps", "type", "next_type", "sBest", "sNext", "dBest1", "dBest2", "dBestA",
                              "dNext1", "dNext2", "dNextA", "jBest", "kBest", "aBest", "jNext", "kNext", "aNext")]
     + [(n, np.float64) for n in ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK", "sumLLK", "sngLLK",
-                                 "bestLLK", "nextLLK", "bestPP", "sngPP", "sngOnlyPP", "sngThirdLLK",
-                                 "dblThirdLLK")],
+                                 "bestLLK", "nextLLK", "bestPP", "sngPP", "sngOnlyPP")],
     align=True,
 )
+CELL_DEEP_SNG, CELL_DEEP_DBL = 2, 4   # bits of DEMUX_CELL["valid"] next to bit 0 (include/muxgl.h)
 FMX_CELL = np.dtype(
     [(n, np.int32) for n in ("type", "clust", "jBest", "kBest", "jNext", "kNext", "sBest", "sNext", "dBest1",
                              "dBest2", "dNext1", "dNext2")]
@@ -56,7 +57,7 @@ FMX_CELL = np.dtype(
 DROPD = np.dtype([("nsnps", np.int32), ("nread1", np.int32), ("nread2", np.int32), ("_pad", np.int32),
                   ("llk0", np.float64), ("llk2", np.float64)], align=True)
 assert DROPD.itemsize == 32
-assert DEMUX_CELL.itemsize == 18 * 4 + 13 * 8
+assert DEMUX_CELL.itemsize == 18 * 4 + 11 * 8
 assert FMX_CELL.itemsize == 12 * 4 + 12 * 8
 
 
@@ -78,6 +79,7 @@ class _FmxParams(C.Structure):
 _VP = C.c_void_p
 SYMBOLS = {
     "muxgl_version": (C.c_int, []),
+    "muxgl_group_peer_stats": (C.c_int, [_VP, _VP]),
     "muxgl_create": (C.c_int, [C.POINTER(_Config), C.POINTER(_VP)]),
     "muxgl_destroy": (None, [_VP]),
     "muxgl_last_error": (C.c_char_p, [_VP]),
@@ -424,6 +426,12 @@ class Engine:
 
     def memcpy_dev(self, dst_ptr, src_ptr, nbytes):
         self._check(self.lib.muxgl_memcpy_dev(self.h, _VP(dst_ptr), _VP(src_ptr), int(nbytes)))
+
+    def group_peer_stats(self):
+        """(member pairs walked, pairs with direct peer access, pairs left on the staged copy) of a device group"""
+        out = np.zeros(3, dtype=np.int32)
+        self._check(self.lib.muxgl_group_peer_stats(self.h, _ptr(out)))
+        return tuple(int(x) for x in out)
 
     def fmx_exact_stats(self):
         """(near-tie cells settled by the exact path, calls it changed, near-tie cells left unresolved) since set_clusters"""

@@ -86,14 +86,15 @@ def test_create_rejects_a_config_of_another_size(lib):
 def test_oracle_and_library_records_share_a_layout():
     import oracle_binding as ob
 
-    # the library's records are the oracle's (= the reference's variables) followed by the two third-largest values the
-    # exact-call pass reads, which the reference has no counterpart of
-    for lib_t, ora_t in ((muxgl.DEMUX_CELL, ob.DEMUX_CELL), (muxgl.FMX_CELL, ob.FMX_CELL)):
-        n = len(ora_t.names)
-        assert lib_t.names[:n] == ora_t.names and lib_t.names[n:] == ("sngThirdLLK", "dblThirdLLK")
-        for f in ora_t.names:
-            assert lib_t.fields[f][:2] == ora_t.fields[f][:2], f
-        assert lib_t.itemsize == ora_t.itemsize + 16
+    # the demuxlet record IS the oracle's (= the reference's variables); the freemuxlet record is the oracle's followed by
+    # the two third-largest values the exact path reads, which the reference has no counterpart of
+    assert ob.DEMUX_CELL == muxgl.DEMUX_CELL
+    lib_t, ora_t = muxgl.FMX_CELL, ob.FMX_CELL
+    n = len(ora_t.names)
+    assert lib_t.names[:n] == ora_t.names and lib_t.names[n:] == ("sngThirdLLK", "dblThirdLLK")
+    for f in ora_t.names:
+        assert lib_t.fields[f][:2] == ora_t.fields[f][:2], f
+    assert lib_t.itemsize == ora_t.itemsize + 16
 
 
 def test_no_cpu_fallback(lib):

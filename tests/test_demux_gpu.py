@@ -183,7 +183,7 @@ def test_ragged_and_edge_inputs(eng, V):
         got, gfull = run_gpu(eng, p, alphas, full=True)
         parity.compare_demux(got, want, alphas, p)
         parity.compare_full_ll(gfull, wfull, V, alphas)
-        assert got["valid"].tolist() == [0, 1, 1, 1, 0, 1, 0]
+        assert (got["valid"] & 1).tolist() == [0, 1, 1, 1, 0, 1, 0]   # (bits 1, 2: near-tie marks for the exact-call pass)
         assert run_gpu(eng, p, alphas).tobytes() == got.tobytes()  # the call made in LDS (no tensor requested)
 
 
@@ -210,7 +210,7 @@ def test_one_sweep_for_all_entries_matches_the_split_sweeps(V, alphas):
     parity.compare_demux(b, want, alphas, p)
     parity.compare_demux(a, want, alphas, p)
     assert parity.compare_full_ll(bfull, wfull, V, alphas) < 1e-7
-    assert b["valid"].tolist() == (lens > 0).astype(int).tolist()
+    assert (b["valid"] & 1).tolist() == (lens > 0).astype(int).tolist()
     # the two sweeps accumulate in different associations (one product over all entries / a sum of two logarithms)
     m = parity.needed_ll_mask(V, alphas)
     assert np.max(np.abs(afull[:, m] - bfull[:, m])) < 1e-8

@@ -51,22 +51,30 @@ def emulate_device(want, full, alphas, doublet_prior, noise, seed=0):
         order = np.lexsort((np.arange(V), -s))            # value descending, position ascending
         o["sBest"], o["sngBestLLK"] = order[0], s[order[0]]
         o["sNext"], o["sngNextLLK"] = (order[1], s[order[1]]) if V > 1 else (-1, -1e300)
-        o["sngThirdLLK"] = s[order[2]] if V > 2 else -1e300
+        third_s = s[order[2]] if V > 2 else -1e300
         hyp = [(dev[c, j, k, n], (j * V + k) * A + n, j, k, n) for j in range(V) for k in range(V) if k != j
                for n in range(1, A) if not (al[n] == 0.5 and k < j)]
         hyp.sort(key=lambda t: (-t[0], t[1]))
         o["dBest1"] = o["dBest2"] = o["dBestA"] = o["dNext1"] = o["dNext2"] = o["dNextA"] = -1
-        o["dblBestLLK"] = o["dblNextLLK"] = o["dblThirdLLK"] = -1e300
+        o["dblBestLLK"] = o["dblNextLLK"] = -1e300
+        third_d = -1e300
         if hyp:
             v, _, j, k, n = hyp[0]
             o["dBest1"], o["dBest2"], o["dBestA"], o["dblBestLLK"] = j, k, n, v
             if al[n] == 0.5:
                 o["dNext1"], o["dNext2"], o["dNextA"], o["dblNextLLK"] = k, j, n, v
-                o["dblThirdLLK"] = hyp[1][0] if len(hyp) > 1 else -1e300
+                third_d = hyp[1][0] if len(hyp) > 1 else -1e300
             elif len(hyp) > 1:
                 v2, _, j2, k2, n2 = hyp[1]
                 o["dNext1"], o["dNext2"], o["dNextA"], o["dblNextLLK"] = j2, k2, n2, v2
-                o["dblThirdLLK"] = hyp[2][0] if len(hyp) > 2 else -1e300
+                third_d = hyp[2][0] if len(hyp) > 2 else -1e300
+        # the two bits the call kernel leaves in `valid` (demux_call_body.hpp): third within reach of the runner-up
+        mag = max([1.0] + [abs(float(o[f])) for f in ("sngBestLLK", "sngNextLLK", "dblBestLLK", "dblNextLLK") if o[f] > -1e299])
+        eps = 1e-9 * mag
+        if o["sngNextLLK"] > -1e299 and third_s > -1e299 and o["sngNextLLK"] - third_s <= eps:
+            o["valid"] |= muxgl.CELL_DEEP_SNG
+        if o["dblNextLLK"] > -1e299 and third_d > -1e299 and o["dblNextLLK"] - third_d <= eps:
+            o["valid"] |= muxgl.CELL_DEEP_DBL
         if o["dblBestLLK"] > o["sngBestLLK"] + 2:
             o["type"] = 1
             o["jBest"], o["kBest"], o["aBest"], o["bestLLK"] = o["dBest1"], o["dBest2"], o["dBestA"], o["dblBestLLK"]

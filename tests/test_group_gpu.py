@@ -227,6 +227,42 @@ def test_device_group_settles_near_tie_calls():
         assert np.array_equal(gg, og) and np.array_equal(gc, oc)
 
 
+def test_group_peer_access_walk(monkeypatch):
+    """muxgl_create's walk over the member pairs (muxgl_group.hip): on a one-GPU box the members share the device and the
+    walk has nothing to do; MUXGL_FLAG_GROUP_PROBE_SELF makes it ask for every pair, which the runtime refuses -- the
+    refusal must leave no sticky error behind and the group must work (its copies then go the runtime's staged way);
+    MUXGL_GROUP_NO_PEER=1 skips the enabling on any box.  On a multi-GPU box the same test also sees pairs enabled."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    K = 5
+    p = synth.make_pileup(80, 900, K, seed=31, mean_entries=100, min_entries=10, with_gp=False)
+    clust0 = (np.arange(p.C) % K).astype(np.int32)
+    with muxgl.Engine(0) as one:
+        one.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+        one.fmx_prepare(p.af)
+        one.fmx_set_clusters(K, clust0)
+        want = [one.fmx_iterate(0.5, 0.1) for _ in range(2)]
+    devs = [i % ndev for i in range(3)]
+    for env, flags in ((None, 0), (None, muxgl.FLAG_GROUP_PROBE_SELF), ("1", muxgl.FLAG_GROUP_PROBE_SELF)):
+        if env:
+            monkeypatch.setenv("MUXGL_GROUP_NO_PEER", env)
+        with muxgl.Engine(devs, flags) as g:
+            pairs, enabled, refused = g.group_peer_stats()
+            distinct = sum(1 for a in range(3) for b in range(3) if a != b and devs[a] != devs[b])
+            assert pairs == (6 if flags else distinct) and enabled + refused == pairs
+            if env:
+                assert enabled == 0
+            elif ndev == 1:
+                assert refused == pairs
+            g.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+            g.fmx_prepare(p.af)
+            g.fmx_set_clusters(K, clust0)
+            for it in range(2):
+                cells, st = g.fmx_iterate(0.5, 0.1)
+                assert cells.tobytes() == want[it][0].tobytes() and tuple(st) == tuple(want[it][1])
+
+
 def test_group_create_errors():
     with pytest.raises(muxgl.MuxglError, match="out of range"):
         muxgl.Engine([0, 99])
