@@ -314,6 +314,8 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
 
   // hypotheses of every listed cell, in the reference's scan order within each scan; one item per (entry, hypothesis)
   std::vector<std::vector<hyp>> hs(nf), hd(nf);
+  std::vector<double> fllrow;
+  const int64_t npairs = (int64_t)K * (K + 1) / 2;
   std::vector<item> items;
   std::vector<int64_t> ioff;
   for (size_t f = 0; f < nf; ++f) {
@@ -325,16 +327,26 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
     auto near = [&](double a, double b) { return a > -1e299 && b > -1e299 && fabs(a - b) <= eps; };
     std::vector<hyp>& s = hs[f];
     std::vector<hyp>& d = hd[f];
-    if (near(x.sngNextLLK, x.sngThirdLLK)) {
-      for (int32_t j = 0; j < K; ++j) s.push_back(hyp{j, j, 0.0});
+    // three or more hypotheses of a scan within reach of each other: every hypothesis of the scan that the kernels' own
+    // numbers (the cell's row of the E-step's result) do not put clearly below the runner-up -- 2 EPS below is beyond
+    // what rounding can bridge, the kernels' deviation being orders of magnitude smaller than EPS
+    const bool deep_s = near(x.sngNextLLK, x.sngThirdLLK), deep_d = near(x.dblNextLLK, x.dblThirdLLK);
+    if (deep_s || deep_d) {
+      fllrow.resize((size_t)npairs);
+      HIPCHK(h, hipMemcpy(fllrow.data(), h->d_fll + (size_t)xs.cells[f] * npairs, sizeof(double) * (size_t)npairs, hipMemcpyDeviceToHost));
+    }
+    if (deep_s) {
+      for (int32_t j = 0; j < K; ++j)
+        if (fllrow[(size_t)j * (j + 1) / 2 + j] >= x.sngNextLLK - 2 * eps) s.push_back(hyp{j, j, 0.0});
     } else {
       if (x.sBest >= 0) s.push_back(hyp{x.sBest, x.sBest, 0.0});
       if (x.sNext >= 0) s.push_back(hyp{x.sNext, x.sNext, 0.0});
       std::sort(s.begin(), s.end(), [](const hyp& a, const hyp& b) { return a.j < b.j; });
     }
-    if (near(x.dblNextLLK, x.dblThirdLLK)) {
+    if (deep_d) {
       for (int32_t j = 0; j < K; ++j)
-        for (int32_t k = 0; k < j; ++k) d.push_back(hyp{j, k, 0.0});
+        for (int32_t k = 0; k < j; ++k)
+          if (fllrow[(size_t)j * (j + 1) / 2 + k] >= x.dblNextLLK - 2 * eps) d.push_back(hyp{j, k, 0.0});
     } else {
       if (x.dBest1 >= 0) d.push_back(hyp{x.dBest1, x.dBest2, 0.0});
       if (x.dNext1 >= 0) d.push_back(hyp{x.dNext1, x.dNext2, 0.0});
@@ -495,14 +507,17 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
 // the three steps on a handle that holds the whole job (muxgl_fmx_iterate)
 int fmx_exact_resolve(muxgl_handle* h, const muxgl_fmx_params* p, bool* reassigned) {
   *reassigned = false;
+  host_timer tm;  // MUXGL_TIMING=1: the three steps on stderr
   std::vector<int32_t> snps;
   if (fmx_exact_snps(h, &snps)) return 1;
+  tm.lap("exact calls: listed cells and their SNPs");
   std::vector<double> rows(snps.size() * (size_t)h->K * 3);
   int64_t deltas[3];
   int32_t re = 0;
-  if (fmx_exact_rows(h, p, snps.data(), (int64_t)snps.size(), rows.data(), nullptr) ||
-      fmx_exact_finish(h, p, snps.data(), (int64_t)snps.size(), rows.data(), deltas, &re))
-    return 1;
+  if (fmx_exact_rows(h, p, snps.data(), (int64_t)snps.size(), rows.data(), nullptr)) return 1;
+  tm.lap("exact calls: posterior rows (ordered chains)");
+  if (fmx_exact_finish(h, p, snps.data(), (int64_t)snps.size(), rows.data(), deltas, &re)) return 1;
+  tm.lap("exact calls: hypotheses, decisions, patch");
   for (int i = 0; i < 3; ++i) h->h_fstat[i] += (int32_t)deltas[i];
   h->h_fstat[3] = 0;
   HIPCHK(h, hipMemcpy(h->d_fstat, h->h_fstat, 4 * sizeof(int32_t), hipMemcpyHostToDevice));

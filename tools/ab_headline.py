@@ -25,4 +25,4 @@ with muxgl.Engine(0) as e:
         e.demux_run(al, 0.5, want_cells=False)
     dt = time.perf_counter() - t0
     ms, k = e.timing_sum()
-    print(os.path.basename(muxgl.LIB_PATH), f"step {dt / n * 1e3:.4f} ms  sweep {ms[muxgl.T_DEMUX_SWEEP] / k:.4f}  finish {ms[muxgl.T_DEMUX_REDUCE] / k:.4f}")
+    print(os.path.basename(muxgl.LIB_PATH), f"step {dt / n * 1e3:.4f} ms  sweep {ms[muxgl.T_DEMUX_SWEEP] / k:.4f}  finish {ms[muxgl.T_DEMUX_REDUCE] / k:.4f}  d2h {ms[muxgl.T_DEMUX_D2H] / k:.4f}")
