@@ -61,12 +61,39 @@ __global__ void __launch_bounds__(256)
   if (snp < s0 || snp >= s1) return;
   double g[9];
   for (int q = 0; q < 9; ++q) g[q] = 1.0;  // snp_droplet_pileup() (sc_drop_seq.h:72-75): what operator[] default-constructs
-  for (int64_t p = snp_ptr[snp], p1 = snp_ptr[snp + 1]; p < p1; ++p) {  // ascending cell id
-    if (prev_clust[snp_cell[p]] != c) continue;
-    const int64_t pe = snp_entry[p];
-    double o[9];
-    entry_pileup(reads, entry_rptr[pe], entry_rptr[pe + 1], lut, o);
-    merge(g, o);
+  // Ascending cell id.  The lanes of a wave walk different chains (SNP, cluster) and a member of a SNP's list belongs to
+  // ONE cluster: merging "when the member is mine" would run the merge -- a pileup from the read bytes and 36 true
+  // divisions -- once per member with a sixteenth of the lanes active.  So every lane first moves its own cursor to its
+  // NEXT member (a cheap scan, eight members' dependent loads in flight at a time), then all lanes merge together: the
+  // heavy part runs as often as the longest chain of the wave has members, not as often as the list is long.
+  int64_t p = snp_ptr[snp];
+  const int64_t p1 = snp_ptr[snp + 1];
+  for (;;) {
+    int64_t hit = -1;
+    while (hit < 0 && p < p1) {
+      int32_t cl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cl[u] = p + u < p1 ? snp_cell[p + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cl[u] = cl[u] >= 0 ? prev_clust[cl[u]] : -2;
+      int u0 = 8;
+#pragma unroll
+      for (int u = 7; u >= 0; --u)
+        if (cl[u] == c) u0 = u;
+      if (u0 < 8) {
+        hit = p + u0;
+        p = hit + 1;
+      } else {
+        p += 8;
+      }
+    }
+    if (!__any(hit >= 0)) break;  // (wave-uniform exit: every lane's list is exhausted)
+    if (hit >= 0) {
+      const int64_t pe = snp_entry[hit];
+      double o[9];
+      entry_pileup(reads, entry_rptr[pe], entry_rptr[pe + 1], lut, o);
+      merge(g, o);
+    }
   }
   const double a = af[snp];
   double gp0s[3], gp1s[3];
