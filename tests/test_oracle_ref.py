@@ -5,9 +5,14 @@ lie and with the reference's flags (CMakeLists.txt:4-5: C++14 -O3 -pthread):
   * sc_drop_seq.cpp:1-92,386-578 unmodified (logAdd, add_snp / add_cell / add_read with the real
     std::map<std::string UMI> containers, calculate_snp_droplet_pileup, calculate_droplet_clust_distance),
     PhredHelper.cpp, Error.cpp;
-  * the hot loops of cmd_cram_demuxlet.cpp (:428-440, :590-622, :634-991) and cmd_cram_freemux2.cpp (:108-109, :114-159,
-    :184-189, :192-262, :277-288, :350-370, :373-605) as verbatim line ranges inside wrapper functions that only declare
-    the locals those lines name and copy their variables out (oracle/ref_hot.cpp.in).
+  * the hot loops of cmd_cram_demuxlet.cpp (:428-440, :590-622, :634-991), cmd_cram_freemux2.cpp (:108-109, :114-159,
+    :184-189, :192-262, :277-288, :350-370, :373-605) and cmd_cram_freemuxlet.cpp (:107-108, :113-161, :359-370, :432-453,
+    :456-653) as verbatim line ranges inside wrapper functions that only declare the locals those lines name and copy
+    their variables out (oracle/ref_hot.cpp.in);
+  * the htslib-free arithmetic of the VCF -> genotype-posterior path: bcf_filtered_reader.cpp :262-324 (PL EM),
+    :422-457 (GP branch), :376-409 (GT branch given genotype indices and allele counts) and sc_drop_seq.cpp:287-315 (the
+    double row handed to add_snp), the same way (oracle/ref_vcf.cpp.in) -- what tests/pyplp.py and the product's loader
+    (popscle_amd/host/vcf.hpp, through `popscle-amd dump-plp`) are held to.
 Every comparison below is BIT FOR BIT (np.array_equal on doubles / raw bytes of the records): the oracle
 (oracle/muxgl_oracle.c) restates the same operations in the same order, and -ffp-contract=off / no FMA on x86-64 makes
 both sides plain IEEE double arithmetic with glibc's log / exp.
