@@ -116,13 +116,22 @@ void dev_pool_release(muxgl_handle* h, bool forget_owner) {
 }
 
 void dev_pool_release_all() {
+  // (one critical section for the walk over ALL handles: a handle that another thread destroys meanwhile leaves the
+  //  registry under the same lock, so no pointer of the set is followed after its handle is gone)
   dev_registry& R = dev_reg();
-  std::vector<muxgl_handle*> hs;
+  std::vector<void*> out;
   {
     std::lock_guard<std::mutex> g(R.mu);
-    hs.assign(R.handles.begin(), R.handles.end());
+    for (muxgl_handle* h : R.handles) {
+      for (auto& kv : h->pool) {
+        out.push_back(kv.second);
+        R.blocks.erase(kv.second);
+      }
+      h->pool.clear();
+      h->pool_bytes = 0;
+    }
   }
-  for (muxgl_handle* h : hs) dev_pool_release(h, false);
+  for (void* q : out) (void)hipFree(q);
 }
 
 

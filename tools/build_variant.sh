@@ -1,7 +1,7 @@
 #!/bin/bash
 # builds popscle_amd/lib/var/libmuxgl_<tag>.so with one translation unit recompiled under extra flags (kernel timing
 # experiments; select with MUXGL_LIB=...):  bash tools/build_variant.sh <tag> <unit[.hip]> <flags...>
-#   e.g.  tools/build_variant.sh skipgen demux_ring -DRING_TIMING_SKIP_GEN
+#   e.g.  tools/build_variant.sh w4 demux_oct -DOCT_WAVES=4   (tuning constants; timing-only arms live as patches under tools/patches)
 set -e
 tag=$1; src=$2; shift 2; flags="$*"
 cd "$(dirname "$0")/../popscle_amd/csrc"
