@@ -213,9 +213,18 @@ int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg);
 
 /* ---- freemuxlet ---------------------------------------------------------------------------------------------- */
 /* b1+b2: calculate_snp_droplet_pileup for every entry (sc_drop_seq.cpp:452-509) and the per-cell singlet scores
- * (cmd_cram_freemux2.cpp:117-160).  af[S] from the .var.gz AF column.  Outputs [C], any may be NULL. */
+ * (cmd_cram_freemux2.cpp:117-160).  af[S] from the .var.gz AF column.  Outputs [C], any may be NULL.
+ * The reference sorts the cells by llk2 - llk0 (ties by index, sc_drop_seq.h:190-198) and the greedy start walks them in
+ * that order, so where two cells' scores are within 1e-9 x max(1, |llk|) of each other -- droplets of single-read entries
+ * score 0 +- rounding noise -- the last bits decide.  When both cell_llk0 and cell_llk2 are asked for on a handle that
+ * holds the whole pileup, the sums of every such cell are therefore recomputed exactly as the reference forms them (IEEE
+ * operations in its order on the device, glibc log on the host, score_exact.hpp); all other cells keep the device's sums
+ * (equal to ~1e-13).  A slabbed handle or a device group returns the device's sums for all cells. */
 int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
                       int32_t* cell_nreads);
+
+/* of the last muxgl_fmx_prepare: the number of cells whose sums were recomputed in the reference's arithmetic */
+int muxgl_fmx_score_stats(const muxgl_handle* h, int64_t* exact_scores);
 
 /* entry pileups (for parity checks and callers that want them): gls[nnz][9],
  * counts[nnz][3] = nreads,nref,nalt.  Either may be NULL. */

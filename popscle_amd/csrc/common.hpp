@@ -181,6 +181,7 @@ struct muxgl_handle {
   // freemuxlet
   double* d_af = nullptr;
   int64_t greedy_near_ties = 0, greedy_overruled = 0;  // of the last muxgl_fmx_greedy_init (fmx_greedy.hip)
+  int64_t fmx_exact_scores = 0;  // of the last muxgl_fmx_prepare (score_exact.hpp)
   double* d_egls = nullptr;       // [nnz][9] entry pileup likelihoods (b1)
   int32_t* d_ecnt = nullptr;      // [nnz][3] nreads,nref,nalt
   int32_t K = 0;

@@ -49,6 +49,18 @@ __device__ __forceinline__ bool greedy_near_tie(double bs, double ss, double eps
   const double scale = fmax(1.0, fmax(fabs(bs), fabs(ss)));
   return !(bs - ss > eps * scale);  // (also true for NaN scores: let the exact path look at them)
 }
+// The score of a cluster from its two products.  Only the STRUCTURAL zero -- both products empty, i.e. exactly 1 -- may
+// come out as 0.0.  A cluster that does share SNPs with the cell and whose score lands within eps of 0 (an entry whose
+// reads are all of another allele has uniform likelihoods: lk2 = lk0 up to rounding, so the reference's score is noise of
+// either sign, +-1e-16, or exactly 0 where this kernel has -1e-17) gets the smallest positive score instead: in front of
+// the structural zeros and within reach of anything near 0, so that the step is a near tie and greedy_exact.hpp decides
+// it -- greedy_near_tie's exemption of two zeros then only ever meets structural ones, with no third candidate hiding
+// just below them.  (A non-empty product of terms < 1 cannot be exactly 1.)
+__device__ __forceinline__ double greedy_score(double m2, int32_t e2, double m0, int32_t e0, double eps) {
+  const double sc = prodacc_log(m2, e2) - prodacc_log(m0, e0);
+  const bool empty = ldexp(m2, e2) == 1.0 && ldexp(m0, e0) == 1.0;
+  return (!empty && fabs(sc) <= eps) ? 1e-300 : sc;
+}
 
 constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
 constexpr int GT = 1024;             // threads of the persistent workgroup
@@ -208,7 +220,7 @@ __global__ void __launch_bounds__(GT)
           b2 += p_x2[g * Kp + c];
           b0 += p_x0[g * Kp + c];
         }
-        const double sc = prodacc_log(a2, b2) - prodacc_log(a0, b0);
+        const double sc = greedy_score(a2, b2, a0, b0, tie_eps);
         if (best < 0 || sc > bs) {
           ss = bs;
           bs = sc;
@@ -879,7 +891,7 @@ __device__ __forceinline__ int greedy_cell_decide(greedy_lds& L, const greedy_ta
         prodacc_renorm(m.x, e.x);
         prodacc_renorm(m.y, e.y);
       }
-      sc = prodacc_log(m.x, e.x) - prodacc_log(m.y, e.y);
+      sc = greedy_score(m.x, e.x, m.y, e.y, T.tie_eps);
     }
     best = greedy_wave_argmax2(sc, lane, K, T.tie_eps, near);
   }
@@ -1652,8 +1664,10 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
         }
       }
       if (e != hipSuccess || !overruled) break;
-      if (++reruns > 64) {
-        h->err = "muxgl_fmx_greedy_init: more than 64 near-tie decisions overruled by the exact path";
+      // (every rerun pins one more step for good, so the loop ends after at most n of them; beyond a number no real
+      //  pileup has come near, give up loudly rather than take hours)
+      if (++reruns > 64 + (int)std::min<size_t>(n, 4096)) {
+        h->err = "muxgl_fmx_greedy_init: thousands of near-tie decisions overruled by the exact path";
         e = hipErrorUnknown;
         break;
       }

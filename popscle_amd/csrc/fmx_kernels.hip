@@ -21,6 +21,7 @@
 
 #include "common.hpp"
 #include "demux_call_body.hpp"
+#include "score_exact.hpp"
 
 namespace {
 
@@ -840,6 +841,13 @@ int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
   if (e != hipSuccess) MUXGL_FAIL(h, "muxgl_fmx_prepare: %s", hipGetErrorString(e));
   collect_timing(h);
   tm.lap("fmx_prepare: entry kernels + scores D2H");
+  // the cells whose place in the reference's order hangs on the last bits of their score: the reference's own sums
+  h->fmx_exact_scores = 0;
+  if (cell_llk0 && cell_llk2 && !h->col) {
+    if (score_exact::settle(h, cell_llk0, cell_llk2, &h->fmx_exact_scores)) return 1;
+    if (tm.on) fprintf(stderr, "[muxgl] fmx_prepare: %lld cells' scores recomputed exactly\n", (long long)h->fmx_exact_scores);
+    tm.lap("fmx_prepare: near-tied scores in the reference's arithmetic");
+  }
 
   if (h->col) {  // slabbed: the SNP-major side lives in the column slab
     if (fmx_prepare_cols(h->col, af)) {
@@ -1223,6 +1231,12 @@ int muxgl_fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int
 int muxgl_fmx_exact_pending(const muxgl_handle* h, int64_t* cells) {
   if (!h || !cells) return 1;
   *cells = h->group ? 0 : h->fmx_listed;
+  return 0;
+}
+
+int muxgl_fmx_score_stats(const muxgl_handle* h, int64_t* exact_scores) {
+  if (!h) return 1;
+  if (exact_scores) *exact_scores = h->fmx_exact_scores;
   return 0;
 }
 

@@ -94,6 +94,7 @@ SYMBOLS = {
     "muxgl_fmx_get_entry_gls": (C.c_int, [_VP, _VP, _VP]),
     "muxgl_fmx_greedy_init": (C.c_int, [_VP, C.c_int32, _VP, C.c_double, C.c_double, _VP]),
     "muxgl_fmx_greedy_stats": (C.c_int, [_VP, _VP, _VP]),
+    "muxgl_fmx_score_stats": (C.c_int, [_VP, _VP]),
     "muxgl_fmx_set_clusters": (C.c_int, [_VP, C.c_int32, _VP]),
     "muxgl_fmx_iterate": (C.c_int, [_VP, C.POINTER(_FmxParams), _VP, _VP, _VP, _VP, _VP]),
     "muxgl_fmx_get_cluster_pileup": (C.c_int, [_VP, _VP, _VP]),
@@ -337,6 +338,12 @@ class Engine:
         self._check(self.lib.muxgl_fmx_greedy_init(self.h, int(K), _ptr(scores), float(frac_init_clust),
                                                     float(singlet_score_thres), _ptr(clust)))
         return clust
+
+    def fmx_score_stats(self):
+        """cells whose llk0 / llk2 the last fmx_prepare recomputed in the reference's arithmetic (near-tied scores)"""
+        a = C.c_int64()
+        self._check(self.lib.muxgl_fmx_score_stats(self.h, C.byref(a)))
+        return a.value
 
     def fmx_greedy_stats(self):
         """(near ties decided by the exact path, of those against the kernel's choice) of the last fmx_greedy_init"""
