@@ -556,8 +556,8 @@ __global__ void __launch_bounds__(256)
     fmx_mstep_kernel(int64_t S, int64_t s0, int64_t s1, int K, const int64_t* __restrict__ snp_ptr,
                      const int64_t* __restrict__ snp_entry,
                      const int32_t* __restrict__ entry_cell, const int32_t* __restrict__ clust,
-                     const double* __restrict__ egls, const int32_t* __restrict__ ecnt, double* __restrict__ cgls,
-                     int32_t* __restrict__ ccnt) {
+                     const double* __restrict__ egls, const double* __restrict__ segls6,
+                     const int32_t* __restrict__ ecnt, double* __restrict__ cgls, int32_t* __restrict__ ccnt) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (s1 - s0) * K) return;
   const int64_t s = s0 + tid / K;
@@ -570,7 +570,17 @@ __global__ void __launch_bounds__(256)
   for (int64_t p = snp_ptr[s]; p < p1; ++p) {
     const int64_t e = snp_entry[p];
     if (clust[entry_cell[e]] != k) continue;
-    const double* o = egls + (size_t)e * 9;
+    double o[9];
+    if (egls) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o[i] = egls[(size_t)e * 9 + i];
+    } else {  // a column slab keeps the SNP-major six-value copy only (fmx_prepare_cols): the matrix is symmetric
+      const double* a = segls6 + (size_t)p * 6;
+      o[0] = a[0], o[4] = a[1], o[8] = a[2];
+      o[1] = o[3] = a[3];
+      o[2] = o[6] = a[4];
+      o[5] = o[7] = a[5];
+    }
     const int32_t* oc = ecnt + (size_t)e * 3;
     nreads += oc[0];
     nref += oc[1];
@@ -676,8 +686,8 @@ static int fmx_mstep_launch(muxgl_handle* h) {
   }
   // beyond 64 clusters (no BASELINE shape), or under MUXGL_FLAG_FORCE_TILE_SWEEP: lane = (SNP, cluster), every chain on its own
   hipLaunchKernelGGL(fmx_mstep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->S, h->fs0, h->fs1,
-                     h->K, h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_ecnt, h->d_cgls,
-                     h->d_ccnt);
+                     h->K, h->d_snp_ptr, h->d_snp_entry, h->d_entry_cell, h->d_clust, h->d_egls, h->d_segls6, h->d_ecnt,
+                     h->d_cgls, h->d_ccnt);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -774,7 +784,7 @@ static int fmx_prepare_cols(muxgl_handle* h, const double* af) {
     HIPCHK(h, hipGetLastError());
   }
   if (fmx_build_snp_major(h, tm)) return 1;
-  if (!(h->flags & MUXGL_FLAG_FORCE_TILE_SWEEP)) dev_free(&h->d_egls);  // the plain M-step kernel gathers from it
+  dev_free(&h->d_egls);  // (both M-step kernels read the SNP-major six-value copy on a column slab)
   h->fmx_prepared = true;
   h->K = 0;
   h->fc0 = 0;

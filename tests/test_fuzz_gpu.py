@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import parity  # noqa: E402
 import ref_binding as rb  # noqa: E402
-from popscle_amd import muxgl, synth  # noqa: E402
+from popscle_amd import freemuxlet, muxgl, shard, synth  # noqa: E402
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not rb.available(), reason="oracle/_ref/libscdrop_ref.so not built")]
@@ -33,6 +33,12 @@ GRIDS = [(0.0, 0.5)] * 5 + [(0.0, 0.1, 0.2, 0.3, 0.4, 0.5)] * 2 + [(0.0, 0.25, 0
 DEMUX_V = [2, 3, 4, 5, 8, 12, 15, 16, 16, 16, 17, 24, 31, 32, 33, 40, 64, 65, 70]
 FMX_K = [2, 3, 4, 8, 15, 16, 16, 17, 24, 32, 33, 64, 65]
 FUZZ_SEEDS = list(range(12))
+# kernel families by flag (include/muxgl.h), drawn per case: the default dispatch most of the time
+DEMUX_FLAGS = [0] * 6 + [muxgl.FLAG_FORCE_ROW_KERNEL, muxgl.FLAG_FORCE_WAVE_KERNEL, muxgl.FLAG_FORCE_TILE_SWEEP,
+                         muxgl.FLAG_NO_LINEAR_ENTRIES, muxgl.FLAG_SPLIT_GENERAL_SWEEP,
+                         muxgl.FLAG_FORCE_ROW_KERNEL | muxgl.FLAG_NO_LINEAR_ENTRIES]
+FMX_FLAGS = [0] * 6 + [muxgl.FLAG_FORCE_ROW_KERNEL, muxgl.FLAG_FORCE_WAVE_KERNEL, muxgl.FLAG_NO_LINEAR_ENTRIES,
+                       muxgl.FLAG_NO_PIVOT_SUMS, muxgl.FLAG_FORCE_WAVE_KERNEL | muxgl.FLAG_NO_PIVOT_SUMS]
 
 
 def _shape(r, width, per_hyp):
@@ -73,16 +79,42 @@ def demux_case(seed):
         gp = 0.9 * g.astype(np.float64) + 0.1 * g.astype(np.float64).mean(axis=1, keepdims=True)
     p.gp = np.ascontiguousarray(gp)
     dp = float(r.choice([0.5, 0.5, 0.1, 0.9]))
-    return dict(kind="demux", seed=seed, V=V, alphas=alphas, C=C, S=S, ment=ment, mode=mode, dp=dp), p
+    flags = int(DEMUX_FLAGS[int(r.integers(len(DEMUX_FLAGS)))])
+    how = str(r.choice(["one", "one", "one", "group"]))   # group: a device group of two members on this GPU
+    return dict(kind="demux", seed=seed, V=V, alphas=alphas, C=C, S=S, ment=ment, mode=mode, dp=dp, flags=flags,
+                how=how), p
+
+
+def _engine(eng, info):
+    """the shared engine for the default dispatch on one device, else one made for the case (closed by the caller)"""
+    if info.get("how", "one") == "group":
+        return muxgl.Engine([0, 0], flags=info["flags"]), True
+    if info["flags"]:
+        return muxgl.Engine(0, flags=info["flags"]), True
+    return eng, False
 
 
 def run_demux(eng, info, p):
+    eng, own = _engine(eng, info)
+    try:
+        return _run_demux(eng, info, p)
+    finally:
+        if own:
+            eng.close()
+
+
+def _run_demux(eng, info, p):
     alphas, dp, V = info["alphas"], info["dp"], info["V"]
     want, _, want_ll = rb.RefScl.from_packed(p).demux(alphas, doublet_prior=dp, full_ll=True)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     eng.demux_set_gp(p.gp, p.has_gp)
     got = eng.demux_run(alphas, dp)                      # the product path (calls made next to the sweep)
     rep = parity.compare_demux(got, want, alphas, p, doublet_prior=dp)
+    if info.get("how", "one") == "group":
+        assert rep["max_abs_ll_diff"] < 1e-7, rep
+        st = rep["exact_pass"]
+        return dict(ll=rep["max_abs_ll_diff"], looked_at=int(st["cells"]), near=int(st["near_ties"]),
+                    deep=int(st["deep"]), changed=int(st["changed"]), raw_differing=rep["raw_records_differing"])
     got2, full = eng.demux_run(alphas, dp, want_full_ll=True)   # the tensor path
     rep2 = parity.compare_demux(got2, want, alphas, p, doublet_prior=dp)
     worst = parity.compare_full_ll(full, want_ll, V, alphas)
@@ -101,36 +133,115 @@ def fmx_case(seed):
                 False)
     dp = float(r.choice([0.5, 0.5, 0.1]))
     ge = float(r.choice([0.1, 0.1, 0.01]))
-    return dict(kind="fmx", seed=seed, K=K, C=C, S=S, ment=ment, dp=dp, ge=ge), p
+    flags = int(FMX_FLAGS[int(r.integers(len(FMX_FLAGS)))])
+    # one: muxgl_fmx_iterate on one handle; group: a device group of two members on this GPU; shard: the phases of a
+    # multi-rank run driven by hand, two or three handles as ranks, the exact path across them (freemuxlet.settle_near_ties)
+    how = str(r.choice(["one", "one", "one", "group", "shard"]))
+    return dict(kind="fmx", seed=seed, K=K, C=C, S=S, ment=ment, dp=dp, ge=ge, flags=flags, how=how,
+                world=int(r.choice([2, 3]))), p
+
+
+def _allgather(engs, which, ranges, row_bytes):
+    for owner, (b, e) in enumerate(ranges):
+        if e <= b:
+            continue
+        src, _ = engs[owner].fmx_buffer(which)
+        for r, other in enumerate(engs):
+            if r != owner:
+                dst, _ = other.fmx_buffer(which)
+                other.memcpy_dev(dst + b * row_bytes, src + b * row_bytes, (e - b) * row_bytes)
+
+
+def _check_iteration(it, ref, cells, st, K):
+    rep = parity.compare_fmx(cells, ref["cells"][it])
+    assert tuple(int(x) for x in st) == tuple(ref["counters"][it]), (it, st, ref["counters"][it])
+    return rep
+
+
+def _check_cplp(g, c, w, s0=None, s1=None):
+    sl = slice(s0, s1)
+    assert np.array_equal(c[:, sl], np.stack([w["nreads"], w["nref"], w["nalt"]], axis=-1)[:, sl])
+    assert np.allclose(g[:, sl], w["gls"][:, sl], rtol=1e-11, atol=1e-300)
 
 
 def run_fmx(eng, info, p):
-    K, dp, ge = info["K"], info["dp"], info["ge"]
+    K, dp, ge, how = info["K"], info["dp"], info["ge"], info.get("how", "one")
     ref = rb.RefScl.from_packed(p).freemux2(K, doublet_prior=dp, geno_error=ge, full_ll=True, cluster_pileups=True)
+    # the start on one device with the whole pileup (the greedy pass is sequential over all cells)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     llk0, llk2, ns, nr = eng.fmx_prepare(p.af)
     assert np.max(np.abs(llk0 - ref["llk0"])) < 1e-7 and np.max(np.abs(llk2 - ref["llk2"])) < 1e-7
     assert np.array_equal(ns, ref["nsnps"]) and np.array_equal(nr, ref["nreads"])
     clust = eng.fmx_greedy_init(K, llk2 - llk0)
     assert np.array_equal(clust, ref["clust0"]), ("greedy start", np.flatnonzero(clust != ref["clust0"])[:5])
-    eng.fmx_set_clusters(K, clust)
+    out = dict(iters=int(ref["n_iter"]), exact_scores=int(eng.fmx_score_stats()),
+               greedy_near=[int(x) for x in eng.fmx_greedy_stats()])
     worst, near = 0.0, 0
-    for it in range(ref["n_iter"]):
-        cells, st, full = eng.fmx_iterate(dp, ge, want_full_ll=True)
-        rep = parity.compare_fmx(cells, ref["cells"][it])
-        assert tuple(st) == tuple(ref["counters"][it]), (it, st, ref["counters"][it])
-        d = np.abs(full - ref["full_ll"][it])
-        d = d[np.isfinite(d)]
-        worst = max(worst, rep["max_abs_ll_diff"], float(d.max()) if d.size else 0.0)
-        near += rep["near_tie_cells"]
-        g, c = eng.fmx_cluster_pileup()
-        w = ref["cplp"][it]
-        assert np.array_equal(c, np.stack([w["nreads"], w["nref"], w["nalt"]], axis=-1)), it
-        assert np.allclose(g, w["gls"], rtol=1e-11, atol=1e-300), it
+    if how == "shard":
+        world = info["world"]
+        engs = [muxgl.Engine(0, flags=info["flags"]) for _ in range(world)]
+        try:
+            c_ranges = shard.cell_shards(p.cell_ptr, world)
+            s_ranges = shard.snp_shards(p.entry_snp, p.S, world)
+            for r, e in enumerate(engs):
+                e.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+                e.fmx_prepare(p.af)
+                e.fmx_set_shard(*c_ranges[r], *s_ranges[r])
+                e.fmx_set_clusters(K, clust)
+            for it in range(ref["n_iter"]):
+                for e in engs:
+                    e.fmx_iter_gp(dp, ge)
+                _allgather(engs, muxgl.BUF_CGP, s_ranges, K * 3 * 8)
+                for e in engs:
+                    e.fmx_iter_estep(dp, ge)
+                fetched = [e.fmx_iter_fetch() for e in engs]
+                if sum(e.fmx_exact_pending() for e in engs) > 0:
+                    freemuxlet.settle_near_ties(engs, lambda obj: [obj], dp, ge)
+                    fetched = [e.fmx_iter_fetch() for e in engs]
+                _allgather(engs, muxgl.BUF_CLUST, c_ranges, 4)
+                for e in engs:
+                    e.fmx_iter_mstep()
+                cells = np.zeros(p.C, dtype=muxgl.FMX_CELL)
+                stats = np.zeros(3, dtype=np.int64)
+                for r, (cs, st) in enumerate(fetched):
+                    b, en = c_ranges[r]
+                    cells[b:en] = cs[b:en]
+                    stats += np.array(st)
+                rep = _check_iteration(it, ref, cells, stats, K)
+                worst, near = max(worst, rep["max_abs_ll_diff"]), near + rep["near_tie_cells"]
+                for r, e in enumerate(engs):
+                    g, c = e.fmx_cluster_pileup()
+                    _check_cplp(g, c, ref["cplp"][it], *s_ranges[r])
+            out["exact"] = [int(sum(e.fmx_exact_stats()[k] for e in engs)) for k in range(3)]
+        finally:
+            for e in engs:
+                e.close()
+    else:
+        run, own = _engine(eng, info)
+        try:
+            if own:
+                run.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+                run.fmx_prepare(p.af)
+            run.fmx_set_clusters(K, clust)
+            for it in range(ref["n_iter"]):
+                if how == "group":
+                    cells, st = run.fmx_iterate(dp, ge)
+                else:
+                    cells, st, full = run.fmx_iterate(dp, ge, want_full_ll=True)
+                    d = np.abs(full - ref["full_ll"][it])
+                    d = d[np.isfinite(d)]
+                    worst = max(worst, float(d.max()) if d.size else 0.0)
+                rep = _check_iteration(it, ref, cells, st, K)
+                worst, near = max(worst, rep["max_abs_ll_diff"]), near + rep["near_tie_cells"]
+                g, c = run.fmx_cluster_pileup()
+                _check_cplp(g, c, ref["cplp"][it])
+            out["exact"] = [int(x) for x in run.fmx_exact_stats()]
+        finally:
+            if own:
+                run.close()
     assert worst < 1e-7, worst
-    ex = eng.fmx_exact_stats()
-    return dict(ll=worst, iters=int(ref["n_iter"]), near=near, exact=[int(x) for x in ex],
-                greedy_near=[int(x) for x in eng.fmx_greedy_stats()])
+    out.update(ll=worst, near=near)
+    return out
 
 
 def run_case(eng, kind, seed):
