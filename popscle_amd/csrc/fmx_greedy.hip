@@ -59,7 +59,7 @@ __device__ __forceinline__ bool greedy_near_tie(double bs, double ss, double eps
 __device__ __forceinline__ double greedy_score(double m2, int32_t e2, double m0, int32_t e0, double eps) {
   const double sc = prodacc_log(m2, e2) - prodacc_log(m0, e0);
   const bool empty = ldexp(m2, e2) == 1.0 && ldexp(m0, e0) == 1.0;
-  return (!empty && fabs(sc) <= eps) ? 1e-300 : sc;
+  return (!empty && fabs(sc) <= fmin(eps, 1e-6)) ? 1e-300 : sc;  // (tests raise eps to 1e300: flags, not scores, change)
 }
 
 constexpr double kMinNormGL = 1e-6;  // sc_drop_seq.h:14
@@ -1590,9 +1590,16 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
     //      decisions before the first flagged step are the reference's (their margins exceed what the arithmetic can
     //      differ by); the flagged step is decided in the reference's own arithmetic given those.  If that confirms the
     //      kernel's choice, everything behind it stands as well and the next flagged step is looked at; if not, the
-    //      choice is forced and the run repeated (the steps behind it saw another state).
+    //      choice is forced and the run repeated -- the steps behind it saw another state WHERE THEY SHARE A SNP with the
+    //      overruled cell, or with a cell that does, and so on: those steps ("touched", tracked as a set of SNPs) are left
+    //      to the repeated run, while an untouched step read none of the changed states, so its flag and the exact
+    //      path's decision for it hold in the repeated run as well and are pinned in the same pass.  A pileup of many
+    //      small droplets (sparse overlaps, many noise-level ties) therefore takes a few repeats, not one per overruled
+    //      step; a dense one, where everything behind an overruled step is touched, one per overruled step as before.
     std::vector<int32_t> forced(npad, -1);
     std::vector<uint8_t> near(npad, 0);
+    std::vector<int32_t> hsnp;     // host copy of entry_snp, fetched at the first overruled step
+    std::vector<uint64_t> touched; // one bit per SNP
     int reruns = 0;
     int64_t n_near = 0, n_overruled = 0;
     for (;;) {
@@ -1639,7 +1646,16 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       if (e != hipSuccess) break;
       tm.lap(use_batched ? "greedy_init: batches drained" : "greedy_init: serial kernel drained");
       bool overruled = false;
-      for (size_t i = 0; i < n && !overruled; ++i) {
+      for (size_t i = 0; i < n; ++i) {
+        if (overruled) {  // does the step read a state that the repeated run will find changed?
+          const int32_t* sn = hsnp.data() + he0[i];
+          bool hit = false;
+          for (int32_t k = 0; k < hlen[i] && !hit; ++k) hit = (touched[(size_t)sn[k] >> 6] >> (sn[k] & 63)) & 1u;
+          if (hit) {
+            for (int32_t k = 0; k < hlen[i]; ++k) touched[(size_t)sn[k] >> 6] |= (uint64_t)1 << (sn[k] & 63);
+            continue;
+          }
+        }
         if (!near[i] || forced[i] >= 0) continue;
         ++n_near;
         if (!d_step) {  // step index of every cell, once
@@ -1659,8 +1675,18 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
         }
         forced[i] = w;
         if (w != clust_out[hcell[i]]) {
-          overruled = true;
           ++n_overruled;
+          if (!overruled) {
+            overruled = true;
+            if (hsnp.empty() && h->nnz) {
+              hsnp.resize((size_t)h->nnz);
+              e = hipMemcpy(hsnp.data(), h->d_entry_snp, sizeof(int32_t) * (size_t)h->nnz, hipMemcpyDeviceToHost);
+              if (e != hipSuccess) break;
+            }
+            touched.assign((size_t)(S + 63) / 64, 0);
+          }
+          const int32_t* sn = hsnp.data() + he0[i];
+          for (int32_t k = 0; k < hlen[i]; ++k) touched[(size_t)sn[k] >> 6] |= (uint64_t)1 << (sn[k] & 63);
         }
       }
       if (e != hipSuccess || !overruled) break;
