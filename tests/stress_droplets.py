@@ -1,0 +1,85 @@
+"""A pileup as `freemuxlet` meets it when nobody filters barcodes: a few thousand cells among many droplets of one to a
+handful of reads.  The droplets' singlet scores are 0 +- rounding noise and many of their greedy / EM decisions are
+noise-level ties: the start's order, the greedy pass and every iteration must still be the reference's
+(oracle/_ref/libscdrop_ref.so), and the exact paths must not take over the run time.
+
+    python tests/stress_droplets.py [cells] [droplets] [K] [S]      (prints one JSON line)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import parity  # noqa: E402
+import ref_binding as rb  # noqa: E402
+from popscle_amd import muxgl, synth  # noqa: E402
+
+
+def mixed(cells, droplets, K, S, seed=77):
+    a = synth.make_pileup(cells, S, K, seed=seed, mean_entries=800, with_gp=False, donor_seed=seed)
+    b = synth.make_pileup(droplets, S, K, seed=seed + 1, mean_entries=2.5, sigma=0.9, min_entries=1, with_gp=False,
+                          donor_seed=seed, reads_lambda=0.1, other=0.01)
+    rng = np.random.default_rng(seed + 2)
+    order = rng.permutation(cells + droplets)          # droplets and cells interleaved, as barcodes sort
+    lens = np.concatenate([np.diff(a.cell_ptr), np.diff(b.cell_ptr)])[order]
+    starts = np.concatenate([a.cell_ptr[:-1], b.cell_ptr[:-1] + a.nnz])[order]
+    esnp = np.concatenate([a.entry_snp, b.entry_snp])
+    nre = np.concatenate([np.diff(a.entry_rptr), np.diff(b.entry_rptr)])
+    rstart = np.concatenate([a.entry_rptr[:-1], b.entry_rptr[:-1] + a.R])
+    reads = np.concatenate([a.reads, b.reads])
+    eidx = synth._ranges(starts, lens)
+    cell_ptr = np.zeros(order.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=cell_ptr[1:])
+    rl = nre[eidx]
+    entry_rptr = np.zeros(eidx.size + 1, dtype=np.int64)
+    np.cumsum(rl, out=entry_rptr[1:])
+    ridx = synth._ranges(rstart[eidx], rl)
+    return synth.Pileup(order.size, S, cell_ptr, esnp[eidx].astype(np.int32), entry_rptr, reads[ridx], a.af)
+
+
+def main(argv):
+    cells, droplets, K, S = (int(x) for x in (argv + ["3000", "30000", "8", "30000"][len(argv):]))
+    p = mixed(cells, droplets, K, S)
+    out = dict(cells=cells, droplets=droplets, K=K, S=S, nnz=int(p.nnz))
+    t = time.time()
+    ref = rb.RefScl.from_packed(p).freemux2(K)
+    out["reference_s"] = round(time.time() - t, 2)
+    eng = muxgl.Engine(0)
+    t0 = time.time()
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    t = time.time()
+    llk0, llk2, ns, nr = eng.fmx_prepare(p.af)
+    out["prepare_s"] = round(time.time() - t, 3)
+    out["exact_scores"] = int(eng.fmx_score_stats())
+    t = time.time()
+    clust = eng.fmx_greedy_init(K, llk2 - llk0)
+    out["greedy_s"] = round(time.time() - t, 3)
+    out["greedy_near_overruled"] = [int(x) for x in eng.fmx_greedy_stats()]
+    out["greedy_cells_differing"] = int((clust != ref["clust0"]).sum())
+    eng.fmx_set_clusters(K, clust)
+    t = time.time()
+    bad = 0
+    for it in range(ref["n_iter"]):
+        cellsr, st = eng.fmx_iterate(0.5, 0.1)
+        try:
+            parity.compare_fmx(cellsr, ref["cells"][it])
+            assert tuple(st) == tuple(ref["counters"][it]), (st, ref["counters"][it])
+        except AssertionError as ex:
+            bad += 1
+            out.setdefault("first_error", f"iteration {it}: {str(ex)[:300]}")
+    out["em_s"] = round(time.time() - t, 3)
+    out["iterations"] = int(ref["n_iter"])
+    out["iterations_differing"] = bad
+    out["em_exact"] = [int(x) for x in eng.fmx_exact_stats()]
+    out["device_total_s"] = round(time.time() - t0, 3)
+    print(json.dumps(out), flush=True)
+    return 1 if (bad or out["greedy_cells_differing"]) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -268,6 +268,14 @@ def test_freemuxlet_fuzz(eng, seed):
     run_case(eng, "fmx", seed)
 
 
+def test_unfiltered_droplets_among_cells():
+    """a few hundred cells among thousands of droplets of one to a handful of reads (tests/stress_droplets.py): scores of
+    0 +- rounding noise, noise-level ties in the greedy pass and in every iteration -- all of it the reference's"""
+    import stress_droplets
+
+    assert stress_droplets.main(["300", "3000", "8", "30000"]) == 0
+
+
 def main(argv):
     import argparse
     import traceback
