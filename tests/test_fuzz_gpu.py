@@ -30,8 +30,8 @@ pytestmark = [pytest.mark.gpu,
 
 GRIDS = [(0.0, 0.5)] * 5 + [(0.0, 0.1, 0.2, 0.3, 0.4, 0.5)] * 2 + [(0.0, 0.25, 0.5), (0.0, 0.1, 0.3), (0.0, 0.5, 0.2),
                                                                    (0.0,), (0.0, 0.3)]
-DEMUX_V = [2, 3, 4, 5, 8, 12, 15, 16, 16, 16, 17, 24, 31, 32, 33, 40, 64, 65, 70]
-FMX_K = [2, 3, 4, 8, 15, 16, 16, 17, 24, 32, 33, 64, 65]
+DEMUX_V = [1, 2, 3, 4, 5, 8, 12, 15, 16, 16, 16, 17, 24, 31, 32, 33, 40, 64, 65, 70, 96, 130, 255]
+FMX_K = [2, 3, 4, 8, 15, 16, 16, 17, 24, 32, 33, 64, 65, 100, 130, 255]
 FUZZ_SEEDS = list(range(12))
 # kernel families by flag (include/muxgl.h), drawn per case: the default dispatch most of the time
 DEMUX_FLAGS = [0] * 6 + [muxgl.FLAG_FORCE_ROW_KERNEL, muxgl.FLAG_FORCE_WAVE_KERNEL, muxgl.FLAG_FORCE_TILE_SWEEP,
@@ -44,9 +44,11 @@ FMX_FLAGS = [0] * 6 + [muxgl.FLAG_FORCE_ROW_KERNEL, muxgl.FLAG_FORCE_WAVE_KERNEL
 def _shape(r, width, per_hyp):
     """(C, S, mean entries, min entries, sigma): tiny cells more often than not; C bounded by the reference's run time"""
     ment = float(r.choice([1.5, 3, 8, 30, 120, 400], p=[0.2, 0.2, 0.2, 0.15, 0.15, 0.1]))
+    if width > 80:   # (the widest shapes: the reference's time goes with the square of the width)
+        ment = min(ment, 8.0)
     S = int(max(40, ment * float(r.choice([2, 8, 40]))))
     budget = 2.5e8
-    C = int(np.clip(budget / (max(ment, 4) * per_hyp), max(8, 2 * width), 600))
+    C = int(np.clip(budget / (max(ment, 4) * per_hyp), max(8, 2 * width if width <= 80 else 60), 600))
     return C, S, ment, int(r.choice([0, 1, 2])), float(r.choice([0.3, 0.8, 1.3]))
 
 
@@ -65,7 +67,7 @@ def demux_case(seed):
     alphas = GRIDS[int(r.integers(len(GRIDS)))]
     C, S, ment, mine, sigma = _shape(r, V, V * V * len(alphas) * 9)
     p = _pileup(r, 3000 + seed, C, S, V, ment, mine, sigma, True)
-    mode = str(r.choice(["gt", "gt", "dup", "all_same", "float_rows"]))
+    mode = str(r.choice(["gt", "gt", "dup", "all_same", "float_rows", "hard"]))
     gp = p.gp
     if mode == "dup" and V > 1:       # some samples are copies of others: exact ties between hypotheses
         for _ in range(max(1, V // 3)):
@@ -73,6 +75,8 @@ def demux_case(seed):
             gp[:, a, :] = gp[:, b, :]
     elif mode == "all_same":          # every sample the same: every singlet ties, every pair ties
         gp[:, :, :] = gp[:, :1, :]
+    elif mode == "hard":              # hard calls with almost no error mixed in: factors down to 1e-6 x 1e-10
+        gp = synth.gt_to_gp(p.truth["G"].astype(np.int64), 1e-6)
     elif mode == "float_rows":        # rows as --field GP leaves them: normalised in float, sums off one by ~1e-8
         g = r.dirichlet([0.3, 0.3, 0.3], size=(p.S, V)).astype(np.float32) + np.float32(1e-4)
         g = g / g.sum(axis=2, keepdims=True, dtype=np.float32)
@@ -128,9 +132,8 @@ def fmx_case(seed):
     r = np.random.default_rng([seed, 78])
     K = int(r.choice(FMX_K))
     C, S, ment, mine, sigma = _shape(r, 2 * K, K * K * 9 * 6)
-    C = max(C, 3 * K)
-    p = _pileup(r, 5000 + seed, C, S, max(2, int(r.choice([K, max(2, K // 2), K + 1]))), ment, max(mine, 1), sigma,
-                False)
+    C = max(C, 3 * K) if K <= 70 else K + 20   # (beyond 70 clusters the reference takes seconds per hundred cells)
+    p = _pileup(r, 5000 + seed, C, S, max(2, int(r.choice([K, max(2, K // 2), K + 1]))), ment, mine, sigma, False)
     dp = float(r.choice([0.5, 0.5, 0.1]))
     ge = float(r.choice([0.1, 0.1, 0.01]))
     flags = int(FMX_FLAGS[int(r.integers(len(FMX_FLAGS)))])
