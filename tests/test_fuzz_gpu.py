@@ -140,8 +140,16 @@ def fmx_case(seed):
     # one: muxgl_fmx_iterate on one handle; group: a device group of two members on this GPU; shard: the phases of a
     # multi-rank run driven by hand, two or three handles as ranks, the exact path across them (freemuxlet.settle_near_ties)
     how = str(r.choice(["one", "one", "one", "group", "shard"]))
+    # the start: the greedy pass over every cell; over a fraction of them / above a score threshold (the others start
+    # without a cluster); or clusters handed in (--init-cluster), some cells without one
+    start = str(r.choice(["greedy", "greedy", "greedy", "partial", "given"]))
+    frac = float(r.choice([0.3, 0.8])) if start == "partial" else 1.0
+    thres = float(r.choice([-1e300, -0.5, 0.0])) if start == "partial" else -1e300
+    init = None
+    if start == "given":
+        init = r.integers(-1 if r.random() < 0.7 else 0, K, size=p.C).astype(np.int32)
     return dict(kind="fmx", seed=seed, K=K, C=C, S=S, ment=ment, dp=dp, ge=ge, flags=flags, how=how,
-                world=int(r.choice([2, 3]))), p
+                world=int(r.choice([2, 3])), start=start, frac=frac, thres=thres, init=init), p
 
 
 def _allgather(engs, which, ranges, row_bytes):
@@ -169,14 +177,20 @@ def _check_cplp(g, c, w, s0=None, s1=None):
 
 def run_fmx(eng, info, p):
     K, dp, ge, how = info["K"], info["dp"], info["ge"], info.get("how", "one")
-    ref = rb.RefScl.from_packed(p).freemux2(K, doublet_prior=dp, geno_error=ge, full_ll=True, cluster_pileups=True)
+    init = info.get("init")
+    ref = rb.RefScl.from_packed(p).freemux2(K, doublet_prior=dp, geno_error=ge, frac_init_clust=info.get("frac", 1.0),
+                                            singlet_score_thres=info.get("thres", -1e300), init_clust=init, full_ll=True,
+                                            cluster_pileups=True)
     # the start on one device with the whole pileup (the greedy pass is sequential over all cells)
     eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
     llk0, llk2, ns, nr = eng.fmx_prepare(p.af)
     assert np.max(np.abs(llk0 - ref["llk0"])) < 1e-7 and np.max(np.abs(llk2 - ref["llk2"])) < 1e-7
     assert np.array_equal(ns, ref["nsnps"]) and np.array_equal(nr, ref["nreads"])
-    clust = eng.fmx_greedy_init(K, llk2 - llk0)
-    assert np.array_equal(clust, ref["clust0"]), ("greedy start", np.flatnonzero(clust != ref["clust0"])[:5])
+    if init is None:
+        clust = eng.fmx_greedy_init(K, llk2 - llk0, info.get("frac", 1.0), info.get("thres", -1e300))
+        assert np.array_equal(clust, ref["clust0"]), ("greedy start", np.flatnonzero(clust != ref["clust0"])[:5])
+    else:
+        clust = init
     out = dict(iters=int(ref["n_iter"]), exact_scores=int(eng.fmx_score_stats()),
                greedy_near=[int(x) for x in eng.fmx_greedy_stats()])
     worst, near = 0.0, 0
@@ -251,6 +265,7 @@ def run_case(eng, kind, seed):
     info, p = (demux_case if kind == "demux" else fmx_case)(seed)
     info["nnz"] = int(p.nnz)
     info.update((run_demux if kind == "demux" else run_fmx)(eng, info, p))
+    info.pop("init", None)
     return info
 
 
@@ -304,6 +319,7 @@ def main(argv):
                 rec["ok"] = True
             except Exception as ex:  # noqa: BLE001  (a campaign reports and goes on or stops, as asked)
                 info, _ = (demux_case if kind == "demux" else fmx_case)(seed)
+                info.pop("init", None)
                 rec = dict(info, ok=False, error=f"{type(ex).__name__}: {str(ex)[:600]}",
                            where=traceback.format_exc().strip().splitlines()[-3:])
                 fails += 1
