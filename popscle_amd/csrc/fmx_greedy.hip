@@ -1410,6 +1410,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   uint8_t* d_near = nullptr;    // [npad] by step: near tie (greedy_near_tie)
   int32_t* d_forced = nullptr;  // [npad] by step: cluster decided by the exact path, or -1
   int32_t* d_step = nullptr;    // [C] step index of a cell (exact path, on first use)
+  greedy_exact::by_step d_bystep;  // the SNP-major view in (SNP, step) order (exact path, on first use)
   bool use_batched = batched;
   int wgs = 0;
   double tie_eps = 1e-9;
@@ -1665,8 +1666,9 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
           if (dev_alloc(h, &d_step, (size_t)C)) { e = hipErrorOutOfMemory; break; }
           e = hipMemcpy(d_step, step.data(), sizeof(int32_t) * (size_t)C, hipMemcpyHostToDevice);
           if (e != hipSuccess) break;
+          if (greedy_exact::build_by_step(h, d_step, &d_bystep)) { e = hipErrorUnknown; break; }
         }
-        const int w = greedy_exact::decide(h, he0[i], hlen[i], (int)K, (int32_t)i, d_step, d_clust, exact_scores.data());
+        const int w = greedy_exact::decide(h, he0[i], hlen[i], (int)K, (int32_t)i, d_bystep, d_clust, exact_scores.data());
         if (w < 0) { e = hipErrorUnknown; break; }
         if (dump) {
           const int64_t st = (int64_t)i;
@@ -1740,6 +1742,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_near);
   dev_free(&d_forced);
   dev_free(&d_step);
+  greedy_exact::release(&d_bystep);
   dev_free(&d_clust);
   dev_free(&d_diag);
   dev_free(&d_offd);

@@ -18,13 +18,16 @@
 // the reference's argmax (strict '>' from cluster 0, cmd_cram_freemux2.cpp:233-242).  No tolerance is involved: the
 // result is the reference's decision given the earlier ones.
 //
-// A thread = one (entry of the cell, cluster).  The SNP's other entries come from the SNP-major view (ascending cell id);
-// the chain needs them in processing order, so the thread repeatedly picks the member with the smallest step index
-// above the last one (lists are a few hundred long and this path runs for a handful of cells per run, if any).
+// A thread = one (entry of the cell, cluster).  The chain needs the SNP's other entries in PROCESSING order, while the
+// SNP-major view lists them by cell id: the view is therefore sorted once per run by (SNP, step index) -- by_step, built at
+// the first near tie of a muxgl_fmx_greedy_init call (one radix sort of the pileup's entries) -- and a thread walks its
+// SNP's stretch up to the current step: one pass over the list instead of a rescan per chain link.
 #pragma once
 #include <math.h>
 
 #include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.hpp"
 #include "exact_arith.hpp"
@@ -34,12 +37,72 @@ namespace greedy_exact {
 using exact_arith::entry_pileup;
 using exact_arith::merge;
 
+// the SNP-major view in (SNP, step) order: key = SNP << 32 | step index of the entry's cell (0x7fffffff: not clustered),
+// pos = the entry's position in the SNP-major arrays (snp_entry / snp_cell); SNP s owns [snp_ptr[s], snp_ptr[s + 1]) here
+// as there
+struct by_step {
+  uint64_t* key = nullptr;
+  int64_t* pos = nullptr;
+};
+
+__global__ void __launch_bounds__(256)
+    by_step_keys_kernel(int64_t nnz, const int64_t* __restrict__ snp_entry, const int32_t* __restrict__ snp_cell,
+                        const int32_t* __restrict__ entry_snp, const int32_t* __restrict__ step_of_cell,
+                        uint64_t* __restrict__ key, int64_t* __restrict__ pos) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+    key[p] = ((uint64_t)(uint32_t)entry_snp[snp_entry[p]] << 32) | (uint32_t)step_of_cell[snp_cell[p]];
+    pos[p] = p;
+  }
+}
+
+inline void release(by_step* b) {
+  dev_free(&b->key);
+  dev_free(&b->pos);
+}
+
+// d_step_of_cell[C] as for decide().  0, or 1 with h->err set.
+inline int build_by_step(muxgl_handle* h, const int32_t* d_step_of_cell, by_step* b) {
+  const int64_t nnz = h->nnz;
+  release(b);
+  if (nnz == 0) return 0;
+  uint64_t* key_in = nullptr;
+  int64_t* pos_in = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  hipError_t e = hipSuccess;
+  int rc = dev_alloc(h, &key_in, (size_t)nnz) || dev_alloc(h, &pos_in, (size_t)nnz) || dev_alloc(h, &b->key, (size_t)nnz) ||
+           dev_alloc(h, &b->pos, (size_t)nnz);
+  if (!rc) {
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(by_step_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, nnz, h->d_snp_entry, h->d_snp_cell,
+                       h->d_entry_snp, d_step_of_cell, key_in, pos_in);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+      e = rocprim::radix_sort_pairs(nullptr, tb, key_in, b->key, pos_in, b->pos, (size_t)nnz, 0u, 64u, h->stream);
+    if (e == hipSuccess) e = dev_malloc_retry(&tmp, tb ? tb : 1);
+    if (e == hipSuccess)
+      e = rocprim::radix_sort_pairs(tmp, tb, key_in, b->key, pos_in, b->pos, (size_t)nnz, 0u, 64u, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  if (tmp) (void)hipFree(tmp);
+  dev_free(&key_in);
+  dev_free(&pos_in);
+  if (rc || e != hipSuccess) {
+    release(b);
+    if (h->err.empty()) h->err = std::string("muxgl_fmx_greedy_init (exact path, members by step): ") +
+                                 (rc ? "device allocation failed" : hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
 // out[(t * K + c) * 2] = {lk2, lk0} of entry e0 + t against cluster c; lk2 = -1 marks "the cluster does not hold the SNP"
 __global__ void __launch_bounds__(256)
     terms_kernel(int64_t e0, int L, int K, int32_t step, const int32_t* __restrict__ entry_snp,
                  const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads, const double* __restrict__ lut,
                  const double* __restrict__ af, const int64_t* __restrict__ snp_ptr, const int64_t* __restrict__ snp_entry,
-                 const int32_t* __restrict__ snp_cell, const int32_t* __restrict__ step_of_cell,
+                 const int32_t* __restrict__ snp_cell, const uint64_t* __restrict__ bs_key, const int64_t* __restrict__ bs_pos,
                  const int32_t* __restrict__ clust, double* __restrict__ out) {
 #pragma clang fp contract(off)
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,25 +113,16 @@ __global__ void __launch_bounds__(256)
   double gljs[9];
   for (int i = 0; i < 9; ++i) gljs[i] = 1.0;  // snp_droplet_pileup() (sc_drop_seq.h:72-75)
   bool present = false;
-  int32_t last = -1;
-  const int64_t p0 = snp_ptr[snp], p1 = snp_ptr[snp + 1];
-  for (;;) {  // members in processing order: the smallest step index above `last`
-    int32_t nxt = 0x7fffffff;
-    int64_t pe = -1;
-    for (int64_t p = p0; p < p1; ++p) {
-      const int32_t cell = snp_cell[p];
-      const int32_t st = step_of_cell[cell];
-      if (st > last && st < step && st < nxt && clust[cell] == c) {
-        nxt = st;
-        pe = snp_entry[p];
-      }
-    }
-    if (pe < 0) break;
+  const int64_t p1 = snp_ptr[snp + 1];
+  for (int64_t q = snp_ptr[snp]; q < p1; ++q) {  // members in processing order, up to the current step
+    if ((uint32_t)bs_key[q] >= (uint32_t)step) break;
+    const int64_t p = bs_pos[q];
+    if (clust[snp_cell[p]] != c) continue;
+    const int64_t pe = snp_entry[p];
     double o[9];
     entry_pileup(reads, entry_rptr[pe], entry_rptr[pe + 1], lut, o);
     merge(gljs, o);
     present = true;
-    last = nxt;
   }
   double lk2 = -1.0, lk0 = -1.0;
   if (present) {
@@ -91,17 +145,18 @@ __global__ void __launch_bounds__(256)
 }
 
 // The reference's decision for step `step` (cell with entries [e0, e0 + L)) given the decisions of the earlier steps in
-// d_clust.  d_step_of_cell[C]: step index of a cell in the processing order, or a value >= the number of steps for cells
-// that are not clustered.  scores_out: NULL or [K] (llk2 - llk0 per cluster).  Returns the cluster, or -1 on a HIP error.
-inline int decide(muxgl_handle* h, int64_t e0, int L, int K, int32_t step, const int32_t* d_step_of_cell,
-                  const int32_t* d_clust, double* scores_out) {
+// d_clust.  bs: build_by_step() of the run's step indices (a cell's index in the processing order, or a value >= the
+// number of steps for cells that are not clustered).  scores_out: NULL or [K] (llk2 - llk0 per cluster).  Returns the
+// cluster, or -1 on a HIP error.
+inline int decide(muxgl_handle* h, int64_t e0, int L, int K, int32_t step, const by_step& bs, const int32_t* d_clust,
+                  double* scores_out) {
   if (L == 0) return 0;  // every distance is a sum over nothing: maxClust = 0 (:232-233)
   double* d_out = nullptr;
   if (dev_alloc(h, &d_out, (size_t)L * K * 2)) return -1;
   const int64_t n = (int64_t)L * K;
   hipLaunchKernelGGL(terms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, e0, L, K, step,
                      h->d_entry_snp, h->d_entry_rptr, h->d_reads, h->d_lut, h->d_af, h->d_snp_ptr, h->d_snp_entry,
-                     h->d_snp_cell, d_step_of_cell, d_clust, d_out);
+                     h->d_snp_cell, bs.key, bs.pos, d_clust, d_out);
   std::vector<double> out((size_t)n * 2);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream);

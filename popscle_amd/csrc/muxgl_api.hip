@@ -27,9 +27,19 @@ int dev_alloc_bytes(muxgl_handle* h, void** p, size_t bytes) {
       }
     }
     if (hit) {
-      // whatever still reads or writes the block was enqueued on this handle's stream (or has completed): drain it, as
-      // the hipFree this replaces would have drained the device
-      if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+      // whatever still reads or writes the block was enqueued on this handle's stream (or has completed) -- a handle's
+      // blocks are only ever touched by work on its own stream; exchanges between the members of a device group are
+      // ordered against it by events before the phase returns (muxgl_group.hip) -- so draining that stream is what the
+      // hipFree this replaces did for the block
+      const hipError_t e = h->stream ? hipStreamSynchronize(h->stream) : hipSuccess;
+      if (e != hipSuccess) {  // the block is still registered to this handle: give it back to the driver, do not lose it
+        {
+          std::lock_guard<std::mutex> g(R.mu);
+          R.blocks.erase(hit);
+        }
+        (void)hipFree(hit);
+        MUXGL_FAIL(h, "hipStreamSynchronize before reusing a cached block: %s", hipGetErrorString(e));
+      }
       *p = hit;
       return 0;
     }
