@@ -1419,7 +1419,6 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   if (const char* ev = getenv("MUXGL_GREEDY_TEST_MISDECIDE")) misdecide = atoll(ev);
   FILE* dump = nullptr;    // (tests: the exact path's scores of every step it decides, as {int64 step, double[K]} records)
   if (const char* ev = getenv("MUXGL_GREEDY_DUMP_SCORES")) dump = fopen(ev, "wb");
-  std::vector<double> exact_scores((size_t)K);
   h->greedy_near_ties = h->greedy_overruled = 0;
   do {
     if (dev_alloc(h, &d_he0, npad) || dev_alloc(h, &d_hlen, npad) || dev_alloc(h, &d_hcell, npad)) break;
@@ -1646,8 +1645,35 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
       }
       if (e != hipSuccess) break;
       tm.lap(use_batched ? "greedy_init: batches drained" : "greedy_init: serial kernel drained");
+      // the flagged steps of this run that are not pinned yet, decided together (each against the run's decisions before it)
+      std::vector<greedy_exact::step_req> rq;
+      std::vector<size_t> rq_step;
+      for (size_t i = 0; i < n; ++i)
+        if (near[i] && forced[i] < 0) {
+          rq.push_back(greedy_exact::step_req{he0[i], 0, hlen[i], (int32_t)i});
+          rq_step.push_back(i);
+        }
+      std::vector<int32_t> win;
+      std::vector<double> exact_scores;
+      if (!rq.empty()) {
+        if (!d_step) {  // step index of every cell and the SNP-major view in (SNP, step) order, once
+          if (!h->d_snp_ptr && plan_build_snp_major(h)) { e = hipErrorUnknown; break; }
+          std::vector<int32_t> step((size_t)C, 0x7fffffff);
+          for (size_t k = 0; k < n; ++k) step[(size_t)todo[k]] = (int32_t)k;
+          if (dev_alloc(h, &d_step, (size_t)C)) { e = hipErrorOutOfMemory; break; }
+          e = hipMemcpy(d_step, step.data(), sizeof(int32_t) * (size_t)C, hipMemcpyHostToDevice);
+          if (e != hipSuccess) break;
+          if (greedy_exact::build_by_step(h, d_step, &d_bystep)) { e = hipErrorUnknown; break; }
+        }
+        if (greedy_exact::decide_many(h, rq, (int)K, d_bystep, d_clust, win, exact_scores)) { e = hipErrorUnknown; break; }
+      }
+      tm.lap("greedy_init: near-tie steps in the reference's arithmetic");
       bool overruled = false;
+      size_t r = 0;  // next request
       for (size_t i = 0; i < n; ++i) {
+        const bool flagged = r < rq_step.size() && rq_step[r] == i;
+        const size_t ri = r;
+        if (flagged) ++r;
         if (overruled) {  // does the step read a state that the repeated run will find changed?
           const int32_t* sn = hsnp.data() + he0[i];
           bool hit = false;
@@ -1657,23 +1683,13 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
             continue;
           }
         }
-        if (!near[i] || forced[i] >= 0) continue;
+        if (!flagged) continue;
         ++n_near;
-        if (!d_step) {  // step index of every cell, once
-          if (!h->d_snp_ptr && plan_build_snp_major(h)) { e = hipErrorUnknown; break; }
-          std::vector<int32_t> step((size_t)C, 0x7fffffff);
-          for (size_t k = 0; k < n; ++k) step[(size_t)todo[k]] = (int32_t)k;
-          if (dev_alloc(h, &d_step, (size_t)C)) { e = hipErrorOutOfMemory; break; }
-          e = hipMemcpy(d_step, step.data(), sizeof(int32_t) * (size_t)C, hipMemcpyHostToDevice);
-          if (e != hipSuccess) break;
-          if (greedy_exact::build_by_step(h, d_step, &d_bystep)) { e = hipErrorUnknown; break; }
-        }
-        const int w = greedy_exact::decide(h, he0[i], hlen[i], (int)K, (int32_t)i, d_bystep, d_clust, exact_scores.data());
-        if (w < 0) { e = hipErrorUnknown; break; }
+        const int w = win[ri];
         if (dump) {
           const int64_t st = (int64_t)i;
           fwrite(&st, sizeof(st), 1, dump);
-          fwrite(exact_scores.data(), sizeof(double), (size_t)K, dump);
+          fwrite(exact_scores.data() + ri * (size_t)K, sizeof(double), (size_t)K, dump);
         }
         forced[i] = w;
         if (w != clust_out[hcell[i]]) {

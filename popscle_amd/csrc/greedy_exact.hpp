@@ -18,7 +18,7 @@
 // the reference's argmax (strict '>' from cluster 0, cmd_cram_freemux2.cpp:233-242).  No tolerance is involved: the
 // result is the reference's decision given the earlier ones.
 //
-// A thread = one (entry of the cell, cluster).  The chain needs the SNP's other entries in PROCESSING order, while the
+// A thread = one (entry of a flagged cell, cluster); all flagged steps of a pass share launches.  The chain needs the SNP's other entries in PROCESSING order, while the
 // SNP-major view lists them by cell id: the view is therefore sorted once per run by (SNP, step index) -- by_step, built at
 // the first near tie of a muxgl_fmx_greedy_init call (one radix sort of the pileup's entries) -- and a thread walks its
 // SNP's stretch up to the current step: one pass over the list instead of a rescan per chain link.
@@ -97,25 +97,37 @@ inline int build_by_step(muxgl_handle* h, const int32_t* d_step_of_cell, by_step
   return 0;
 }
 
-// out[(t * K + c) * 2] = {lk2, lk0} of entry e0 + t against cluster c; lk2 = -1 marks "the cluster does not hold the SNP"
+// One request = one step of the processing order: the cell's entries [e0, e0 + L), its step index, and where its
+// L x K pairs of terms go.
+struct step_req {
+  int64_t e0;
+  int64_t off;  // first (t, c) slot of the request in the launch's output
+  int32_t L;
+  int32_t step;
+};
+
+// out[(off + t * K + c) * 2] = {lk2, lk0} of entry e0 + t against cluster c; lk2 = -1 marks "the cluster does not hold the
+// SNP".  Workgroup b works on request blk_req[b], threads blk_first[b] ... of its L x K.
 __global__ void __launch_bounds__(256)
-    terms_kernel(int64_t e0, int L, int K, int32_t step, const int32_t* __restrict__ entry_snp,
-                 const int64_t* __restrict__ entry_rptr, const uint8_t* __restrict__ reads, const double* __restrict__ lut,
-                 const double* __restrict__ af, const int64_t* __restrict__ snp_ptr, const int64_t* __restrict__ snp_entry,
+    terms_kernel(const step_req* __restrict__ req, const int32_t* __restrict__ blk_req, const int32_t* __restrict__ blk_first,
+                 int K, const int32_t* __restrict__ entry_snp, const int64_t* __restrict__ entry_rptr,
+                 const uint8_t* __restrict__ reads, const double* __restrict__ lut, const double* __restrict__ af,
+                 const int64_t* __restrict__ snp_ptr, const int64_t* __restrict__ snp_entry,
                  const int32_t* __restrict__ snp_cell, const uint64_t* __restrict__ bs_key, const int64_t* __restrict__ bs_pos,
                  const int32_t* __restrict__ clust, double* __restrict__ out) {
 #pragma clang fp contract(off)
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (int64_t)L * K) return;
+  const step_req r = req[blk_req[blockIdx.x]];
+  const int64_t tid = (int64_t)blk_first[blockIdx.x] + threadIdx.x;
+  if (tid >= (int64_t)r.L * K) return;
   const int t = (int)(tid / K), c = (int)(tid % K);
-  const int64_t e = e0 + t;
+  const int64_t e = r.e0 + t;
   const int32_t snp = entry_snp[e];
   double gljs[9];
   for (int i = 0; i < 9; ++i) gljs[i] = 1.0;  // snp_droplet_pileup() (sc_drop_seq.h:72-75)
   bool present = false;
   const int64_t p1 = snp_ptr[snp + 1];
   for (int64_t q = snp_ptr[snp]; q < p1; ++q) {  // members in processing order, up to the current step
-    if ((uint32_t)bs_key[q] >= (uint32_t)step) break;
+    if ((uint32_t)bs_key[q] >= (uint32_t)r.step) break;
     const int64_t p = bs_pos[q];
     if (clust[snp_cell[p]] != c) continue;
     const int64_t pe = snp_entry[p];
@@ -140,49 +152,92 @@ __global__ void __launch_bounds__(256)
       for (int gj = 0; gj < 3; ++gj) lk0 += (glis[gi * 3 + gi] * gljs[gj * 3 + gj] * gps[gi] * gps[gj]);
     }
   }
-  out[tid * 2] = lk2;
-  out[tid * 2 + 1] = lk0;
+  out[(r.off + tid) * 2] = lk2;
+  out[(r.off + tid) * 2 + 1] = lk0;
 }
 
-// The reference's decision for step `step` (cell with entries [e0, e0 + L)) given the decisions of the earlier steps in
-// d_clust.  bs: build_by_step() of the run's step indices (a cell's index in the processing order, or a value >= the
-// number of steps for cells that are not clustered).  scores_out: NULL or [K] (llk2 - llk0 per cluster).  Returns the
-// cluster, or -1 on a HIP error.
-inline int decide(muxgl_handle* h, int64_t e0, int L, int K, int32_t step, const by_step& bs, const int32_t* d_clust,
-                  double* scores_out) {
-  if (L == 0) return 0;  // every distance is a sum over nothing: maxClust = 0 (:232-233)
-  double* d_out = nullptr;
-  if (dev_alloc(h, &d_out, (size_t)L * K * 2)) return -1;
-  const int64_t n = (int64_t)L * K;
-  hipLaunchKernelGGL(terms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, e0, L, K, step,
-                     h->d_entry_snp, h->d_entry_rptr, h->d_reads, h->d_lut, h->d_af, h->d_snp_ptr, h->d_snp_entry,
-                     h->d_snp_cell, bs.key, bs.pos, d_clust, d_out);
-  std::vector<double> out((size_t)n * 2);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  dev_free(&d_out);
-  if (e != hipSuccess) return -1;
-  int maxClust = 0;
-  double maxScore = 0;
-  for (int c = 0; c < K; ++c) {
-    double llk2 = 0, llk0 = 0;  // dropD (sc_drop_seq.h:45-52)
-    for (int t = 0; t < L; ++t) {
-      const double lk2 = out[((size_t)t * K + c) * 2], lk0 = out[((size_t)t * K + c) * 2 + 1];
-      if (lk2 < 0) continue;  // jt == clustPileup.end()
-      llk2 += log(lk2);
-      llk0 += log(lk0);
+// The reference's decisions for the steps rq[] (cells with entries [e0, e0 + L)), each given the decisions of the steps
+// before it as they stand in d_clust -- the requests do not see each other's results; the caller uses a decision only
+// where that is right (muxgl_fmx_greedy_init: steps that share no SNP with an overruled one).  bs: build_by_step() of the
+// run's step indices.  win[n]: the cluster per request; scores[n * K]: llk2 - llk0 per cluster.  All requests of a pass
+// share launches (at most 2^24 pairs of terms each) and one copy back per launch.  0, or 1 with h->err set.
+inline int decide_many(muxgl_handle* h, std::vector<step_req>& rq, int K, const by_step& bs, const int32_t* d_clust,
+                       std::vector<int32_t>& win, std::vector<double>& scores) {
+  const size_t n = rq.size();
+  win.assign(n, 0);
+  scores.assign(n * (size_t)K, 0.0);
+  constexpr int64_t MAX_SLOTS = (int64_t)1 << 24;
+  size_t k0 = 0;
+  while (k0 < n) {
+    std::vector<int32_t> blk_req, blk_first;
+    int64_t slots = 0;
+    size_t k1 = k0;
+    while (k1 < n && (k1 == k0 || slots + (int64_t)rq[k1].L * K <= MAX_SLOTS)) {
+      rq[k1].off = slots;
+      const int64_t m = (int64_t)rq[k1].L * K;
+      for (int64_t f = 0; f < m; f += 256) {
+        blk_req.push_back((int32_t)(k1 - k0));
+        blk_first.push_back((int32_t)f);
+      }
+      slots += m;
+      ++k1;
     }
-    const double sc = llk2 - llk0;
-    if (scores_out) scores_out[c] = sc;
-    if (c == 0) {
-      maxScore = sc;
-    } else if (sc > maxScore) {  // :235-242
-      maxClust = c;
-      maxScore = sc;
+    std::vector<double> out((size_t)slots * 2);
+    if (slots > 0) {
+      step_req* d_req = nullptr;
+      int32_t *d_br = nullptr, *d_bf = nullptr;
+      double* d_out = nullptr;
+      const size_t nb = blk_req.size();
+      const int rc = dev_alloc(h, &d_req, k1 - k0) || dev_alloc(h, &d_br, nb) || dev_alloc(h, &d_bf, nb) ||
+                     dev_alloc(h, &d_out, (size_t)slots * 2);
+      hipError_t e = rc ? hipErrorOutOfMemory : hipSuccess;
+      if (e == hipSuccess) e = hipMemcpyAsync(d_req, rq.data() + k0, sizeof(step_req) * (k1 - k0), hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_br, blk_req.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_bf, blk_first.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(terms_kernel, dim3((unsigned)nb), dim3(256), 0, h->stream, d_req, d_br, d_bf, K, h->d_entry_snp,
+                           h->d_entry_rptr, h->d_reads, h->d_lut, h->d_af, h->d_snp_ptr, h->d_snp_entry, h->d_snp_cell, bs.key,
+                           bs.pos, d_clust, d_out);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      dev_free(&d_req);
+      dev_free(&d_br);
+      dev_free(&d_bf);
+      dev_free(&d_out);
+      if (e != hipSuccess) {
+        if (h->err.empty()) h->err = std::string("muxgl_fmx_greedy_init (exact path): ") + hipGetErrorString(e);
+        return 1;
+      }
     }
+    for (size_t k = k0; k < k1; ++k) {
+      const int L = rq[k].L;
+      const double* o = out.data() + (size_t)rq[k].off * 2;
+      int maxClust = 0;  // (L == 0: every distance is a sum over nothing, maxClust = 0, :232-233)
+      double maxScore = 0;
+      for (int c = 0; c < K; ++c) {
+        double llk2 = 0, llk0 = 0;  // dropD (sc_drop_seq.h:45-52)
+        for (int t = 0; t < L; ++t) {
+          const double lk2 = o[((size_t)t * K + c) * 2], lk0 = o[((size_t)t * K + c) * 2 + 1];
+          if (lk2 < 0) continue;  // jt == clustPileup.end()
+          llk2 += log(lk2);
+          llk0 += log(lk0);
+        }
+        const double sc = llk2 - llk0;
+        scores[k * (size_t)K + c] = sc;
+        if (c == 0) {
+          maxScore = sc;
+        } else if (sc > maxScore) {  // :235-242
+          maxClust = c;
+          maxScore = sc;
+        }
+      }
+      win[k] = maxClust;
+    }
+    k0 = k1;
   }
-  return maxClust;
+  return 0;
 }
 
 }  // namespace greedy_exact
