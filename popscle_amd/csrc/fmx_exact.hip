@@ -205,10 +205,45 @@ struct top2 {  // the reference's update rule (:469-497): strict >, first come f
   }
 };
 
+// dst[dst_off[b] + i] = src[src_off[b] + i] for i < dst_off[b + 1] - dst_off[b]: spans of a device array side by side (one
+// workgroup per span), so that what the host needs of many cells comes over in one copy
+template <class T>
+__global__ void __launch_bounds__(256)
+    gather_spans_kernel(const int64_t* __restrict__ src_off, const int64_t* __restrict__ dst_off, const T* __restrict__ src,
+                        T* __restrict__ dst) {
+  const int64_t s0 = src_off[blockIdx.x], d0 = dst_off[blockIdx.x], n = dst_off[blockIdx.x + 1] - d0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) dst[d0 + i] = src[s0 + i];
+}
+
 template <class T>
 int upload(muxgl_handle* h, T** d, const T* v, size_t n) {
   if (dev_alloc(h, d, n ? n : 1)) return 1;
   if (n) HIPCHK(h, hipMemcpyAsync(*d, v, sizeof(T) * n, hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+// out[dst_off[b] ...) = src[src_off[b] ...) for the nb spans (dst_off has nb + 1 entries); one launch, one copy back
+template <class T>
+int gather_spans(muxgl_handle* h, const std::vector<int64_t>& src_off, const std::vector<int64_t>& dst_off, const T* d_src,
+                 T* out) {
+  const size_t nb = src_off.size();
+  const int64_t tot = dst_off.back();
+  if (nb == 0 || tot == 0) return 0;
+  int64_t *d_so = nullptr, *d_do = nullptr;
+  T* d_out = nullptr;
+  int rc = upload(h, &d_so, src_off.data(), nb) || upload(h, &d_do, dst_off.data(), nb + 1) || dev_alloc(h, &d_out, (size_t)tot);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    hipLaunchKernelGGL(gather_spans_kernel<T>, dim3((unsigned)nb), dim3(256), 0, h->stream, d_so, d_do, d_src, d_out);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(T) * (size_t)tot, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  dev_free(&d_so);
+  dev_free(&d_do);
+  dev_free(&d_out);
+  if (rc) return 1;
+  if (e != hipSuccess) MUXGL_FAIL(h, "exact calls (gather): %s", hipGetErrorString(e));
   return 0;
 }
 
@@ -263,15 +298,10 @@ int fmx_exact_snps(muxgl_handle* h, std::vector<int32_t>* snps) {
     xs.cptr.push_back((int64_t)xs.ent.size());
   }
   xs.esnp.resize(xs.ent.size());
-  if (xs.cells.size() > 1024) {  // many cells: the whole column once instead of a copy per cell
-    std::vector<int32_t> es((size_t)h->nnz);
-    HIPCHK(h, hipMemcpy(es.data(), h->d_entry_snp, sizeof(int32_t) * (size_t)h->nnz, hipMemcpyDeviceToHost));
-    for (size_t t = 0; t < xs.ent.size(); ++t) xs.esnp[t] = es[(size_t)xs.ent[t]];
-  } else {
-    for (size_t f = 0; f < xs.cells.size(); ++f) {  // a cell's entries are contiguous
-      const int64_t e0 = xs.info[f].e0, n = xs.cptr[f + 1] - xs.cptr[f];
-      if (n) HIPCHK(h, hipMemcpy(xs.esnp.data() + xs.cptr[f], h->d_entry_snp + e0, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
-    }
+  {  // the listed cells' SNPs (a cell's entries are contiguous), gathered on the device: one copy
+    std::vector<int64_t> so(xs.cells.size());
+    for (size_t f = 0; f < xs.cells.size(); ++f) so[f] = xs.info[f].e0;
+    if (gather_spans<int32_t>(h, so, xs.cptr, h->d_entry_snp, xs.esnp.data())) return 1;
   }
   *snps = xs.esnp;
   std::sort(snps->begin(), snps->end());
@@ -341,27 +371,44 @@ int fmx_exact_finish(muxgl_handle* h, const muxgl_fmx_params* p, const int32_t* 
 
   // hypotheses of every listed cell, in the reference's scan order within each scan; one item per (entry, hypothesis)
   std::vector<std::vector<hyp>> hs(nf), hd(nf);
-  std::vector<double> fllrow;
   const int64_t npairs = (int64_t)K * (K + 1) / 2;
   std::vector<item> items;
   std::vector<int64_t> ioff;
-  for (size_t f = 0; f < nf; ++f) {
-    const muxgl_fmx_cell& x = xs.info[f].rec;
+  auto eps_of = [](const muxgl_fmx_cell& x) {
     double mag = 1.0;
     for (double v : {x.sngBestLLK, x.sngNextLLK, x.dblBestLLK, x.dblNextLLK})
       if (v > -1e299) mag = std::max(mag, fabs(v));
-    const double eps = 1e-9 * mag;
-    auto near = [&](double a, double b) { return a > -1e299 && b > -1e299 && fabs(a - b) <= eps; };
+    return 1e-9 * mag;
+  };
+  auto near_by = [](double a, double b, double eps) { return a > -1e299 && b > -1e299 && fabs(a - b) <= eps; };
+  // the E-step's rows of the cells with a deep tie (below), gathered on the device: one copy
+  std::vector<int64_t> deep_at(nf, -1);
+  std::vector<double> deep_rows;
+  {
+    std::vector<int64_t> so, dof{0};
+    for (size_t f = 0; f < nf; ++f) {
+      const muxgl_fmx_cell& x = xs.info[f].rec;
+      const double eps = eps_of(x);
+      if (near_by(x.sngNextLLK, x.sngThirdLLK, eps) || near_by(x.dblNextLLK, x.dblThirdLLK, eps)) {
+        deep_at[f] = dof.back();
+        so.push_back((int64_t)xs.cells[f] * npairs);
+        dof.push_back(dof.back() + npairs);
+      }
+    }
+    deep_rows.resize((size_t)dof.back());
+    if (gather_spans<double>(h, so, dof, h->d_fll, deep_rows.data())) return 1;
+  }
+  for (size_t f = 0; f < nf; ++f) {
+    const muxgl_fmx_cell& x = xs.info[f].rec;
+    const double eps = eps_of(x);
+    auto near = [&](double a, double b) { return near_by(a, b, eps); };
     std::vector<hyp>& s = hs[f];
     std::vector<hyp>& d = hd[f];
     // three or more hypotheses of a scan within reach of each other: every hypothesis of the scan that the kernels' own
     // numbers (the cell's row of the E-step's result) do not put clearly below the runner-up -- 2 EPS below is beyond
     // what rounding can bridge, the kernels' deviation being orders of magnitude smaller than EPS
     const bool deep_s = near(x.sngNextLLK, x.sngThirdLLK), deep_d = near(x.dblNextLLK, x.dblThirdLLK);
-    if (deep_s || deep_d) {
-      fllrow.resize((size_t)npairs);
-      HIPCHK(h, hipMemcpy(fllrow.data(), h->d_fll + (size_t)xs.cells[f] * npairs, sizeof(double) * (size_t)npairs, hipMemcpyDeviceToHost));
-    }
+    const double* fllrow = (deep_s || deep_d) ? deep_rows.data() + deep_at[f] : nullptr;
     if (deep_s) {
       for (int32_t j = 0; j < K; ++j)
         if (fllrow[(size_t)j * (j + 1) / 2 + j] >= x.sngNextLLK - 2 * eps) s.push_back(hyp{j, j, 0.0});
