@@ -219,7 +219,8 @@ int muxgl_demux_get_entry_pg(muxgl_handle* h, double* pg);
  * score 0 +- rounding noise -- the last bits decide.  When both cell_llk0 and cell_llk2 are asked for on a handle that
  * holds the whole pileup, the sums of every such cell are therefore recomputed exactly as the reference forms them (IEEE
  * operations in its order on the device, glibc log on the host, score_exact.hpp); all other cells keep the device's sums
- * (equal to ~1e-13).  A slabbed handle or a device group returns the device's sums for all cells. */
+ * (equal to ~1e-13); a device group does the same, each member for its cells.  A slabbed handle (one rank of a sharded run:
+ * it sees only its own cells) returns the device's sums for all of them. */
 int muxgl_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, double* cell_llk2, int32_t* cell_nsnps,
                       int32_t* cell_nreads);
 

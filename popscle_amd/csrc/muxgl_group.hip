@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "score_exact.hpp"
 
 struct muxgl_group {
   int n = 0;
@@ -308,6 +309,33 @@ int group_fmx_prepare(muxgl_handle* h, const double* af, double* cell_llk0, doub
                                  cell_nreads ? cell_nreads + c0 : nullptr);
       }))
     return 1;
+  // cells whose scores come within rounding reach of each other (in the whole job's order): the reference's own sums, each
+  // from the member that holds the cell (score_exact.hpp) -- the group returns what a one-device handle returns
+  h->fmx_exact_scores = 0;
+  if (cell_llk0 && cell_llk2) {
+    std::vector<std::vector<int64_t>> cps((size_t)g->n);
+    auto exact_sums = [&](const std::vector<int32_t>& cells) -> int {
+      size_t a = 0;
+      for (int r = 0; r < g->n && a < cells.size(); ++r) {
+        const int64_t c0 = g->cb[(size_t)r], c1 = g->cb[(size_t)r + 1];
+        size_t b = a;
+        while (b < cells.size() && cells[b] < c1) ++b;
+        if (b > a) {
+          muxgl_handle* m = g->m[(size_t)r];
+          std::vector<int32_t> local(cells.begin() + (long)a, cells.begin() + (long)b);
+          for (int32_t& c : local) c -= (int32_t)c0;
+          if (hipSetDevice(m->device) != hipSuccess || (cps[(size_t)r].empty() && score_exact::fetch_cell_ptr(m, &cps[(size_t)r])) ||
+              score_exact::compute(m, local, cps[(size_t)r], cell_llk0 + c0, cell_llk2 + c0)) {
+            h->err = "device group member: " + m->err;
+            return 1;
+          }
+        }
+        a = b;
+      }
+      return 0;
+    };
+    if (score_exact::settle_with(g->C, cell_llk0, cell_llk2, &h->fmx_exact_scores, &h->err, exact_sums)) return 1;
+  }
   g->prepared = true;
   g->K = 0;
   max_timing(g);

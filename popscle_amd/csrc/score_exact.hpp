@@ -27,7 +27,8 @@
 namespace score_exact {
 
 // out[(off[k] + i) * 2] = {lk0, lk2} of entry i of cell cells[k]; one workgroup per listed cell
-__global__ void __launch_bounds__(256)
+// (static: the header is part of two translation units)
+static __global__ void __launch_bounds__(256)
     terms_kernel(const int32_t* __restrict__ cells, const int64_t* __restrict__ off, const int64_t* __restrict__ cell_ptr,
                  const int32_t* __restrict__ entry_snp, const int64_t* __restrict__ entry_rptr,
                  const uint8_t* __restrict__ reads, const double* __restrict__ lut, const double* __restrict__ af,
@@ -127,16 +128,16 @@ inline int compute(muxgl_handle* h, const std::vector<int32_t>& cells, const std
 }
 
 // l0 / l2: [C] sums as the device made them; on return the cells whose place in the reference's order could depend on the
-// last bits hold the reference's own sums.  *n_exact: how many cells that were.
-inline int settle(muxgl_handle* h, double* l0, double* l2, int64_t* n_exact) {
-  const int64_t C = h->C;
+// last bits hold the reference's own sums.  *n_exact: how many cells that were.  exact_sums(cells): fills l0 / l2 of the
+// listed cells (ascending) with the reference's sums; 0 = ok.
+template <class F>
+int settle_with(int64_t C, double* l0, double* l2, int64_t* n_exact, std::string* err, F&& exact_sums) {
   *n_exact = 0;
   if (C < 2) return 0;
   for (int64_t i = 0; i < C; ++i)
     if (!std::isfinite(l0[i]) || !std::isfinite(l2[i])) return 0;  // (no strict weak order to reproduce: std::sort's whim)
   std::vector<int32_t> ord((size_t)C);
   std::vector<uint8_t> exact((size_t)C, 0);
-  std::vector<int64_t> cp;
   auto before = [&](int32_t a, int32_t b) {  // sc_drop_seq.h:193-197
     const double cmp = (l2[a] - l0[a]) - (l2[b] - l0[b]);
     if (cmp != 0) return cmp > 0;
@@ -161,20 +162,32 @@ inline int settle(muxgl_handle* h, double* l0, double* l2, int64_t* n_exact) {
       }
     }
     if (todo.empty()) return 0;
-    if (cp.empty()) {
-      cp.resize((size_t)C + 1);
-      const hipError_t e = hipMemcpy(cp.data(), h->d_cell_ptr, sizeof(int64_t) * (size_t)(C + 1), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) {
-        h->err = std::string("muxgl_fmx_prepare (exact scores): ") + hipGetErrorString(e);
-        return 1;
-      }
-    }
     std::sort(todo.begin(), todo.end());
-    if (compute(h, todo, cp, l0, l2)) return 1;
+    if (exact_sums(todo)) return 1;
     *n_exact += (int64_t)todo.size();
   }
-  h->err = "muxgl_fmx_prepare (exact scores): the set of near-tied scores did not close in 8 rounds";
+  *err = "muxgl_fmx_prepare (exact scores): the set of near-tied scores did not close in 8 rounds";
   return 1;
+}
+
+// host copy of a handle's cell_ptr
+inline int fetch_cell_ptr(muxgl_handle* h, std::vector<int64_t>* cp) {
+  cp->resize((size_t)h->C + 1);
+  const hipError_t e = hipMemcpy(cp->data(), h->d_cell_ptr, sizeof(int64_t) * (size_t)(h->C + 1), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    h->err = std::string("muxgl_fmx_prepare (exact scores): ") + hipGetErrorString(e);
+    return 1;
+  }
+  return 0;
+}
+
+// one handle holding the whole pileup
+inline int settle(muxgl_handle* h, double* l0, double* l2, int64_t* n_exact) {
+  std::vector<int64_t> cp;
+  return settle_with(h->C, l0, l2, n_exact, &h->err, [&](const std::vector<int32_t>& cells) -> int {
+    if (cp.empty() && fetch_cell_ptr(h, &cp)) return 1;
+    return compute(h, cells, cp, l0, l2);
+  });
 }
 
 }  // namespace score_exact
