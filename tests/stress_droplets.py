@@ -20,8 +20,8 @@ import ref_binding as rb  # noqa: E402
 from popscle_amd import muxgl, synth  # noqa: E402
 
 
-def mixed(cells, droplets, K, S, seed=77):
-    a = synth.make_pileup(cells, S, K, seed=seed, mean_entries=800, with_gp=False, donor_seed=seed)
+def mixed(cells, droplets, K, S, seed=77, with_gp=False):
+    a = synth.make_pileup(cells, S, K, seed=seed, mean_entries=800, with_gp=with_gp, donor_seed=seed)
     b = synth.make_pileup(droplets, S, K, seed=seed + 1, mean_entries=2.5, sigma=0.9, min_entries=1, with_gp=False,
                           donor_seed=seed, reads_lambda=0.1, other=0.01)
     rng = np.random.default_rng(seed + 2)
@@ -39,10 +39,40 @@ def mixed(cells, droplets, K, S, seed=77):
     entry_rptr = np.zeros(eidx.size + 1, dtype=np.int64)
     np.cumsum(rl, out=entry_rptr[1:])
     ridx = synth._ranges(rstart[eidx], rl)
-    return synth.Pileup(order.size, S, cell_ptr, esnp[eidx].astype(np.int32), entry_rptr, reads[ridx], a.af)
+    return synth.Pileup(order.size, S, cell_ptr, esnp[eidx].astype(np.int32), entry_rptr, reads[ridx], a.af, a.gp, a.has_gp)
+
+
+def main_demux(argv):
+    """demuxlet over the same shape (V samples): records against the reference's, and what the exact-call pass costs"""
+    cells, droplets, V, S = (int(x) for x in (argv + ["3000", "30000", "16", "30000"][len(argv):]))
+    p = mixed(cells, droplets, V, S, with_gp=True)
+    out = dict(kind="demuxlet", cells=cells, droplets=droplets, V=V, S=S, nnz=int(p.nnz))
+    t = time.time()
+    want, _, _ = rb.RefScl.from_packed(p).demux((0.0, 0.5), doublet_prior=0.5)
+    out["reference_s"] = round(time.time() - t, 2)
+    eng = muxgl.Engine(0)
+    t0 = time.time()
+    eng.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
+    eng.demux_set_gp(p.gp, p.has_gp)
+    out["handover_s"] = round(time.time() - t0, 3)
+    t = time.time()
+    got = eng.demux_run((0.0, 0.5), 0.5)
+    out["run_s"] = round(time.time() - t, 4)
+    t = time.time()
+    try:
+        rep = parity.compare_demux(got, want, (0.0, 0.5), p)
+        out.update(exact_pass=rep["exact_pass"], raw_records_differing=rep["raw_records_differing"],
+                   max_abs_ll_diff=rep["max_abs_ll_diff"], differing=0)
+    except AssertionError as ex:
+        out.update(differing=1, first_error=str(ex)[:300])
+    out["exact_pass_and_compare_s"] = round(time.time() - t, 3)
+    print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)), flush=True)
+    return out["differing"]
 
 
 def main(argv):
+    if argv and argv[0] == "demux":
+        return main_demux(argv[1:])
     cells, droplets, K, S = (int(x) for x in (argv + ["3000", "30000", "8", "30000"][len(argv):]))
     p = mixed(cells, droplets, K, S)
     out = dict(cells=cells, droplets=droplets, K=K, S=S, nnz=int(p.nnz))
