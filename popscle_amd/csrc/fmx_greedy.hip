@@ -1414,11 +1414,15 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   bool use_batched = batched;
   int wgs = 0;
   double tie_eps = 1e-9;
-  if (const char* ev = getenv("MUXGL_GREEDY_TIE_EPS")) tie_eps = atof(ev);  // (tests: 1e300 sends every step through the exact path)
-  int64_t misdecide = -1;  // (tests of the rerun path: the kernel decides this step wrongly and flags it)
-  if (const char* ev = getenv("MUXGL_GREEDY_TEST_MISDECIDE")) misdecide = atoll(ev);
-  FILE* dump = nullptr;    // (tests: the exact path's scores of every step it decides, as {int64 step, double[K]} records)
-  if (const char* ev = getenv("MUXGL_GREEDY_DUMP_SCORES")) dump = fopen(ev, "wb");
+  // test hooks, honoured only under MUXGL_TEST_HOOKS=1 (tests/test_fmx_gpu.py): a stray variable of one of these names in
+  // a user's environment neither changes a decision nor opens a file
+  const bool hooks = getenv("MUXGL_TEST_HOOKS") != nullptr && getenv("MUXGL_TEST_HOOKS")[0] == '1';
+  const char* ev = nullptr;
+  if (hooks && (ev = getenv("MUXGL_GREEDY_TIE_EPS"))) tie_eps = atof(ev);  // 1e300 sends every step through the exact path
+  int64_t misdecide = -1;  // (the rerun path: the kernel decides this step wrongly and flags it)
+  if (hooks && (ev = getenv("MUXGL_GREEDY_TEST_MISDECIDE"))) misdecide = atoll(ev);
+  FILE* dump = nullptr;    // (the exact path's scores of every step it decides, as {int64 step, double[K]} records)
+  if (hooks && (ev = getenv("MUXGL_GREEDY_DUMP_SCORES"))) dump = fopen(ev, "wb");
   h->greedy_near_ties = h->greedy_overruled = 0;
   do {
     if (dev_alloc(h, &d_he0, npad) || dev_alloc(h, &d_hlen, npad) || dev_alloc(h, &d_hcell, npad)) break;

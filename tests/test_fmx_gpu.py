@@ -327,6 +327,7 @@ def test_greedy_exact_path_is_the_references_arithmetic(tmp_path, monkeypatch, f
     scores = o2 - o0
     want, want_sc = ob.fmx_greedy_init_scores(p, e, K, scores, ob.fmx_sort(scores))
     dump = str(tmp_path / "scores.bin")
+    monkeypatch.setenv("MUXGL_TEST_HOOKS", "1")
     monkeypatch.setenv("MUXGL_GREEDY_TIE_EPS", "1e300")
     monkeypatch.setenv("MUXGL_GREEDY_DUMP_SCORES", dump)
     with muxgl.Engine(0, flags) as en:
@@ -350,6 +351,7 @@ def test_greedy_exact_path_overrules_a_wrong_decision(monkeypatch, flags):
     o0, o2, _, _ = ob.fmx_cell_scores(p, e)
     scores = o2 - o0
     want = ob.fmx_greedy_init(p, e, K, scores, ob.fmx_sort(scores))
+    monkeypatch.setenv("MUXGL_TEST_HOOKS", "1")
     monkeypatch.setenv("MUXGL_GREEDY_TEST_MISDECIDE", "137")
     with muxgl.Engine(0, flags) as en:
         en.set_pileup(p.S, p.cell_ptr, p.entry_snp, p.entry_rptr, p.reads)
