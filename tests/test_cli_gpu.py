@@ -108,9 +108,17 @@ def test_demuxlet_cli(tmp_path, V, alphas, field):
     assert len(got) == 1 + int((cells["valid"] == 1).sum())
 
 
-def test_freemuxlet_cli(tmp_path):
+@pytest.mark.parametrize("shape", ["cells", "droplets"])
+def test_freemuxlet_cli(tmp_path, shape):
     K = 4
-    p = synth.make_pileup(150, 1200, K, seed=8, mean_entries=200, min_entries=30, with_gp=False)
+    if shape == "cells":
+        p = synth.make_pileup(150, 1200, K, seed=8, mean_entries=200, min_entries=30, with_gp=False)
+    else:
+        # unfiltered barcodes: a hundred cells among 1 500 droplets of one to a handful of reads -- start scores of
+        # 0 +- rounding noise, noise-level ties in the greedy pass and in the iterations (tests/stress_droplets.py)
+        import stress_droplets
+
+        p = stress_droplets.mixed(100, 1500, K, 5000, seed=31)
     prefix = str(tmp_path / "plp")
     plpio.write_plp(prefix, p, seed=8)
     out = str(tmp_path / "out")
