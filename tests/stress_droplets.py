@@ -39,7 +39,8 @@ def mixed(cells, droplets, K, S, seed=77, with_gp=False):
     entry_rptr = np.zeros(eidx.size + 1, dtype=np.int64)
     np.cumsum(rl, out=entry_rptr[1:])
     ridx = synth._ranges(rstart[eidx], rl)
-    return synth.Pileup(order.size, S, cell_ptr, esnp[eidx].astype(np.int32), entry_rptr, reads[ridx], a.af, a.gp, a.has_gp)
+    return synth.Pileup(order.size, S, cell_ptr, esnp[eidx].astype(np.int32), entry_rptr, reads[ridx], a.af, a.gp, a.has_gp,
+                        {"G": a.truth["G"]})
 
 
 def main_demux(argv):

@@ -53,14 +53,21 @@ def as_pileup(d):
                         d["gp"] if d["nv"] else None, d["has_gp"] if d["nv"] else None)
 
 
-@pytest.mark.parametrize("V,alphas,field", [
+@pytest.mark.parametrize("V,alphas,field,shape", [(v, a, f, "cells") for v, a, f in [
     (4, None, "GT"),   # BASELINE configs[0]'s shape: 4-sample GT VCF, default grid
     (6, None, "GT"), (6, (0.0, 0.1, 0.3, 0.5), "GT"), (20, None, "GT"),
     # posteriors from FORMAT/GP (float normalisation) and from FORMAT/PL (the 10-iteration EM); the
     # loader's arithmetic for both is pinned to the reference's own lines in tests/test_oracle_ref.py
-    (6, None, "GP"), (6, None, "PL"), (4, (0.0, 0.25, 0.5), "PL"), (20, None, "GP")])
-def test_demuxlet_cli(tmp_path, V, alphas, field):
-    p = synth.make_pileup(60, 800, V, seed=5, mean_entries=150, min_entries=20, doublet_frac=0.3)
+    (6, None, "GP"), (6, None, "PL"), (4, (0.0, 0.25, 0.5), "PL"), (20, None, "GP")]] + [
+    # unfiltered barcodes: cells among droplets of one to a handful of reads (most hypotheses of a droplet tie exactly)
+    (6, None, "GT", "droplets"), (16, None, "GP", "droplets")])
+def test_demuxlet_cli(tmp_path, V, alphas, field, shape):
+    if shape == "droplets":
+        import stress_droplets
+
+        p = stress_droplets.mixed(40, 700, V, 800, seed=5, with_gp=True)
+    else:
+        p = synth.make_pileup(60, 800, V, seed=5, mean_entries=150, min_entries=20, doublet_frac=0.3)
     prefix = str(tmp_path / "plp")
     plpio.write_plp(prefix, p, seed=5, extra_cells=1)
     vcf = str(tmp_path / "g.vcf.gz")
