@@ -53,7 +53,7 @@ def _shape(r, width, per_hyp):
 
 
 def _pileup(r, seed, C, S, V, ment, mine, sigma, with_gp):
-    cap = int(r.choice([20, 20, 40, 60, 93]))
+    cap = int(r.choice([20, 20, 40, 60, 93, 127]))
     return synth.make_pileup(C, S, V, seed=seed, mean_entries=ment, sigma=sigma, min_entries=mine,
                              reads_lambda=float(r.choice([0.0, 0.3, 0.3, 1.5, 6.0, 6.0, 60.0])),
                              other=float(r.choice([0.0, 0.02, 0.5])), doublet_frac=float(r.choice([0.0, 0.25, 0.6])),
