@@ -243,9 +243,10 @@ int muxgl_fmx_get_entry_gls(muxgl_handle* h, double* gls, int32_t* counts);
  * (products instead of sums of logs), equal to ~1e-13 relative: a decision whose margin over the runner-up is within
  * 1e-9 x max(1, |score|) is therefore not taken by them but by greedy_exact.hpp, which recomputes that step's K distances
  * in the reference's own arithmetic (IEEE operations in the reference's order on the device, glibc log on the host) given
- * the earlier decisions -- all such steps of a pass in one launch; where it overrules the kernel the pass is repeated with
- * that decision pinned, together with the decisions of the later near-tie steps that share no SNP, directly or through
- * other cells, with an overruled one (they read none of the states that change).  A score of exactly 0 counts as the
+ * the earlier decisions -- all such steps of a pass in one launch.  Where it overrules the kernel, the steps behind it that
+ * cover a SNP of a cell whose decision changed are decided again the same way against the corrected assignments, in
+ * order; every other step stands (it read none of the states that changed).  Only if that walk outlasts twice the pass
+ * itself is the pass repeated with the decisions so far pinned.  A score of exactly 0 counts as the
  * structural tie of clusters sharing no SNP with the cell only when both of its products are empty.  The result is the
  * reference's clustering, not an approximation of it (muxgl_fmx_greedy_stats reports how often the exact path was taken).
  * One device, whole pileup: not available on a device group or a slabbed handle.

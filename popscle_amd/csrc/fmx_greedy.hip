@@ -22,6 +22,7 @@
 // The per-(cluster, SNP) states built here are discarded afterwards, exactly as in the reference, which rebuilds the
 // cluster pileups from the assignment in ascending cell order (:277-288 -> muxgl_fmx_set_clusters).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <thread>
 #include <vector>
@@ -1411,6 +1412,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   int32_t* d_forced = nullptr;  // [npad] by step: cluster decided by the exact path, or -1
   int32_t* d_step = nullptr;    // [C] step index of a cell (exact path, on first use)
   greedy_exact::by_step d_bystep;  // the SNP-major view in (SNP, step) order (exact path, on first use)
+  greedy_exact::scratch d_xscr;    // device buffers of the exact path's launches
   bool use_batched = batched;
   int wgs = 0;
   double tie_eps = 1e-9;
@@ -1605,13 +1607,14 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
     std::vector<int32_t> hsnp;     // host copy of entry_snp, fetched at the first overruled step
     std::vector<uint64_t> touched; // one bit per SNP
     int reruns = 0;
-    int64_t n_near = 0, n_overruled = 0;
+    int64_t n_near = 0, n_overruled = 0, n_redecided = 0;
     for (;;) {
       if (e == hipSuccess) e = hipMemcpyAsync(d_forced, forced.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice, h->stream);
       if (e == hipSuccess) e = hipMemsetAsync(d_near, 0, npad, h->stream);
       if (e == hipSuccess) e = hipMemsetAsync(d_clust, 0xFF, sizeof(int32_t) * (size_t)C, h->stream);
       if (e == hipSuccess) e = hipMemsetAsync(d_diag, 0, sizeof(double) * (size_t)S * K * 4, h->stream);
       if (e != hipSuccess) break;
+      const auto t_pass = std::chrono::steady_clock::now();
       if (use_batched) {
         (void)hipMemsetAsync(d_hist, 0, sizeof(int32_t) * (GB + 2), h->stream);
         (void)hipMemsetAsync(d_passw, 0, sizeof(unsigned long long) * (GB + 1) * GB, h->stream);
@@ -1648,6 +1651,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
         }
       }
       if (e != hipSuccess) break;
+      const double pass_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pass).count();
       tm.lap(use_batched ? "greedy_init: batches drained" : "greedy_init: serial kernel drained");
       // the flagged steps of this run that are not pinned yet, decided together (each against the run's decisions before it)
       std::vector<greedy_exact::step_req> rq;
@@ -1669,35 +1673,81 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
           if (e != hipSuccess) break;
           if (greedy_exact::build_by_step(h, d_step, &d_bystep)) { e = hipErrorUnknown; break; }
         }
-        if (greedy_exact::decide_many(h, rq, (int)K, d_bystep, d_clust, win, exact_scores)) { e = hipErrorUnknown; break; }
+        if (greedy_exact::decide_many(h, rq, (int)K, d_bystep, d_clust, win, exact_scores, &d_xscr)) { e = hipErrorUnknown; break; }
       }
       tm.lap("greedy_init: near-tie steps in the reference's arithmetic");
-      bool overruled = false;
+      // The walk over the steps in order, REPAIRING the run as it goes: `touched` holds the SNPs of the cells whose decision
+      // changed so far -- the only places where a later step can read a state other than the one this run showed it (a cell
+      // that keeps its cluster merges the same likelihoods into the same states as before).  A step that reads none of them
+      // stands: its kernel decision, or for a flagged step the exact decision of the batch above.  A step that does is decided
+      // again in the reference's arithmetic against the corrected assignments (one small launch: the decisions are
+      // sequential from here), flagged or not.  Every decision taken here is the reference's given the ones before it, so
+      // when the walk reaches the end the clustering is final and no repeat of the pass is needed -- the case of a pileup
+      // of many small droplets, whose overlaps are sparse.  Where almost every later step is touched (an overruled step among
+      // large cells) the walk would decide thousands of steps one by one: past a time budget of twice the pass it stops,
+      // what it decided stays pinned, and the pass is repeated.
+      const auto t_rep = std::chrono::steady_clock::now();
+      bool overruled = false, gave_up = false;
       size_t r = 0;  // next request
+      // (touched steps are decided LOOK steps at a time -- the next ones that the changes so far touch -- and a result
+      //  is used as long as no decision has changed since its launch; after a change the rest of the group is decided anew)
+      constexpr size_t LOOK = 64;
+      std::vector<greedy_exact::step_req> grp;
+      std::vector<size_t> grp_step;
+      std::vector<int32_t> gw;
+      std::vector<double> gsc;
+      size_t gnext = 0;        // next unused result of the group
+      bool grp_valid = false;  // no decision has changed since the group was launched
+      auto touches = [&](size_t i) {
+        const int32_t* sn = hsnp.data() + he0[i];
+        for (int32_t k = 0; k < hlen[i]; ++k)
+          if ((touched[(size_t)sn[k] >> 6] >> (sn[k] & 63)) & 1u) return true;
+        return false;
+      };
       for (size_t i = 0; i < n; ++i) {
         const bool flagged = r < rq_step.size() && rq_step[r] == i;
         const size_t ri = r;
         if (flagged) ++r;
-        if (overruled) {  // does the step read a state that the repeated run will find changed?
-          const int32_t* sn = hsnp.data() + he0[i];
-          bool hit = false;
-          for (int32_t k = 0; k < hlen[i] && !hit; ++k) hit = (touched[(size_t)sn[k] >> 6] >> (sn[k] & 63)) & 1u;
-          if (hit) {
-            for (int32_t k = 0; k < hlen[i]; ++k) touched[(size_t)sn[k] >> 6] |= (uint64_t)1 << (sn[k] & 63);
-            continue;
+        const bool hit = overruled && touches(i);  // does the step read a state that a changed decision has changed?
+        if (!flagged && !hit) continue;
+        int w;
+        const double* wsc;
+        if (hit) {
+          if (!(grp_valid && gnext < grp_step.size() && grp_step[gnext] == i)) {
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rep).count() > 2.0 * pass_ms + 5.0) {
+              gave_up = true;
+              break;
+            }
+            grp.clear();
+            grp_step.clear();
+            for (size_t j = i; j < n && grp.size() < LOOK; ++j)
+              if (j == i || touches(j)) {
+                grp.push_back(greedy_exact::step_req{he0[j], 0, hlen[j], (int32_t)j});
+                grp_step.push_back(j);
+              }
+            if (greedy_exact::decide_many(h, grp, (int)K, d_bystep, d_clust, gw, gsc, &d_xscr)) { e = hipErrorUnknown; break; }
+            gnext = 0;
+            grp_valid = true;
+          }
+          w = gw[gnext];
+          wsc = gsc.data() + gnext * (size_t)K;
+          ++gnext;
+          ++n_redecided;
+        } else {
+          w = win[ri];
+          wsc = exact_scores.data() + ri * (size_t)K;
+        }
+        if (flagged) {
+          ++n_near;
+          if (dump) {
+            const int64_t st = (int64_t)i;
+            fwrite(&st, sizeof(st), 1, dump);
+            fwrite(wsc, sizeof(double), (size_t)K, dump);
           }
         }
-        if (!flagged) continue;
-        ++n_near;
-        const int w = win[ri];
-        if (dump) {
-          const int64_t st = (int64_t)i;
-          fwrite(&st, sizeof(st), 1, dump);
-          fwrite(exact_scores.data() + ri * (size_t)K, sizeof(double), (size_t)K, dump);
-        }
-        forced[i] = w;
+        forced[i] = w;  // the reference's decision given the decisions before it: holds in a repeated pass as well
         if (w != clust_out[hcell[i]]) {
-          ++n_overruled;
+          if (flagged) ++n_overruled;
           if (!overruled) {
             overruled = true;
             if (hsnp.empty() && h->nnz) {
@@ -1707,11 +1757,17 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
             }
             touched.assign((size_t)(S + 63) / 64, 0);
           }
+          grp_valid = false;  // (results launched before this change may have read what it changes)
+          clust_out[hcell[i]] = w;
+          const int32_t w32 = w;
+          e = hipMemcpy(d_clust + hcell[i], &w32, sizeof(int32_t), hipMemcpyHostToDevice);
+          if (e != hipSuccess) break;
           const int32_t* sn = hsnp.data() + he0[i];
           for (int32_t k = 0; k < hlen[i]; ++k) touched[(size_t)sn[k] >> 6] |= (uint64_t)1 << (sn[k] & 63);
         }
       }
-      if (e != hipSuccess || !overruled) break;
+      tm.lap("greedy_init: the walk over the steps (decisions behind a changed one taken again)");
+      if (e != hipSuccess || !gave_up) break;
       // (every rerun pins one more step for good, so the loop ends after at most n of them; beyond a number no real
       //  pileup has come near, give up loudly rather than take hours)
       if (++reruns > 64 + (int)std::min<size_t>(n, 4096)) {
@@ -1723,8 +1779,8 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
     h->greedy_near_ties = n_near;
     h->greedy_overruled = n_overruled;
     if (tm.on)
-      fprintf(stderr, "[muxgl] greedy_init: %lld near ties decided by the exact path, %lld of them against the kernel's choice (%d reruns)\n",
-              (long long)n_near, (long long)n_overruled, reruns);
+      fprintf(stderr, "[muxgl] greedy_init: %lld near ties decided by the exact path, %lld of them against the kernel's choice; %lld steps behind a changed decision decided again; %d repeats of the pass\n",
+              (long long)n_near, (long long)n_overruled, (long long)n_redecided, reruns);
     if (e != hipSuccess) {
       if (h->err.empty()) h->err = std::string("muxgl_fmx_greedy_init: ") + hipGetErrorString(e);
       break;
@@ -1763,6 +1819,7 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
   dev_free(&d_forced);
   dev_free(&d_step);
   greedy_exact::release(&d_bystep);
+  greedy_exact::release(&d_xscr);
   dev_free(&d_clust);
   dev_free(&d_diag);
   dev_free(&d_offd);

@@ -25,6 +25,9 @@
 #pragma once
 #include <math.h>
 
+#include <algorithm>
+
+#include <thread>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -156,13 +159,54 @@ __global__ void __launch_bounds__(256)
   out[(r.off + tid) * 2 + 1] = lk0;
 }
 
+// device buffers of decide_many, kept between calls (a repair decides steps one at a time: no allocation per step)
+struct scratch {
+  step_req* d_req = nullptr;
+  int32_t *d_br = nullptr, *d_bf = nullptr;
+  double* d_out = nullptr;
+  size_t n_req = 0, n_blk = 0, n_out = 0;
+};
+inline void release(scratch* s) {
+  dev_free(&s->d_req);
+  dev_free(&s->d_br);
+  dev_free(&s->d_bf);
+  dev_free(&s->d_out);
+  s->n_req = s->n_blk = s->n_out = 0;
+}
+inline int reserve(muxgl_handle* h, scratch* s, size_t n_req, size_t n_blk, size_t n_out) {
+  if (n_req > s->n_req) {
+    dev_free(&s->d_req);
+    s->n_req = 0;
+    const size_t want = std::max<size_t>(n_req, 256);
+    if (dev_alloc(h, &s->d_req, want)) return 1;
+    s->n_req = want;
+  }
+  if (n_blk > s->n_blk) {
+    dev_free(&s->d_br);
+    dev_free(&s->d_bf);
+    s->n_blk = 0;
+    const size_t want = std::max<size_t>(n_blk + n_blk / 2, 4096);
+    if (dev_alloc(h, &s->d_br, want) || dev_alloc(h, &s->d_bf, want)) return 1;
+    s->n_blk = want;
+  }
+  if (n_out > s->n_out) {
+    dev_free(&s->d_out);
+    s->n_out = 0;
+    const size_t want = std::max<size_t>(n_out + n_out / 2, (size_t)1 << 18);
+    if (dev_alloc(h, &s->d_out, want)) return 1;
+    s->n_out = want;
+  }
+  return 0;
+}
+
 // The reference's decisions for the steps rq[] (cells with entries [e0, e0 + L)), each given the decisions of the steps
 // before it as they stand in d_clust -- the requests do not see each other's results; the caller uses a decision only
 // where that is right (muxgl_fmx_greedy_init: steps that share no SNP with an overruled one).  bs: build_by_step() of the
-// run's step indices.  win[n]: the cluster per request; scores[n * K]: llk2 - llk0 per cluster.  All requests of a pass
-// share launches (at most 2^24 pairs of terms each) and one copy back per launch.  0, or 1 with h->err set.
+// run's step indices.  win[n]: the cluster per request; scores[n * K]: llk2 - llk0 per cluster.  All requests of a call
+// share launches (at most 2^24 pairs of terms each) and one copy back per launch; scr keeps the device buffers between
+// calls.  0, or 1 with h->err set.
 inline int decide_many(muxgl_handle* h, std::vector<step_req>& rq, int K, const by_step& bs, const int32_t* d_clust,
-                       std::vector<int32_t>& win, std::vector<double>& scores) {
+                       std::vector<int32_t>& win, std::vector<double>& scores, scratch* scr) {
   const size_t n = rq.size();
   win.assign(n, 0);
   scores.assign(n * (size_t)K, 0.0);
@@ -184,12 +228,11 @@ inline int decide_many(muxgl_handle* h, std::vector<step_req>& rq, int K, const 
     }
     std::vector<double> out((size_t)slots * 2);
     if (slots > 0) {
-      step_req* d_req = nullptr;
-      int32_t *d_br = nullptr, *d_bf = nullptr;
-      double* d_out = nullptr;
       const size_t nb = blk_req.size();
-      const int rc = dev_alloc(h, &d_req, k1 - k0) || dev_alloc(h, &d_br, nb) || dev_alloc(h, &d_bf, nb) ||
-                     dev_alloc(h, &d_out, (size_t)slots * 2);
+      const int rc = reserve(h, scr, k1 - k0, nb, (size_t)slots * 2);
+      step_req* d_req = scr->d_req;
+      int32_t *d_br = scr->d_br, *d_bf = scr->d_bf;
+      double* d_out = scr->d_out;
       hipError_t e = rc ? hipErrorOutOfMemory : hipSuccess;
       if (e == hipSuccess) e = hipMemcpyAsync(d_req, rq.data() + k0, sizeof(step_req) * (k1 - k0), hipMemcpyHostToDevice, h->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(d_br, blk_req.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, h->stream);
@@ -202,38 +245,53 @@ inline int decide_many(muxgl_handle* h, std::vector<step_req>& rq, int K, const 
       }
       if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(double) * out.size(), hipMemcpyDeviceToHost, h->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-      dev_free(&d_req);
-      dev_free(&d_br);
-      dev_free(&d_bf);
-      dev_free(&d_out);
       if (e != hipSuccess) {
         if (h->err.empty()) h->err = std::string("muxgl_fmx_greedy_init (exact path): ") + hipGetErrorString(e);
         return 1;
       }
     }
-    for (size_t k = k0; k < k1; ++k) {
-      const int L = rq[k].L;
-      const double* o = out.data() + (size_t)rq[k].off * 2;
-      int maxClust = 0;  // (L == 0: every distance is a sum over nothing, maxClust = 0, :232-233)
-      double maxScore = 0;
-      for (int c = 0; c < K; ++c) {
-        double llk2 = 0, llk0 = 0;  // dropD (sc_drop_seq.h:45-52)
-        for (int t = 0; t < L; ++t) {
-          const double lk2 = o[((size_t)t * K + c) * 2], lk0 = o[((size_t)t * K + c) * 2 + 1];
-          if (lk2 < 0) continue;  // jt == clustPileup.end()
-          llk2 += log(lk2);
-          llk0 += log(lk0);
+    auto sum_requests = [&](size_t ka, size_t kb) {
+      for (size_t k = ka; k < kb; ++k) {
+        const int L = rq[k].L;
+        const double* o = out.data() + (size_t)rq[k].off * 2;
+        int maxClust = 0;  // (L == 0: every distance is a sum over nothing, maxClust = 0, :232-233)
+        double maxScore = 0;
+        for (int c = 0; c < K; ++c) {
+          double llk2 = 0, llk0 = 0;  // dropD (sc_drop_seq.h:45-52)
+          for (int t = 0; t < L; ++t) {
+            const double lk2 = o[((size_t)t * K + c) * 2], lk0 = o[((size_t)t * K + c) * 2 + 1];
+            if (lk2 < 0) continue;  // jt == clustPileup.end()
+            llk2 += log(lk2);
+            llk0 += log(lk0);
+          }
+          const double sc = llk2 - llk0;
+          scores[k * (size_t)K + c] = sc;
+          if (c == 0) {
+            maxScore = sc;
+          } else if (sc > maxScore) {  // :235-242
+            maxClust = c;
+            maxScore = sc;
+          }
         }
-        const double sc = llk2 - llk0;
-        scores[k * (size_t)K + c] = sc;
-        if (c == 0) {
-          maxScore = sc;
-        } else if (sc > maxScore) {  // :235-242
-          maxClust = c;
-          maxScore = sc;
-        }
+        win[k] = maxClust;
       }
-      win[k] = maxClust;
+    };
+    // (two logs per slot: with many slots the requests are shared out to host threads, by slots)
+    const int nt = slots > (1 << 15) && k1 - k0 > 1 ? (int)std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nt <= 1) {
+      sum_requests(k0, k1);
+    } else {
+      std::vector<std::thread> th;
+      size_t a = k0;
+      for (int t = 0; t < nt && a < k1; ++t) {
+        const int64_t want = slots * (t + 1) / nt;
+        size_t b = a;
+        while (b < k1 && (b + 1 == k1 ? slots : rq[b + 1].off) <= want) ++b;
+        if (t == nt - 1) b = k1;
+        if (b > a) th.emplace_back(sum_requests, a, b);
+        a = b;
+      }
+      for (auto& x : th) x.join();
     }
     k0 = k1;
   }
