@@ -1756,6 +1756,21 @@ extern "C" int muxgl_fmx_greedy_init(muxgl_handle* h, int32_t K, const double* s
               if (e != hipSuccess) break;
             }
             touched.assign((size_t)(S + 63) / 64, 0);
+            // Is the walk worth starting?  The cells that cover a SNP of this one bound the steps it will have to decide
+            // again; at the pileup's mean cell size and ~20 ns per (entry, cluster) of such a decision (kernel + two glibc
+            // logs), a changed decision among large cells comes to many times the pass itself: then the pass is repeated
+            // with this decision pinned, as before the walk existed.
+            std::vector<int64_t> sp((size_t)S + 1);
+            e = hipMemcpy(sp.data(), h->d_snp_ptr, sizeof(int64_t) * (size_t)(S + 1), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) break;
+            const int32_t* sn0 = hsnp.data() + he0[i];
+            double cover = 0;
+            for (int32_t k = 0; k < hlen[i]; ++k) cover += (double)(sp[(size_t)sn0[k] + 1] - sp[(size_t)sn0[k]]);
+            const double est_ms = std::min(cover, (double)(n - i)) * ((double)h->nnz / (double)std::max<int64_t>(C, 1)) * K * 2e-5;
+            if (est_ms > 2.0 * pass_ms + 5.0) {
+              gave_up = true;
+              break;
+            }
           }
           grp_valid = false;  // (results launched before this change may have read what it changes)
           clust_out[hcell[i]] = w;
