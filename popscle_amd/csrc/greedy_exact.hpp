@@ -63,7 +63,8 @@ inline void release(by_step* b) {
   dev_free(&b->pos);
 }
 
-// d_step_of_cell[C] as for decide().  0, or 1 with h->err set.
+// d_step_of_cell[C]: a cell's index in the processing order, or a value >= the number of steps for cells that are not
+// clustered.  0, or 1 with h->err set.
 inline int build_by_step(muxgl_handle* h, const int32_t* d_step_of_cell, by_step* b) {
   const int64_t nnz = h->nnz;
   release(b);
