@@ -193,3 +193,36 @@ def test_pass_is_idempotent_and_thread_count_independent():
     muxgl.demux_exact_calls(p, alphas, b, 0.5, nthreads=2)   # already the reference's records: unchanged
     assert a.tobytes() == b.tobytes()
     check_exact(a, want, None)
+
+
+def _fuzz_seeds(n=40, vmax=16, cmax=200):
+    """seeds of tests/test_fuzz_gpu.py's demuxlet generator whose cases the Python emulation can afford"""
+    import test_fuzz_gpu as fz
+
+    out = []
+    seed = 0
+    while len(out) < n and seed < 400:
+        r = np.random.default_rng([seed, 77])
+        if int(r.choice(fz.DEMUX_V)) <= vmax:
+            out.append(seed)
+        seed += 1
+    return out
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
+def test_unfriendly_generator_cases(seed):
+    """the GPU suite's randomised generator (tests/test_fuzz_gpu.py: droplets of a few entries, duplicated or identical
+    samples, markers without genotypes, hard calls, float-normalised rows, deep entries, odd grids and priors) through the
+    emulated device and the host pass: the records must be the reference's"""
+    import test_fuzz_gpu as fz
+
+    info, p = fz.demux_case(seed)
+    if p.C > 200:
+        p = p.subset_cells(np.arange(200))
+    alphas, dp = info["alphas"], info["dp"]
+    want, full = reference_records(p, alphas, doublet_prior=dp)
+    if not np.isfinite(full[want["valid"] == 1]).all():
+        pytest.skip("non-finite log-likelihoods: the emulation's noise model does not apply")
+    got = emulate_device(want, full, alphas, dp, noise=1e-13, seed=seed)
+    st = muxgl.demux_exact_calls(p, alphas, got, dp, nthreads=2)
+    check_exact(got, want, st)
