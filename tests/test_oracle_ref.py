@@ -596,3 +596,48 @@ def test_packed_synthetic_pileup_through_the_reference():
     got, got_ll = ob.demux(p, (0.0, 0.5), full_ll=True)
     assert same_records(got, want) == []
     assert np.array_equal(got_ll, want_ll)
+
+
+# ------------------------------------------------------------------ the oracle on the GPU suite's unfriendly generator
+@pytest.mark.parametrize("seed", range(30))
+def test_oracle_is_the_reference_on_unfriendly_cases(seed):
+    """tests/test_fuzz_gpu.py's generator (droplets of a few entries, identical samples, markers without genotypes, entries
+    of ~60 reads or with reads of another allele only, qualities up to 127, hard calls, partial and handed-in starts): the
+    oracle -- the checker of most GPU tests -- must be the reference bit for bit there too"""
+    import test_fuzz_gpu as fz
+
+    info, p = fz.demux_case(seed)
+    if info["V"] <= 40:
+        want, _, wll = rb.RefScl.from_packed(p).demux(info["alphas"], doublet_prior=info["dp"], full_ll=True)
+        got, gll = ob.demux(p, info["alphas"], doublet_prior=info["dp"], full_ll=True)
+        assert same_records(got, want) == [], info
+        m = parity_mask(info["V"], info["alphas"])
+        assert np.array_equal(gll[:, m], wll[:, m], equal_nan=True), info
+    info, p = fz.fmx_case(seed)
+    if info["K"] <= 33:
+        K = info["K"]
+        want = rb.RefScl.from_packed(p).freemux2(K, doublet_prior=info["dp"], geno_error=info["ge"],
+                                                frac_init_clust=info["frac"], singlet_score_thres=info["thres"],
+                                                init_clust=info["init"], full_ll=True, cluster_pileups=True)
+        got = oracle_freemux2(p, K, info["dp"], info["ge"], info["frac"], info["thres"], info["init"])
+        for k in ("llk0", "llk2", "nsnps", "nreads", "clust0"):
+            assert np.array_equal(got[k], want[k]), (k, info)
+        if info["init"] is None:
+            assert np.array_equal(got["order"], want["order"]), info
+        assert len(got["iters"]) == want["n_iter"], info
+        for it, (cells, counters, full, cplp) in enumerate(got["iters"]):
+            assert counters == tuple(want["counters"][it]), (it, info)
+            assert same_records(cells, want["cells"][it]) == [], (it, info)
+            assert np.array_equal(full, want["full_ll"][it], equal_nan=True), (it, info)
+            assert cplp.tobytes() == want["cplp"][it].tobytes(), (it, info)
+
+
+def parity_mask(V, alphas):
+    """the llksAB slots the reference ever writes: (j, 0, 0) and (j, k != j, n >= 1)"""
+    A = len(alphas)
+    m = np.zeros((V, V, A), dtype=bool)
+    m[:, 0, 0] = True
+    off = ~np.eye(V, dtype=bool)
+    for n in range(1, A):
+        m[:, :, n] = off
+    return m
